@@ -1,0 +1,81 @@
+"""ctypes loader of libgaussctrl_hip.so (the C-ABI of include/gaussctrl_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol cannot be resolved
+this module raises.  (The CPU oracle under oracle/ is test infrastructure and is never imported
+from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgaussctrl_hip.so")
+
+# every symbol include/gaussctrl_hip.h declares (tests/test_abi.py checks the header against this list)
+SYMBOLS = [
+    "gc_last_error_string", "gc_abi_version",
+    "gc_project_gaussians_fwd", "gc_project_gaussians_bwd", "gc_sh_fwd", "gc_sh_bwd",
+    "gc_raster_scan_workspace_bytes", "gc_raster_scan_tiles", "gc_raster_read_count",
+    "gc_raster_map_intersects", "gc_raster_pad_intersects", "gc_raster_sort_workspace_bytes",
+    "gc_raster_sort_intersects", "gc_raster_tile_bins", "gc_rasterize_fwd", "gc_rasterize_bwd",
+    "gc_project_sh_fwd", "gc_project_sh_bwd", "gc_raster_finalize",
+]
+
+_lib = None
+
+
+class GaussCtrlHipError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GaussCtrlHipError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+        l = C.CDLL(LIB_PATH)
+        for s in SYMBOLS:
+            if not hasattr(l, s):
+                raise GaussCtrlHipError(f"libgaussctrl_hip.so does not export {s}")
+        l.gc_last_error_string.restype = C.c_char_p
+        l.gc_raster_scan_workspace_bytes.restype = C.c_size_t
+        l.gc_raster_sort_workspace_bytes.restype = C.c_size_t
+        for s in SYMBOLS:
+            if s.endswith("_bytes"):
+                continue
+            if s not in ("gc_last_error_string",):
+                getattr(l, s).restype = C.c_int
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().gc_last_error_string().decode("utf-8", "replace")
+        raise GaussCtrlHipError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or NULL for None) as c_void_p."""
+    if t is None:
+        return C.c_void_p(0)
+    return C.c_void_p(t.data_ptr())
+
+
+def host_floats(values):
+    """small host float array (camera matrices) -> ctypes float array."""
+    vals = [float(v) for v in values]
+    return (C.c_float * len(vals))(*vals)
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+i64 = C.c_int64
+i32 = C.c_int
+f32 = C.c_float

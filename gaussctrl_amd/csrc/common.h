@@ -1,0 +1,29 @@
+// common.h -- shared host-side helpers of libgaussctrl_hip.so (error channel, launch checks).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/gaussctrl_hip.h"
+
+namespace gc {
+void set_error(const char *fmt, ...);
+inline int check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return GC_ELAUNCH;
+    }
+    return GC_OK;
+}
+inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
+inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
+}  // namespace gc
+
+#define GC_REQUIRE(cond, msg)                \
+    do {                                     \
+        if (!(cond)) {                       \
+            gc::set_error("%s: %s", __func__, msg); \
+            return GC_EINVAL;                \
+        }                                    \
+    } while (0)

@@ -1,0 +1,574 @@
+// raster_project.hip -- per-Gaussian front end of the splat rasterizer for gfx950.
+//
+// Replaces gsplat 0.1.3's project_gaussians / spherical_harmonics (+ their backward) as called from
+// /root/reference/gaussctrl/gc_model.py:140-154,166 and adds the fused "one pass over the 59-float
+// parameter record" kernels used by the product path (gc_model.py:138-169,181 in one launch).
+//
+// HBM-bound, 1 lane per Gaussian, wave64, no LDS needed: the record is read once with 16-byte loads
+// where alignment allows.  This translation unit is compiled with -ffp-contract=off: the projection
+// arithmetic is written as explicit IEEE binary32 operations in a fixed order so that the integer
+// outputs (radii, tile boxes, num_tiles_hit -> sort keys) are bit-identical to the CPU oracle.
+#include "common.h"
+
+namespace {
+
+constexpr int TILE = 16;
+
+struct Cam {
+    float V[12];   // row-major 3x4 world->camera
+    float P[16];   // row-major 4x4 full projection
+    float fx, fy, cx, cy;
+    int H, W, tiles_x, tiles_y;
+    float clip, glob;
+    float ox, oy, oz;   // camera origin (world) for view directions
+};
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(hi, fmaxf(lo, v)); }
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+struct Rot {
+    float R[9];
+    float qn[4];
+    float inv_norm;
+};
+
+__device__ __forceinline__ void quat_to_rotmat(float w, float x, float y, float z, Rot &o)
+{
+    float n2 = ((w * w + x * x) + y * y) + z * z;
+    float s = 1.f / sqrtf(n2);
+    w = w * s; x = x * s; y = y * s; z = z * s;
+    o.qn[0] = w; o.qn[1] = x; o.qn[2] = y; o.qn[3] = z; o.inv_norm = s;
+    o.R[0] = 1.f - 2.f * (y * y + z * z);
+    o.R[1] = 2.f * (x * y - w * z);
+    o.R[2] = 2.f * (x * z + w * y);
+    o.R[3] = 2.f * (x * y + w * z);
+    o.R[4] = 1.f - 2.f * (x * x + z * z);
+    o.R[5] = 2.f * (y * z - w * x);
+    o.R[6] = 2.f * (x * z - w * y);
+    o.R[7] = 2.f * (y * z + w * x);
+    o.R[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+__device__ __forceinline__ void scale_rot_to_cov3d(float s0, float s1, float s2, float glob, const float *R,
+                                                   float *c, float *m)
+{
+    float sx = glob * s0, sy = glob * s1, sz = glob * s2;
+    m[0] = R[0] * sx; m[1] = R[1] * sy; m[2] = R[2] * sz;
+    m[3] = R[3] * sx; m[4] = R[4] * sy; m[5] = R[5] * sz;
+    m[6] = R[6] * sx; m[7] = R[7] * sy; m[8] = R[8] * sz;
+    c[0] = (m[0] * m[0] + m[1] * m[1]) + m[2] * m[2];
+    c[1] = (m[0] * m[3] + m[1] * m[4]) + m[2] * m[5];
+    c[2] = (m[0] * m[6] + m[1] * m[7]) + m[2] * m[8];
+    c[3] = (m[3] * m[3] + m[4] * m[4]) + m[5] * m[5];
+    c[4] = (m[3] * m[6] + m[4] * m[7]) + m[5] * m[8];
+    c[5] = (m[6] * m[6] + m[7] * m[7]) + m[8] * m[8];
+}
+
+struct Proj {
+    float cov3d[6];
+    float xy[2];
+    float depth;
+    float conic[3];
+    int radius;
+    int tiles_hit;
+};
+
+// SURVEY.md Appendix A.1; op order mirrors oracle/raster_ref.c::project_one exactly.
+__device__ __forceinline__ bool project_one(const Cam &cam, float p0, float p1, float p2, float s0, float s1,
+                                            float s2, float qw, float qx, float qy, float qz, Proj &o)
+{
+    const float *V = cam.V, *P = cam.P;
+    o.radius = 0; o.tiles_hit = 0; o.depth = 0.f; o.xy[0] = o.xy[1] = 0.f;
+    o.conic[0] = o.conic[1] = o.conic[2] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o.cov3d[k] = 0.f;
+    float tx = ((V[0] * p0 + V[1] * p1) + V[2] * p2) + V[3];
+    float ty = ((V[4] * p0 + V[5] * p1) + V[6] * p2) + V[7];
+    float tz = ((V[8] * p0 + V[9] * p1) + V[10] * p2) + V[11];
+    if (tz <= cam.clip) return false;
+    Rot rot; float m[9];
+    quat_to_rotmat(qw, qx, qy, qz, rot);
+    scale_rot_to_cov3d(s0, s1, s2, cam.glob, rot.R, o.cov3d, m);
+    float lim_x = 1.3f * (0.5f * (float)cam.W / cam.fx);
+    float lim_y = 1.3f * (0.5f * (float)cam.H / cam.fy);
+    float txc = tz * clampf(tx / tz, -lim_x, lim_x);
+    float tyc = tz * clampf(ty / tz, -lim_y, lim_y);
+    float rz = 1.f / tz;
+    float rz2 = rz * rz;
+    float j00 = cam.fx * rz, j02 = -(cam.fx * txc) * rz2;
+    float j11 = cam.fy * rz, j12 = -(cam.fy * tyc) * rz2;
+    float t00 = j00 * V[0] + j02 * V[8], t01 = j00 * V[1] + j02 * V[9], t02 = j00 * V[2] + j02 * V[10];
+    float t10 = j11 * V[4] + j12 * V[8], t11 = j11 * V[5] + j12 * V[9], t12 = j11 * V[6] + j12 * V[10];
+    const float *c = o.cov3d;
+    float u00 = (t00 * c[0] + t01 * c[1]) + t02 * c[2];
+    float u01 = (t00 * c[1] + t01 * c[3]) + t02 * c[4];
+    float u02 = (t00 * c[2] + t01 * c[4]) + t02 * c[5];
+    float u10 = (t10 * c[0] + t11 * c[1]) + t12 * c[2];
+    float u11 = (t10 * c[1] + t11 * c[3]) + t12 * c[4];
+    float u12 = (t10 * c[2] + t11 * c[4]) + t12 * c[5];
+    float a = ((u00 * t00 + u01 * t01) + u02 * t02) + 0.3f;
+    float b = (u00 * t10 + u01 * t11) + u02 * t12;
+    float d = ((u10 * t10 + u11 * t11) + u12 * t12) + 0.3f;
+    float det = a * d - b * b;
+    if (det == 0.f) return false;
+    float inv_det = 1.f / det;
+    float con0 = d * inv_det, con1 = -b * inv_det, con2 = a * inv_det;
+    float mid = 0.5f * (a + d);
+    float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
+    float v1 = mid + disc, v2 = mid - disc;
+    float radius = ceilf(3.f * sqrtf(fmaxf(v1, v2)));
+    float hx = ((P[0] * p0 + P[1] * p1) + P[2] * p2) + P[3];
+    float hy = ((P[4] * p0 + P[5] * p1) + P[6] * p2) + P[7];
+    float hw = ((P[12] * p0 + P[13] * p1) + P[14] * p2) + P[15];
+    float rw = 1.f / (hw + 1e-6f);
+    float px = (0.5f * (float)cam.W) * (hx * rw) + cam.cx - 0.5f;
+    float py = (0.5f * (float)cam.H) * (hy * rw) + cam.cy - 0.5f;
+    float tcx = px / (float)TILE, tcy = py / (float)TILE, tr = radius / (float)TILE;
+    int minx = clampi((int)(tcx - tr), 0, cam.tiles_x), maxx = clampi((int)(tcx + tr + 1.f), 0, cam.tiles_x);
+    int miny = clampi((int)(tcy - tr), 0, cam.tiles_y), maxy = clampi((int)(tcy + tr + 1.f), 0, cam.tiles_y);
+    int area = (maxx - minx) * (maxy - miny);
+    if (area <= 0) return false;
+    o.tiles_hit = area; o.depth = tz; o.radius = (int)radius;
+    o.xy[0] = px; o.xy[1] = py;
+    o.conic[0] = con0; o.conic[1] = con1; o.conic[2] = con2;
+    return true;
+}
+
+struct ProjGrad {
+    float vm[3], vs[3], vq[4];
+};
+
+// True VJP of project_one w.r.t. (mean, scale, raw quat); mirrors oracle orc_project_gaussians_bwd.
+__device__ __forceinline__ void project_one_bwd(const Cam &cam, float p0, float p1, float p2, float s0, float s1,
+                                                float s2, float qw, float qx, float qy, float qz,
+                                                float X00, float X01, float X11, float vx, float vy, float vz,
+                                                float g0, float g1, float g2, ProjGrad &o)
+{
+    const float *V = cam.V, *P = cam.P;
+    float hx = ((P[0] * p0 + P[1] * p1) + P[2] * p2) + P[3];
+    float hy = ((P[4] * p0 + P[5] * p1) + P[6] * p2) + P[7];
+    float hw = ((P[12] * p0 + P[13] * p1) + P[14] * p2) + P[15];
+    float rw = 1.f / (hw + 1e-6f);
+    float vnx = 0.5f * (float)cam.W * vx, vny = 0.5f * (float)cam.H * vy;
+    float vhx = vnx * rw, vhy = vny * rw, vhw = -(vnx * hx + vny * hy) * rw * rw;
+    o.vm[0] = P[0] * vhx + P[4] * vhy + P[12] * vhw;
+    o.vm[1] = P[1] * vhx + P[5] * vhy + P[13] * vhw;
+    o.vm[2] = P[2] * vhx + P[6] * vhy + P[14] * vhw;
+    o.vm[0] += V[8] * vz; o.vm[1] += V[9] * vz; o.vm[2] += V[10] * vz;
+    float G00 = g0, G01 = 0.5f * g1, G11 = g2;
+    float a00 = X00 * G00 + X01 * G01, a01 = X00 * G01 + X01 * G11;
+    float a10 = X01 * G00 + X11 * G01, a11 = X01 * G01 + X11 * G11;
+    float C00 = -(a00 * X00 + a01 * X01), C01 = -(a00 * X01 + a01 * X11), C11 = -(a10 * X01 + a11 * X11);
+    float tx = ((V[0] * p0 + V[1] * p1) + V[2] * p2) + V[3];
+    float ty = ((V[4] * p0 + V[5] * p1) + V[6] * p2) + V[7];
+    float tz = ((V[8] * p0 + V[9] * p1) + V[10] * p2) + V[11];
+    float lim_x = 1.3f * (0.5f * (float)cam.W / cam.fx), lim_y = 1.3f * (0.5f * (float)cam.H / cam.fy);
+    float rx = tx / tz, ry = ty / tz;
+    float rxc = clampf(rx, -lim_x, lim_x), ryc = clampf(ry, -lim_y, lim_y);
+    bool clx = (rx != rxc), cly = (ry != ryc);
+    float txc = tz * rxc, tyc = tz * ryc;
+    float rz = 1.f / tz, rz2 = rz * rz;
+    float fx = cam.fx, fy = cam.fy;
+    float j00 = fx * rz, j02 = -(fx * txc) * rz2, j11 = fy * rz, j12 = -(fy * tyc) * rz2;
+    float T[6] = {j00 * V[0] + j02 * V[8], j00 * V[1] + j02 * V[9], j00 * V[2] + j02 * V[10],
+                  j11 * V[4] + j12 * V[8], j11 * V[5] + j12 * V[9], j11 * V[6] + j12 * V[10]};
+    Rot rot; float M[9], c3[6];
+    quat_to_rotmat(qw, qx, qy, qz, rot);
+    scale_rot_to_cov3d(s0, s1, s2, cam.glob, rot.R, c3, M);
+    float S[9] = {c3[0], c3[1], c3[2], c3[1], c3[3], c3[4], c3[2], c3[4], c3[5]};
+    float GT[6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { GT[k] = C00 * T[k] + C01 * T[3 + k]; GT[3 + k] = C01 * T[k] + C11 * T[3 + k]; }
+    float vS[9], vT[6], vM[9], vR[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) vS[3 * r + k] = T[r] * GT[k] + T[3 + r] * GT[3 + k];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            vT[3 * r + k] = 2.f * (GT[3 * r] * S[k] + GT[3 * r + 1] * S[3 + k] + GT[3 * r + 2] * S[6 + k]);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            vM[3 * r + k] = 2.f * (vS[3 * r] * M[k] + vS[3 * r + 1] * M[3 + k] + vS[3 * r + 2] * M[6 + k]);
+    float sc[3] = {s0, s1, s2};
+    const float *R = rot.R;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) vR[3 * r + k] = vM[3 * r + k] * (cam.glob * sc[k]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o.vs[k] = cam.glob * (R[k] * vM[k] + R[3 + k] * vM[3 + k] + R[6 + k] * vM[6 + k]);
+    float w = rot.qn[0], x = rot.qn[1], y = rot.qn[2], z = rot.qn[3];
+    float vqn[4];
+    vqn[0] = 2.f * (x * (vR[7] - vR[5]) + y * (vR[2] - vR[6]) + z * (vR[3] - vR[1]));
+    vqn[1] = 2.f * (-2.f * x * (vR[4] + vR[8]) + y * (vR[1] + vR[3]) + z * (vR[2] + vR[6]) + w * (vR[7] - vR[5]));
+    vqn[2] = 2.f * (x * (vR[1] + vR[3]) - 2.f * y * (vR[0] + vR[8]) + z * (vR[5] + vR[7]) + w * (vR[2] - vR[6]));
+    vqn[3] = 2.f * (x * (vR[2] + vR[6]) + y * (vR[5] + vR[7]) - 2.f * z * (vR[0] + vR[4]) + w * (vR[3] - vR[1]));
+    float dotq = rot.qn[0] * vqn[0] + rot.qn[1] * vqn[1] + rot.qn[2] * vqn[2] + rot.qn[3] * vqn[3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o.vq[k] = (vqn[k] - rot.qn[k] * dotq) * rot.inv_norm;
+    float vj00 = vT[0] * V[0] + vT[1] * V[1] + vT[2] * V[2];
+    float vj02 = vT[0] * V[8] + vT[1] * V[9] + vT[2] * V[10];
+    float vj11 = vT[3] * V[4] + vT[4] * V[5] + vT[5] * V[6];
+    float vj12 = vT[3] * V[8] + vT[4] * V[9] + vT[5] * V[10];
+    float v_rz = fx * vj00 + fy * vj11 - 2.f * rz * (fx * txc * vj02 + fy * tyc * vj12);
+    float v_txc = -fx * rz2 * vj02, v_tyc = -fy * rz2 * vj12;
+    float v_tz = -rz2 * v_rz, v_tx = 0.f, v_ty = 0.f;
+    if (clx) v_tz += rxc * v_txc; else v_tx += v_txc;
+    if (cly) v_tz += ryc * v_tyc; else v_ty += v_tyc;
+    o.vm[0] += V[0] * v_tx + V[4] * v_ty + V[8] * v_tz;
+    o.vm[1] += V[1] * v_tx + V[5] * v_ty + V[9] * v_tz;
+    o.vm[2] += V[2] * v_tx + V[6] * v_ty + V[10] * v_tz;
+}
+
+// ---------------------------------------------------------------- SH (Appendix A.2)
+__device__ __forceinline__ void sh_basis(int n, float x, float y, float z, float *B)
+{
+    const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) B[k] = 0.f;
+    B[0] = C0;
+    if (n < 1) return;
+    B[1] = -C1 * y; B[2] = C1 * z; B[3] = -C1 * x;
+    if (n < 2) return;
+    float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    B[4] = 1.0925484305920792f * xy; B[5] = -1.0925484305920792f * yz;
+    B[6] = 0.31539156525252005f * (2.f * zz - xx - yy);
+    B[7] = -1.0925484305920792f * xz; B[8] = 0.5462742152960396f * (xx - yy);
+    if (n < 3) return;
+    B[9] = -0.5900435899266435f * y * (3.f * xx - yy);
+    B[10] = 2.890611442640554f * xy * z;
+    B[11] = -0.4570457994644658f * y * (4.f * zz - xx - yy);
+    B[12] = 0.3731763325901154f * z * (2.f * zz - 3.f * xx - 3.f * yy);
+    B[13] = -0.4570457994644658f * x * (4.f * zz - xx - yy);
+    B[14] = 1.445305721320277f * z * (xx - yy);
+    B[15] = -0.5900435899266435f * x * (xx - 3.f * yy);
+}
+
+// ---------------------------------------------------------------- kernels: gsplat operator surface
+__global__ __launch_bounds__(256) void k_project_fwd(int64_t N, Cam cam, const float *__restrict__ means,
+                                                     const float *__restrict__ scales, const float *__restrict__ quats,
+                                                     float *__restrict__ cov3d, float *__restrict__ xys,
+                                                     float *__restrict__ depths, int32_t *__restrict__ radii,
+                                                     float *__restrict__ conics, int32_t *__restrict__ tiles_hit)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    Proj o;
+    project_one(cam, means[3 * i], means[3 * i + 1], means[3 * i + 2], scales[3 * i], scales[3 * i + 1],
+                scales[3 * i + 2], quats[4 * i], quats[4 * i + 1], quats[4 * i + 2], quats[4 * i + 3], o);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cov3d[6 * i + k] = o.cov3d[k];
+    xys[2 * i] = o.xy[0]; xys[2 * i + 1] = o.xy[1];
+    depths[i] = o.depth; radii[i] = o.radius; tiles_hit[i] = o.tiles_hit;
+    conics[3 * i] = o.conic[0]; conics[3 * i + 1] = o.conic[1]; conics[3 * i + 2] = o.conic[2];
+}
+
+__global__ __launch_bounds__(256) void k_project_bwd(int64_t N, Cam cam, const float *__restrict__ means,
+                                                     const float *__restrict__ scales, const float *__restrict__ quats,
+                                                     const int32_t *__restrict__ radii, const float *__restrict__ conics,
+                                                     const float *__restrict__ v_xy, const float *__restrict__ v_depth,
+                                                     const float *__restrict__ v_conic, float *__restrict__ v_mean,
+                                                     float *__restrict__ v_scale, float *__restrict__ v_quat)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    ProjGrad g;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { g.vm[k] = 0.f; g.vs[k] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g.vq[k] = 0.f;
+    if (radii[i] > 0)
+        project_one_bwd(cam, means[3 * i], means[3 * i + 1], means[3 * i + 2], scales[3 * i], scales[3 * i + 1],
+                        scales[3 * i + 2], quats[4 * i], quats[4 * i + 1], quats[4 * i + 2], quats[4 * i + 3],
+                        conics[3 * i], conics[3 * i + 1], conics[3 * i + 2], v_xy[2 * i], v_xy[2 * i + 1],
+                        v_depth ? v_depth[i] : 0.f, v_conic[3 * i], v_conic[3 * i + 1], v_conic[3 * i + 2], g);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { v_mean[3 * i + k] = g.vm[k]; v_scale[3 * i + k] = g.vs[k]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v_quat[4 * i + k] = g.vq[k];
+}
+
+__global__ __launch_bounds__(256) void k_sh_fwd(int64_t N, int K, int n, const float *__restrict__ dirs,
+                                                const float *__restrict__ coeffs, float *__restrict__ colors)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float B[16];
+    sh_basis(n, dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], B);
+    int Ku = (n + 1) * (n + 1);
+    float acc[3] = {0.f, 0.f, 0.f};
+    const float *c = coeffs + (size_t)i * K * 3;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if (k < Ku) {
+            acc[0] += B[k] * c[3 * k]; acc[1] += B[k] * c[3 * k + 1]; acc[2] += B[k] * c[3 * k + 2];
+        }
+    colors[3 * i] = acc[0]; colors[3 * i + 1] = acc[1]; colors[3 * i + 2] = acc[2];
+}
+
+__global__ __launch_bounds__(256) void k_sh_bwd(int64_t N, int K, int n, const float *__restrict__ dirs,
+                                                const float *__restrict__ v_colors, float *__restrict__ v_coeffs)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float B[16];
+    sh_basis(n, dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], B);
+    int Ku = (n + 1) * (n + 1);
+    float v0 = v_colors[3 * i], v1 = v_colors[3 * i + 1], v2 = v_colors[3 * i + 2];
+    float *o = v_coeffs + (size_t)i * K * 3;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if (k < K) {
+            float b = k < Ku ? B[k] : 0.f;
+            o[3 * k] = b * v0; o[3 * k + 1] = b * v1; o[3 * k + 2] = b * v2;
+        }
+}
+
+// ---------------------------------------------------------------- kernels: fused product path
+// One pass over the 59-float record (236 B/Gaussian read, 48 B written).  Mirrors the reference
+// op-by-op: exp(scales), q/|q| (gc_model.py:144), project, viewdirs (gc_model.py:163-164),
+// SH, clamp(+0.5,min 0) (:167), sigmoid(opacity) (:181).
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + __expf(-x)); }
+
+template <int K>
+__global__ __launch_bounds__(256) void k_project_sh_fwd(int64_t N, Cam cam, int n_use,
+                                                        const float *__restrict__ means, const float *__restrict__ log_scales,
+                                                        const float *__restrict__ quats, const float *__restrict__ op_logit,
+                                                        const float *__restrict__ f_dc, const float *__restrict__ f_rest,
+                                                        float *__restrict__ xys, float *__restrict__ depths,
+                                                        int32_t *__restrict__ radii, float *__restrict__ conics,
+                                                        int32_t *__restrict__ tiles_hit, float *__restrict__ rgbs,
+                                                        float *__restrict__ opac)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float p0 = means[3 * i], p1 = means[3 * i + 1], p2 = means[3 * i + 2];
+    float s0 = expf(log_scales[3 * i]), s1 = expf(log_scales[3 * i + 1]), s2 = expf(log_scales[3 * i + 2]);
+    float4 q = *reinterpret_cast<const float4 *>(quats + 4 * i);
+    float qn = sqrtf(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w);
+    q.x = q.x / qn; q.y = q.y / qn; q.z = q.z / qn; q.w = q.w / qn;
+    Proj o;
+    bool ok = project_one(cam, p0, p1, p2, s0, s1, s2, q.x, q.y, q.z, q.w, o);
+    xys[2 * i] = o.xy[0]; xys[2 * i + 1] = o.xy[1];
+    depths[i] = o.depth; radii[i] = o.radius; tiles_hit[i] = o.tiles_hit;
+    conics[3 * i] = o.conic[0]; conics[3 * i + 1] = o.conic[1]; conics[3 * i + 2] = o.conic[2];
+    opac[i] = sigmoidf(op_logit[i]);
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    if (ok) {   // culled Gaussians never reach a tile list: skip their 180-byte SH read
+        float dx = p0 - cam.ox, dy = p1 - cam.oy, dz = p2 - cam.oz;
+        float dn = sqrtf((dx * dx + dy * dy) + dz * dz);
+        dx = dx / dn; dy = dy / dn; dz = dz / dn;
+        float B[16];
+        sh_basis(n_use, dx, dy, dz, B);
+        c0 = B[0] * f_dc[3 * i]; c1 = B[0] * f_dc[3 * i + 1]; c2 = B[0] * f_dc[3 * i + 2];
+        const float *r = f_rest + (size_t)i * (K - 1) * 3;
+        int Ku = (n_use + 1) * (n_use + 1);
+#pragma unroll
+        for (int k = 1; k < K; ++k)
+            if (k < Ku) {
+                c0 += B[k] * r[3 * (k - 1)]; c1 += B[k] * r[3 * (k - 1) + 1]; c2 += B[k] * r[3 * (k - 1) + 2];
+            }
+        c0 = fmaxf(c0 + 0.5f, 0.f); c1 = fmaxf(c1 + 0.5f, 0.f); c2 = fmaxf(c2 + 0.5f, 0.f);
+    }
+    rgbs[3 * i] = c0; rgbs[3 * i + 1] = c1; rgbs[3 * i + 2] = c2;
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void k_project_sh_bwd(int64_t N, Cam cam, int n_use,
+                                                        const float *__restrict__ means, const float *__restrict__ log_scales,
+                                                        const float *__restrict__ quats, const float *__restrict__ op_logit,
+                                                        const float *__restrict__ f_dc, const float *__restrict__ f_rest,
+                                                        const int32_t *__restrict__ radii, const float *__restrict__ conics,
+                                                        const float *__restrict__ v_xy, const float *__restrict__ v_conic,
+                                                        const float *__restrict__ v_rgbs, const float *__restrict__ v_opac,
+                                                        float *__restrict__ v_means, float *__restrict__ v_ls,
+                                                        float *__restrict__ v_quats, float *__restrict__ v_oplogit,
+                                                        float *__restrict__ v_dc, float *__restrict__ v_rest)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float *vr = v_rest + (size_t)i * (K - 1) * 3;
+    if (radii[i] <= 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { v_means[3 * i + k] = 0.f; v_ls[3 * i + k] = 0.f; v_dc[3 * i + k] = 0.f; }
+        *reinterpret_cast<float4 *>(v_quats + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        v_oplogit[i] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3 * (K - 1); ++k) vr[k] = 0.f;
+        return;
+    }
+    float p0 = means[3 * i], p1 = means[3 * i + 1], p2 = means[3 * i + 2];
+    float s0 = expf(log_scales[3 * i]), s1 = expf(log_scales[3 * i + 1]), s2 = expf(log_scales[3 * i + 2]);
+    float4 qr = *reinterpret_cast<const float4 *>(quats + 4 * i);
+    float qn = sqrtf(((qr.x * qr.x + qr.y * qr.y) + qr.z * qr.z) + qr.w * qr.w);
+    float q0 = qr.x / qn, q1 = qr.y / qn, q2 = qr.z / qn, q3 = qr.w / qn;
+    ProjGrad g;
+    project_one_bwd(cam, p0, p1, p2, s0, s1, s2, q0, q1, q2, q3, conics[3 * i], conics[3 * i + 1], conics[3 * i + 2],
+                    v_xy[2 * i], v_xy[2 * i + 1], 0.f, v_conic[3 * i], v_conic[3 * i + 1], v_conic[3 * i + 2], g);
+    v_means[3 * i] = g.vm[0]; v_means[3 * i + 1] = g.vm[1]; v_means[3 * i + 2] = g.vm[2];
+    v_ls[3 * i] = g.vs[0] * s0; v_ls[3 * i + 1] = g.vs[1] * s1; v_ls[3 * i + 2] = g.vs[2] * s2;
+    // outer normalisation q/|q| (gc_model.py:144)
+    float dq = q0 * g.vq[0] + q1 * g.vq[1] + q2 * g.vq[2] + q3 * g.vq[3];
+    *reinterpret_cast<float4 *>(v_quats + 4 * i) =
+        make_float4((g.vq[0] - q0 * dq) / qn, (g.vq[1] - q1 * dq) / qn, (g.vq[2] - q2 * dq) / qn, (g.vq[3] - q3 * dq) / qn);
+    float op = sigmoidf(op_logit[i]);
+    v_oplogit[i] = v_opac[i] * op * (1.f - op);
+    // SH backward with the clamp(+0.5, min 0) mask recomputed from the forward value
+    float dx = p0 - cam.ox, dy = p1 - cam.oy, dz = p2 - cam.oz;
+    float dn = sqrtf((dx * dx + dy * dy) + dz * dz);
+    dx = dx / dn; dy = dy / dn; dz = dz / dn;
+    float B[16];
+    sh_basis(n_use, dx, dy, dz, B);
+    int Ku = (n_use + 1) * (n_use + 1);
+    float c0 = B[0] * f_dc[3 * i], c1 = B[0] * f_dc[3 * i + 1], c2 = B[0] * f_dc[3 * i + 2];
+    const float *r = f_rest + (size_t)i * (K - 1) * 3;
+#pragma unroll
+    for (int k = 1; k < K; ++k)
+        if (k < Ku) {
+            c0 += B[k] * r[3 * (k - 1)]; c1 += B[k] * r[3 * (k - 1) + 1]; c2 += B[k] * r[3 * (k - 1) + 2];
+        }
+    float v0 = (c0 + 0.5f) >= 0.f ? v_rgbs[3 * i] : 0.f;
+    float v1 = (c1 + 0.5f) >= 0.f ? v_rgbs[3 * i + 1] : 0.f;
+    float v2 = (c2 + 0.5f) >= 0.f ? v_rgbs[3 * i + 2] : 0.f;
+    v_dc[3 * i] = B[0] * v0; v_dc[3 * i + 1] = B[0] * v1; v_dc[3 * i + 2] = B[0] * v2;
+#pragma unroll
+    for (int k = 1; k < K; ++k) {
+        float b = k < Ku ? B[k] : 0.f;
+        vr[3 * (k - 1)] = b * v0; vr[3 * (k - 1) + 1] = b * v1; vr[3 * (k - 1) + 2] = b * v2;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_finalize(int64_t npix, float *__restrict__ img, float *__restrict__ extra,
+                                                  const float *__restrict__ final_T, float *__restrict__ alpha)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    float a = 1.f - final_T[i];
+    alpha[i] = a;
+    img[3 * i] = fminf(img[3 * i], 1.f); img[3 * i + 1] = fminf(img[3 * i + 1], 1.f); img[3 * i + 2] = fminf(img[3 * i + 2], 1.f);
+    if (extra) extra[i] = a > 0.f ? extra[i] / a : 1000.f;
+}
+
+Cam make_cam(const float *viewmat, const float *projmat, float fx, float fy, float cx, float cy, int H, int W,
+             int tx, int ty, float clip, float glob, const float *origin)
+{
+    Cam c;
+    for (int k = 0; k < 12; ++k) c.V[k] = viewmat[k];
+    for (int k = 0; k < 16; ++k) c.P[k] = projmat[k];
+    c.fx = fx; c.fy = fy; c.cx = cx; c.cy = cy; c.H = H; c.W = W; c.tiles_x = tx; c.tiles_y = ty;
+    c.clip = clip; c.glob = glob;
+    c.ox = origin ? origin[0] : 0.f; c.oy = origin ? origin[1] : 0.f; c.oz = origin ? origin[2] : 0.f;
+    return c;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gc_project_gaussians_fwd(int64_t N, const float *means3d, const float *scales, float glob_scale,
+                             const float *quats, const float *viewmat, const float *projmat, float fx, float fy,
+                             float cx, float cy, int img_h, int img_w, int tiles_x, int tiles_y, float clip_thresh,
+                             float *cov3d, float *xys, float *depths, int32_t *radii, float *conics,
+                             int32_t *num_tiles_hit, void *stream)
+{
+    GC_REQUIRE(N >= 0 && viewmat && projmat, "bad arguments");
+    if (N == 0) return GC_OK;
+    Cam cam = make_cam(viewmat, projmat, fx, fy, cx, cy, img_h, img_w, tiles_x, tiles_y, clip_thresh, glob_scale, nullptr);
+    hipLaunchKernelGGL(k_project_fwd, dim3(gc::cdiv(N, 256)), dim3(256), 0, gc::S(stream), N, cam, means3d, scales,
+                       quats, cov3d, xys, depths, radii, conics, num_tiles_hit);
+    return gc::check_launch("gc_project_gaussians_fwd");
+}
+
+int gc_project_gaussians_bwd(int64_t N, const float *means3d, const float *scales, float glob_scale,
+                             const float *quats, const float *viewmat, const float *projmat, float fx, float fy,
+                             float cx, float cy, int img_h, int img_w, const int32_t *radii, const float *conics,
+                             const float *v_xy, const float *v_depth, const float *v_conic, float *v_mean3d,
+                             float *v_scale, float *v_quat, void *stream)
+{
+    GC_REQUIRE(N >= 0 && viewmat && projmat, "bad arguments");
+    if (N == 0) return GC_OK;
+    Cam cam = make_cam(viewmat, projmat, fx, fy, cx, cy, img_h, img_w, 0, 0, 0.f, glob_scale, nullptr);
+    hipLaunchKernelGGL(k_project_bwd, dim3(gc::cdiv(N, 256)), dim3(256), 0, gc::S(stream), N, cam, means3d, scales,
+                       quats, radii, conics, v_xy, v_depth, v_conic, v_mean3d, v_scale, v_quat);
+    return gc::check_launch("gc_project_gaussians_bwd");
+}
+
+int gc_sh_fwd(int64_t N, int degree, int degrees_to_use, const float *viewdirs, const float *coeffs, float *colors,
+              void *stream)
+{
+    GC_REQUIRE(degree >= 0 && degree <= 3 && degrees_to_use >= 0 && degrees_to_use <= degree, "SH degree must be 0..3");
+    if (N == 0) return GC_OK;
+    int K = (degree + 1) * (degree + 1);
+    hipLaunchKernelGGL(k_sh_fwd, dim3(gc::cdiv(N, 256)), dim3(256), 0, gc::S(stream), N, K, degrees_to_use, viewdirs,
+                       coeffs, colors);
+    return gc::check_launch("gc_sh_fwd");
+}
+
+int gc_sh_bwd(int64_t N, int degree, int degrees_to_use, const float *viewdirs, const float *v_colors,
+              float *v_coeffs, void *stream)
+{
+    GC_REQUIRE(degree >= 0 && degree <= 3 && degrees_to_use >= 0 && degrees_to_use <= degree, "SH degree must be 0..3");
+    if (N == 0) return GC_OK;
+    int K = (degree + 1) * (degree + 1);
+    hipLaunchKernelGGL(k_sh_bwd, dim3(gc::cdiv(N, 256)), dim3(256), 0, gc::S(stream), N, K, degrees_to_use, viewdirs,
+                       v_colors, v_coeffs);
+    return gc::check_launch("gc_sh_bwd");
+}
+
+#define GC_SH_DISPATCH(KERNEL, ...)                                                                               \
+    switch (sh_degree) {                                                                                          \
+    case 0: hipLaunchKernelGGL(KERNEL<1>, dim3(gc::cdiv(N, 256)), dim3(256), 0, gc::S(stream), __VA_ARGS__); break; \
+    case 1: hipLaunchKernelGGL(KERNEL<4>, dim3(gc::cdiv(N, 256)), dim3(256), 0, gc::S(stream), __VA_ARGS__); break; \
+    case 2: hipLaunchKernelGGL(KERNEL<9>, dim3(gc::cdiv(N, 256)), dim3(256), 0, gc::S(stream), __VA_ARGS__); break; \
+    default: hipLaunchKernelGGL(KERNEL<16>, dim3(gc::cdiv(N, 256)), dim3(256), 0, gc::S(stream), __VA_ARGS__); break; \
+    }
+
+int gc_project_sh_fwd(int64_t N, const float *means, const float *log_scales, const float *quats,
+                      const float *opacity_logits, const float *features_dc, const float *features_rest,
+                      int sh_degree, int degrees_to_use, const float *viewmat, const float *projmat,
+                      const float *cam_origin, float fx, float fy, float cx, float cy, int img_h, int img_w,
+                      int tiles_x, int tiles_y, float clip_thresh, float *xys, float *depths, int32_t *radii,
+                      float *conics, int32_t *num_tiles_hit, float *rgbs, float *opac, void *stream)
+{
+    GC_REQUIRE(sh_degree >= 0 && sh_degree <= 3 && degrees_to_use >= 0 && degrees_to_use <= sh_degree, "SH degree must be 0..3");
+    GC_REQUIRE(viewmat && projmat && cam_origin, "camera pointers are host pointers and must not be NULL");
+    if (N == 0) return GC_OK;
+    Cam cam = make_cam(viewmat, projmat, fx, fy, cx, cy, img_h, img_w, tiles_x, tiles_y, clip_thresh, 1.f, cam_origin);
+    GC_SH_DISPATCH(k_project_sh_fwd, N, cam, degrees_to_use, means, log_scales, quats, opacity_logits, features_dc,
+                   features_rest, xys, depths, radii, conics, num_tiles_hit, rgbs, opac)
+    return gc::check_launch("gc_project_sh_fwd");
+}
+
+int gc_project_sh_bwd(int64_t N, const float *means, const float *log_scales, const float *quats,
+                      const float *opacity_logits, const float *features_dc, const float *features_rest,
+                      int sh_degree, int degrees_to_use, const float *viewmat, const float *projmat,
+                      const float *cam_origin, float fx, float fy, float cx, float cy, int img_h, int img_w,
+                      const int32_t *radii, const float *conics, const float *v_xy, const float *v_conic,
+                      const float *v_rgbs, const float *v_opac, float *v_means, float *v_log_scales, float *v_quats,
+                      float *v_opacity_logits, float *v_features_dc, float *v_features_rest, void *stream)
+{
+    GC_REQUIRE(sh_degree >= 0 && sh_degree <= 3 && degrees_to_use >= 0 && degrees_to_use <= sh_degree, "SH degree must be 0..3");
+    GC_REQUIRE(viewmat && projmat && cam_origin, "camera pointers are host pointers and must not be NULL");
+    if (N == 0) return GC_OK;
+    Cam cam = make_cam(viewmat, projmat, fx, fy, cx, cy, img_h, img_w, 0, 0, 0.f, 1.f, cam_origin);
+    GC_SH_DISPATCH(k_project_sh_bwd, N, cam, degrees_to_use, means, log_scales, quats, opacity_logits, features_dc,
+                   features_rest, radii, conics, v_xy, v_conic, v_rgbs, v_opac, v_means, v_log_scales, v_quats,
+                   v_opacity_logits, v_features_dc, v_features_rest)
+    return gc::check_launch("gc_project_sh_bwd");
+}
+
+int gc_raster_finalize(int64_t num_pixels, float *out_img, float *out_extra, const float *final_Ts, float *alpha,
+                       void *stream)
+{
+    if (num_pixels == 0) return GC_OK;
+    hipLaunchKernelGGL(k_finalize, dim3(gc::cdiv(num_pixels, 256)), dim3(256), 0, gc::S(stream), num_pixels, out_img,
+                       out_extra, final_Ts, alpha);
+    return gc::check_launch("gc_raster_finalize");
+}
+
+}  // extern "C"

@@ -1,0 +1,315 @@
+"""Operator surface of the rasterizer: drop-in for the three gsplat 0.1.3 functions the reference calls.
+
+    project_gaussians    /root/reference/gaussctrl/gc_model.py:140-154  (import :35)
+    spherical_harmonics  /root/reference/gaussctrl/gc_model.py:166      (import :32)
+    rasterize_gaussians  /root/reference/gaussctrl/gc_model.py:174-186,191-202 (import :36)
+
+Same names, argument order, tuple arity (6-tuple from project_gaussians, gsplat <= 0.1.3) and
+autograd behaviour; every call goes through the C ABI of include/gaussctrl_hip.h (hand-written HIP
+kernels for gfx950).  There is no CPU / eager fallback: tensors must live on the GPU.
+
+`render_view` is the fused product path used by gaussctrl_amd.gc_model.GaussCtrlModel.get_outputs:
+one launch over the 59-float parameter record (exp/normalise/project/SH/sigmoid), one sort, one
+compositing sweep for RGB + depth + alpha, and a fused backward to the six leaf tensors.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+
+TILE = 16
+
+
+def num_sh_bases(degree: int) -> int:
+    """gsplat.sh.num_sh_bases"""
+    if degree == 0:
+        return 1
+    if degree == 1:
+        return 4
+    if degree == 2:
+        return 9
+    if degree == 3:
+        return 16
+    return 25
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.GaussCtrlHipError("gaussctrl_amd ops need GPU tensors (HIP path only; no CPU fallback)")
+
+
+def _c(t, dtype=torch.float32):
+    return t.detach().to(dtype).contiguous()
+
+
+def _host_mat(m, n):
+    """small camera matrix (device or host tensor / array) -> ctypes float array of n entries."""
+    if isinstance(m, torch.Tensor):
+        m = m.detach().to("cpu", torch.float32).reshape(-1)
+    else:
+        import numpy as np
+        m = torch.from_numpy(np.asarray(m, dtype="float32").reshape(-1))
+    if m.numel() < n:
+        raise ValueError(f"camera matrix needs >= {n} entries")
+    return L.host_floats(m[:n].tolist())
+
+
+# --------------------------------------------------------------------------------------------- project
+class _ProjectGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3d, scales, glob_scale, quats, viewmat, projmat, fx, fy, cx, cy, H, W, tile_bounds, clip):
+        _need_gpu(means3d, scales, quats)
+        N = means3d.shape[0]
+        dev = means3d.device
+        m, s, q = _c(means3d), _c(scales), _c(quats)
+        V, P = _host_mat(viewmat, 12), _host_mat(projmat, 16)
+        cov3d = torch.empty(N, 6, device=dev); xys = torch.empty(N, 2, device=dev); depths = torch.empty(N, device=dev)
+        radii = torch.empty(N, dtype=torch.int32, device=dev); conics = torch.empty(N, 3, device=dev)
+        nth = torch.empty(N, dtype=torch.int32, device=dev)
+        L.check(L.lib().gc_project_gaussians_fwd(
+            L.i64(N), L.ptr(m), L.ptr(s), L.f32(glob_scale), L.ptr(q), V, P, L.f32(fx), L.f32(fy), L.f32(cx), L.f32(cy),
+            L.i32(H), L.i32(W), L.i32(tile_bounds[0]), L.i32(tile_bounds[1]), L.f32(clip), L.ptr(cov3d), L.ptr(xys),
+            L.ptr(depths), L.ptr(radii), L.ptr(conics), L.ptr(nth), L.stream_ptr()), "gc_project_gaussians_fwd")
+        ctx.save_for_backward(m, s, q, radii, conics)
+        ctx.cam = (V, P, float(glob_scale), float(fx), float(fy), float(cx), float(cy), int(H), int(W))
+        ctx.mark_non_differentiable(radii, nth)
+        return xys, depths, radii, conics, nth, cov3d
+
+    @staticmethod
+    def backward(ctx, v_xys, v_depths, v_radii, v_conics, v_nth, v_cov3d):
+        m, s, q, radii, conics = ctx.saved_tensors
+        V, P, glob, fx, fy, cx, cy, H, W = ctx.cam
+        N = m.shape[0]
+        dev = m.device
+        v_xy = _c(v_xys) if v_xys is not None else torch.zeros(N, 2, device=dev)
+        v_con = _c(v_conics) if v_conics is not None else torch.zeros(N, 3, device=dev)
+        v_dep = _c(v_depths) if v_depths is not None else None
+        vm = torch.empty(N, 3, device=dev); vs = torch.empty(N, 3, device=dev); vq = torch.empty(N, 4, device=dev)
+        L.check(L.lib().gc_project_gaussians_bwd(
+            L.i64(N), L.ptr(m), L.ptr(s), L.f32(glob), L.ptr(q), V, P, L.f32(fx), L.f32(fy), L.f32(cx), L.f32(cy),
+            L.i32(H), L.i32(W), L.ptr(radii), L.ptr(conics), L.ptr(v_xy), L.ptr(v_dep), L.ptr(v_con), L.ptr(vm),
+            L.ptr(vs), L.ptr(vq), L.stream_ptr()), "gc_project_gaussians_bwd")
+        return (vm, vs, None, vq) + (None,) * 10
+
+
+def project_gaussians(means3d, scales, glob_scale, quats, viewmat, projmat, fx, fy, cx, cy, img_height, img_width,
+                      tile_bounds, clip_thresh=0.01):
+    """gsplat 0.1.3 signature; returns (xys, depths, radii, conics, num_tiles_hit, cov3d)."""
+    return _ProjectGaussians.apply(means3d, scales, glob_scale, quats, viewmat, projmat, fx, fy, cx, cy,
+                                   img_height, img_width, tile_bounds, clip_thresh)
+
+
+# --------------------------------------------------------------------------------------------- SH
+class _SphericalHarmonics(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, degrees_to_use, viewdirs, coeffs):
+        _need_gpu(viewdirs, coeffs)
+        N, K = coeffs.shape[0], coeffs.shape[1]
+        degree = {1: 0, 4: 1, 9: 2, 16: 3}[K]
+        d, c = _c(viewdirs), _c(coeffs)
+        out = torch.empty(N, 3, device=coeffs.device)
+        L.check(L.lib().gc_sh_fwd(L.i64(N), L.i32(degree), L.i32(degrees_to_use), L.ptr(d), L.ptr(c), L.ptr(out),
+                                  L.stream_ptr()), "gc_sh_fwd")
+        ctx.save_for_backward(d)
+        ctx.meta = (degree, int(degrees_to_use), K)
+        return out
+
+    @staticmethod
+    def backward(ctx, v_colors):
+        (d,) = ctx.saved_tensors
+        degree, n, K = ctx.meta
+        N = d.shape[0]
+        vc = _c(v_colors)
+        out = torch.empty(N, K, 3, device=d.device)
+        L.check(L.lib().gc_sh_bwd(L.i64(N), L.i32(degree), L.i32(n), L.ptr(d), L.ptr(vc), L.ptr(out), L.stream_ptr()),
+                "gc_sh_bwd")
+        return None, None, out
+
+
+def spherical_harmonics(degrees_to_use, viewdirs, coeffs):
+    """gsplat.sh.spherical_harmonics(degrees_to_use, viewdirs[N,3], coeffs[N,K,3]) -> colors[N,3]"""
+    return _SphericalHarmonics.apply(degrees_to_use, viewdirs, coeffs)
+
+
+# --------------------------------------------------------------------------------------------- binning
+def bin_and_sort_gaussians(N, xys, depths, radii, num_tiles_hit, tile_bounds):
+    """cumsum -> map -> sort -> tile bins.  Returns (M, isect_ids_sorted, gaussian_ids_sorted, tile_bins)."""
+    lib = L.lib()
+    dev = xys.device
+    st = L.stream_ptr()
+    T = tile_bounds[0] * tile_bounds[1]
+    cum = torch.empty(N, dtype=torch.int32, device=dev)
+    cnt = torch.empty(1, dtype=torch.int32, device=dev)
+    ws_bytes = lib.gc_raster_scan_workspace_bytes(L.i64(N))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    L.check(lib.gc_raster_scan_tiles(L.i64(N), L.ptr(num_tiles_hit), L.ptr(cum), L.ptr(cnt), L.ptr(ws),
+                                     L.C.c_size_t(ws_bytes), st), "gc_raster_scan_tiles")
+    m_host = L.C.c_int32(0)
+    L.check(lib.gc_raster_read_count(L.ptr(cnt), L.C.byref(m_host), st), "gc_raster_read_count")
+    M = int(m_host.value)
+    bins = torch.empty(T, 2, dtype=torch.int32, device=dev)
+    keys = torch.empty(M, dtype=torch.int64, device=dev); ids = torch.empty(M, dtype=torch.int32, device=dev)
+    keys_s = torch.empty(M, dtype=torch.int64, device=dev); ids_s = torch.empty(M, dtype=torch.int32, device=dev)
+    if M > 0:
+        L.check(lib.gc_raster_map_intersects(L.i64(N), L.i64(M), L.ptr(xys), L.ptr(depths), L.ptr(radii), L.ptr(cum),
+                                             L.i32(tile_bounds[0]), L.i32(tile_bounds[1]), L.ptr(keys), L.ptr(ids), st),
+                "gc_raster_map_intersects")
+        sb = lib.gc_raster_sort_workspace_bytes(L.i64(M), L.i32(T))
+        sws = torch.empty(max(int(sb), 1), dtype=torch.uint8, device=dev)
+        L.check(lib.gc_raster_sort_intersects(L.i64(M), L.i32(T), L.ptr(keys), L.ptr(ids), L.ptr(keys_s), L.ptr(ids_s),
+                                              L.ptr(sws), L.C.c_size_t(int(sb)), st), "gc_raster_sort_intersects")
+    L.check(lib.gc_raster_tile_bins(L.i64(M), L.i32(T), L.ptr(keys_s), L.ptr(bins), st), "gc_raster_tile_bins")
+    return M, keys_s, ids_s, bins, cum
+
+
+def _rasterize_fwd(H, W, tb, ids_s, bins, xys, conics, colors, opac, extra, background):
+    dev = xys.device
+    out = torch.empty(H, W, 3, device=dev)
+    out_e = torch.empty(H, W, device=dev) if extra is not None else None
+    fT = torch.empty(H, W, device=dev)
+    fi = torch.empty(H, W, dtype=torch.int32, device=dev)
+    L.check(L.lib().gc_rasterize_fwd(L.i32(H), L.i32(W), L.i32(tb[0]), L.i32(tb[1]), L.ptr(ids_s), L.ptr(bins),
+                                     L.ptr(xys), L.ptr(conics), L.ptr(colors), L.ptr(opac), L.ptr(extra),
+                                     L.ptr(background), L.ptr(out), L.ptr(out_e), L.ptr(fT), L.ptr(fi), L.stream_ptr()),
+            "gc_rasterize_fwd")
+    return out, out_e, fT, fi
+
+
+def _rasterize_bwd(H, W, tb, N, ids_s, bins, xys, conics, colors, opac, background, fT, fi, v_out, v_alpha):
+    dev = xys.device
+    v_xy = torch.zeros(N, 2, device=dev); v_conic = torch.zeros(N, 3, device=dev)
+    v_col = torch.zeros(N, 3, device=dev); v_op = torch.zeros(N, device=dev)
+    L.check(L.lib().gc_rasterize_bwd(L.i32(H), L.i32(W), L.i32(tb[0]), L.i32(tb[1]), L.i64(N), L.ptr(ids_s), L.ptr(bins),
+                                     L.ptr(xys), L.ptr(conics), L.ptr(colors), L.ptr(opac), L.ptr(background), L.ptr(fT),
+                                     L.ptr(fi), L.ptr(v_out), L.ptr(v_alpha), L.ptr(v_xy), L.ptr(v_conic), L.ptr(v_col),
+                                     L.ptr(v_op), L.stream_ptr()), "gc_rasterize_bwd")
+    return v_xy, v_conic, v_col, v_op
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xys, depths, radii, conics, num_tiles_hit, colors, opacity, H, W, background, return_alpha):
+        _need_gpu(xys, colors)
+        if colors.dim() != 2 or colors.shape[1] != 3:
+            raise ValueError("rasterize_gaussians: colors must be [N,3] (the reference only uses 3 channels)")
+        N = xys.shape[0]
+        dev = xys.device
+        tb = ((W + TILE - 1) // TILE, (H + TILE - 1) // TILE, 1)
+        x, d, r, c, nth = _c(xys), _c(depths), _c(radii, torch.int32), _c(conics), _c(num_tiles_hit, torch.int32)
+        col, op = _c(colors), _c(opacity).reshape(-1)
+        bg = _c(background) if background is not None else torch.ones(3, device=dev)
+        M, keys_s, ids_s, bins, _ = bin_and_sort_gaussians(N, x, d, r, nth, tb)
+        out, _, fT, fi = _rasterize_fwd(H, W, tb, ids_s, bins, x, c, col, op, None, bg)
+        ctx.save_for_backward(ids_s, bins, x, c, col, op, bg, fT, fi)
+        ctx.meta = (H, W, tb, N)
+        if return_alpha:
+            return out, 1 - fT
+        return out
+
+    @staticmethod
+    def backward(ctx, v_out, v_alpha=None):
+        ids_s, bins, x, c, col, op, bg, fT, fi = ctx.saved_tensors
+        H, W, tb, N = ctx.meta
+        vo = _c(v_out)
+        va = _c(v_alpha) if v_alpha is not None else None
+        v_xy, v_conic, v_col, v_op = _rasterize_bwd(H, W, tb, N, ids_s, bins, x, c, col, op, bg, fT, fi, vo, va)
+        return v_xy, None, None, v_conic, None, v_col, v_op[:, None], None, None, None, None
+
+
+def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height, img_width,
+                        background=None, return_alpha=False):
+    """gsplat 0.1.3 signature; out_img[H,W,3] (, out_alpha[H,W])."""
+    return _RasterizeGaussians.apply(xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height, img_width,
+                                     background, return_alpha)
+
+
+# --------------------------------------------------------------------------------------------- fused path
+class RenderAux:
+    """Side outputs of render_view (non-differentiable state the model keeps, gc_model.py:140,159-160)."""
+    xys = None
+    radii = None
+    num_tiles_hit = None
+    xys_grad = None
+    M = 0
+    gaussian_ids_sorted = None
+    tile_bins = None
+    final_index = None
+    isect_ids_sorted = None
+
+
+class _RenderView(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, log_scales, quats, opacities, features_dc, features_rest, cam, background, want_depth,
+                sh_degree_to_use, aux):
+        _need_gpu(means)
+        lib = L.lib()
+        st = L.stream_ptr()
+        N = means.shape[0]
+        dev = means.device
+        H, W = cam["H"], cam["W"]
+        tb = ((W + TILE - 1) // TILE, (H + TILE - 1) // TILE, 1)
+        K = features_rest.shape[1] + 1
+        sh_degree = {1: 0, 4: 1, 9: 2, 16: 3}[K]
+        m, ls, q = _c(means), _c(log_scales), _c(quats)
+        op, dc, rest = _c(opacities).reshape(-1), _c(features_dc), _c(features_rest)
+        V, P, O = L.host_floats(cam["viewmat"]), L.host_floats(cam["fullproj"]), L.host_floats(cam["origin"])
+        xys = torch.empty(N, 2, device=dev); depths = torch.empty(N, device=dev)
+        radii = torch.empty(N, dtype=torch.int32, device=dev); conics = torch.empty(N, 3, device=dev)
+        nth = torch.empty(N, dtype=torch.int32, device=dev)
+        rgbs = torch.empty(N, 3, device=dev); opac = torch.empty(N, device=dev)
+        L.check(lib.gc_project_sh_fwd(
+            L.i64(N), L.ptr(m), L.ptr(ls), L.ptr(q), L.ptr(op), L.ptr(dc), L.ptr(rest), L.i32(sh_degree),
+            L.i32(sh_degree_to_use), V, P, O, L.f32(cam["fx"]), L.f32(cam["fy"]), L.f32(cam["cx"]), L.f32(cam["cy"]),
+            L.i32(H), L.i32(W), L.i32(tb[0]), L.i32(tb[1]), L.f32(0.01), L.ptr(xys), L.ptr(depths), L.ptr(radii),
+            L.ptr(conics), L.ptr(nth), L.ptr(rgbs), L.ptr(opac), st), "gc_project_sh_fwd")
+        M, keys_s, ids_s, bins, _ = bin_and_sort_gaussians(N, xys, depths, radii, nth, tb)
+        bg = _c(background)
+        extra = depths if want_depth else None
+        img, dep, fT, fi = _rasterize_fwd(H, W, tb, ids_s, bins, xys, conics, rgbs, opac, extra, bg)
+        alpha = torch.empty(H, W, device=dev)
+        pre_clamp = img.clone() if any(ctx.needs_input_grad[:6]) else None
+        L.check(lib.gc_raster_finalize(L.i64(H * W), L.ptr(img), L.ptr(dep), L.ptr(fT), L.ptr(alpha), st),
+                "gc_raster_finalize")
+        if aux is not None:
+            aux.xys, aux.radii, aux.num_tiles_hit, aux.M = xys, radii, nth, M
+            aux.gaussian_ids_sorted, aux.tile_bins, aux.final_index, aux.isect_ids_sorted = ids_s, bins, fi, keys_s
+            aux.xys_grad = None
+        ctx.save_for_backward(m, ls, q, op, dc, rest, radii, conics, xys, rgbs, opac, ids_s, bins, bg, fT, fi, pre_clamp)
+        ctx.meta = (cam, tb, N, sh_degree, int(sh_degree_to_use), V, P, O)
+        ctx.aux = aux
+        ctx.mark_non_differentiable(*( [dep] if dep is not None else []))
+        if dep is None:
+            dep = torch.empty(0, device=dev)
+        return img, alpha, dep
+
+    @staticmethod
+    def backward(ctx, v_img, v_alpha, v_dep):
+        (m, ls, q, op, dc, rest, radii, conics, xys, rgbs, opac, ids_s, bins, bg, fT, fi, pre_clamp) = ctx.saved_tensors
+        cam, tb, N, sh_degree, n_use, V, P, O = ctx.meta
+        H, W = cam["H"], cam["W"]
+        dev = m.device
+        vo = _c(v_img) if v_img is not None else torch.zeros(H, W, 3, device=dev)
+        vo = vo * (pre_clamp <= 1.0)                       # clamp(max=1) backward, gc_model.py:188
+        va = _c(v_alpha) if v_alpha is not None else None
+        v_xy, v_conic, v_col, v_op = _rasterize_bwd(H, W, tb, N, ids_s, bins, xys, conics, rgbs, opac, bg, fT, fi, vo, va)
+        if ctx.aux is not None:
+            ctx.aux.xys_grad = v_xy
+        vm = torch.empty(N, 3, device=dev); vls = torch.empty(N, 3, device=dev); vq = torch.empty(N, 4, device=dev)
+        vop = torch.empty(N, device=dev); vdc = torch.empty(N, 3, device=dev)
+        vrest = torch.empty(rest.shape, device=dev)
+        L.check(L.lib().gc_project_sh_bwd(
+            L.i64(N), L.ptr(m), L.ptr(ls), L.ptr(q), L.ptr(op), L.ptr(dc), L.ptr(rest), L.i32(sh_degree), L.i32(n_use),
+            V, P, O, L.f32(cam["fx"]), L.f32(cam["fy"]), L.f32(cam["cx"]), L.f32(cam["cy"]), L.i32(H), L.i32(W),
+            L.ptr(radii), L.ptr(conics), L.ptr(v_xy), L.ptr(v_conic), L.ptr(v_col), L.ptr(v_op), L.ptr(vm), L.ptr(vls),
+            L.ptr(vq), L.ptr(vop), L.ptr(vdc), L.ptr(vrest), L.stream_ptr()), "gc_project_sh_bwd")
+        return vm, vls, vq, vop[:, None], vdc, vrest, None, None, None, None, None
+
+
+def render_view(means, log_scales, quats, opacities, features_dc, features_rest, cam: dict, background, want_depth: bool,
+                sh_degree_to_use: int = 3, aux: RenderAux | None = None):
+    """Fused get_outputs core.  cam: dict(viewmat[12], fullproj[16], origin[3], fx, fy, cx, cy, H, W) of HOST floats.
+    Returns (rgb[H,W,3] clamped to <=1, alpha[H,W], depth[H,W] (normalised, 1000 where alpha==0) or empty)."""
+    return _RenderView.apply(means, log_scales, quats, opacities, features_dc, features_rest, cam, background, want_depth,
+                             sh_degree_to_use, aux)

@@ -1,0 +1,152 @@
+/*
+ * gaussctrl_hip.h -- C ABI of libgaussctrl_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the hot path of GaussCtrl's multi-view edit loop.  Every entry point takes
+ * plain device pointers + sizes + a hipStream_t (as void*); no torch types cross this boundary.
+ *
+ * Conventions (all entry points):
+ *   - returns 0 on success, a negative GC_E* code otherwise; never throws, never exits; text of
+ *     the last error of the calling thread: gc_last_error_string().
+ *   - the caller owns every buffer (including workspaces); the library allocates nothing, frees
+ *     nothing and keeps no pointer after return.  Launches go only to `stream`; no hidden
+ *     device-wide synchronisation (gc_raster_read_count is the single documented blocking call).
+ *   - re-entrant: all state is in the arguments.
+ *   - all float tensors are contiguous float32 unless a name says bf16.
+ *
+ * Each block cites the reference interface it replaces (paths under /root/reference/).
+ */
+#ifndef GAUSSCTRL_HIP_H
+#define GAUSSCTRL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GC_OK 0
+#define GC_EINVAL (-1)   /* bad argument */
+#define GC_ELAUNCH (-2)  /* HIP launch / runtime error */
+#define GC_ENOSPC (-3)   /* workspace or capacity too small */
+
+const char *gc_last_error_string(void);
+int gc_abi_version(void);
+
+/* ===================================================================================== */
+/* Part A -- 3D-Gaussian rasterizer (replaces gsplat 0.1.3 as called by gaussctrl/gc_model.py) */
+/* ===================================================================================== */
+
+/* gsplat.project_gaussians forward -- call site gaussctrl/gc_model.py:140-154.
+ * means3d[N,3] scales[N,3] quats[N,4](wxyz); viewmat[>=12] (row-major 3x4), projmat[16] (row-major,
+ * full projection P*V) and cam_origin[3] are HOST pointers (28+3 floats travel as kernel arguments) -> cov3d[N,6] xys[N,2] depths[N] radii[N]i32 conics[N,3] num_tiles_hit[N]i32.
+ * Culled Gaussians get radii = num_tiles_hit = 0 and zeroed float outputs. */
+int gc_project_gaussians_fwd(int64_t N, const float *means3d, const float *scales, float glob_scale,
+                             const float *quats, const float *viewmat, const float *projmat,
+                             float fx, float fy, float cx, float cy, int img_h, int img_w,
+                             int tiles_x, int tiles_y, float clip_thresh,
+                             float *cov3d, float *xys, float *depths, int32_t *radii, float *conics,
+                             int32_t *num_tiles_hit, void *stream);
+
+/* autograd backward of the above (fired by gaussctrl/gc_trainer.py:275).
+ * v_xy[N,2] v_depth[N](may be NULL) v_conic[N,3] -> v_mean3d[N,3] v_scale[N,3] v_quat[N,4]. */
+int gc_project_gaussians_bwd(int64_t N, const float *means3d, const float *scales, float glob_scale,
+                             const float *quats, const float *viewmat, const float *projmat,
+                             float fx, float fy, float cx, float cy, int img_h, int img_w,
+                             const int32_t *radii, const float *conics,
+                             const float *v_xy, const float *v_depth, const float *v_conic,
+                             float *v_mean3d, float *v_scale, float *v_quat, void *stream);
+
+/* gsplat.sh.spherical_harmonics forward/backward -- call site gaussctrl/gc_model.py:166.
+ * coeffs[N,K,3], K=(degree+1)^2 stored bases, only the first (degrees_to_use+1)^2 are used. */
+int gc_sh_fwd(int64_t N, int degree, int degrees_to_use, const float *viewdirs, const float *coeffs,
+              float *colors, void *stream);
+int gc_sh_bwd(int64_t N, int degree, int degrees_to_use, const float *viewdirs, const float *v_colors,
+              float *v_coeffs, void *stream);
+
+/* Tile binning (inside gsplat.rasterize_gaussians: cumsum -> map_gaussian_to_intersects -> sort ->
+ * get_tile_bin_edges; call sites gaussctrl/gc_model.py:174-186,191-202).
+ *
+ * gc_raster_scan_tiles: cum_tiles_hit[N] = inclusive scan of num_tiles_hit; *count_dev (device
+ * int32[1]) = M = total intersections.  workspace >= gc_raster_scan_workspace_bytes(N). */
+size_t gc_raster_scan_workspace_bytes(int64_t N);
+int gc_raster_scan_tiles(int64_t N, const int32_t *num_tiles_hit, int32_t *cum_tiles_hit,
+                         int32_t *count_dev, void *workspace, size_t workspace_bytes, void *stream);
+/* blocking 4-byte read-back of a device counter on `stream` (the one host sync the reference also
+ * has: `.item()` on the cumsum total). */
+int gc_raster_read_count(const int32_t *count_dev, int32_t *count_host, void *stream);
+
+/* isect_ids[M_cap] (int64: tile_id<<32 | depth bits), gaussian_ids[M_cap]; entries in [M, M_cap)
+ * are padded with key = tiles<<32 (sorts last).  Writes past M_cap are dropped (GC_ENOSPC is not
+ * detectable without a sync; compare *count_dev with M_cap after the frame). */
+int gc_raster_map_intersects(int64_t N, int64_t M_cap, const float *xys, const float *depths,
+                             const int32_t *radii, const int32_t *cum_tiles_hit, int tiles_x, int tiles_y,
+                             int64_t *isect_ids, int32_t *gaussian_ids, void *stream);
+
+/* sync-free variant: fill [*count_dev, M_cap) with the padding key tiles<<32 so a fixed-size sort
+ * over M_cap entries leaves the real intersections first. */
+int gc_raster_pad_intersects(int64_t M_cap, const int32_t *count_dev, int num_tiles, int64_t *isect_ids,
+                             int32_t *gaussian_ids, void *stream);
+
+/* stable sort of (isect_ids, gaussian_ids) by key over M entries; ties keep emission order
+ * (= ascending Gaussian id).  workspace >= gc_raster_sort_workspace_bytes(M, tiles). */
+size_t gc_raster_sort_workspace_bytes(int64_t M, int num_tiles);
+int gc_raster_sort_intersects(int64_t M, int num_tiles, const int64_t *isect_ids, const int32_t *gaussian_ids,
+                              int64_t *isect_ids_sorted, int32_t *gaussian_ids_sorted,
+                              void *workspace, size_t workspace_bytes, void *stream);
+
+/* tile_bins[T,2] = [start,end) of each tile in the sorted list (zeros for empty tiles). */
+int gc_raster_tile_bins(int64_t M, int num_tiles, const int64_t *isect_ids_sorted, int32_t *tile_bins,
+                        void *stream);
+
+/* gsplat.rasterize_gaussians forward: RGB (+ optional extra channel, used for the reference's
+ * second "depth" pass gc_model.py:191-202, composited in the same sweep) + final_Ts + final_index.
+ * colors[N,3], opacities[N], extra[N] or NULL, background[3] (device) ->
+ * out_img[H,W,3], out_extra[H,W] or NULL, final_Ts[H,W], final_index[H,W]. */
+int gc_rasterize_fwd(int img_h, int img_w, int tiles_x, int tiles_y,
+                     const int32_t *gaussian_ids_sorted, const int32_t *tile_bins,
+                     const float *xys, const float *conics, const float *colors, const float *opacities,
+                     const float *extra, const float *background,
+                     float *out_img, float *out_extra, float *final_Ts, int32_t *final_index, void *stream);
+
+/* backward of the compositing.  v_out[H,W,3], v_out_alpha[H,W] or NULL.  The four gradient
+ * buffers must be zero-filled by the caller (results are accumulated atomically). */
+int gc_rasterize_bwd(int img_h, int img_w, int tiles_x, int tiles_y, int64_t N,
+                     const int32_t *gaussian_ids_sorted, const int32_t *tile_bins,
+                     const float *xys, const float *conics, const float *colors, const float *opacities,
+                     const float *background, const float *final_Ts, const int32_t *final_index,
+                     const float *v_out, const float *v_out_alpha,
+                     float *v_xy, float *v_conic, float *v_colors, float *v_opacity, void *stream);
+
+/* Fused per-Gaussian front end of GaussCtrlModel.get_outputs (gaussctrl/gc_model.py:138-169,181):
+ * exp(scales), quat normalisation, projection, view directions, SH(+0.5, clamp min 0), sigmoid(opacity)
+ * in ONE pass over the 59-float parameter record.
+ * means[N,3] log_scales[N,3] quats[N,4] opacity_logits[N] features_dc[N,3] features_rest[N,K-1,3]
+ * cam_origin[3] (host floats) -> xys depths radii conics num_tiles_hit rgbs[N,3] opac[N]. */
+int gc_project_sh_fwd(int64_t N, const float *means, const float *log_scales, const float *quats,
+                      const float *opacity_logits, const float *features_dc, const float *features_rest,
+                      int sh_degree, int degrees_to_use, const float *viewmat, const float *projmat,
+                      const float *cam_origin, float fx, float fy, float cx, float cy, int img_h, int img_w,
+                      int tiles_x, int tiles_y, float clip_thresh,
+                      float *xys, float *depths, int32_t *radii, float *conics, int32_t *num_tiles_hit,
+                      float *rgbs, float *opac, void *stream);
+
+/* Fused backward: v_xy,v_conic,v_rgbs,v_opac -> gradients of the six leaf tensors. */
+int gc_project_sh_bwd(int64_t N, const float *means, const float *log_scales, const float *quats,
+                      const float *opacity_logits, const float *features_dc, const float *features_rest,
+                      int sh_degree, int degrees_to_use, const float *viewmat, const float *projmat,
+                      const float *cam_origin, float fx, float fy, float cx, float cy, int img_h, int img_w,
+                      const int32_t *radii, const float *conics,
+                      const float *v_xy, const float *v_conic, const float *v_rgbs, const float *v_opac,
+                      float *v_means, float *v_log_scales, float *v_quats, float *v_opacity_logits,
+                      float *v_features_dc, float *v_features_rest, void *stream);
+
+/* Epilogue of get_outputs (gc_model.py:188,197-204): rgb=min(rgb,1); alpha=1-final_T;
+ * depth = alpha>0 ? depth/alpha : 1000.  In place on out_img / out_extra; writes alpha[H,W]. */
+int gc_raster_finalize(int64_t num_pixels, float *out_img, float *out_extra, const float *final_Ts,
+                       float *alpha, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAUSSCTRL_HIP_H */
