@@ -112,7 +112,8 @@ __device__ __forceinline__ bool project_one(const Cam &cam, float p0, float p1, 
     float det = a * d - b * b;
     if (det == 0.f) return false;
     float inv_det = 1.f / det;
-    float con0 = d * inv_det, con1 = -b * inv_det, con2 = a * inv_det;
+    // written before the tile-box cull, like gsplat / the oracle (unobservable for culled splats)
+    o.conic[0] = d * inv_det; o.conic[1] = -b * inv_det; o.conic[2] = a * inv_det;
     float mid = 0.5f * (a + d);
     float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
     float v1 = mid + disc, v2 = mid - disc;
@@ -130,7 +131,6 @@ __device__ __forceinline__ bool project_one(const Cam &cam, float p0, float p1, 
     if (area <= 0) return false;
     o.tiles_hit = area; o.depth = tz; o.radius = (int)radius;
     o.xy[0] = px; o.xy[1] = py;
-    o.conic[0] = con0; o.conic[1] = con1; o.conic[2] = con2;
     return true;
 }
 
