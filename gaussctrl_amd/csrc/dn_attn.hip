@@ -1,0 +1,259 @@
+// dn_attn.hip -- fused multi-KV-set flash attention for GaussCtrl's cross-view attention (gfx950).
+//
+// Replaces the unfused baddbmm + softmax + bmm chain of the reference's attention processor,
+// /root/reference/gaussctrl/utils.py:25-37 (compute_attn) and :86-117 (CrossViewAttnProcessor.__call__):
+//     O = a * softmax(Q K_self^T s) V_self + (1 - a)/4 * sum_{r<4} softmax(Q K_ref_r^T s) V_ref_r
+// where K_ref_r / V_ref_r are frame r of the SAME CFG half broadcast over all frames of that half.
+// The reference materialises five [2f*8, L, L] probability tensors per layer; here one Q tile visits up to
+// five K/V sets, each with its own online softmax, and the weighted combination happens in registers.
+// With one set of weight 1 it is ordinary attention (text cross-attention utils.py:111-117, the DDIM
+// inversion path gc_pipeline.py:136-137).
+//
+// CDNA4 mapping (wave64, v_mfma_f32_16x16x32): both GEMMs are issued "transposed" --
+//     S^T[key][q] = K Q^T       (A operand = K rows from LDS, B operand = Q rows kept in VGPRs)
+//     O^T[d][q]  += V^T P^T     (A operand = V^T rows from LDS, B operand = P straight from the S registers)
+// so a lane owns ONE query row (q = lane & 15): softmax statistics, the online rescale and the final
+// 1/l are lane-local, P never leaves registers (the k-slot order of an MFMA is free as long as A and B
+// agree), and the output store is 8 contiguous bytes per accumulator.  V arrives already transposed
+// ([B][C][L], written by the projection GEMM's epilogue) so no transpose happens here.
+#include "dn_common.h"
+
+namespace {
+using namespace dn;
+
+struct AttnArgs {
+    const unsigned short *Q; int64_t ldq, q_bs;      // [B][Lq][ldq]
+    const unsigned short *K; int64_t ldk, k_bs;      // [Bk][Lk][ldk]
+    const unsigned short *Vt; int64_t ldvt, vt_bs;   // [Bk][H*D][ldvt]  (token-contiguous)
+    const unsigned short *Kr; int64_t kr_bs;         // reference-frame bank (may alias K): [halves*ref_fph][Lk][ldk]
+    const unsigned short *Vtr; int64_t vtr_bs;
+    int ref_fph;                                     // frames per CFG half inside the reference bank
+    unsigned short *O; int64_t ldo, o_bs;            // [B][Lq][ldo]
+    int Lq, Lk, H, f;
+    int nsets; int set_kind[5]; float set_w[5];      // kind -1: own frame; -2: frame b / f (shared text K/V); r >= 0: reference r of the half
+    float scale_log2e;
+};
+
+template <class T, int D, int QT>
+__global__ __launch_bounds__(256) void k_attn(const AttnArgs a)
+{
+    constexpr int DP = (D + 31) / 32 * 32;      // contraction length of QK^T, padded to the MFMA k = 32
+    constexpr int DV = (D + 15) / 16 * 16;      // output rows of O^T, padded to the MFMA m = 16
+    constexpr int KS = DP / 32, DT = DV / 16;
+    constexpr int KROW = (DP + 8) * 2;          // bytes per key row of the K tile (+16 B pad)
+    constexpr int VROW = (64 + 8) * 2;          // bytes per channel row of the V^T tile
+    __shared__ __attribute__((aligned(16))) unsigned char sK[64 * KROW];
+    __shared__ __attribute__((aligned(16))) unsigned char sV[DV * VROW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int fr = lane & 15, g = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q_wave0 = (blockIdx.x * 4 + wid) * (QT * 16);
+
+    // zero the LDS once: pad columns / pad rows are never written again
+    for (int i = tid; i < (int)(sizeof(sK) / 16); i += 256) reinterpret_cast<uint4 *>(sK)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < (int)(sizeof(sV) / 16); i += 256) reinterpret_cast<uint4 *>(sV)[i] = make_uint4(0, 0, 0, 0);
+
+    // Q fragments (B operand): lane holds Q[q = fr][d = 32*ks + 8*g .. +8]
+    uint4 qf[QT][KS];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int q = q_wave0 + qt * 16 + fr;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d = ks * 32 + g * 8;
+            qf[qt][ks] = (q < a.Lq && d + 8 <= D)
+                             ? *reinterpret_cast<const uint4 *>(a.Q + (int64_t)b * a.q_bs + (int64_t)q * a.ldq + h * D + d)
+                             : make_uint4(0, 0, 0, 0);
+        }
+    }
+
+    f32x4 otot[DT][QT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) otot[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ntiles = (a.Lk + 63) / 64;
+    const int lk8 = (a.Lk + 7) / 8 * 8;
+    for (int s = 0; s < a.nsets; ++s) {
+        const int kind = a.set_kind[s];
+        const unsigned short *Kb, *Vb;
+        if (kind >= 0) {
+            const int kvb = (b / a.f) * a.ref_fph + kind;
+            Kb = a.Kr + (int64_t)kvb * a.kr_bs + h * D;
+            Vb = a.Vtr + (int64_t)kvb * a.vtr_bs + (int64_t)h * D * a.ldvt;
+        } else {
+            const int kvb = kind == -1 ? b : b / a.f;
+            Kb = a.K + (int64_t)kvb * a.k_bs + h * D;
+            Vb = a.Vt + (int64_t)kvb * a.vt_bs + (int64_t)h * D * a.ldvt;
+        }
+        f32x4 os[DT][QT];
+        float mrow[QT], lrow[QT];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            mrow[qt] = -1e30f; lrow[qt] = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) os[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        for (int tile = 0; tile < ntiles; ++tile) {
+            const int key0 = tile * 64;
+            __syncthreads();   // previous tile fully consumed (also orders the initial zero fill)
+            for (int c = tid; c < 64 * (D / 8); c += 256) {
+                const int r = c / (D / 8), cc = c - r * (D / 8);
+                const int key = key0 + r;
+                const uint4 v = key < a.Lk ? *reinterpret_cast<const uint4 *>(Kb + (int64_t)key * a.ldk + cc * 8) : make_uint4(0, 0, 0, 0);
+                *reinterpret_cast<uint4 *>(sK + r * KROW + cc * 16) = v;
+            }
+            for (int c = tid; c < D * 8; c += 256) {
+                const int r = c >> 3, cc = c & 7;
+                const int key = key0 + cc * 8;
+                const uint4 v = key < lk8 ? *reinterpret_cast<const uint4 *>(Vb + (int64_t)r * a.ldvt + key) : make_uint4(0, 0, 0, 0);
+                *reinterpret_cast<uint4 *>(sV + r * VROW + cc * 16) = v;
+            }
+            __syncthreads();
+
+            // ---- S^T = K Q^T : st[kt][qt][reg] = S[q = fr][key = key0 + 16*kt + 4*g + reg]
+            f32x4 st[4][QT];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) st[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    const uint4 kf = *reinterpret_cast<const uint4 *>(sK + (kt * 16 + fr) * KROW + (ks * 32 + g * 8) * 2);
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) st[kt][qt] = T::mfma(kf, qf[qt][ks], st[kt][qt]);
+                }
+            // ---- online softmax per query row (lane-local + 2 cross-lane steps over g)
+            uint4 pf[QT][2];
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                float tmax = -1e30f;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = key0 + kt * 16 + g * 4 + r;
+                        const float v = key < a.Lk ? st[kt][qt][r] * a.scale_log2e : -1e30f;
+                        st[kt][qt][r] = v;
+                        tmax = fmaxf(tmax, v);
+                    }
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                const float mnew = fmaxf(mrow[qt], tmax);
+                const float alpha = exp2f(mrow[qt] - mnew);
+                mrow[qt] = mnew;
+                float psum = 0.f;
+                float p[4][4];
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = exp2f(st[kt][qt][r] - mnew);
+                        p[kt][r] = e;
+                        psum += e;
+                    }
+                lrow[qt] = lrow[qt] * alpha + psum;     // per-lane partial; reduced over g at the end of the set
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) os[dt][qt][r] *= alpha;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+                    pf[qt][kb] = make_uint4(pack2<T>(p[2 * kb][0], p[2 * kb][1]), pack2<T>(p[2 * kb][2], p[2 * kb][3]),
+                                            pack2<T>(p[2 * kb + 1][0], p[2 * kb + 1][1]), pack2<T>(p[2 * kb + 1][2], p[2 * kb + 1][3]));
+            }
+            // ---- O^T += V^T P^T
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    const unsigned char *vr = sV + (dt * 16 + fr) * VROW;
+                    const uint2 lo = *reinterpret_cast<const uint2 *>(vr + ((2 * kb) * 16 + g * 4) * 2);
+                    const uint2 hi = *reinterpret_cast<const uint2 *>(vr + ((2 * kb + 1) * 16 + g * 4) * 2);
+                    const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) os[dt][qt] = T::mfma(vf, pf[qt][kb], os[dt][qt]);
+                }
+        }
+        // ---- fold this set into the weighted total
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            float l = lrow[qt];
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+            const float inv = a.set_w[s] / l;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) otot[dt][qt][r] += os[dt][qt][r] * inv;
+        }
+    }
+    // ---- store: lane owns O[q = fr][d = 16*dt + 4*g .. +4]
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int q = q_wave0 + qt * 16 + fr;
+        if (q >= a.Lq) continue;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d = dt * 16 + g * 4;
+            if (d + 4 > D) continue;
+            *reinterpret_cast<uint2 *>(a.O + (int64_t)b * a.o_bs + (int64_t)q * a.ldo + h * D + d) =
+                make_uint2(pack2<T>(otot[dt][qt][0], otot[dt][qt][1]), pack2<T>(otot[dt][qt][2], otot[dt][qt][3]));
+        }
+    }
+}
+
+template <class T>
+int launch_attn(const AttnArgs &a, int D, int B, hipStream_t s)
+{
+#define GC_ATT(DD, QQ)                                                                                  \
+    do {                                                                                                \
+        dim3 grid((unsigned)((a.Lq + 64 * QQ - 1) / (64 * QQ)), (unsigned)a.H, (unsigned)B);            \
+        hipLaunchKernelGGL((k_attn<T, DD, QQ>), grid, dim3(256), 0, s, a);                              \
+    } while (0)
+    switch (D) {
+    case 8: GC_ATT(8, 2); break;
+    case 16: GC_ATT(16, 2); break;
+    case 32: GC_ATT(32, 2); break;
+    case 40: GC_ATT(40, 2); break;
+    case 64: GC_ATT(64, 2); break;
+    case 80: GC_ATT(80, 2); break;
+    case 160: GC_ATT(160, 1); break;
+    default: gc::set_error("gc_dn_attention: unsupported head dim %d", D); return GC_EINVAL;
+    }
+#undef GC_ATT
+    return GC_OK;
+}
+
+}  // namespace
+
+extern "C" int gc_dn_attention(const gc_attn_desc *d, void *stream)
+{
+    GC_REQUIRE(d && d->Q && d->K && d->Vt && d->O, "null operand");
+    GC_REQUIRE(d->nsets >= 1 && d->nsets <= 5, "1..5 K/V sets");
+    GC_REQUIRE(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldvt % 8 == 0 && d->ldo % 4 == 0 && d->head_dim % 8 == 0,
+               "leading dimensions must keep 16-byte alignment");
+    GC_REQUIRE(d->ldvt >= (d->Lk + 7) / 8 * 8, "Vt rows must hold round_up(Lk, 8) tokens (zero padded)");
+    AttnArgs a;
+    a.Q = (const unsigned short *)d->Q; a.ldq = d->ldq; a.q_bs = d->q_batch_stride;
+    a.K = (const unsigned short *)d->K; a.ldk = d->ldk; a.k_bs = d->k_batch_stride;
+    a.Vt = (const unsigned short *)d->Vt; a.ldvt = d->ldvt; a.vt_bs = d->vt_batch_stride;
+    a.O = (unsigned short *)d->O; a.ldo = d->ldo; a.o_bs = d->o_batch_stride;
+    a.Lq = d->Lq; a.Lk = d->Lk; a.H = d->heads; a.f = d->frames_per_half > 0 ? d->frames_per_half : 1;
+    a.nsets = d->nsets;
+    for (int i = 0; i < 5; ++i) { a.set_kind[i] = d->set_kind[i]; a.set_w[i] = d->set_weight[i]; }
+    a.Kr = d->Kref ? (const unsigned short *)d->Kref : a.K; a.kr_bs = d->Kref ? d->kref_batch_stride : a.k_bs;
+    a.Vtr = d->Vtref ? (const unsigned short *)d->Vtref : a.Vt; a.vtr_bs = d->Vtref ? d->vtref_batch_stride : a.vt_bs;
+    a.ref_fph = d->Kref ? d->ref_frames_per_half : a.f;
+    GC_REQUIRE((d->Kref == nullptr) == (d->Vtref == nullptr), "Kref and Vtref must be given together");
+    for (int i = 0; i < d->nsets; ++i) GC_REQUIRE(d->set_kind[i] >= -2 && d->set_kind[i] < a.ref_fph, "bad set_kind");
+    a.scale_log2e = d->scale * 1.4426950408889634f;
+    int rc = d->dtype == DT_BF16 ? launch_attn<BF16>(a, d->head_dim, d->batch, gc::S(stream))
+             : d->dtype == DT_F16 ? launch_attn<F16>(a, d->head_dim, d->batch, gc::S(stream)) : GC_EINVAL;
+    if (rc != GC_OK) return rc;
+    return gc::check_launch("gc_dn_attention");
+}

@@ -1,0 +1,75 @@
+// dn_common.h -- element types and small device helpers shared by the denoise kernels (gfx950).
+#pragma once
+#include "common.h"
+
+namespace dn {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// dtype codes of the C ABI
+enum { DT_BF16 = 0, DT_F16 = 1 };
+
+struct BF16 {
+    using elem = __bf16;
+    using vec8 = bf16x8;
+    static __device__ __forceinline__ f32x4 mfma(uint4 a, uint4 b, f32x4 c)
+    {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float to_f(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
+    static __device__ __forceinline__ unsigned short from_f(float f)
+    {
+        __bf16 h = (__bf16)f;
+        return __builtin_bit_cast(unsigned short, h);
+    }
+};
+
+struct F16 {
+    using elem = _Float16;
+    using vec8 = f16x8;
+    static __device__ __forceinline__ f32x4 mfma(uint4 a, uint4 b, f32x4 c)
+    {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float to_f(unsigned short u) { return (float)__builtin_bit_cast(_Float16, u); }
+    static __device__ __forceinline__ unsigned short from_f(float f)
+    {
+        _Float16 h = (_Float16)f;
+        return __builtin_bit_cast(unsigned short, h);
+    }
+};
+
+template <class T>
+__device__ __forceinline__ unsigned pack2(float a, float b)
+{
+    return (unsigned)T::from_f(a) | ((unsigned)T::from_f(b) << 16);
+}
+
+template <class T>
+__device__ __forceinline__ void unpack8(uint4 v, float *f)
+{
+    f[0] = T::to_f((unsigned short)(v.x & 0xffff)); f[1] = T::to_f((unsigned short)(v.x >> 16));
+    f[2] = T::to_f((unsigned short)(v.y & 0xffff)); f[3] = T::to_f((unsigned short)(v.y >> 16));
+    f[4] = T::to_f((unsigned short)(v.z & 0xffff)); f[5] = T::to_f((unsigned short)(v.z >> 16));
+    f[6] = T::to_f((unsigned short)(v.w & 0xffff)); f[7] = T::to_f((unsigned short)(v.w >> 16));
+}
+
+template <class T>
+__device__ __forceinline__ uint4 pack8(const float *f)
+{
+    return make_uint4(pack2<T>(f[0], f[1]), pack2<T>(f[2], f[3]), pack2<T>(f[4], f[5]), pack2<T>(f[6], f[7]));
+}
+
+__device__ __forceinline__ float silu(float x) { return x / (1.f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float wave_sum_f(float v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+}  // namespace dn

@@ -1,0 +1,340 @@
+// dn_norm.hip -- HBM-bound normalisation / elementwise kernels of the SD1.5 UNet / ControlNet / VAE on
+// NHWC ("tokens x channels") bf16/f16 tensors (gfx950).  Replaces torch.nn.GroupNorm / LayerNorm / SiLU /
+// cat / add and the scheduler + CFG arithmetic diffusers runs for
+// /root/reference/gaussctrl/gc_pipeline.py:142-145,209-219.
+//
+// All kernels move 16 bytes per lane per access, statistics in fp32.
+#include "dn_common.h"
+
+namespace {
+using namespace dn;
+
+// ------------------------------------------------------------------------------------------ GroupNorm
+// stats[b][g] = {sum(x - shift), sum((x - shift)^2)} with shift = x[b, pixel 0, first channel of g]
+// (shifted single pass: no catastrophic cancellation when |mean| >> std).
+template <class T>
+__global__ __launch_bounds__(256) void k_gn_stats(const unsigned short *__restrict__ x, int64_t HW, int C, int G,
+                                                  int nchb, int pix_per_block, float *__restrict__ stats)
+{
+    extern __shared__ float sg[];   // [2*G]
+    const int b = blockIdx.z, cpg = C / G;
+    const int lanes = 256 / nchb;                       // pixel lanes per block
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 2 * G; i += 256) sg[i] = 0.f;
+    __syncthreads();
+    const int cch = tid % nchb, pl = tid / nchb;
+    const int c0 = (blockIdx.y * nchb + cch) * 8;
+    const unsigned short *xb = x + (int64_t)b * HW * C;
+    if (pl < lanes) {
+        float sh[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sh[j] = T::to_f(xb[((c0 + j) / cpg) * cpg]);
+        float s1[8], s2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+        const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+        const int64_t p1 = min(p0 + pix_per_block, HW);
+        for (int64_t p = p0 + pl; p < p1; p += lanes) {
+            float f[8];
+            unpack8<T>(*reinterpret_cast<const uint4 *>(xb + p * C + c0), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = f[j] - sh[j]; s1[j] += d; s2[j] += d * d; }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int gi = (c0 + j) / cpg;
+            atomicAdd(&sg[2 * gi], s1[j]);
+            atomicAdd(&sg[2 * gi + 1], s2[j]);
+        }
+    }
+    __syncthreads();
+    // only the groups this y-slice touches are non-zero
+    const int g_lo = (blockIdx.y * nchb * 8) / cpg, g_hi = min(G - 1, ((blockIdx.y + 1) * nchb * 8 - 1) / cpg);
+    for (int i = 2 * g_lo + tid; i <= 2 * g_hi + 1; i += 256) unsafeAtomicAdd(&stats[(int64_t)b * 2 * G + i], sg[i]);
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void k_gn_apply(const unsigned short *__restrict__ x, unsigned short *__restrict__ y,
+                                                  int64_t HW, int C, int G, const float *__restrict__ stats,
+                                                  const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                  float eps, int act, int64_t total_chunks)
+{
+    const int cpg = C / G, nch = C / 8;
+    const float inv_n = 1.f / ((float)HW * (float)cpg);
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total_chunks; q += (int64_t)gridDim.x * 256) {
+        const int64_t pix = q / nch;
+        const int c0 = (int)(q - pix * nch) * 8;
+        const int64_t b = pix / HW;
+        const unsigned short *xb = x + b * HW * C;
+        float f[8];
+        unpack8<T>(*reinterpret_cast<const uint4 *>(x + pix * C + c0), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c0 + j, gi = c / cpg;
+            const float sh = T::to_f(xb[gi * cpg]);
+            const float m1 = stats[(b * G + gi) * 2] * inv_n, m2 = stats[(b * G + gi) * 2 + 1] * inv_n;
+            const float mean = sh + m1, var = fmaxf(m2 - m1 * m1, 0.f);
+            float v = (f[j] - mean) * rsqrtf(var + eps) * gamma[c] + beta[c];
+            if (act) v = silu(v);
+            f[j] = v;
+        }
+        *reinterpret_cast<uint4 *>(y + pix * C + c0) = pack8<T>(f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ LayerNorm
+// one wave64 per token row; exact two-pass in registers (C <= 64*8*4).
+template <class T>
+__global__ __launch_bounds__(256) void k_layernorm(const unsigned short *__restrict__ x, unsigned short *__restrict__ y,
+                                                   int64_t M, int C, const float *__restrict__ gamma,
+                                                   const float *__restrict__ beta, float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nch = C / 8;
+    float f[4][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+            unpack8<T>(*reinterpret_cast<const uint4 *>(x + row * C + ch * 8), f[i]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += f[i][j];
+        }
+    }
+    const float mean = wave_sum_f(s) / (float)C;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (lane + 64 * i < nch) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = f[i][j] - mean; v += d * d; }
+        }
+    const float rstd = rsqrtf(wave_sum_f(v) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (f[i][j] - mean) * rstd * gamma[ch * 8 + j] + beta[ch * 8 + j];
+            *reinterpret_cast<uint4 *>(y + row * C + ch * 8) = pack8<T>(o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ elementwise
+// out[M, C1+C2] = [a[M,C1] | b[M,C2] (+ c[M,C2])]   (skip concat of the up blocks, with the ControlNet
+// residual add of `down_block_res_samples` folded in)
+template <class T>
+__global__ __launch_bounds__(256) void k_concat_add(const unsigned short *__restrict__ a, int C1,
+                                                    const unsigned short *__restrict__ b, const unsigned short *__restrict__ c,
+                                                    int C2, unsigned short *__restrict__ out, int64_t total_chunks)
+{
+    const int nch = (C1 + C2) / 8, n1 = C1 / 8;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total_chunks; q += (int64_t)gridDim.x * 256) {
+        const int64_t m = q / nch;
+        const int ch = (int)(q - m * nch);
+        uint4 v;
+        if (ch < n1) v = *reinterpret_cast<const uint4 *>(a + m * C1 + ch * 8);
+        else {
+            v = *reinterpret_cast<const uint4 *>(b + m * C2 + (ch - n1) * 8);
+            if (c) {
+                float fb[8], fc[8];
+                unpack8<T>(v, fb);
+                unpack8<T>(*reinterpret_cast<const uint4 *>(c + m * C2 + (ch - n1) * 8), fc);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) fb[j] += fc[j];
+                v = pack8<T>(fb);
+            }
+        }
+        *reinterpret_cast<uint4 *>(out + m * (int64_t)(C1 + C2) + ch * 8) = v;
+    }
+}
+
+// out = a*sa + b*sb (b may be null); act: 0 none, 1 silu
+template <class T>
+__global__ __launch_bounds__(256) void k_axpby(const unsigned short *__restrict__ a, float sa, const unsigned short *__restrict__ b,
+                                               float sb, int act, unsigned short *__restrict__ out, int64_t total_chunks)
+{
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total_chunks; q += (int64_t)gridDim.x * 256) {
+        float fa[8], fb[8];
+        unpack8<T>(*reinterpret_cast<const uint4 *>(a + q * 8), fa);
+        if (b) unpack8<T>(*reinterpret_cast<const uint4 *>(b + q * 8), fb);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = fa[j] * sa + (b ? fb[j] * sb : 0.f);
+            fa[j] = act ? silu(v) : v;
+        }
+        *reinterpret_cast<uint4 *>(out + q * 8) = pack8<T>(fa);
+    }
+}
+
+// fp32 -> T with optional silu (time-embedding vectors)
+template <class T>
+__global__ __launch_bounds__(256) void k_cast_f32(const float *__restrict__ a, int act, unsigned short *__restrict__ out, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float v = a[i];
+        out[i] = T::from_f(act ? silu(v) : v);
+    }
+}
+
+// row softmax in place over [M, N] T (VAE mid-block attention scores), one workgroup per row
+template <class T>
+__global__ __launch_bounds__(256) void k_softmax_rows(unsigned short *__restrict__ s, int64_t N, int64_t ld, float scale)
+{
+    __shared__ float red[4];
+    unsigned short *row = s + (int64_t)blockIdx.x * ld;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    float mx = -1e30f;
+    for (int64_t i = tid; i < N; i += 256) mx = fmaxf(mx, T::to_f(row[i]) * scale);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+    if (lane == 0) red[wid] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int64_t i = tid; i < N; i += 256) sum += __expf(T::to_f(row[i]) * scale - mx);
+    sum = wave_sum_f(sum);
+    if (lane == 0) red[wid] = sum;
+    __syncthreads();
+    const float inv = 1.f / (red[0] + red[1] + red[2] + red[3]);
+    for (int64_t i = tid; i < N; i += 256) row[i] = T::from_f(__expf(T::to_f(row[i]) * scale - mx) * inv);
+}
+
+// CFG combine + DDIM step fused with the re-packing of the next UNet input:
+//   eps = eps_u + gs*(eps_c - eps_u); x0 = (x - sqrt(1-a_t) eps)/sqrt(a_t); x' = sqrt(a_p) x0 + sqrt(1-a_p) eps
+// eps: fp32 [2f or f][HW][ldE] (conv_out, channels padded to ldE); lat: fp32 master [f][HW][4];
+// xin: T [nrep*f][HW][8] (channels 4..7 stay zero) -- the `cat([latents]*2)` of the pipeline.
+template <class T>
+__global__ __launch_bounds__(256) void k_cfg_ddim(const float *__restrict__ eps, int ldE, int64_t f, int64_t HW, float gs,
+                                                  int cfg, float c_x, float c_e, float *__restrict__ lat,
+                                                  unsigned short *__restrict__ xin, int nrep)
+{
+    const int64_t n = f * HW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float4 eu = *reinterpret_cast<const float4 *>(eps + i * ldE);
+        float4 e = eu;
+        if (cfg) {
+            const float4 ec = *reinterpret_cast<const float4 *>(eps + (n + i) * ldE);
+            e = make_float4(eu.x + gs * (ec.x - eu.x), eu.y + gs * (ec.y - eu.y), eu.z + gs * (ec.z - eu.z), eu.w + gs * (ec.w - eu.w));
+        }
+        float4 x = *reinterpret_cast<float4 *>(lat + i * 4);
+        // x' = c_x * x + c_e * eps  with c_x = sqrt(a_p/a_t), c_e = sqrt(1-a_p) - sqrt(a_p (1-a_t)/a_t)
+        x = make_float4(c_x * x.x + c_e * e.x, c_x * x.y + c_e * e.y, c_x * x.z + c_e * e.z, c_x * x.w + c_e * e.w);
+        *reinterpret_cast<float4 *>(lat + i * 4) = x;
+        const uint4 p = make_uint4(pack2<T>(x.x, x.y), pack2<T>(x.z, x.w), 0u, 0u);
+        for (int r = 0; r < nrep; ++r) *reinterpret_cast<uint4 *>(xin + (r * n + i) * 8) = p;
+    }
+}
+
+inline unsigned ew_grid(int64_t items) { return (unsigned)std::min<int64_t>((items + 255) / 256, 256 * 8); }
+
+}  // namespace
+
+#define DN_DISPATCH(dtype, CALL_BF16, CALL_F16)                 \
+    do {                                                       \
+        if ((dtype) == DT_BF16) { CALL_BF16; }                 \
+        else if ((dtype) == DT_F16) { CALL_F16; }              \
+        else { gc::set_error("%s: bad dtype", __func__); return GC_EINVAL; } \
+    } while (0)
+
+extern "C" {
+
+int gc_dn_groupnorm(int dtype, const void *x, void *y, int64_t B, int64_t HW, int C, int G, const float *gamma,
+                    const float *beta, float eps, int act, float *stats_ws, void *stream)
+{
+    GC_REQUIRE(C % 8 == 0 && C % G == 0 && stats_ws, "groupnorm: C must be a multiple of 8 and of G");
+    hipStream_t s = gc::S(stream);
+    if (hipMemsetAsync(stats_ws, 0, sizeof(float) * 2 * G * B, s) != hipSuccess) return GC_ELAUNCH;
+    const int nch = C / 8;
+    int ny = 1;
+    while (nch % ny != 0 || nch / ny > 256) ++ny;
+    const int nchb = nch / ny;
+    const int lanes = 256 / nchb;
+    int ppb = 64;                                         // pixels per block: enough blocks to fill the chip
+    while (ppb > lanes && (HW + ppb - 1) / ppb * ny * B < 1024) ppb >>= 1;
+    if (ppb < lanes) ppb = lanes;
+    dim3 grid((unsigned)((HW + ppb - 1) / ppb), ny, (unsigned)B);
+    const size_t lds = sizeof(float) * 2 * G;
+    DN_DISPATCH(dtype,
+                hipLaunchKernelGGL((k_gn_stats<BF16>), grid, dim3(256), lds, s, (const unsigned short *)x, HW, C, G, nchb, ppb, stats_ws),
+                hipLaunchKernelGGL((k_gn_stats<F16>), grid, dim3(256), lds, s, (const unsigned short *)x, HW, C, G, nchb, ppb, stats_ws));
+    const int64_t chunks = B * HW * nch;
+    DN_DISPATCH(dtype,
+                hipLaunchKernelGGL((k_gn_apply<BF16>), dim3(ew_grid(chunks)), dim3(256), 0, s, (const unsigned short *)x,
+                                   (unsigned short *)y, HW, C, G, stats_ws, gamma, beta, eps, act, chunks),
+                hipLaunchKernelGGL((k_gn_apply<F16>), dim3(ew_grid(chunks)), dim3(256), 0, s, (const unsigned short *)x,
+                                   (unsigned short *)y, HW, C, G, stats_ws, gamma, beta, eps, act, chunks));
+    return gc::check_launch("gc_dn_groupnorm");
+}
+
+int gc_dn_layernorm(int dtype, const void *x, void *y, int64_t M, int C, const float *gamma, const float *beta,
+                    float eps, void *stream)
+{
+    GC_REQUIRE(C % 8 == 0 && C <= 2048, "layernorm: C must be a multiple of 8 and <= 2048");
+    dim3 grid((unsigned)((M + 3) / 4));
+    DN_DISPATCH(dtype,
+                hipLaunchKernelGGL((k_layernorm<BF16>), grid, dim3(256), 0, gc::S(stream), (const unsigned short *)x, (unsigned short *)y, M, C, gamma, beta, eps),
+                hipLaunchKernelGGL((k_layernorm<F16>), grid, dim3(256), 0, gc::S(stream), (const unsigned short *)x, (unsigned short *)y, M, C, gamma, beta, eps));
+    return gc::check_launch("gc_dn_layernorm");
+}
+
+int gc_dn_concat_add(int dtype, const void *a, int C1, const void *b, const void *c, int C2, void *out, int64_t M, void *stream)
+{
+    GC_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0, "concat: channel counts must be multiples of 8");
+    const int64_t chunks = M * ((C1 + C2) / 8);
+    DN_DISPATCH(dtype,
+                hipLaunchKernelGGL((k_concat_add<BF16>), dim3(ew_grid(chunks)), dim3(256), 0, gc::S(stream), (const unsigned short *)a, C1,
+                                   (const unsigned short *)b, (const unsigned short *)c, C2, (unsigned short *)out, chunks),
+                hipLaunchKernelGGL((k_concat_add<F16>), dim3(ew_grid(chunks)), dim3(256), 0, gc::S(stream), (const unsigned short *)a, C1,
+                                   (const unsigned short *)b, (const unsigned short *)c, C2, (unsigned short *)out, chunks));
+    return gc::check_launch("gc_dn_concat_add");
+}
+
+int gc_dn_axpby(int dtype, const void *a, float sa, const void *b, float sb, int act, void *out, int64_t n, void *stream)
+{
+    GC_REQUIRE(n % 8 == 0, "axpby: element count must be a multiple of 8");
+    const int64_t chunks = n / 8;
+    DN_DISPATCH(dtype,
+                hipLaunchKernelGGL((k_axpby<BF16>), dim3(ew_grid(chunks)), dim3(256), 0, gc::S(stream), (const unsigned short *)a, sa,
+                                   (const unsigned short *)b, sb, act, (unsigned short *)out, chunks),
+                hipLaunchKernelGGL((k_axpby<F16>), dim3(ew_grid(chunks)), dim3(256), 0, gc::S(stream), (const unsigned short *)a, sa,
+                                   (const unsigned short *)b, sb, act, (unsigned short *)out, chunks));
+    return gc::check_launch("gc_dn_axpby");
+}
+
+int gc_dn_cast_f32(int dtype, const float *a, int act, void *out, int64_t n, void *stream)
+{
+    DN_DISPATCH(dtype,
+                hipLaunchKernelGGL((k_cast_f32<BF16>), dim3(ew_grid(n)), dim3(256), 0, gc::S(stream), a, act, (unsigned short *)out, n),
+                hipLaunchKernelGGL((k_cast_f32<F16>), dim3(ew_grid(n)), dim3(256), 0, gc::S(stream), a, act, (unsigned short *)out, n));
+    return gc::check_launch("gc_dn_cast_f32");
+}
+
+int gc_dn_softmax_rows(int dtype, void *s, int64_t M, int64_t N, int64_t ld, float scale, void *stream)
+{
+    DN_DISPATCH(dtype,
+                hipLaunchKernelGGL((k_softmax_rows<BF16>), dim3((unsigned)M), dim3(256), 0, gc::S(stream), (unsigned short *)s, N, ld, scale),
+                hipLaunchKernelGGL((k_softmax_rows<F16>), dim3((unsigned)M), dim3(256), 0, gc::S(stream), (unsigned short *)s, N, ld, scale));
+    return gc::check_launch("gc_dn_softmax_rows");
+}
+
+int gc_dn_cfg_ddim_step(int dtype, const float *eps, int ld_eps, int64_t frames, int64_t HW, float guidance, int cfg,
+                        float alpha_t, float alpha_prev, float *latents, void *xin, int nrep, void *stream)
+{
+    GC_REQUIRE(ld_eps >= 4 && ld_eps % 4 == 0 && alpha_t > 0.f, "cfg_ddim: bad arguments");
+    const float c_x = sqrtf(alpha_prev / alpha_t);
+    const float c_e = sqrtf(1.f - alpha_prev) - sqrtf(alpha_prev * (1.f - alpha_t) / alpha_t);
+    const int64_t n = frames * HW;
+    DN_DISPATCH(dtype,
+                hipLaunchKernelGGL((k_cfg_ddim<BF16>), dim3(ew_grid(n)), dim3(256), 0, gc::S(stream), eps, ld_eps, frames, HW, guidance, cfg, c_x, c_e, latents, (unsigned short *)xin, nrep),
+                hipLaunchKernelGGL((k_cfg_ddim<F16>), dim3(ew_grid(n)), dim3(256), 0, gc::S(stream), eps, ld_eps, frames, HW, guidance, cfg, c_x, c_e, latents, (unsigned short *)xin, nrep));
+    return gc::check_launch("gc_dn_cfg_ddim_step");
+}
+
+}  // extern "C"

@@ -1,0 +1,210 @@
+"""Thin ctypes wrappers over the Part-B entry points of include/gaussctrl_hip.h.
+
+Tensors are torch GPU tensors used only as device memory (2-byte activations in channels-last
+"tokens x channels" layout, fp32 parameters for norms / biases); every arithmetic op is a hand-written HIP
+kernel behind the C ABI.  No CPU / eager fallback exists.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from .. import _lib as L
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("mode", C.c_int), ("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64),
+                ("A", C.c_void_p), ("lda", C.c_int64),
+                ("B", C.c_int), ("Hi", C.c_int), ("Wi", C.c_int), ("Cin", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int),
+                ("stride", C.c_int), ("upsample", C.c_int),
+                ("W", C.c_void_p), ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("ld_rowvec", C.c_int64),
+                ("rows_per_batch", C.c_int64), ("residual", C.c_void_p), ("ldr", C.c_int64), ("out_scale", C.c_float),
+                ("act", C.c_int), ("geglu", C.c_int), ("out", C.c_void_p), ("ldc", C.c_int64), ("out_f32", C.c_int),
+                ("out_t", C.c_void_p), ("ldt", C.c_int64), ("t_batch_stride", C.c_int64)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("batch", C.c_int), ("heads", C.c_int), ("head_dim", C.c_int), ("Lq", C.c_int),
+                ("Lk", C.c_int), ("frames_per_half", C.c_int), ("nsets", C.c_int), ("set_kind", C.c_int * 5),
+                ("set_weight", C.c_float * 5), ("scale", C.c_float),
+                ("Q", C.c_void_p), ("ldq", C.c_int64), ("q_batch_stride", C.c_int64),
+                ("K", C.c_void_p), ("ldk", C.c_int64), ("k_batch_stride", C.c_int64),
+                ("Vt", C.c_void_p), ("ldvt", C.c_int64), ("vt_batch_stride", C.c_int64),
+                ("O", C.c_void_p), ("ldo", C.c_int64), ("o_batch_stride", C.c_int64),
+                ("Kref", C.c_void_p), ("kref_batch_stride", C.c_int64), ("Vtref", C.c_void_p),
+                ("vtref_batch_stride", C.c_int64), ("ref_frames_per_half", C.c_int)]
+
+
+DT = {torch.bfloat16: 0, torch.float16: 1}
+
+
+def _dt(t):
+    try:
+        return DT[t.dtype]
+    except KeyError:
+        raise L.GaussCtrlHipError(f"denoise kernels take bf16 / f16 activations, got {t.dtype}")
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.GaussCtrlHipError("denoise ops need GPU tensors (HIP path only; no CPU fallback)")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def linear(x, w, bias=None, residual=None, act=0, geglu=False, out_f32=False, scale=1.0, rowvec=None, rows_per_batch=0,
+           ld_rowvec=None, out=None, want_out=True, out_t=None, ldt=0, t_batch_stride=0):
+    """x [..., K] (last dim contiguous, rows strided by x.stride(-2)) @ w[N,K]^T with fused epilogue."""
+    _gpu(x, w)
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = w.shape[0]
+    lda = x.stride(-2) if x.dim() > 1 else K
+    d = GemmDesc()
+    d.dtype = _dt(x); d.mode = 0; d.M, d.N, d.K = M, N, K
+    d.A = x.data_ptr(); d.lda = lda; d.W = w.data_ptr()
+    d.bias = None if bias is None else bias.data_ptr()
+    if rowvec is not None:
+        d.rowvec = rowvec.data_ptr(); d.ld_rowvec = rowvec.stride(0) if ld_rowvec is None else ld_rowvec
+    d.rows_per_batch = rows_per_batch
+    No = N // 2 if geglu else N
+    if residual is not None:
+        d.residual = residual.data_ptr(); d.ldr = residual.stride(-2)
+    d.out_scale = scale; d.act = act; d.geglu = int(geglu)
+    if want_out:
+        if out is None:
+            out = torch.empty(x.shape[:-1] + (No,), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+        d.out = out.data_ptr(); d.ldc = out.stride(-2); d.out_f32 = int(out_f32)
+    if out_t is not None:
+        d.out_t = out_t.data_ptr(); d.ldt = ldt; d.t_batch_stride = t_batch_stride
+    L.check(L.lib().gc_dn_gemm(C.byref(d), _stream()), "gc_dn_gemm")
+    return out
+
+
+def conv3x3(x, w, bias=None, stride=1, upsample=False, rowvec=None, ld_rowvec=None, residual=None, act=0, scale=1.0,
+            out_f32=False):
+    """x [B,H,W,Cin] NHWC, w [N, 9*Cin] ((tap, cin) order), pad 1."""
+    _gpu(x, w)
+    B, H, W_, Cin = x.shape
+    Hin, Win = (2 * H, 2 * W_) if upsample else (H, W_)
+    Ho, Wo = (Hin + 2 - 3) // stride + 1, (Win + 2 - 3) // stride + 1
+    N = w.shape[0]
+    out = torch.empty(B, Ho, Wo, N, dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    d = GemmDesc()
+    d.dtype = _dt(x); d.mode = 1; d.M, d.N, d.K = B * Ho * Wo, N, 9 * Cin
+    d.A = x.data_ptr(); d.lda = Cin
+    d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.stride, d.upsample = B, H, W_, Cin, Ho, Wo, stride, int(upsample)
+    d.W = w.data_ptr(); d.bias = None if bias is None else bias.data_ptr()
+    if rowvec is not None:
+        d.rowvec = rowvec.data_ptr(); d.ld_rowvec = rowvec.stride(0) if ld_rowvec is None else ld_rowvec
+    d.rows_per_batch = Ho * Wo
+    if residual is not None:
+        d.residual = residual.data_ptr(); d.ldr = N
+    d.out_scale = scale; d.act = act
+    d.out = out.data_ptr(); d.ldc = N; d.out_f32 = int(out_f32)
+    L.check(L.lib().gc_dn_gemm(C.byref(d), _stream()), "gc_dn_gemm(conv3x3)")
+    return out
+
+
+_gn_ws = {}
+
+
+def groupnorm(x, gamma, beta, groups, eps, silu):
+    """x [B,H,W,C] (or [B,HW,C])"""
+    _gpu(x)
+    B, Cc = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * Cc)
+    key = (x.device, B, groups)
+    ws = _gn_ws.get(key)
+    if ws is None:
+        ws = _gn_ws[key] = torch.empty(2 * groups * B, dtype=torch.float32, device=x.device)
+    y = torch.empty_like(x)
+    L.check(L.lib().gc_dn_groupnorm(_dt(x), _p(x), _p(y), C.c_int64(B), C.c_int64(HW), Cc, groups, _p(gamma), _p(beta),
+                                    C.c_float(eps), int(silu), _p(ws), _stream()), "gc_dn_groupnorm")
+    return y
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    _gpu(x)
+    Cc = x.shape[-1]
+    y = torch.empty_like(x)
+    L.check(L.lib().gc_dn_layernorm(_dt(x), _p(x), _p(y), C.c_int64(x.numel() // Cc), Cc, _p(gamma), _p(beta),
+                                    C.c_float(eps), _stream()), "gc_dn_layernorm")
+    return y
+
+
+def concat_add(a, b, c=None):
+    """cat([a, b (+ c)], dim=-1) on channels-last tensors."""
+    _gpu(a, b, c)
+    C1, C2 = a.shape[-1], b.shape[-1]
+    M = a.numel() // C1
+    out = torch.empty(a.shape[:-1] + (C1 + C2,), dtype=a.dtype, device=a.device)
+    L.check(L.lib().gc_dn_concat_add(_dt(a), _p(a), C1, _p(b), _p(c), C2, _p(out), C.c_int64(M), _stream()),
+            "gc_dn_concat_add")
+    return out
+
+
+def axpby(a, sa=1.0, b=None, sb=1.0, act=0):
+    _gpu(a, b)
+    out = torch.empty_like(a)
+    L.check(L.lib().gc_dn_axpby(_dt(a), _p(a), C.c_float(sa), _p(b), C.c_float(sb), act, _p(out), C.c_int64(a.numel()),
+                                _stream()), "gc_dn_axpby")
+    return out
+
+
+def cast_f32(a, dtype, silu=False):
+    _gpu(a)
+    out = torch.empty(a.shape, dtype=dtype, device=a.device)
+    L.check(L.lib().gc_dn_cast_f32(DT[dtype], _p(a), int(silu), _p(out), C.c_int64(a.numel()), _stream()), "gc_dn_cast_f32")
+    return out
+
+
+def softmax_rows_(s, scale):
+    _gpu(s)
+    N = s.shape[-1]
+    L.check(L.lib().gc_dn_softmax_rows(_dt(s), _p(s), C.c_int64(s.numel() // N), C.c_int64(N), C.c_int64(s.stride(-2)),
+                                       C.c_float(scale), _stream()), "gc_dn_softmax_rows")
+    return s
+
+
+def attention(q, k, vt, heads, sets, frames_per_half, Lk=None, kref=None, vtref=None, ref_fph=0, scale=None):
+    """q [B,Lq,C], k [Bk,Lk,C], vt [Bk,C,Lkp] (token-contiguous, zero padded).  sets: [(kind, weight)]:
+    kind -1 = own frame, -2 = frame b // frames_per_half, r >= 0 = reference r (bank = kref/vtref or k/vt)."""
+    _gpu(q, k, vt)
+    B, Lq, Cc = q.shape
+    D = Cc // heads
+    Lk = k.shape[1] if Lk is None else Lk
+    o = torch.empty(B, Lq, Cc, dtype=q.dtype, device=q.device)
+    d = AttnDesc()
+    d.dtype = _dt(q); d.batch, d.heads, d.head_dim, d.Lq, d.Lk = B, heads, D, Lq, Lk
+    d.frames_per_half = frames_per_half; d.nsets = len(sets)
+    for i, (kind, w) in enumerate(sets):
+        d.set_kind[i] = kind; d.set_weight[i] = w
+    d.scale = (D ** -0.5) if scale is None else scale
+    d.Q = q.data_ptr(); d.ldq = q.stride(1); d.q_batch_stride = q.stride(0)
+    d.K = k.data_ptr(); d.ldk = k.stride(1); d.k_batch_stride = k.stride(0)
+    d.Vt = vt.data_ptr(); d.ldvt = vt.stride(1); d.vt_batch_stride = vt.stride(0)
+    d.O = o.data_ptr(); d.ldo = Cc; d.o_batch_stride = Lq * Cc
+    if kref is not None:
+        d.Kref = kref.data_ptr(); d.kref_batch_stride = kref.stride(0)
+        d.Vtref = vtref.data_ptr(); d.vtref_batch_stride = vtref.stride(0); d.ref_frames_per_half = ref_fph
+    L.check(L.lib().gc_dn_attention(C.byref(d), _stream()), "gc_dn_attention")
+    return o
+
+
+def cfg_ddim_step(eps, latents, xin, guidance, cfg, alpha_t, alpha_prev, nrep):
+    """eps fp32 [(2)f, H, W, ld]; latents fp32 [f,H,W,4] (in place); xin dtype [nrep*f,H,W,8] (rewritten)."""
+    _gpu(eps, latents, xin)
+    f = latents.shape[0]
+    HW = latents.shape[1] * latents.shape[2]
+    L.check(L.lib().gc_dn_cfg_ddim_step(_dt(xin), _p(eps), eps.shape[-1], C.c_int64(f), C.c_int64(HW), C.c_float(guidance),
+                                        int(cfg), C.c_float(alpha_t), C.c_float(alpha_prev), _p(latents), _p(xin), nrep,
+                                        _stream()), "gc_dn_cfg_ddim_step")

@@ -1,0 +1,64 @@
+"""Weight preparation: diffusers-format state dicts (fp32, NCHW conv kernels) -> the layouts the HIP
+kernels consume.  Key names follow diffusers so real SD1.5 / sd-controlnet-depth / VAE checkpoints load
+unchanged (the reference loads them at /root/reference/gaussctrl/gc_pipeline.py:97-102).
+
+  conv 3x3  [Cout,Cin,3,3] -> [Cout_p, 9*Cin_p]  (tap-major, channels-last; Cin/Cout zero-padded to multiples of 8)
+  conv 1x1  [Cout,Cin,1,1] -> [Cout, Cin]        (a Linear on channels-last tokens)
+  Linear    [out,in]       -> as is
+  GEGLU     ff.net.0.proj rows permuted in 16-blocks [x | gate] so the GEMM epilogue pairs them lane-locally
+  norms / biases stay fp32.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+def conv3x3_weight(w, dtype):
+    cout, cin = w.shape[0], w.shape[1]
+    cp, op = _pad8(cin), _pad8(cout)
+    out = torch.zeros(op, 3, 3, cp, dtype=torch.float32, device=w.device)
+    out[:cout, :, :, :cin] = w.float().permute(0, 2, 3, 1)
+    return out.reshape(op, 9 * cp).to(dtype).contiguous()
+
+
+def pad_bias(b, mult=8):
+    n = b.shape[0]
+    out = torch.zeros(_pad8(n) if mult == 8 else n, dtype=torch.float32, device=b.device)
+    out[:n] = b.float()
+    return out
+
+
+def geglu_permute(w, b):
+    """rows [x_0..x_{n-1} | g_0..g_{n-1}] -> 16-blocks [x_0..15 | g_0..15 | x_16..31 | g_16..31 ...]"""
+    n = w.shape[0] // 2
+    assert n % 16 == 0
+    idx = torch.arange(n, device=w.device).reshape(n // 16, 16)
+    perm = torch.cat([idx, idx + n], dim=1).reshape(-1)
+    return w[perm].contiguous(), (None if b is None else b[perm].contiguous())
+
+
+def prepare(sd: dict, dtype, device) -> dict:
+    """Generic pass over a diffusers state dict."""
+    out = {}
+    for k, v in sd.items():
+        v = v.to(device)
+        if k.endswith(".weight") and v.dim() == 4:
+            if v.shape[-1] == 3:
+                out[k] = conv3x3_weight(v, dtype)
+            else:
+                out[k] = v.reshape(v.shape[0], v.shape[1]).to(dtype).contiguous()
+        elif k.endswith(".weight") and v.dim() == 2:
+            out[k] = v.to(dtype).contiguous()
+        elif k.endswith(".bias") and (k[:-5] + ".weight") in sd and sd[k[:-5] + ".weight"].dim() == 4 and sd[k[:-5] + ".weight"].shape[-1] == 3:
+            out[k] = pad_bias(v)
+        else:
+            out[k] = v.float().contiguous()       # norm affine, linear / 1x1 biases
+    for k in list(out.keys()):
+        if k.endswith("ff.net.0.proj.weight"):
+            b = k[:-6] + "bias"
+            out[k], out[b] = geglu_permute(out[k], out[b])
+    return out

@@ -146,6 +146,88 @@ int gc_project_sh_bwd(int64_t N, const float *means, const float *log_scales, co
 int gc_raster_finalize(int64_t num_pixels, float *out_img, float *out_extra, const float *final_Ts,
                        float *alpha, void *stream);
 
+/* ===================================================================================== */
+/* Part B -- ControlNet + UNet denoise step (replaces the diffusers / cuBLAS / cuDNN calls behind  */
+/* gaussctrl/gc_pipeline.py:142-145,209-219 and the attention processor gaussctrl/utils.py:25-133) */
+/* ===================================================================================== */
+/* Activations are channels-last ("tokens x channels") 2-byte tensors; dtype 0 = bf16, 1 = f16;    */
+/* accumulation and statistics are fp32.                                                          */
+
+/* GEMM / implicit-GEMM 3x3 convolution with fused epilogue (torch.nn.Linear / Conv2d of the UNet,  */
+/* ControlNet and VAE).  out[m][n] = (act(acc + bias[n] + rowvec[m / rows_per_batch][n])) * out_scale */
+/*                                   + residual[m][n];  acc = sum_k Act[m][k] * W[n][k].            */
+typedef struct gc_gemm_desc {
+    int dtype;                 /* 0 bf16, 1 f16 */
+    int mode;                  /* 0: Act = A[M][lda] (Linear, 1x1 conv);  1: 3x3 conv, pad 1, on NHWC A[B][Hi][Wi][Cin] */
+    int64_t M, N, K;           /* mode 1: M = B*Ho*Wo, K = 9*Cin ordered (tap, cin) */
+    const void *A;
+    int64_t lda;
+    int B, Hi, Wi, Cin, Ho, Wo, stride, upsample;   /* upsample=1: nearest x2 of the input fused into the loader */
+    const void *W;             /* [N][K] */
+    const float *bias;         /* [N] or NULL */
+    const float *rowvec;       /* [M / rows_per_batch][ld_rowvec] or NULL (time-embedding add of ResnetBlock2D) */
+    int64_t ld_rowvec;
+    int64_t rows_per_batch;
+    const void *residual;      /* [M][ldr] or NULL */
+    int64_t ldr;
+    float out_scale;
+    int act;                   /* 0 none, 1 SiLU */
+    int geglu;                 /* 1: W rows permuted in 16-blocks [x|gate]; out[m][n/2] = x * gelu(gate), ldc = N/2 */
+    void *out;                 /* [M][ldc] (NULL to skip) */
+    int64_t ldc;
+    int out_f32;               /* 1: `out` is float32 */
+    void *out_t;               /* optional transposed copy [M / rows_per_batch][N][ldt] (V operand of gc_dn_attention) */
+    int64_t ldt;
+    int64_t t_batch_stride;
+} gc_gemm_desc;
+int gc_dn_gemm(const gc_gemm_desc *desc, void *stream);
+
+/* Fused multi-K/V-set attention = CrossViewAttnProcessor core, gaussctrl/utils.py:86-117 (+ compute_attn :25-37). */
+/* O[b] = sum_s set_weight[s] * softmax(scale * Q[b] K[kv(b,s)]^T) V[kv(b,s)],                                   */
+/* kv(b,s) = b if set_kind[s] == -1; b / frames_per_half if -2 (text K/V shared by a CFG half);                  */
+/*           reference frame r = set_kind[s] >= 0 of b's half: row (b / frames_per_half) * ref_frames_per_half + r */
+/*           of the reference bank Kref / Vtref (NULL: the bank is K / Vt itself, ref_frames_per_half =           */
+/*           frames_per_half, i.e. the references are the first frames of each half as in gc_pipeline.py:206-207). */
+typedef struct gc_attn_desc {
+    int dtype;
+    int batch, heads, head_dim;      /* head_dim in {8,16,32,40,64,80,160} */
+    int Lq, Lk;
+    int frames_per_half;             /* video_length = B // unet_chunk_size (utils.py:94) */
+    int nsets;
+    int set_kind[5];
+    float set_weight[5];
+    float scale;
+    const void *Q; int64_t ldq, q_batch_stride;     /* [B][Lq][ldq], head h at column h*head_dim */
+    const void *K; int64_t ldk, k_batch_stride;     /* [Bk][Lk][ldk] */
+    const void *Vt; int64_t ldvt, vt_batch_stride;  /* [Bk][heads*head_dim][ldvt], token-contiguous, zero padded */
+    void *O; int64_t ldo, o_batch_stride;
+    const void *Kref; int64_t kref_batch_stride;    /* optional cached reference K / V^T (same ldk / ldvt) */
+    const void *Vtref; int64_t vtref_batch_stride;
+    int ref_frames_per_half;
+} gc_attn_desc;
+int gc_dn_attention(const gc_attn_desc *desc, void *stream);
+
+/* GroupNorm(G groups, eps)(+SiLU) on [B][HW][C]; stats_ws: float[2*G*B] scratch. */
+int gc_dn_groupnorm(int dtype, const void *x, void *y, int64_t B, int64_t HW, int C, int G, const float *gamma,
+                    const float *beta, float eps, int act, float *stats_ws, void *stream);
+/* LayerNorm over C on [M][C]. */
+int gc_dn_layernorm(int dtype, const void *x, void *y, int64_t M, int C, const float *gamma, const float *beta,
+                    float eps, void *stream);
+/* out[M][C1+C2] = [a | b (+ c)] : skip concat of the up blocks with the ControlNet residual add folded in. */
+int gc_dn_concat_add(int dtype, const void *a, int C1, const void *b, const void *c, int C2, void *out, int64_t M,
+                     void *stream);
+/* out = act(a*sa + b*sb) over n elements (b may be NULL). */
+int gc_dn_axpby(int dtype, const void *a, float sa, const void *b, float sb, int act, void *out, int64_t n, void *stream);
+/* float32 -> dtype with optional SiLU (time-embedding vectors). */
+int gc_dn_cast_f32(int dtype, const float *a, int act, void *out, int64_t n, void *stream);
+/* in-place row softmax(scale * s) on [M][ld] (VAE mid-block attention). */
+int gc_dn_softmax_rows(int dtype, void *s, int64_t M, int64_t N, int64_t ld, float scale, void *stream);
+/* CFG combine + DDIM / inverse-DDIM step (eta = 0) + re-pack of the next UNet input (pipeline `cat([latents]*2)`):
+ * eps float32 [cfg ? 2f : f][HW][ld_eps], latents float32 [f][HW][4] (updated in place),
+ * xin dtype [nrep*f][HW][8].  alpha_t / alpha_prev are the two alphas_cumprod of the step. */
+int gc_dn_cfg_ddim_step(int dtype, const float *eps, int ld_eps, int64_t frames, int64_t HW, float guidance, int cfg,
+                        float alpha_t, float alpha_prev, float *latents, void *xin, int nrep, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

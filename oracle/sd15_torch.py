@@ -1,0 +1,420 @@
+"""oracle/sd15_torch.py -- TEST INFRASTRUCTURE ONLY (CPU oracle of the denoise half of the hot path).
+
+Plain PyTorch (fp32 by default) restatement of what the reference executes through
+diffusers==0.26.0 (third-party, pinned at /root/reference/requirements.txt:2, NOT under
+/root/reference and not installable here) when GaussCtrlPipeline.edit_images / render_reverse call
+`self.pipe(...)` (/root/reference/gaussctrl/gc_pipeline.py:142-145,209-219):
+
+  * UNet2DConditionModel (SD1.x config) and ControlNetModel (sd-controlnet-depth config) forward,
+    SURVEY.md Appendix B;
+  * the attention layers as the reference's CrossViewAttnProcessor computes them
+    (/root/reference/gaussctrl/utils.py:25-133) -- THIS part is pinned: tests/golden/xview_attn_*.npz
+    were produced by importing utils.py itself (tests/golden/make_xview_golden.py);
+  * DDIM / inverse-DDIM step and the pipeline's CFG arithmetic, SURVEY.md Appendix C;
+  * AutoencoderKL decoder (vae.decode inside pipe(output_type='pt')).
+
+PARITY UNPINNED for everything except the attention processor: diffusers and the SD1.5/ControlNet
+weights are unavailable, so architecture semantics follow the published configs from memory
+([recall] in SURVEY.md) with seeded random weights of the exact shapes.  State-dict keys follow the
+diffusers naming so real checkpoints can be dropped in.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+SD15 = dict(block_out_channels=(320, 640, 1280, 1280), layers_per_block=2, heads=8, cross_dim=768,
+            in_channels=4, out_channels=4, groups=32, attn_levels=(True, True, True, False),
+            cond_channels=(16, 32, 96, 256), text_len=77)
+# narrow variant with the same topology for fast CPU tests
+TINY = dict(block_out_channels=(32, 64, 128, 128), layers_per_block=2, heads=2, cross_dim=64,
+            in_channels=4, out_channels=4, groups=8, attn_levels=(True, True, True, False),
+            cond_channels=(8, 8, 16, 32), text_len=7)
+VAE_SD = dict(block_out_channels=(128, 256, 512, 512), layers_per_block=2, latent_channels=4, groups=32)
+VAE_TINY = dict(block_out_channels=(16, 32, 64, 64), layers_per_block=2, latent_channels=4, groups=8)
+
+
+# =========================================================================================== weights
+class _Init:
+    def __init__(self, seed):
+        self.g = torch.Generator().manual_seed(seed)
+        self.w = {}
+
+    def conv(self, name, cin, cout, k, zero=False, std=None):
+        fan = cin * k * k
+        bound = 1.0 / math.sqrt(fan)
+        if zero:   # "zero convs" of ControlNet, re-initialised N(0, 0.02^2) so residuals are non-trivial
+            self.w[name + ".weight"] = torch.randn(cout, cin, k, k, generator=self.g) * 0.02
+            self.w[name + ".bias"] = torch.randn(cout, generator=self.g) * 0.02
+        else:
+            self.w[name + ".weight"] = (torch.rand(cout, cin, k, k, generator=self.g) * 2 - 1) * bound
+            self.w[name + ".bias"] = (torch.rand(cout, generator=self.g) * 2 - 1) * bound
+
+    def linear(self, name, cin, cout, bias=True):
+        bound = 1.0 / math.sqrt(cin)
+        self.w[name + ".weight"] = (torch.rand(cout, cin, generator=self.g) * 2 - 1) * bound
+        if bias:
+            self.w[name + ".bias"] = (torch.rand(cout, generator=self.g) * 2 - 1) * bound
+
+    def norm(self, name, c):
+        self.w[name + ".weight"] = 1.0 + 0.1 * torch.randn(c, generator=self.g)
+        self.w[name + ".bias"] = 0.1 * torch.randn(c, generator=self.g)
+
+    def resnet(self, name, cin, cout, temb):
+        self.norm(name + ".norm1", cin); self.conv(name + ".conv1", cin, cout, 3)
+        if temb:
+            self.linear(name + ".time_emb_proj", temb, cout)
+        self.norm(name + ".norm2", cout); self.conv(name + ".conv2", cout, cout, 3)
+        if cin != cout:
+            self.conv(name + ".conv_shortcut", cin, cout, 1)
+
+    def transformer(self, name, c, cross):
+        self.norm(name + ".norm", c); self.conv(name + ".proj_in", c, c, 1)
+        t = name + ".transformer_blocks.0"
+        for n in ("norm1", "norm2", "norm3"):
+            self.norm(f"{t}.{n}", c)
+        for a, kd in (("attn1", c), ("attn2", cross)):
+            self.linear(f"{t}.{a}.to_q", c, c, bias=False); self.linear(f"{t}.{a}.to_k", kd, c, bias=False)
+            self.linear(f"{t}.{a}.to_v", kd, c, bias=False); self.linear(f"{t}.{a}.to_out.0", c, c)
+        self.linear(f"{t}.ff.net.0.proj", c, 8 * c); self.linear(f"{t}.ff.net.2", 4 * c, c)
+        self.conv(name + ".proj_out", c, c, 1)
+
+
+def _encoder_weights(I: _Init, cfg):
+    boc = cfg["block_out_channels"]; temb = 4 * boc[0]
+    I.conv("conv_in", cfg["in_channels"], boc[0], 3)
+    I.linear("time_embedding.linear_1", boc[0], temb); I.linear("time_embedding.linear_2", temb, temb)
+    cin = boc[0]
+    for i, cout in enumerate(boc):
+        for j in range(cfg["layers_per_block"]):
+            I.resnet(f"down_blocks.{i}.resnets.{j}", cin, cout, temb)
+            if cfg["attn_levels"][i]:
+                I.transformer(f"down_blocks.{i}.attentions.{j}", cout, cfg["cross_dim"])
+            cin = cout
+        if i < len(boc) - 1:
+            I.conv(f"down_blocks.{i}.downsamplers.0.conv", cout, cout, 3)
+    I.resnet("mid_block.resnets.0", boc[-1], boc[-1], temb)
+    I.transformer("mid_block.attentions.0", boc[-1], cfg["cross_dim"])
+    I.resnet("mid_block.resnets.1", boc[-1], boc[-1], temb)
+
+
+def skip_channels(cfg):
+    boc = cfg["block_out_channels"]
+    ch = [boc[0]]
+    for i, c in enumerate(boc):
+        ch += [c] * cfg["layers_per_block"]
+        if i < len(boc) - 1:
+            ch.append(c)
+    return ch
+
+
+def make_unet_weights(cfg=SD15, seed=100):
+    I = _Init(seed)
+    _encoder_weights(I, cfg)
+    boc = cfg["block_out_channels"]; temb = 4 * boc[0]
+    skips = skip_channels(cfg)
+    rev = list(reversed(boc))
+    prev = rev[0]
+    for i, cout in enumerate(rev):
+        for j in range(cfg["layers_per_block"] + 1):
+            sk = skips.pop()
+            I.resnet(f"up_blocks.{i}.resnets.{j}", prev + sk, cout, temb)
+            if list(reversed(cfg["attn_levels"]))[i]:
+                I.transformer(f"up_blocks.{i}.attentions.{j}", cout, cfg["cross_dim"])
+            prev = cout
+        if i < len(rev) - 1:
+            I.conv(f"up_blocks.{i}.upsamplers.0.conv", cout, cout, 3)
+    I.norm("conv_norm_out", boc[0]); I.conv("conv_out", boc[0], cfg["out_channels"], 3)
+    return I.w
+
+
+def make_controlnet_weights(cfg=SD15, seed=200):
+    I = _Init(seed)
+    _encoder_weights(I, cfg)
+    cc = cfg["cond_channels"]; boc = cfg["block_out_channels"]
+    I.conv("controlnet_cond_embedding.conv_in", 3, cc[0], 3)
+    k = 0
+    for i in range(len(cc) - 1):
+        I.conv(f"controlnet_cond_embedding.blocks.{k}", cc[i], cc[i], 3); k += 1
+        I.conv(f"controlnet_cond_embedding.blocks.{k}", cc[i], cc[i + 1], 3); k += 1
+    I.conv("controlnet_cond_embedding.conv_out", cc[-1], boc[0], 3, zero=True)
+    for n, c in enumerate(skip_channels(cfg)):
+        I.conv(f"controlnet_down_blocks.{n}", c, c, 1, zero=True)
+    I.conv("controlnet_mid_block", boc[-1], boc[-1], 1, zero=True)
+    return I.w
+
+
+def make_vae_decoder_weights(cfg=VAE_SD, seed=300):
+    I = _Init(seed)
+    boc = cfg["block_out_channels"]; lc = cfg["latent_channels"]
+    I.conv("post_quant_conv", lc, lc, 1)
+    I.conv("decoder.conv_in", lc, boc[-1], 3)
+    I.resnet("decoder.mid_block.resnets.0", boc[-1], boc[-1], 0)
+    a = "decoder.mid_block.attentions.0"
+    I.norm(a + ".group_norm", boc[-1])
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        I.linear(f"{a}.{n}", boc[-1], boc[-1])
+    I.resnet("decoder.mid_block.resnets.1", boc[-1], boc[-1], 0)
+    rev = list(reversed(boc)); prev = rev[0]
+    for i, cout in enumerate(rev):
+        for j in range(cfg["layers_per_block"] + 1):
+            I.resnet(f"decoder.up_blocks.{i}.resnets.{j}", prev, cout, 0); prev = cout
+        if i < len(rev) - 1:
+            I.conv(f"decoder.up_blocks.{i}.upsamplers.0.conv", cout, cout, 3)
+    I.norm("decoder.conv_norm_out", boc[0]); I.conv("decoder.conv_out", boc[0], 3, 3)
+    return I.w
+
+
+# =========================================================================================== attention
+def _heads(t, h):
+    b, l, c = t.shape
+    return t.reshape(b, l, h, c // h).permute(0, 2, 1, 3)          # [B,H,L,D]
+
+
+def plain_attention(q, k, v, heads):
+    """softmax(q k^T / sqrt(d)) v -- diffusers AttnProcessor / get_attention_scores."""
+    qh, kh, vh = _heads(q, heads), _heads(k, heads), _heads(v, heads)
+    s = (qh @ kh.transpose(-1, -2)) * (qh.shape[-1] ** -0.5)
+    o = s.softmax(-1) @ vh
+    b, h, l, d = o.shape
+    return o.permute(0, 2, 1, 3).reshape(b, l, h * d)
+
+
+def cross_view_attention(q, k, v, heads, self_attn_coeff, unet_chunk_size=2, num_refs=4):
+    """utils.py:86-117: a*self + (1-a)*mean_r attn(Q, K_ref_r, V_ref_r); the r-th reference is frame r of the
+    SAME chunk (CFG half) broadcast over the frames of that half (compute_attn, utils.py:25-37)."""
+    B = k.shape[0]
+    f = B // unet_chunk_size                                             # video_length, utils.py:94
+    out_self = plain_attention(q, k, v, heads)
+    acc = 0
+    for r in range(num_refs):                                            # exactly 4 refs are hard-wired, utils.py:95-102
+        idx = torch.arange(B) // f * f + r
+        acc = acc + plain_attention(q, k[idx], v[idx], heads)
+    return self_attn_coeff * out_self + (1 - self_attn_coeff) * (acc / num_refs)
+
+
+def attention_layer(w, p, x, ctx, heads, mode, coeff):
+    """One CrossViewAttnProcessor.__call__ (utils.py:44-133) for a [B,L,C] input; mode in {"plain","xview"}.
+    Text cross-attention (ctx given) is ordinary attention in both modes (utils.py:111-117)."""
+    q = x @ w[p + ".to_q.weight"].T
+    src = x if ctx is None else ctx
+    k = src @ w[p + ".to_k.weight"].T
+    v = src @ w[p + ".to_v.weight"].T
+    if ctx is None and mode == "xview":
+        o = cross_view_attention(q, k, v, heads, coeff)
+    else:
+        o = plain_attention(q, k, v, heads)
+    return o @ w[p + ".to_out.0.weight"].T + w[p + ".to_out.0.bias"]
+
+
+# =========================================================================================== blocks
+def timestep_embedding(t, dim):
+    """diffusers get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0)."""
+    half = dim // 2
+    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half
+    emb = t.to(torch.float32)[:, None] * torch.exp(exponent)[None, :]
+    return torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)
+
+
+def _gn(w, p, x, groups, eps):
+    return F.group_norm(x, groups, w[p + ".weight"], w[p + ".bias"], eps)
+
+
+def _conv(w, p, x, stride=1, pad=None):
+    k = w[p + ".weight"].shape[-1]
+    return F.conv2d(x, w[p + ".weight"], w[p + ".bias"], stride=stride, padding=(k // 2 if pad is None else pad))
+
+
+def resnet(w, p, x, temb, groups, eps=1e-5):
+    h = _conv(w, p + ".conv1", F.silu(_gn(w, p + ".norm1", x, groups, eps)))
+    if temb is not None:
+        h = h + (F.silu(temb) @ w[p + ".time_emb_proj.weight"].T + w[p + ".time_emb_proj.bias"])[:, :, None, None]
+    h = _conv(w, p + ".conv2", F.silu(_gn(w, p + ".norm2", h, groups, eps)))
+    if (p + ".conv_shortcut.weight") in w:
+        x = _conv(w, p + ".conv_shortcut", x)
+    return x + h
+
+
+def transformer(w, p, x, ctx, cfg, mode, coeff):
+    B, C, H, W = x.shape
+    res = x
+    h = _conv(w, p + ".proj_in", _gn(w, p + ".norm", x, cfg["groups"], 1e-6))
+    h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
+    t = p + ".transformer_blocks.0"
+    ln = lambda n, z: F.layer_norm(z, (C,), w[f"{t}.{n}.weight"], w[f"{t}.{n}.bias"], 1e-5)
+    h = attention_layer(w, t + ".attn1", ln("norm1", h), None, cfg["heads"], mode, coeff) + h
+    h = attention_layer(w, t + ".attn2", ln("norm2", h), ctx, cfg["heads"], mode, coeff) + h
+    n3 = ln("norm3", h)
+    pr = n3 @ w[t + ".ff.net.0.proj.weight"].T + w[t + ".ff.net.0.proj.bias"]
+    hid, gate = pr.chunk(2, dim=-1)
+    h = (hid * F.gelu(gate)) @ w[t + ".ff.net.2.weight"].T + w[t + ".ff.net.2.bias"] + h
+    h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
+    return _conv(w, p + ".proj_out", h) + res
+
+
+def _time_embed(w, t, B, cfg):
+    t = torch.as_tensor(t, dtype=torch.float32).reshape(-1).expand(B) if not (torch.is_tensor(t) and t.numel() == B) else t
+    e = timestep_embedding(t, cfg["block_out_channels"][0])
+    e = F.silu(e @ w["time_embedding.linear_1.weight"].T + w["time_embedding.linear_1.bias"])
+    return e @ w["time_embedding.linear_2.weight"].T + w["time_embedding.linear_2.bias"]
+
+
+def _encoder(w, x, temb, ctx, cfg, mode, coeff):
+    skips = [x]
+    boc = cfg["block_out_channels"]
+    for i in range(len(boc)):
+        for j in range(cfg["layers_per_block"]):
+            x = resnet(w, f"down_blocks.{i}.resnets.{j}", x, temb, cfg["groups"])
+            if cfg["attn_levels"][i]:
+                x = transformer(w, f"down_blocks.{i}.attentions.{j}", x, ctx, cfg, mode, coeff)
+            skips.append(x)
+        if i < len(boc) - 1:
+            x = _conv(w, f"down_blocks.{i}.downsamplers.0.conv", x, stride=2, pad=1)
+            skips.append(x)
+    x = resnet(w, "mid_block.resnets.0", x, temb, cfg["groups"])
+    x = transformer(w, "mid_block.attentions.0", x, ctx, cfg, mode, coeff)
+    x = resnet(w, "mid_block.resnets.1", x, temb, cfg["groups"])
+    return x, skips
+
+
+def controlnet_forward(w, sample, t, ctx, cond, cfg=SD15, conditioning_scale=1.0, mode="xview", coeff=0.0):
+    """ControlNetModel.forward -> (12 down residuals, mid residual).  coeff=0: gc_pipeline.py:166-168."""
+    temb = _time_embed(w, t, sample.shape[0], cfg)
+    x = _conv(w, "conv_in", sample)
+    c = F.silu(_conv(w, "controlnet_cond_embedding.conv_in", cond))
+    nblk = 2 * (len(cfg["cond_channels"]) - 1)
+    for k in range(nblk):
+        c = F.silu(_conv(w, f"controlnet_cond_embedding.blocks.{k}", c, stride=2 if k % 2 == 1 else 1, pad=1))
+    c = _conv(w, "controlnet_cond_embedding.conv_out", c)
+    x = x + c
+    x, skips = _encoder(w, x, temb, ctx, cfg, mode, coeff)
+    down = [_conv(w, f"controlnet_down_blocks.{n}", s) * conditioning_scale for n, s in enumerate(skips)]
+    mid = _conv(w, "controlnet_mid_block", x) * conditioning_scale
+    return down, mid
+
+
+def unet_forward(w, sample, t, ctx, down_res=None, mid_res=None, cfg=SD15, mode="xview", coeff=0.6):
+    """UNet2DConditionModel.forward with ControlNet residuals.  coeff=0.6: gc_pipeline.py:163-165."""
+    temb = _time_embed(w, t, sample.shape[0], cfg)
+    x = _conv(w, "conv_in", sample)
+    x, skips = _encoder(w, x, temb, ctx, cfg, mode, coeff)
+    if down_res is not None:
+        skips = [s + r for s, r in zip(skips, down_res)]
+    if mid_res is not None:
+        x = x + mid_res
+    boc = cfg["block_out_channels"]
+    rev_attn = list(reversed(cfg["attn_levels"]))
+    for i in range(len(boc)):
+        for j in range(cfg["layers_per_block"] + 1):
+            x = torch.cat([x, skips.pop()], dim=1)
+            x = resnet(w, f"up_blocks.{i}.resnets.{j}", x, temb, cfg["groups"])
+            if rev_attn[i]:
+                x = transformer(w, f"up_blocks.{i}.attentions.{j}", x, ctx, cfg, mode, coeff)
+        if i < len(boc) - 1:
+            x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+            x = _conv(w, f"up_blocks.{i}.upsamplers.0.conv", x)
+    x = F.silu(_gn(w, "conv_norm_out", x, cfg["groups"], 1e-5))
+    return _conv(w, "conv_out", x)
+
+
+def vae_decode(w, z, cfg=VAE_SD):
+    """AutoencoderKL.decode(z) (z already divided by 0.18215 by the caller) -> image in [-1,1]."""
+    g = cfg["groups"]
+    x = _conv(w, "post_quant_conv", z)
+    x = _conv(w, "decoder.conv_in", x)
+    x = resnet(w, "decoder.mid_block.resnets.0", x, None, g, 1e-6)
+    a = "decoder.mid_block.attentions.0"
+    B, C, H, W = x.shape
+    h = _gn(w, a + ".group_norm", x, g, 1e-6).reshape(B, C, H * W).transpose(1, 2)
+    q = h @ w[a + ".to_q.weight"].T + w[a + ".to_q.bias"]
+    k = h @ w[a + ".to_k.weight"].T + w[a + ".to_k.bias"]
+    v = h @ w[a + ".to_v.weight"].T + w[a + ".to_v.bias"]
+    o = plain_attention(q, k, v, 1) @ w[a + ".to_out.0.weight"].T + w[a + ".to_out.0.bias"]
+    x = x + o.transpose(1, 2).reshape(B, C, H, W)
+    x = resnet(w, "decoder.mid_block.resnets.1", x, None, g, 1e-6)
+    n = len(cfg["block_out_channels"])
+    for i in range(n):
+        for j in range(cfg["layers_per_block"] + 1):
+            x = resnet(w, f"decoder.up_blocks.{i}.resnets.{j}", x, None, g, 1e-6)
+        if i < n - 1:
+            x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+            x = _conv(w, f"decoder.up_blocks.{i}.upsamplers.0.conv", x)
+    x = F.silu(_gn(w, "decoder.conv_norm_out", x, g, 1e-6))
+    return _conv(w, "decoder.conv_out", x)
+
+
+# =========================================================================================== scheduler
+class DDIM:
+    """DDIMScheduler / DDIMInverseScheduler arithmetic for SD1.x scheduler_config:
+    scaled_linear betas 0.00085..0.012 over 1000, steps_offset 1, set_alpha_to_one False, leading spacing,
+    eta 0, epsilon prediction, no clipping."""
+
+    def __init__(self, num_train=1000):
+        betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, num_train, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.final_alpha = self.alphas_cumprod[0]
+        self.num_train = num_train
+
+    def timesteps(self, n, inverse=False):
+        ratio = self.num_train // n
+        ts = (torch.arange(0, n) * ratio).round().to(torch.int64) + 1          # leading + steps_offset 1
+        return ts if inverse else ts.flip(0)
+
+    def step(self, eps, t, x, n):
+        """x_t -> x_{t-ratio}"""
+        ratio = self.num_train // n
+        prev = int(t) - ratio
+        a_t = self.alphas_cumprod[int(t)]
+        a_p = self.alphas_cumprod[prev] if prev >= 0 else self.final_alpha
+        x0 = (x - (1 - a_t).sqrt() * eps) / a_t.sqrt()
+        return a_p.sqrt() * x0 + (1 - a_p).sqrt() * eps
+
+    def inverse_step(self, eps, t, x, n):
+        """DDIMInverseScheduler.step: alpha_prod_t at t - ratio (initial value if negative), next at t."""
+        ratio = self.num_train // n
+        prev = int(t) - ratio
+        a_t = self.alphas_cumprod[prev] if prev >= 0 else self.final_alpha   # [recall] diffusers 0.26: initial_alpha_cumprod
+        a_n = self.alphas_cumprod[int(t)]
+        x0 = (x - (1 - a_t).sqrt() * eps) / a_t.sqrt()
+        return a_n.sqrt() * x0 + (1 - a_n).sqrt() * eps
+
+
+def denoise_chunk(unet_w, cn_w, latents, disparity, ctx_neg, ctx_pos, guidance, steps, cfg=SD15, num_steps_total=None,
+                  mode="xview"):
+    """The 20-step loop inside pipe() as edit_images drives it (gc_pipeline.py:209-219):
+    latents [f,4,h,w] with the 4 reference frames FIRST, disparity [f,3,8h,8w], text [1,77,768] each.
+    `steps` = how many of the `num_steps_total` DDIM steps to run (tests run a prefix)."""
+    n = num_steps_total or steps
+    sch = DDIM()
+    f = latents.shape[0]
+    ctx = torch.cat([ctx_neg.expand(f, -1, -1), ctx_pos.expand(f, -1, -1)], 0)     # [negative || positive]
+    cond = torch.cat([disparity, disparity], 0)
+    x = latents
+    for t in sch.timesteps(n)[:steps]:
+        xin = torch.cat([x, x], 0)
+        down, mid = controlnet_forward(cn_w, xin, t, ctx, cond, cfg, 1.0, mode, 0.0)
+        eps = unet_forward(unet_w, xin, t, ctx, down, mid, cfg, mode, 0.6)
+        eu, ec = eps.chunk(2)
+        x = sch.step(eu + guidance * (ec - eu), t, x, n)
+    return x
+
+
+# =========================================================================================== glue
+def depth2disparity(depth):
+    """gc_pipeline.py:258-266: depth [1,H,W] -> disparity [1,3,H,W] = 1/(d+1e-5) / max."""
+    disp = 1 / (depth + 1e-5)
+    disp = disp / disp.max()
+    return torch.cat([disp, disp, disp], 0)[None]
+
+
+def postprocess_image(x):
+    """pipe(output_type='pt'): (x/2 + 0.5).clamp(0,1)"""
+    return (x / 2 + 0.5).clamp(0, 1)
+
+
+def mask_composite(edited, unedited_hwc, mask):
+    """gc_pipeline.py:226-234: edited [3,H,W], unedited [H,W,3], mask [H,W] -> [H,W,3] fp32."""
+    out = edited * mask[None] + unedited_hwc.permute(2, 0, 1) * (1 - mask)[None]
+    return out.permute(1, 2, 0).to(torch.float32)

@@ -1,0 +1,63 @@
+"""CPU tests pinning the denoise oracle: the cross-view attention restatement against golden vectors the
+REFERENCE's own utils.py produced (tests/golden/make_xview_golden.py), plus structural checks."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sd15_torch as sd
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "xview_attn_*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
+def test_xview_attention_matches_reference_golden(path):
+    z = np.load(path)
+    f, L, H, D, Lt, Ct = [int(v) for v in z["meta"]]
+    coeff = float(z["coeff"])
+    for kind in ("self", "text"):
+        w = {"a.to_q.weight": torch.tensor(z[f"{kind}_wq"]), "a.to_k.weight": torch.tensor(z[f"{kind}_wk"]),
+             "a.to_v.weight": torch.tensor(z[f"{kind}_wv"]), "a.to_out.0.weight": torch.tensor(z[f"{kind}_wo"]),
+             "a.to_out.0.bias": torch.tensor(z[f"{kind}_bo"])}
+        x = torch.tensor(z[f"{kind}_x"])
+        ctx = torch.tensor(z[f"{kind}_ctx"]) if kind == "text" else None
+        y = sd.attention_layer(w, "a", x, ctx, H, "xview", coeff)
+        np.testing.assert_allclose(y.numpy(), z[f"{kind}_y"], rtol=0, atol=2e-6)
+
+
+def test_golden_present():
+    assert len(GOLD) >= 4
+
+
+def test_tiny_unet_controlnet_shapes_and_ref_independence():
+    """refs attend only to refs (utils.py:94-117): the first 4 frames' outputs do not depend on the chunk frames."""
+    cfg = sd.TINY
+    torch.manual_seed(0)
+    uw, cw = sd.make_unet_weights(cfg, 1), sd.make_controlnet_weights(cfg, 2)
+    f, h = 6, 8
+    lat = torch.randn(f, 4, h, h); disp = torch.rand(f, 3, 8 * h, 8 * h)
+    cn, cp = torch.randn(1, cfg["text_len"], cfg["cross_dim"]), torch.randn(1, cfg["text_len"], cfg["cross_dim"])
+    a = sd.denoise_chunk(uw, cw, lat, disp, cn, cp, 5.0, 2, cfg, 20)
+    assert a.shape == lat.shape and torch.isfinite(a).all()
+    lat2 = lat.clone(); lat2[4:] = torch.randn(2, 4, h, h)
+    b = sd.denoise_chunk(uw, cw, lat2, disp, cn, cp, 5.0, 2, cfg, 20)
+    assert torch.allclose(a[:4], b[:4], atol=1e-5)
+    assert not torch.allclose(a[4:], b[4:], atol=1e-3)
+
+
+def test_ddim_schedule():
+    s = sd.DDIM()
+    assert s.timesteps(20).tolist() == list(range(951, 0, -50))
+    assert s.timesteps(20, inverse=True).tolist() == list(range(1, 1000, 50))
+    x = torch.randn(2, 4, 8, 8); e = torch.randn(2, 4, 8, 8)
+    # one inverse step followed by the matching forward step with the same eps is the identity
+    y = s.inverse_step(e, 51, x, 20)
+    np.testing.assert_allclose(s.step(e, 51, y, 20).numpy(), x.numpy(), atol=1e-5)
+
+
+def test_vae_decode_shape():
+    w = sd.make_vae_decoder_weights(sd.VAE_TINY, 3)
+    img = sd.vae_decode(w, torch.randn(1, 4, 4, 4), sd.VAE_TINY)
+    assert img.shape == (1, 3, 32, 32)
