@@ -181,6 +181,9 @@ __global__ __launch_bounds__(NT) void k_gemm(const GemmArgs g)
             if (g.act == 1) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = silu(v[r]);
+            } else if (g.act == 2) {   // image post-process of pipe(output_type='pt'): (x/2 + 0.5).clamp(0,1)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r] * 0.5f + 0.5f, 0.f), 1.f);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] *= g.out_scale;

@@ -1,0 +1,132 @@
+"""Denoise pipeline: the 20-step ControlNet + UNet loop with CFG and DDIM that the reference drives through
+diffusers' StableDiffusionControlNetPipeline.__call__ (/root/reference/gaussctrl/gc_pipeline.py:142-145 for
+DDIM inversion, :209-219 for the cross-view edit), on the HIP kernels.
+
+Everything stays on the device between steps (the reference stages latents / depth through CPU numpy,
+gc_pipeline.py:268-274,186-187,200-204).  Text embeddings are inputs: the CLIP text tower runs once per
+prompt, outside the hot path.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops
+from .unet import AttnCtx, ControlNet, RefBank, UNet
+from .vae import VAEDecoder
+
+
+class DDIMSchedule:
+    """DDIMScheduler / DDIMInverseScheduler constants of the SD1.x scheduler_config."""
+
+    def __init__(self, num_train: int = 1000):
+        betas = np.linspace(0.00085 ** 0.5, 0.012 ** 0.5, num_train, dtype=np.float32) ** 2
+        self.alphas_cumprod = np.cumprod(1.0 - betas).astype(np.float32)
+        self.final_alpha = float(self.alphas_cumprod[0])
+        self.num_train = num_train
+
+    def timesteps(self, n: int, inverse: bool = False):
+        ratio = self.num_train // n
+        ts = [i * ratio + 1 for i in range(n)]              # leading spacing, steps_offset 1
+        return ts if inverse else ts[::-1]
+
+    def alphas(self, t: int, n: int, inverse: bool = False):
+        """(alpha of the state the step starts from, alpha of the state it produces)."""
+        ratio = self.num_train // n
+        prev = t - ratio
+        a_prev = float(self.alphas_cumprod[prev]) if prev >= 0 else self.final_alpha
+        a_t = float(self.alphas_cumprod[t])
+        return (a_prev, a_t) if inverse else (a_t, a_prev)
+
+
+def to_nhwc8(x_nchw: torch.Tensor, dtype) -> torch.Tensor:
+    """[B,C<=8,H,W] float -> [B,H,W,8] activation dtype, zero padded channels (layout plumbing)."""
+    B, Cc, H, W = x_nchw.shape
+    out = torch.zeros(B, H, W, 8, dtype=dtype, device=x_nchw.device)
+    out[..., :Cc] = x_nchw.permute(0, 2, 3, 1).to(dtype)
+    return out
+
+
+class DenoisePipeline:
+    def __init__(self, unet_w: dict, controlnet_w: dict, vae_w: dict | None, num_inference_steps: int = 20,
+                 guidance_scale: float = 5.0, controlnet_conditioning_scale: float = 1.0):
+        self.unet = UNet(unet_w, name="unet")
+        self.controlnet = ControlNet(controlnet_w, name="controlnet")
+        self.vae = VAEDecoder(vae_w) if vae_w is not None else None
+        self.dtype = self.unet.dtype
+        self.sched = DDIMSchedule()
+        self.n = num_inference_steps
+        self.guidance = guidance_scale
+        self.cn_scale = controlnet_conditioning_scale
+        self.text_kv = {}          # per-layer text K / V^T cache, valid for one (negative, positive) prompt pair
+        self._text_key = None
+
+    def _ctx(self, ctx_neg, ctx_pos):
+        ctx = torch.cat([ctx_neg, ctx_pos], 0).to(self.dtype).contiguous() if ctx_neg is not None else ctx_pos.to(self.dtype).contiguous()
+        key = (ctx.data_ptr(), tuple(ctx.shape), float(ctx.float().abs().sum()))
+        if key != self._text_key:
+            self.text_kv = {}
+            self._text_key = key
+            self._ctx_tensor = ctx
+        return self._ctx_tensor
+
+    # ---------------------------------------------------------------------------------- core loop
+    def _denoise(self, latents, disparity, ctx, cfg: bool, mode: str, coeff_unet: float, coeff_cn: float,
+                 guidance: float, inverse: bool, steps: int | None, bank: RefBank | None, fph: int):
+        """latents fp32 [f,4,h,w]; disparity fp32 [f,3,H,W].  Returns latents fp32 [f,4,h,w]."""
+        dev = latents.device
+        f = latents.shape[0]
+        rep = 2 if cfg else 1
+        lat = latents.permute(0, 2, 3, 1).contiguous().float()            # master copy fp32 [f,h,w,4]
+        xin = to_nhwc8(latents, self.dtype)
+        xin = torch.cat([xin] * rep, 0).contiguous()                        # cat([latents]*2)
+        cond = to_nhwc8(disparity, self.dtype)
+        cemb = self.controlnet.cond_embedding(cond)                         # once per chunk
+        cemb = torch.cat([cemb] * rep, 0).contiguous() if rep > 1 else cemb
+        ts = self.sched.timesteps(self.n, inverse)
+        ts = ts if steps is None else ts[:steps]
+        for i, t in enumerate(ts):
+            if bank is not None:
+                bank.step = i
+            a_cn = AttnCtx(mode, coeff_cn, fph, self.text_kv, bank, "controlnet")
+            a_un = AttnCtx(mode, coeff_unet, fph, self.text_kv, bank, "unet")
+            down, mid = self.controlnet.forward(xin, t, ctx, cemb, a_cn, self.cn_scale)
+            eps = self.unet.forward(xin, t, ctx, down, mid, a_un)
+            a_from, a_to = self.sched.alphas(t, self.n, inverse)
+            ops.cfg_ddim_step(eps, lat, xin, guidance, cfg, a_from, a_to, rep)
+        return lat.permute(0, 3, 1, 2).contiguous()
+
+    # ---------------------------------------------------------------------------------- public API
+    def edit_chunk(self, latents, disparity, ctx_neg, ctx_pos, steps=None):
+        """Reference-faithful chunk: `latents` / `disparity` hold the 4 reference frames FIRST, then the chunk
+        (gc_pipeline.py:206-219); every frame attends to frames 0..3 of its CFG half."""
+        ctx = self._ctx(ctx_neg, ctx_pos)
+        return self._denoise(latents, disparity, ctx, True, "xview", 0.6, 0.0, self.guidance, False, steps, None,
+                             latents.shape[0])
+
+    def build_ref_bank(self, ref_latents, ref_disparity, ctx_neg, ctx_pos, steps=None) -> RefBank:
+        """Run the 4 reference frames once and keep every layer's K / V^T for every step."""
+        ctx = self._ctx(ctx_neg, ctx_pos)
+        bank = RefBank()
+        bank.mode = "record"
+        self._denoise(ref_latents, ref_disparity, ctx, True, "xview", 0.6, 0.0, self.guidance, False, steps, bank,
+                      ref_latents.shape[0])
+        bank.mode = "use"
+        return bank
+
+    def edit_chunk_cached(self, latents, disparity, ctx_neg, ctx_pos, bank: RefBank, steps=None):
+        """Chunk frames only; reference K / V^T come from `bank` (same result as edit_chunk()[4:])."""
+        ctx = self._ctx(ctx_neg, ctx_pos)
+        return self._denoise(latents, disparity, ctx, True, "xview", 0.6, 0.0, self.guidance, False, steps, bank,
+                             latents.shape[0])
+
+    def invert(self, latents, disparity, ctx_pos, steps=None):
+        """DDIM inversion with plain attention, guidance 0 -> no CFG batch (gc_pipeline.py:136-145), batched over views."""
+        ctx = self._ctx(None, ctx_pos)
+        return self._denoise(latents, disparity, ctx, False, "plain", 0.0, 0.0, 0.0, True, steps, None, latents.shape[0])
+
+    def decode(self, latents):
+        """latents fp32 [f,4,h,w] -> images fp32 [f,3,8h,8w] in [0,1] (vae.decode(z/0.18215); (x/2+0.5).clamp(0,1))."""
+        z = to_nhwc8(latents / 0.18215, self.dtype)
+        img = self.vae.decode(z, postprocess=True)[..., :3]
+        return img.permute(0, 3, 1, 2).contiguous()

@@ -1,0 +1,223 @@
+"""SD1.x UNet2DConditionModel + depth ControlNetModel forward graphs on the HIP kernels (channels-last, bf16/f16).
+
+Host-side mirror of what diffusers 0.26.0 executes when the reference calls `self.pipe(...)`
+(/root/reference/gaussctrl/gc_pipeline.py:142-145,209-219) with the reference's attention processor
+(/root/reference/gaussctrl/utils.py:39-133) installed on every attention layer
+(gc_pipeline.py:136-137 plain, :163-168 cross-view).  Layer inventory: SURVEY.md Appendix B.
+
+Differences from the reference's execution that do not change results:
+  * one fused multi-K/V attention kernel instead of five materialised probability tensors per layer;
+  * ControlNet's self-attention term has weight 0 (gc_pipeline.py:167) and is skipped, not multiplied by 0;
+  * text K/V are computed once per CFG half (the prompt is the same for every frame, gc_pipeline.py:210-211)
+    and cached per layer for the whole trajectory (they do not depend on t);
+  * the conditioning embedding of ControlNet depends only on the disparity image and is computed once per chunk;
+  * reference-frame K / V^T can be read from a cache (`RefBank`) instead of being recomputed in every chunk
+    (reference frames attend only to reference frames, utils.py:94-117, so their trajectory is chunk independent).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import ops
+
+CFG_SD15 = dict(block_out_channels=(320, 640, 1280, 1280), layers_per_block=2, heads=8, cross_dim=768,
+                groups=32, attn_levels=(True, True, True, False), n_cond_blocks=6)
+
+
+def timestep_embedding(t: float, dim: int) -> torch.Tensor:
+    """diffusers get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0) for one timestep (host)."""
+    half = dim // 2
+    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half
+    emb = float(t) * torch.exp(exponent)
+    return torch.cat([torch.cos(emb), torch.sin(emb)])[None, :]
+
+
+class RefBank:
+    """Cache of the reference frames' per-layer K / V^T for every denoise step.
+    mode 'record': layers append their K / V^T of the reference batch; mode 'use': layers read them."""
+
+    def __init__(self):
+        self.store = {}
+        self.mode = "off"
+        self.step = 0
+
+    def key(self, layer):
+        return (self.step, layer)
+
+
+class AttnCtx:
+    """Per-forward attention configuration (what `set_attn_processor` configures in the reference)."""
+
+    def __init__(self, mode: str, coeff: float, frames_per_half: int, text_kv: dict, bank: RefBank | None = None,
+                 net: str = "unet"):
+        self.mode = mode                    # "plain" (AttnProcessor) | "xview" (CrossViewAttnProcessor)
+        self.coeff = coeff                  # self_attn_coeff
+        self.f = frames_per_half            # video_length = B // unet_chunk_size
+        self.text_kv = text_kv              # layer prefix -> (K [2,77,C], Vt [2,C,80]) cache
+        self.bank = bank
+        self.net = net
+
+
+class SDNet:
+    """Shared machinery of the UNet / ControlNet graphs."""
+
+    def __init__(self, weights: dict, cfg: dict = CFG_SD15, name: str = "unet"):
+        self.w = weights
+        self.cfg = cfg
+        self.name = name
+        self.dtype = weights["conv_in.weight"].dtype
+
+    # ---------------------------------------------------------------------------------------- blocks
+    def time_embed(self, t: float, device):
+        """-> silu(temb) [1,1280] in the activation dtype (every consumer applies SiLU first)."""
+        w = self.w
+        e = timestep_embedding(t, self.cfg["block_out_channels"][0]).to(device).to(self.dtype)
+        h = ops.linear(e, w["time_embedding.linear_1.weight"], w["time_embedding.linear_1.bias"], act=1)
+        return ops.linear(h, w["time_embedding.linear_2.weight"], w["time_embedding.linear_2.bias"], act=1)
+
+    def resnet(self, p, x, temb_act, eps=1e-5):
+        w = self.w
+        g = self.cfg["groups"]
+        h = ops.groupnorm(x, w[p + ".norm1.weight"], w[p + ".norm1.bias"], g, eps, True)
+        rv = None
+        if temb_act is not None:
+            rv = ops.linear(temb_act, w[p + ".time_emb_proj.weight"], w[p + ".time_emb_proj.bias"], out_f32=True)
+        h = ops.conv3x3(h, w[p + ".conv1.weight"], w[p + ".conv1.bias"], rowvec=rv, ld_rowvec=0)
+        h = ops.groupnorm(h, w[p + ".norm2.weight"], w[p + ".norm2.bias"], g, eps, True)
+        sc = x
+        if (p + ".conv_shortcut.weight") in w:
+            sc = ops.linear(x, w[p + ".conv_shortcut.weight"], w[p + ".conv_shortcut.bias"])
+        return ops.conv3x3(h, w[p + ".conv2.weight"], w[p + ".conv2.bias"], residual=sc)
+
+    def _self_attention(self, p, n, actx: AttnCtx):
+        w = self.w
+        heads = self.cfg["heads"]
+        B, L, Cc = n.shape
+        Lp = (L + 7) // 8 * 8
+        q = ops.linear(n, w[p + ".to_q.weight"])
+        k = ops.linear(n, w[p + ".to_k.weight"])
+        vt = torch.zeros(B, Cc, Lp, dtype=n.dtype, device=n.device) if Lp != L else torch.empty(B, Cc, Lp, dtype=n.dtype, device=n.device)
+        ops.linear(n, w[p + ".to_v.weight"], want_out=False, rows_per_batch=L, out_t=vt, ldt=Lp, t_batch_stride=Cc * Lp)
+        if actx.mode == "plain":
+            return ops.attention(q, k, vt, heads, [(-1, 1.0)], actx.f, Lk=L)
+        a = actx.coeff
+        sets = ([(-1, a)] if a != 0.0 else []) + [(r, (1.0 - a) / 4.0) for r in range(4)]    # utils.py:95-102,117
+        bank = actx.bank
+        if bank is not None and bank.mode == "record":
+            bank.store[bank.key((actx.net, p))] = (k, vt)            # the batch IS the reference batch [2*4]
+        if bank is not None and bank.mode == "use":
+            kr, vtr = bank.store[bank.key((actx.net, p))]
+            return ops.attention(q, k, vt, heads, sets, actx.f, Lk=L, kref=kr, vtref=vtr, ref_fph=kr.shape[0] // 2)
+        return ops.attention(q, k, vt, heads, sets, actx.f, Lk=L)
+
+    def _text_kv(self, p, ctx, actx: AttnCtx):
+        key = (actx.net, p)
+        if key not in actx.text_kv:
+            w = self.w
+            Bc, Lt, _ = ctx.shape
+            Cc = w[p + ".to_k.weight"].shape[0]
+            Lp = (Lt + 7) // 8 * 8
+            k = ops.linear(ctx, w[p + ".to_k.weight"])
+            vt = torch.zeros(Bc, Cc, Lp, dtype=ctx.dtype, device=ctx.device)
+            ops.linear(ctx, w[p + ".to_v.weight"], want_out=False, rows_per_batch=Lt, out_t=vt, ldt=Lp, t_batch_stride=Cc * Lp)
+            actx.text_kv[key] = (k, vt, Lt)
+        return actx.text_kv[key]
+
+    def transformer(self, p, x, ctx, actx: AttnCtx):
+        w = self.w
+        B, H, W_, Cc = x.shape
+        g = self.cfg["groups"]
+        h = ops.groupnorm(x, w[p + ".norm.weight"], w[p + ".norm.bias"], g, 1e-6, False)
+        h = ops.linear(h.view(B, H * W_, Cc), w[p + ".proj_in.weight"], w[p + ".proj_in.bias"])
+        t = p + ".transformer_blocks.0"
+        n = ops.layernorm(h, w[t + ".norm1.weight"], w[t + ".norm1.bias"])
+        o = self._self_attention(t + ".attn1", n, actx)
+        h = ops.linear(o, w[t + ".attn1.to_out.0.weight"], w[t + ".attn1.to_out.0.bias"], residual=h)
+        n = ops.layernorm(h, w[t + ".norm2.weight"], w[t + ".norm2.bias"])
+        q = ops.linear(n, w[t + ".attn2.to_q.weight"])
+        k, vt, Lt = self._text_kv(t + ".attn2", ctx, actx)
+        # ctx holds one text row per CFG half ([negative || positive]); frame b reads row b // f (kind -2)
+        o = ops.attention(q, k, vt, self.cfg["heads"], [(-2, 1.0)], B // k.shape[0], Lk=Lt)
+        h = ops.linear(o, w[t + ".attn2.to_out.0.weight"], w[t + ".attn2.to_out.0.bias"], residual=h)
+        n = ops.layernorm(h, w[t + ".norm3.weight"], w[t + ".norm3.bias"])
+        ff = ops.linear(n, w[t + ".ff.net.0.proj.weight"], w[t + ".ff.net.0.proj.bias"], geglu=True)
+        h = ops.linear(ff, w[t + ".ff.net.2.weight"], w[t + ".ff.net.2.bias"], residual=h)
+        out = ops.linear(h, w[p + ".proj_out.weight"], w[p + ".proj_out.bias"], residual=x.view(B, H * W_, Cc))
+        return out.view(B, H, W_, Cc)
+
+    def encoder(self, x, temb_act, ctx, actx):
+        cfg = self.cfg
+        skips = [x]
+        n = len(cfg["block_out_channels"])
+        for i in range(n):
+            for j in range(cfg["layers_per_block"]):
+                x = self.resnet(f"down_blocks.{i}.resnets.{j}", x, temb_act)
+                if cfg["attn_levels"][i]:
+                    x = self.transformer(f"down_blocks.{i}.attentions.{j}", x, ctx, actx)
+                skips.append(x)
+            if i < n - 1:
+                p = f"down_blocks.{i}.downsamplers.0.conv"
+                x = ops.conv3x3(x, self.w[p + ".weight"], self.w[p + ".bias"], stride=2)
+                skips.append(x)
+        x = self.resnet("mid_block.resnets.0", x, temb_act)
+        x = self.transformer("mid_block.attentions.0", x, ctx, actx)
+        x = self.resnet("mid_block.resnets.1", x, temb_act)
+        return x, skips
+
+
+class ControlNet(SDNet):
+    def cond_embedding(self, cond):
+        """controlnet_cond_embedding on the [B,H,W,8] (3 used) disparity image -> [B,H/8,W/8,320].  Depends only
+        on the control image: computed once per chunk, not per step."""
+        w = self.w
+        p = "controlnet_cond_embedding"
+        c = ops.conv3x3(cond, w[p + ".conv_in.weight"], w[p + ".conv_in.bias"], act=1)
+        for k in range(self.cfg["n_cond_blocks"]):
+            c = ops.conv3x3(c, w[f"{p}.blocks.{k}.weight"], w[f"{p}.blocks.{k}.bias"], stride=2 if k % 2 == 1 else 1, act=1)
+        return ops.conv3x3(c, w[p + ".conv_out.weight"], w[p + ".conv_out.bias"])
+
+    def forward(self, xin, t, ctx, cond_emb, actx: AttnCtx, conditioning_scale=1.0):
+        """xin [B,h,w,8] -> (12 down residuals, mid residual), all [B,*,*,C] channels-last."""
+        w = self.w
+        temb_act = self.time_embed(t, xin.device)
+        x = ops.conv3x3(xin, w["conv_in.weight"], w["conv_in.bias"], residual=cond_emb)
+        x, skips = self.encoder(x, temb_act, ctx, actx)
+        down = []
+        for n, s in enumerate(skips):
+            B, H, W_, Cc = s.shape
+            o = ops.linear(s.view(B, H * W_, Cc), w[f"controlnet_down_blocks.{n}.weight"], w[f"controlnet_down_blocks.{n}.bias"],
+                           scale=conditioning_scale)
+            down.append(o.view(B, H, W_, Cc))
+        B, H, W_, Cc = x.shape
+        mid = ops.linear(x.view(B, H * W_, Cc), w["controlnet_mid_block.weight"], w["controlnet_mid_block.bias"],
+                         scale=conditioning_scale).view(B, H, W_, Cc)
+        return down, mid
+
+
+class UNet(SDNet):
+    def forward(self, xin, t, ctx, down_res, mid_res, actx: AttnCtx):
+        """xin [B,h,w,8] -> eps fp32 [B,h,w,8] (channels 0..3 valid)."""
+        w = self.w
+        cfg = self.cfg
+        temb_act = self.time_embed(t, xin.device)
+        x = ops.conv3x3(xin, w["conv_in.weight"], w["conv_in.bias"])
+        x, skips = self.encoder(x, temb_act, ctx, actx)
+        if mid_res is not None:
+            x = ops.axpby(x, 1.0, mid_res, 1.0)
+        n = len(cfg["block_out_channels"])
+        rev_attn = list(reversed(cfg["attn_levels"]))
+        for i in range(n):
+            for j in range(cfg["layers_per_block"] + 1):
+                s = skips.pop()
+                r = down_res.pop() if down_res is not None else None
+                x = ops.concat_add(x, s, r)                  # cat([x, skip + controlnet residual])
+                x = self.resnet(f"up_blocks.{i}.resnets.{j}", x, temb_act)
+                if rev_attn[i]:
+                    x = self.transformer(f"up_blocks.{i}.attentions.{j}", x, ctx, actx)
+            if i < n - 1:
+                p = f"up_blocks.{i}.upsamplers.0.conv"
+                x = ops.conv3x3(x, w[p + ".weight"], w[p + ".bias"], upsample=True)
+        x = ops.groupnorm(x, w["conv_norm_out.weight"], w["conv_norm_out.bias"], cfg["groups"], 1e-5, True)
+        return ops.conv3x3(x, w["conv_out.weight"], w["conv_out.bias"], out_f32=True)

@@ -171,7 +171,7 @@ typedef struct gc_gemm_desc {
     const void *residual;      /* [M][ldr] or NULL */
     int64_t ldr;
     float out_scale;
-    int act;                   /* 0 none, 1 SiLU */
+    int act;                   /* 0 none, 1 SiLU, 2 image post-process clamp(x/2+0.5, 0, 1) */
     int geglu;                 /* 1: W rows permuted in 16-blocks [x|gate]; out[m][n/2] = x * gelu(gate), ldc = N/2 */
     void *out;                 /* [M][ldc] (NULL to skip) */
     int64_t ldc;

@@ -132,7 +132,7 @@ def test_cross_view_attention(dt, f, L, heads, D, coeff):
         ref = ref + (1 - coeff) / 4 * _ref_attn(q, k[idx], v[idx], heads, scale)
     sets = ([(-1, coeff)] if coeff != 0 else []) + [(r, (1 - coeff) / 4) for r in range(4)]
     got = ops.attention(q, k, vt, heads, sets, f, Lk=L)
-    _close(got, ref, dt, extra=4.0)
+    _close(got, ref, dt, extra=8.0)      # P is rounded to the activation dtype before P V (as in the reference's fp16 bmm)
     # the same through a separate reference bank (cached reference K/V)
     bank_idx = torch.cat([torch.arange(4), f + torch.arange(4)]).to(DEV)
     got2 = ops.attention(q, k, vt, heads, sets, f, Lk=L, kref=k[bank_idx].contiguous(), vtref=vt[bank_idx].contiguous(), ref_fph=4)
@@ -151,7 +151,7 @@ def test_text_attention_and_rescale_branch(dt):
     idx = torch.arange(B, device=DEV) // f
     ref = _ref_attn(q, k[idx], v[idx], heads, D ** -0.5)
     got = ops.attention(q, k, vt, heads, [(-2, 1.0)], f, Lk=Lt)
-    _close(got, ref, dt, extra=4.0)
+    _close(got, ref, dt, extra=8.0)
 
 
 @pytest.mark.parametrize("dt", DTS)
