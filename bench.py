@@ -1,0 +1,283 @@
+#!/usr/bin/env python
+"""bench.py -- edited views/sec @512x512 (ControlNet denoise + splat render+bwd) on N MI355X GPUs.
+
+One "step" = one chunk of `chunk_size` views pushed through the whole hot path:
+  (a) eval render of each view (rgb + depth + alpha, one fused compositing sweep)            [rasterizer fwd]
+  (b) 20-step CFG ControlNet+UNet cross-view denoise of the chunk against the 4 reference views' K/V.
+      The reference trajectory (4 views) is computed INSIDE the timed region once per ceil(V/chunk) steps,
+      i.e. each chunk pays its share of the reference work (V=40, c=3 -> every 14 steps).
+  (c) VAE decode of the chunk's edited latents
+  (d) one training render of each view, forward + backward to the six Gaussian parameter tensors with an
+      L1 loss gradient against the edited image, gradients all-reduced over ranks (RCCL) when N > 1.
+Workload (BASELINE.json configs[1]): "bear"-like scene, V=40 views, 4 reference views, chunk_size=3, ~1M synthetic
+Gaussians, SD1.5 + ControlNet-depth shapes with seeded random weights (no checkpoints / network), bf16.
+
+Prints ONE JSON line on rank 0.  N > 1: launched by torch.distributed.run, one rank per GPU, views sharded over
+ranks (weak scaling: every rank edits its own `chunk_size` views per step; no data-path collective in the denoise
+half -- reference K/V are replicated -- and one gradient all-reduce per step in the render half).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+UNET_GFLOP_XVIEW = 1293.3      # per sample-forward, SURVEY.md Appendix B (analytic, 2*MAC)
+CN_GFLOP_XVIEW = 430.0         # ControlNet with the weight-0 self term skipped
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--views", type=int, default=40)
+    ap.add_argument("--chunk-size", type=int, default=3)
+    ap.add_argument("--denoise-steps", type=int, default=20)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="edit", choices=["edit", "raster"])
+    return ap.parse_args()
+
+
+class GemmProfiler:
+    """Brackets every gc_dn_gemm launch with HIP events on the launch stream (one instrumented step)."""
+
+    def __init__(self):
+        self.rec = []
+
+    def wrap(self, ops):
+        self._lin, self._conv = ops.linear, ops.conv3x3
+        prof = self
+
+        def lin(x, w, *a, **k):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = prof._lin(x, w, *a, **k)
+            e.record()
+            K = x.shape[-1]
+            prof.rec.append(("linear", 2.0 * (x.numel() // K) * w.shape[0] * K, s, e))
+            return out
+
+        def conv(x, w, *a, **k):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = prof._conv(x, w, *a, **k)
+            e.record()
+            prof.rec.append(("conv3x3", 2.0 * (out.numel() // out.shape[-1]) * w.shape[0] * w.shape[1], s, e))
+            return out
+
+        ops.linear, ops.conv3x3 = lin, conv
+
+    def unwrap(self, ops):
+        ops.linear, ops.conv3x3 = self._lin, self._conv
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for kind, fl, s, e in self.rec:
+            d = out.setdefault(kind, {"launches": 0, "flop": 0.0, "ms": 0.0})
+            d["launches"] += 1; d["flop"] += fl; d["ms"] += s.elapsed_time(e)
+        return out
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist = None
+
+    from gaussctrl_amd import gsplat_ops as gops, synthetic as syn
+    from gaussctrl_amd.camera import camera_to_gsplat
+    from gaussctrl_amd.sd import arch, ops as sdops
+    from gaussctrl_amd.sd.pipeline import DenoisePipeline
+    from gaussctrl_amd.sd.vae import prepare_vae_weights
+    from gaussctrl_amd.sd.weights import prepare
+
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    c, V, nsteps = args.chunk_size, args.views, args.denoise_steps
+    H = W = 512
+    K = syn.BEAR_INTRINSICS
+
+    # ---------------------------------------------------------------- scene, cameras, networks (untimed setup)
+    P = syn.make_gaussians(args.gaussians, seed=0)
+    params = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in P.items()}
+    cams = syn.make_cameras(V * world, seed=1)
+    my_cams = [camera_to_gsplat(cams[rank * V + i], K["fx"], K["fy"], K["cx"], K["cy"], W, H) for i in range(V)]
+    bg = torch.zeros(3, device=dev)
+    pipe = None
+    if args.workload == "edit":
+        uw = prepare(arch.random_state_dict(arch.unet_shapes(), 100, dev), dt, dev)
+        cw = prepare(arch.random_state_dict(arch.controlnet_shapes(), 200, dev), dt, dev)
+        vw = prepare_vae_weights(arch.random_state_dict(arch.vae_decoder_shapes(), 300, dev), dt, dev)
+        pipe = DenoisePipeline(uw, cw, vw, nsteps, 5.0)
+    g = torch.Generator(device=dev).manual_seed(2 + rank)
+    ctx_neg = torch.randn(1, 77, 768, device=dev, generator=g)
+    ctx_pos = torch.randn(1, 77, 768, device=dev, generator=g)
+    z0 = torch.randn(V, 4, 64, 64, device=dev, generator=g)                   # stand-in for the DDIM-inverted latents
+    ref_idx = [4, 11, 29, 31]                                                  # gc_pipeline.py:109-113 for V=40
+    ref_idx = [min(i, V - 1) for i in ref_idx]
+    chunks_per_scene = math.ceil(V / c)
+    stats = {"M": [], "n_visible": []}
+    state = {"bank": None, "disp": {}}
+
+    def render_eval(i):
+        aux = gops.RenderAux()
+        with torch.no_grad():
+            rgb, alpha, depth = gops.render_view(params["means"], params["scales"], params["quats"], params["opacities"],
+                                                 params["features_dc"], params["features_rest"], my_cams[i], bg, True, 3, aux)
+        stats["M"].append(aux.M)
+        return rgb, depth, aux
+
+    def disparity_of(depth):            # gc_pipeline.py:258-266
+        d = 1.0 / (depth + 1e-5)
+        d = d / d.max()
+        return d[None].expand(3, -1, -1)
+
+    def step(s):
+        views = [(s * c + j) % V for j in range(c)]
+        if args.workload == "edit":
+            if s % chunks_per_scene == 0:           # this scene's reference trajectory (shared by its 14 chunks)
+                rd = torch.stack([disparity_of(render_eval(i)[1]) for i in ref_idx])
+                state["bank"] = pipe.build_ref_bank(z0[ref_idx], rd, ctx_neg, ctx_pos)
+            disp = torch.stack([disparity_of(render_eval(i)[1]) for i in views])                           # (a)
+            lat = pipe.edit_chunk_cached(z0[views], disp, ctx_neg, ctx_pos, state["bank"])                 # (b)
+            edited = pipe.decode(lat)                                                                       # (c)
+        else:
+            edited = [None] * c
+        for p in params.values():
+            p.grad = None
+        for j, i in enumerate(views):                                                                       # (d)
+            aux = gops.RenderAux()
+            rgb, alpha, _ = gops.render_view(params["means"], params["scales"], params["quats"], params["opacities"],
+                                             params["features_dc"], params["features_rest"], my_cams[i],
+                                             torch.rand(3, device=dev), False, 3, aux)
+            target = edited[j].permute(1, 2, 0) if edited[j] is not None else torch.zeros_like(rgb)
+            loss = (rgb - target).abs().mean()
+            loss.backward()
+            stats["M"].append(aux.M)
+        if dist is not None:
+            flat = torch.cat([p.grad.reshape(-1) for p in params.values()])
+            dist.all_reduce(flat)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        step(s)
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        step(s)                       # step 0 of the timed region pays the reference trajectory
+    barrier()
+    dt_s = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt_s], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt_s = float(tt.item())
+    views_done = args.steps * c * world
+    value = views_done / dt_s
+
+    # ---------------------------------------------------------------- roofline of the dominant kernel (instrumented extra step)
+    roof = None
+    if args.workload == "edit" and rank == 0:
+        prof = GemmProfiler()
+        prof.wrap(sdops)
+        try:
+            lat = pipe.edit_chunk_cached(z0[:c], torch.rand(c, 3, H, W, device=dev), ctx_neg, ctx_pos, state["bank"])
+        finally:
+            prof.unwrap(sdops)
+        sm = prof.summary()
+        dom = max(sm.items(), key=lambda kv: kv[1]["ms"])
+        kind, d = dom
+        ach = d["flop"] / (d["ms"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": f"k_gemm<{args.dtype},{'conv3x3' if kind == 'conv3x3' else 'linear'}>",
+                "achieved": round(ach, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                "launches": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
+                "algorithmic_gflop_per_launch": round(d["flop"] / d["launches"] / 1e9, 3),
+                "other": {k: {"launches": v["launches"], "ms": round(v["ms"], 2),
+                              "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in sm.items() if k != kind}}
+
+    # ---------------------------------------------------------------- CPU baseline (oracle, rank 0, bounded sample)
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args)
+
+    if rank == 0:
+        out = {"metric": "edited views/sec @512x512 (ControlNet denoise + splat render+bwd)", "value": round(value, 4),
+               "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(1e3 * dt_s / args.steps, 2), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": f"bear-like scene, {V} views/GPU, ref_view_num=4, chunk_size={c}, "
+                                      f"{nsteps} DDIM steps, SD1.5+ControlNet-depth shapes (random weights), "
+                                      f"{args.gaussians} Gaussians, 512x512" if args.workload == "edit" else
+                                      f"raster-only fwd+bwd, {args.gaussians} Gaussians, 512x512",
+                          "views_per_step": c * world, "parallelism": f"views sharded x{world}, reference K/V replicated, grad all-reduce",
+                          "mean_intersections_M": int(np.mean(stats["M"])) if stats["M"] else 0,
+                          "ref_trajectory_in_timed_region": bool(args.workload == "edit")},
+               "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args):
+    """Oracle ("port") timed on the host cores on a bounded sample: ONE CFG ControlNet+UNet cross-view step at the
+    reference's CPU-runnable shape (configs[0]: chunk_size=1 -> f = 4 refs + 1 = 5 frames, batch 10) + one raster
+    fwd+bwd at N=200k; extrapolated to an edited view = 20 steps * step + eval render + train render fwd+bwd."""
+    from oracle import raster_c, sd15_torch as sd
+    from gaussctrl_amd import synthetic as syn
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    with torch.no_grad():
+        uw = sd.make_unet_weights(sd.SD15, 100); cw = sd.make_controlnet_weights(sd.SD15, 200)
+        f = 5
+        lat = torch.randn(f, 4, 64, 64); disp = torch.rand(f, 3, 512, 512)
+        cn, cp = torch.randn(1, 77, 768), torch.randn(1, 77, 768)
+        t0 = time.perf_counter()
+        sd.denoise_chunk(uw, cw, lat, disp, cn, cp, 5.0, 1, sd.SD15, 20)
+        t_step = time.perf_counter() - t0
+    del uw, cw
+    N = 200_000
+    P = syn.make_gaussians(N, seed=0)
+    c2w = syn.make_cameras(1, seed=1)[0]
+    K = syn.BEAR_INTRINSICS
+    bgc = np.zeros(3, np.float32)
+    v_rgb = np.ones((512, 512, 3), np.float32)
+    t0 = time.perf_counter()
+    raster_c.render(P, c2w, K["fx"], K["fy"], K["cx"], K["cy"], 512, 512, bgc, training=False)
+    raster_c.render(P, c2w, K["fx"], K["fy"], K["cx"], K["cy"], 512, 512, bgc, training=True, v_rgb=v_rgb)
+    t_raster = (time.perf_counter() - t0) * (args.gaussians / N)
+    per_view = 20 * t_step + t_raster            # chunk_size 1: the whole f=5 batch buys ONE edited view
+    return {"value": round(1.0 / per_view, 6), "unit": "views/s", "cores": threads, "kind": "port",
+            "sample": f"1 of 20 CFG ControlNet+UNet cross-view steps at f=5 (batch 10, 64x64 latents) = {t_step:.2f}s x20; "
+                      f"C raster eval + train fwd+bwd at N={N} (1 thread) scaled to N={args.gaussians} = {t_raster:.2f}s; VAE decode not included"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,14 @@
+"""Summarise a rocprofv3 rocpd SQLite result (kernel trace) like `--stats`: per-kernel calls, total, avg."""
+import re, sqlite3, sys
+db = sqlite3.connect(sys.argv[1])
+cur = db.cursor()
+tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+rows = cur.execute(f"select s.kernel_name, count(*), sum(d.end-d.start), min(d.end-d.start), max(d.end-d.start) from {kd} d join {ks} s on d.kernel_id = s.id group by s.kernel_name order by 3 desc").fetchall()
+tot = sum(r[2] for r in rows)
+print(f"{'kernel':90s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>9s} {'min_us':>8s} {'max_us':>9s} {'%':>6s}")
+for n, c, t, mn, mx in rows[: int(sys.argv[2]) if len(sys.argv) > 2 else 40]:
+    n = re.sub(r"\(anonymous namespace\)::", "", n)[:90]
+    print(f"{n:90s} {c:7d} {t/1e6:10.2f} {t/c/1e3:9.2f} {mn/1e3:8.2f} {mx/1e3:9.2f} {100*t/tot:6.2f}")
+print(f"TOTAL kernel time {tot/1e6:.2f} ms")
