@@ -25,7 +25,7 @@ struct GemmArgs {
     int64_t M, N, K;
     const void *A; int64_t lda;
     int mode;   // 0 linear, 1 conv3x3
-    int B, Hi, Wi, Cin, Ho, Wo, stride, ups;
+    int B, Hi, Wi, Cin, Ho, Wo, stride, ups, pad;
     const void *W;
     const float *bias;
     const float *rowvec; int64_t ld_rowvec; int64_t rows_per_batch;
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(NT) void k_gemm(const GemmArgs g)
                     const int tap = (int)(k0 / g.Cin);
                     const int ci = (int)(k0 - (int64_t)tap * g.Cin);
                     const int dy = tap / 3, dx = tap - dy * 3;
-                    int yi = a_y[i] * g.stride + dy - 1, xi = a_x[i] * g.stride + dx - 1;
+                    int yi = a_y[i] * g.stride + dy - g.pad, xi = a_x[i] * g.stride + dx - g.pad;
                     if (a_ok[i] && yi >= 0 && yi < Hin && xi >= 0 && xi < Win) {
                         if (g.ups) { yi >>= 1; xi >>= 1; }
                         const int64_t off = (((int64_t)a_b[i] * g.Hi + yi) * g.Wi + xi) * g.Cin + ci;
@@ -221,7 +221,7 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
     GC_REQUIRE(d->dtype == DT_BF16 || d->dtype == DT_F16, "dtype must be 0 (bf16) or 1 (f16)");
     GemmArgs g;
     g.M = d->M; g.N = d->N; g.K = d->K; g.A = d->A; g.lda = d->lda; g.mode = d->mode;
-    g.B = d->B; g.Hi = d->Hi; g.Wi = d->Wi; g.Cin = d->Cin; g.Ho = d->Ho; g.Wo = d->Wo; g.stride = d->stride; g.ups = d->upsample;
+    g.B = d->B; g.Hi = d->Hi; g.Wi = d->Wi; g.Cin = d->Cin; g.Ho = d->Ho; g.Wo = d->Wo; g.stride = d->stride; g.ups = d->upsample; g.pad = d->pad_lo;
     g.W = d->W; g.bias = d->bias; g.rowvec = d->rowvec; g.ld_rowvec = d->ld_rowvec;
     g.rows_per_batch = d->rows_per_batch > 0 ? d->rows_per_batch : 1;
     g.residual = d->residual; g.ldr = d->ldr; g.out_scale = d->out_scale; g.act = d->act; g.geglu = d->geglu;
@@ -229,6 +229,7 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
     if (d->mode == 1) {
         GC_REQUIRE(d->Cin % 8 == 0 && d->K == 9 * (int64_t)d->Cin, "conv3x3: K must be 9*Cin with Cin % 8 == 0");
         GC_REQUIRE(d->M == (int64_t)d->B * d->Ho * d->Wo, "conv3x3: M must be B*Ho*Wo");
+        GC_REQUIRE(d->pad_lo == 0 || d->pad_lo == 1, "conv3x3: pad_lo must be 0 or 1");
     } else {
         GC_REQUIRE(d->lda >= d->K && d->lda % 8 == 0, "linear: lda must be >= K and a multiple of 8");
     }

@@ -232,6 +232,37 @@ __global__ __launch_bounds__(256) void k_cfg_ddim(const float *__restrict__ eps,
     }
 }
 
+__global__ __launch_bounds__(256) void k_disp_max(const float *__restrict__ depth, int64_t n, unsigned *__restrict__ mx)
+{
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, 1.f / (depth[i] + 1e-5f));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(mx, __float_as_uint(m));     // disparity > 0: uint order == float order
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void k_disp_write(const float *__restrict__ depth, int64_t n, const unsigned *__restrict__ mx,
+                                                    unsigned short *__restrict__ out)
+{
+    const float inv = 1.f / __uint_as_float(*mx);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float d = (1.f / (depth[i] + 1e-5f)) * inv;
+        const unsigned h = T::from_f(d);
+        *reinterpret_cast<uint4 *>(out + i * 8) = make_uint4(h | (h << 16), h, 0u, 0u);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mask_composite(const float *__restrict__ e, int ld_e, const float *__restrict__ u,
+                                                        const float *__restrict__ m, float *__restrict__ out, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float w = m ? m[i] : 1.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[3 * i + c] = e[i * ld_e + c] * w + (m ? u[3 * i + c] * (1.f - w) : 0.f);
+    }
+}
+
 inline unsigned ew_grid(int64_t items) { return (unsigned)std::min<int64_t>((items + 255) / 256, 256 * 8); }
 
 }  // namespace
@@ -322,6 +353,25 @@ int gc_dn_softmax_rows(int dtype, void *s, int64_t M, int64_t N, int64_t ld, flo
                 hipLaunchKernelGGL((k_softmax_rows<BF16>), dim3((unsigned)M), dim3(256), 0, gc::S(stream), (unsigned short *)s, N, ld, scale),
                 hipLaunchKernelGGL((k_softmax_rows<F16>), dim3((unsigned)M), dim3(256), 0, gc::S(stream), (unsigned short *)s, N, ld, scale));
     return gc::check_launch("gc_dn_softmax_rows");
+}
+
+int gc_dn_depth_to_disparity(int dtype, const float *depth, int64_t HW, void *out, unsigned *max_ws, void *stream)
+{
+    hipStream_t s = gc::S(stream);
+    if (hipMemsetAsync(max_ws, 0, 4, s) != hipSuccess) return GC_ELAUNCH;
+    hipLaunchKernelGGL(k_disp_max, dim3(ew_grid(HW)), dim3(256), 0, s, depth, HW, max_ws);
+    DN_DISPATCH(dtype,
+                hipLaunchKernelGGL((k_disp_write<BF16>), dim3(ew_grid(HW)), dim3(256), 0, s, depth, HW, max_ws, (unsigned short *)out),
+                hipLaunchKernelGGL((k_disp_write<F16>), dim3(ew_grid(HW)), dim3(256), 0, s, depth, HW, max_ws, (unsigned short *)out));
+    return gc::check_launch("gc_dn_depth_to_disparity");
+}
+
+int gc_dn_mask_composite(const float *edited, int ld_e, const float *unedited, const float *mask, float *out, int64_t HW,
+                         void *stream)
+{
+    GC_REQUIRE(edited && out && (mask == nullptr || unedited != nullptr), "mask_composite: bad arguments");
+    hipLaunchKernelGGL(k_mask_composite, dim3(ew_grid(HW)), dim3(256), 0, gc::S(stream), edited, ld_e, unedited, mask, out, HW);
+    return gc::check_launch("gc_dn_mask_composite");
 }
 
 int gc_dn_cfg_ddim_step(int dtype, const float *eps, int ld_eps, int64_t frames, int64_t HW, float guidance, int cfg,

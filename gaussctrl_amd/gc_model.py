@@ -1,0 +1,152 @@
+"""GaussCtrlModel: drop-in for /root/reference/gaussctrl/gc_model.py (GaussCtrlModelConfig :39-50,
+GaussCtrlModel.get_outputs :57-206, get_outputs_for_camera :208-221) on the HIP rasterizer.
+
+Same contract: get_outputs(camera: Cameras[1]) -> {"rgb"[H,W,3], "depth"[H,W,1] | None,
+"accumulation"[H,W,1]}; training -> random / configured background and no depth; eval -> rgb + depth +
+accumulation from ONE fused compositing sweep (the reference sorts and rasterises twice, :174-202); returns a
+background image when nothing is visible (:89-91,155-156); `self.xys` / `self.radii` are kept for the densification
+callbacks and `self.xys.grad` is populated after backward (:159-160).  Parameter names / optimizer groups are
+splatfacto's (`means, scales, quats, features_dc, features_rest, opacities`; groups xyz, features_dc, features_rest,
+opacity, scaling, rotation -- /root/reference/gaussctrl/gc_config.py:58-87)."""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Union
+
+import torch
+from torch import nn
+
+from . import gsplat_ops as ops
+from .camera import camera_to_gsplat
+from .ns_compat import Cameras
+
+
+@dataclass
+class GaussCtrlModelConfig:
+    """gc_model.py:39-50 (+ the splatfacto fields get_outputs reads)."""
+    sh_degree: int = 3
+    sh_degree_interval: int = 1000
+    background_color: str = "random"
+    use_lpips: bool = True          # never read by the reference (no get_loss_dict override)
+    use_l1: bool = True
+    patch_size: int = 32
+    lpips_loss_mult: float = 1.0
+    ssim_lambda: float = 0.2
+
+    def setup(self, **kw):
+        return GaussCtrlModel(self, **kw)
+
+
+class GaussCtrlModel(nn.Module):
+    config: GaussCtrlModelConfig
+
+    def __init__(self, config: GaussCtrlModelConfig, params: Optional[Dict[str, torch.Tensor]] = None, num_points: int = 0,
+                 device="cuda"):
+        super().__init__()
+        self.config = config
+        k = (config.sh_degree + 1) ** 2 - 1
+        if params is None:
+            params = {"means": torch.zeros(num_points, 3), "scales": torch.zeros(num_points, 3),
+                      "quats": torch.zeros(num_points, 4), "opacities": torch.zeros(num_points, 1),
+                      "features_dc": torch.zeros(num_points, 3), "features_rest": torch.zeros(num_points, k, 3)}
+        for name in ("means", "scales", "quats", "features_dc", "features_rest", "opacities"):
+            setattr(self, name, nn.Parameter(torch.as_tensor(params[name], dtype=torch.float32).to(device).contiguous()))
+        self.step = 30000                        # a loaded splatfacto checkpoint starts here (gc_trainer.py:75)
+        self.crop_box = None
+        self.background_color = torch.zeros(3)
+        self.xys = None
+        self.radii = None
+        self.last_size = None
+        self._aux = ops.RenderAux()
+
+    @property
+    def device(self):
+        return self.means.device
+
+    @property
+    def num_points(self):
+        return self.means.shape[0]
+
+    def set_crop(self, crop_box):
+        self.crop_box = crop_box
+
+    def get_param_groups(self) -> Dict[str, List[nn.Parameter]]:
+        return {"xyz": [self.means], "features_dc": [self.features_dc], "features_rest": [self.features_rest],
+                "opacity": [self.opacities], "scaling": [self.scales], "rotation": [self.quats]}
+
+    # ------------------------------------------------------------------------------------ gc_model.py:57-206
+    def get_outputs(self, camera: Cameras) -> Dict[str, Union[torch.Tensor, List]]:
+        if not isinstance(camera, Cameras):
+            print("Called get_outputs with not a camera")
+            return {}
+        assert camera.shape[0] == 1, "Only one camera at a time"
+        dev = self.device
+        if self.training:                                                       # :72-81
+            bc = self.config.background_color
+            background = (torch.rand(3, device=dev) if bc == "random" else torch.ones(3, device=dev) if bc == "white"
+                          else torch.zeros(3, device=dev) if bc == "black" else self.background_color.to(dev))
+        else:
+            background = self.background_color.to(dev)
+        W, H = int(camera.width.reshape(-1)[0]), int(camera.height.reshape(-1)[0])
+        p = [self.means, self.scales, self.quats, self.opacities, self.features_dc, self.features_rest]
+        if self.crop_box is not None and not self.training:                     # :88-93,123-136
+            crop_ids = self.crop_box.within(self.means).squeeze()
+            if crop_ids.sum() == 0:
+                return {"rgb": background.repeat(H, W, 1)}
+            p = [t[crop_ids] for t in p]
+        cam = camera_to_gsplat(camera.camera_to_worlds[0].detach().cpu().numpy(), float(camera.fx.reshape(-1)[0]),
+                               float(camera.fy.reshape(-1)[0]), float(camera.cx.reshape(-1)[0]),
+                               float(camera.cy.reshape(-1)[0]), W, H)        # :97-121 on the host
+        self.last_size = (H, W)
+        n = min(self.step // self.config.sh_degree_interval, self.config.sh_degree)   # :165
+        aux = self._aux = ops.RenderAux()
+        rgb, alpha, depth = ops.render_view(*p, cam, background, not self.training, n, aux)
+        self.xys, self.radii = aux.xys, aux.radii
+        if aux.M == 0:                                                          # :155-156
+            return {"rgb": background.repeat(H, W, 1)}
+        depth_im = None if self.training else depth[..., None]
+        return {"rgb": rgb, "depth": depth_im, "accumulation": alpha[..., None]}
+
+    forward = get_outputs
+
+    @property
+    def xys_grad(self):
+        """gradient of the loss w.r.t. the projected centres (what splatfacto's after_train reads as xys.grad)."""
+        return self._aux.xys_grad
+
+    @torch.no_grad()
+    def get_outputs_for_camera(self, camera: Cameras, obb_box=None) -> Dict[str, torch.Tensor]:    # :208-221
+        assert camera is not None, "must provide camera to gaussian model"
+        self.set_crop(obb_box)
+        self.training = False
+        outs = self.get_outputs(camera.to(self.device))
+        self.training = True
+        return outs
+
+    # ------------------------------------------------------------------------------------ inherited splatfacto loss
+    def get_metrics_dict(self, outputs, batch) -> Dict[str, torch.Tensor]:
+        gt = batch["image"].to(self.device)
+        mse = ((outputs["rgb"] - gt) ** 2).mean()
+        return {"psnr": -10.0 * torch.log10(mse.clamp_min(1e-12)), "gaussian_count": torch.tensor(self.num_points)}
+
+    def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, torch.Tensor]:
+        """SplatfactoModel.get_loss_dict [recall, SURVEY 8a/A8]: (1-l)*L1 + l*(1-SSIM), l = 0.2."""
+        gt = batch["image"].to(self.device)
+        pred = outputs["rgb"]
+        l1 = (gt - pred).abs().mean()
+        ssim = _ssim(gt.permute(2, 0, 1)[None], pred.permute(2, 0, 1)[None])
+        lam = self.config.ssim_lambda
+        return {"main_loss": (1 - lam) * l1 + lam * (1 - ssim)}
+
+
+def _ssim(a, b, window=11, sigma=1.5):
+    """pytorch_msssim / torchmetrics-style SSIM with a gaussian 11x11 window (host framework loss; 8f-1 'next')."""
+    import torch.nn.functional as F
+    coords = torch.arange(window, dtype=a.dtype, device=a.device) - window // 2
+    g = torch.exp(-(coords ** 2) / (2 * sigma ** 2)); g = (g / g.sum())
+    k = (g[:, None] * g[None, :])[None, None].expand(a.shape[1], 1, window, window)
+    mu = lambda x: F.conv2d(x, k, padding=window // 2, groups=x.shape[1])
+    ma, mb = mu(a), mu(b)
+    va, vb, cab = mu(a * a) - ma * ma, mu(b * b) - mb * mb, mu(a * b) - ma * mb
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    return (((2 * ma * mb + c1) * (2 * cab + c2)) / ((ma * ma + mb * mb + c1) * (va + vb + c2))).mean()

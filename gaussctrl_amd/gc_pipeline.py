@@ -1,0 +1,271 @@
+"""GaussCtrlPipeline: drop-in for /root/reference/gaussctrl/gc_pipeline.py on the HIP kernels.
+
+Same surface: ctor (config, device, test_mode, world_size, local_rank, grad_scaler); attributes
+datamanager / model / _model / test_mode / config.render_rate; methods render_reverse() (:122-157),
+edit_images() (:159-237), image2latent (:239-246), depth2disparity (:248-266), update_datasets (:268-274),
+get_train_loss_dict(step) (:276-287); forward() raises (:289-291).  Config flags of :48-73 keep their names.
+
+What is done differently (results identical up to arithmetic precision):
+  * every tensor stays on the GPU between the phases (the reference stages through CPU numpy, :268-274,186-204);
+  * DDIM inversion of all views is batched (the reference runs batch 1 x V, :124-145);
+  * the 4 reference views' denoise trajectory runs ONCE per scene and its per-layer K / V^T are cached
+    (the reference re-denoises and re-decodes the references in every chunk and discards them, :206-219);
+  * with world_size > 1 the views are sharded over ranks (view v belongs to rank v % world_size), the reference
+    K / V cache is replicated (no data-path collective) and the edited images are all-gathered at the end so every
+    rank trains on the full edited set (the reference's `pipe_device = 'cuda:0'` cannot shard at all, :96,102).
+"""
+from __future__ import annotations
+
+import random
+from dataclasses import dataclass, field
+from typing import Literal, Optional
+
+import torch
+from torch import nn
+
+from .gc_model import GaussCtrlModel, GaussCtrlModelConfig
+from .ns_compat import Cameras
+from .sd import arch, ops as sdops
+from .sd.pipeline import DenoisePipeline, to_nhwc8
+from .sd.vae import VAEEncoder, prepare_vae_encoder_weights, prepare_vae_weights
+from .sd.weights import prepare
+
+
+@dataclass
+class GaussCtrlDataManagerConfig:
+    """gc_datamanager.py:54-66"""
+    subset_num: int = 4
+    sampled_views_every_subset: int = 10
+    load_all: bool = False
+
+
+class SimpleDataManager:
+    """Minimal stand-in for GaussCtrlDataManager (host I/O is out of scope): holds `cameras`
+    and the `train_data` list of dicts the pipeline reads and writes (image, unedited_image, depth_image, z_0_image,
+    mask_image, image_idx) and yields (camera, batch) like next_train (gc_datamanager.py:213-235)."""
+
+    def __init__(self, cameras: Cameras, images=None, seed: int = 0):
+        self.cameras = cameras
+        n = len(cameras)
+        self.train_data = [{"image_idx": i, "image": None if images is None else images[i]} for i in range(n)]
+        self._rng = random.Random(seed)
+        self._unseen = list(range(n))
+
+    def next_train(self, step: int):
+        if not self._unseen:
+            self._unseen = list(range(len(self.cameras)))
+        i = self._unseen.pop(self._rng.randint(0, len(self._unseen) - 1))
+        return self.cameras[i], dict(self.train_data[i])
+
+
+@dataclass
+class GaussCtrlPipelineConfig:
+    """gc_pipeline.py:48-73 (names and defaults kept)."""
+    datamanager: GaussCtrlDataManagerConfig = field(default_factory=GaussCtrlDataManagerConfig)
+    model: GaussCtrlModelConfig = field(default_factory=GaussCtrlModelConfig)
+    render_rate: int = 500
+    edit_prompt: str = ""
+    reverse_prompt: str = ""
+    langsam_obj: str = ""
+    guidance_scale: float = 5
+    num_inference_steps: int = 20
+    chunk_size: int = 5
+    ref_view_num: int = 4
+    diffusion_ckpt: str = "CompVis/stable-diffusion-v1-4"
+    # --- additions of this implementation
+    dtype: str = "f16"                 # the reference runs fp16 (:101); "bf16" is the throughput default of bench.py
+    cache_reference_kv: bool = True
+
+    def setup(self, **kw):
+        return GaussCtrlPipeline(self, **kw)
+
+
+class GaussCtrlPipeline(nn.Module):
+    config: GaussCtrlPipelineConfig
+
+    def __init__(self, config: GaussCtrlPipelineConfig, device: str, test_mode: Literal["test", "val", "inference"] = "val",
+                 world_size: int = 1, local_rank: int = 0, grad_scaler=None, *, datamanager=None, model=None,
+                 diffusion_weights: Optional[dict] = None, text_encoder=None, mask_fn=None):
+        super().__init__()
+        self.config = config
+        self.device = torch.device(device)
+        self.test_mode = test_mode
+        self.world_size, self.local_rank = world_size, local_rank
+        self.datamanager = datamanager
+        self._model = model
+        self.edit_prompt, self.reverse_prompt = config.edit_prompt, config.reverse_prompt
+        added_prompt = "best quality, extremely detailed"                                        # :104-107
+        self.positive_prompt = self.edit_prompt + ", " + added_prompt
+        self.positive_reverse_prompt = self.reverse_prompt + ", " + added_prompt
+        self.negative_prompts = ("longbody, lowres, bad anatomy, bad hands, missing fingers, extra digit, fewer digits, "
+                                 "cropped, worst quality, low quality")
+        view_num = len(self.datamanager.cameras)                                                # :109-114
+        anchors = [(view_num * i) // config.ref_view_num for i in range(config.ref_view_num)] + [view_num]
+        random.seed(13789)
+        # the reference's randint upper bound is inclusive and can return view_num: clamp
+        self.ref_indices = [min(random.randint(a, anchors[i + 1]), view_num - 1) for i, a in enumerate(anchors[:-1])]
+        self.num_ref_views = len(self.ref_indices)
+        if self.num_ref_views != 4:
+            raise ValueError("the reference's attention processor hard-wires exactly 4 reference views (utils.py:95-102)")
+        self.num_inference_steps, self.guidance_scale = config.num_inference_steps, config.guidance_scale
+        self.controlnet_conditioning_scale, self.eta, self.chunk_size = 1.0, 0.0, config.chunk_size
+        self.dtype = torch.float16 if config.dtype == "f16" else torch.bfloat16
+        w = diffusion_weights or {}
+        dev = self.device
+
+        def get(name, shapes, seed):
+            sd = w.get(name)
+            if sd is None:      # no checkpoint available (no network): seeded random weights of the exact shapes
+                sd = arch.random_state_dict(shapes, seed, dev)
+            else:
+                arch.check_state_dict(sd, shapes)
+            return sd
+        self.pipe = DenoisePipeline(prepare(get("unet", arch.unet_shapes(), 100), self.dtype, dev),
+                                    prepare(get("controlnet", arch.controlnet_shapes(), 200), self.dtype, dev),
+                                    prepare_vae_weights(get("vae_decoder", arch.vae_decoder_shapes(), 300), self.dtype, dev),
+                                    self.num_inference_steps, self.guidance_scale, self.controlnet_conditioning_scale)
+        self.vae_encoder = VAEEncoder(prepare_vae_encoder_weights(get("vae_encoder", arch.vae_encoder_shapes(), 400), self.dtype, dev))
+        self.text_encoder = text_encoder or _hash_text_encoder     # CLIP text tower is outside the hot path
+        self.mask_fn = mask_fn                                     # LangSAM stand-in: image[H,W,3] -> mask[H,W] (out of scope)
+
+    @property
+    def model(self):
+        return self._model
+
+    def _encode(self, prompt):
+        return self.text_encoder(prompt).to(self.device)
+
+    def _my_views(self):
+        n = len(self.datamanager.cameras)
+        return [i for i in range(n) if i % self.world_size == self.local_rank]
+
+    # ------------------------------------------------------------------------------------ :122-157
+    @torch.no_grad()
+    def render_reverse(self, views=None):
+        """Render rgb + depth of every (local) view and DDIM-invert the renders to z_0 (batched)."""
+        views = self._my_views() if views is None else list(views)
+        td = self.datamanager.train_data
+        for cam_idx in views:
+            out = self._model.get_outputs_for_camera(self.datamanager.cameras[cam_idx])
+            td[cam_idx]["unedited_image"] = out["rgb"]                        # [H,W,3] fp32, stays on the GPU
+            td[cam_idx]["depth_image"] = out["depth"][..., 0]                 # [H,W]
+            if self.config.langsam_obj != "" and self.mask_fn is not None:
+                td[cam_idx]["mask_image"] = self.mask_fn(out["rgb"], self.config.langsam_obj)
+        ctx = self._encode(self.positive_reverse_prompt)
+        for s in range(0, len(views), max(self.chunk_size, 1)):
+            chunk = views[s:s + max(self.chunk_size, 1)]
+            lat0 = torch.cat([self.image2latent(td[i]["unedited_image"]) for i in chunk], 0)
+            disp = torch.stack([self.depth2disparity_torch(td[i]["depth_image"]) for i in chunk])
+            z0 = self.pipe.invert(lat0, disp, ctx)                            # guidance_scale=0 -> no CFG batch (:142-145)
+            for j, i in enumerate(chunk):
+                td[i]["z_0_image"] = z0[j:j + 1]
+
+    # ------------------------------------------------------------------------------------ :159-237
+    @torch.no_grad()
+    def edit_images(self):
+        """Chunked cross-view ControlNet denoise of the (local) views; writes train_data[i]['image'] (HWC fp32)."""
+        td = self.datamanager.train_data
+        cn, cp = self._encode(self.negative_prompts), self._encode(self.positive_prompt)
+        ref_z0 = torch.cat([td[i]["z_0_image"] for i in self.ref_indices], 0) if all("z_0_image" in td[i] for i in self.ref_indices) else None
+        if ref_z0 is None:
+            raise RuntimeError("reference views must be rendered/inverted on every rank (render_reverse with world_size>1 shards "
+                               "views; call render_reverse_refs first)")
+        ref_disp = torch.stack([self.depth2disparity_torch(td[i]["depth_image"]) for i in self.ref_indices])
+        bank = self.pipe.build_ref_bank(ref_z0, ref_disp, cn, cp) if self.config.cache_reference_kv else None
+        views = self._my_views()
+        for s in range(0, len(views), self.chunk_size):
+            chunk = views[s:s + self.chunk_size]
+            lat = torch.cat([td[i]["z_0_image"] for i in chunk], 0)
+            disp = torch.stack([self.depth2disparity_torch(td[i]["depth_image"]) for i in chunk])
+            if bank is not None:
+                out = self.pipe.edit_chunk_cached(lat, disp, cn, cp, bank)
+            else:                                                             # reference order: refs first (:206-207), drop them (:219)
+                out = self.pipe.edit_chunk(torch.cat([ref_z0, lat]), torch.cat([ref_disp, disp]), cn, cp)[self.num_ref_views:]
+            z = to_nhwc8(out / 0.18215, self.dtype)
+            imgs = self.pipe.vae.decode(z, postprocess=True)                  # [c,H,W,8] fp32, channels 0..2 in [0,1]
+            for j, i in enumerate(chunk):
+                mask = td[i].get("mask_image")
+                td[i]["image"] = sdops.mask_composite(imgs[j], td[i]["unedited_image"] if mask is not None else None,
+                                                      None if mask is None else mask.float())        # :226-234
+        if self.world_size > 1:
+            self._allgather_images()
+
+    def render_reverse_refs(self):
+        """world_size > 1: every rank needs the 4 reference views' z_0 / depth (cheap to recompute locally)."""
+        td = self.datamanager.train_data
+        self.render_reverse([i for i in self.ref_indices if "z_0_image" not in td[i]])
+
+    def _allgather_images(self):
+        import torch.distributed as dist
+        td = self.datamanager.train_data
+        n = len(td)
+        H, W = td[self._my_views()[0]]["image"].shape[:2]
+        per = (n + self.world_size - 1) // self.world_size
+        mine = torch.zeros(per, H, W, 3, device=self.device)
+        for j, i in enumerate(self._my_views()):
+            mine[j] = td[i]["image"]
+        allb = [torch.empty_like(mine) for _ in range(self.world_size)]
+        dist.all_gather(allb, mine)
+        for r in range(self.world_size):
+            for j, i in enumerate(range(r, n, self.world_size)):
+                td[i]["image"] = allb[r][j]
+
+    # ------------------------------------------------------------------------------------ :239-274
+    @torch.no_grad()
+    def image2latent(self, image):
+        """image [H,W,3] in [0,1] -> latents [1,4,H/8,W/8] = vae.encode(2x-1).mean * 0.18215"""
+        x = to_nhwc8((image * 2 - 1).permute(2, 0, 1)[None], self.dtype)
+        mean = self.vae_encoder.encode_mean(x)[..., :4]
+        return (mean * 0.18215).permute(0, 3, 1, 2).contiguous()
+
+    def depth2disparity_torch(self, depth):
+        """depth [H,W] (or [1,H,W]) -> disparity [3,H,W] fp32 = 1/(d+1e-5)/max (:258-266)"""
+        d = depth.reshape(depth.shape[-2], depth.shape[-1]).float()
+        disp = sdops.depth_to_disparity(d, self.dtype)[..., :3]
+        return disp.permute(2, 0, 1).float()
+
+    depth2disparity = depth2disparity_torch
+
+    def update_datasets(self, cam_idx, unedited_image, depth, latent, mask):
+        td = self.datamanager.train_data[cam_idx]
+        td["unedited_image"], td["depth_image"], td["z_0_image"] = unedited_image, depth, latent
+        if mask is not None:
+            td["mask_image"] = mask
+
+    # ------------------------------------------------------------------------------------ :276-291
+    def get_train_loss_dict(self, step: int):
+        camera, batch = self.datamanager.next_train(step)
+        model_outputs = self._model(camera)
+        metrics_dict = self._model.get_metrics_dict(model_outputs, batch)
+        loss_dict = self._model.get_loss_dict(model_outputs, batch, metrics_dict)
+        if self.world_size > 1:                 # gradient reduction happens after backward: see reduce_gradients()
+            pass
+        return model_outputs, loss_dict, metrics_dict
+
+    def reduce_gradients(self):
+        """world_size > 1: one RCCL all-reduce of the N x 59 fp32 Gaussian gradients (collective 2)."""
+        if self.world_size <= 1:
+            return
+        import torch.distributed as dist
+        grads = [p.grad for p in self._model.parameters() if p.grad is not None]
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat)
+        flat /= self.world_size
+        o = 0
+        for g in grads:
+            g.copy_(flat[o:o + g.numel()].view_as(g)); o += g.numel()
+
+    def get_param_groups(self):
+        return self._model.get_param_groups()
+
+    def forward(self):
+        """Not implemented since we only want the parameter saving of the nn module, but not forward()"""
+        raise NotImplementedError
+
+
+def _hash_text_encoder(prompt: str) -> torch.Tensor:
+    """Deterministic synthetic [1,77,768] embedding of a prompt (stand-in when no CLIP weights are available)."""
+    import hashlib
+    seed = int.from_bytes(hashlib.sha256(prompt.encode()).digest()[:4], "little")
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(1, 77, 768, generator=g)

@@ -133,6 +133,27 @@ def vae_decoder_shapes(cfg=VAE_CFG) -> dict:
     return s
 
 
+def vae_encoder_shapes(cfg=VAE_CFG) -> dict:
+    s = {}
+    boc = cfg["block_out_channels"]; lc = cfg["latent_channels"]
+    _conv(s, "encoder.conv_in", 3, boc[0], 3)
+    prev = boc[0]
+    for i, cout in enumerate(boc):
+        for j in range(cfg["layers_per_block"]):
+            _resnet(s, f"encoder.down_blocks.{i}.resnets.{j}", prev, cout, 0); prev = cout
+        if i < len(boc) - 1:
+            _conv(s, f"encoder.down_blocks.{i}.downsamplers.0.conv", cout, cout, 3)
+    _resnet(s, "encoder.mid_block.resnets.0", boc[-1], boc[-1], 0)
+    a = "encoder.mid_block.attentions.0"
+    _norm(s, a + ".group_norm", boc[-1])
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        _lin(s, f"{a}.{n}", boc[-1], boc[-1])
+    _resnet(s, "encoder.mid_block.resnets.1", boc[-1], boc[-1], 0)
+    _norm(s, "encoder.conv_norm_out", boc[-1]); _conv(s, "encoder.conv_out", boc[-1], 2 * lc, 3)
+    _conv(s, "quant_conv", 2 * lc, 2 * lc, 1)
+    return s
+
+
 def random_state_dict(shapes: dict, seed: int, device, zero_conv_std: float = 0.02) -> dict:
     """PyTorch-default-like init (uniform +-1/sqrt(fan_in)); norm affine ~ (1, 0) + noise; ControlNet zero-convs
     N(0, 0.02^2) so residuals are non-trivial.  fp32 tensors on `device`."""

@@ -17,7 +17,7 @@ class GemmDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("mode", C.c_int), ("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64),
                 ("A", C.c_void_p), ("lda", C.c_int64),
                 ("B", C.c_int), ("Hi", C.c_int), ("Wi", C.c_int), ("Cin", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int),
-                ("stride", C.c_int), ("upsample", C.c_int),
+                ("stride", C.c_int), ("upsample", C.c_int), ("pad_lo", C.c_int),
                 ("W", C.c_void_p), ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("ld_rowvec", C.c_int64),
                 ("rows_per_batch", C.c_int64), ("residual", C.c_void_p), ("ldr", C.c_int64), ("out_scale", C.c_float),
                 ("act", C.c_int), ("geglu", C.c_int), ("out", C.c_void_p), ("ldc", C.c_int64), ("out_f32", C.c_int),
@@ -90,18 +90,20 @@ def linear(x, w, bias=None, residual=None, act=0, geglu=False, out_f32=False, sc
 
 
 def conv3x3(x, w, bias=None, stride=1, upsample=False, rowvec=None, ld_rowvec=None, residual=None, act=0, scale=1.0,
-            out_f32=False):
+            out_f32=False, pad_lo=1):
     """x [B,H,W,Cin] NHWC, w [N, 9*Cin] ((tap, cin) order), pad 1."""
     _gpu(x, w)
     B, H, W_, Cin = x.shape
     Hin, Win = (2 * H, 2 * W_) if upsample else (H, W_)
-    Ho, Wo = (Hin + 2 - 3) // stride + 1, (Win + 2 - 3) // stride + 1
+    # pad_lo=1: Conv2d(padding=1); pad_lo=0: F.pad(x,(0,1,0,1)) + Conv2d(padding=0) (VAE encoder downsample)
+    Ho, Wo = (Hin + pad_lo + 1 - 3) // stride + 1, (Win + pad_lo + 1 - 3) // stride + 1
     N = w.shape[0]
     out = torch.empty(B, Ho, Wo, N, dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
     d = GemmDesc()
     d.dtype = _dt(x); d.mode = 1; d.M, d.N, d.K = B * Ho * Wo, N, 9 * Cin
     d.A = x.data_ptr(); d.lda = Cin
     d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.stride, d.upsample = B, H, W_, Cin, Ho, Wo, stride, int(upsample)
+    d.pad_lo = pad_lo
     d.W = w.data_ptr(); d.bias = None if bias is None else bias.data_ptr()
     if rowvec is not None:
         d.rowvec = rowvec.data_ptr(); d.ld_rowvec = rowvec.stride(0) if ld_rowvec is None else ld_rowvec
@@ -208,3 +210,29 @@ def cfg_ddim_step(eps, latents, xin, guidance, cfg, alpha_t, alpha_prev, nrep):
     L.check(L.lib().gc_dn_cfg_ddim_step(_dt(xin), _p(eps), eps.shape[-1], C.c_int64(f), C.c_int64(HW), C.c_float(guidance),
                                         int(cfg), C.c_float(alpha_t), C.c_float(alpha_prev), _p(latents), _p(xin), nrep,
                                         _stream()), "gc_dn_cfg_ddim_step")
+
+
+_disp_ws = {}
+
+
+def depth_to_disparity(depth, dtype):
+    """depth fp32 [H,W] -> disparity [H,W,8] (3 used) in the activation dtype: 1/(d+1e-5) / max (gc_pipeline.py:258-266)."""
+    _gpu(depth)
+    ws = _disp_ws.get(depth.device)
+    if ws is None:
+        ws = _disp_ws[depth.device] = torch.zeros(1, dtype=torch.int32, device=depth.device)
+    d = depth.contiguous()
+    out = torch.empty(d.shape[0], d.shape[1], 8, dtype=dtype, device=d.device)
+    L.check(L.lib().gc_dn_depth_to_disparity(DT[dtype], _p(d), C.c_int64(d.numel()), _p(out), _p(ws), _stream()),
+            "gc_dn_depth_to_disparity")
+    return out
+
+
+def mask_composite(edited_hwc, unedited_hwc=None, mask_hw=None):
+    """edited fp32 [H,W,C>=3] (channels-last), unedited fp32 [H,W,3], mask fp32 [H,W] -> fp32 [H,W,3] (gc_pipeline.py:226-234)."""
+    _gpu(edited_hwc, unedited_hwc, mask_hw)
+    H, W = edited_hwc.shape[0], edited_hwc.shape[1]
+    out = torch.empty(H, W, 3, dtype=torch.float32, device=edited_hwc.device)
+    L.check(L.lib().gc_dn_mask_composite(_p(edited_hwc), edited_hwc.shape[-1], _p(unedited_hwc), _p(mask_hw), _p(out),
+                                         C.c_int64(H * W), _stream()), "gc_dn_mask_composite")
+    return out

@@ -72,6 +72,43 @@ class VAEDecoder:
         return ops.conv3x3(x, w["decoder.conv_out.weight"], w["decoder.conv_out.bias"], out_f32=True, act=2 if postprocess else 0)
 
 
+class VAEEncoder(VAEDecoder):
+    """AutoencoderKL.encode(x).latent_dist.mean -- image2latent of the reference (gc_pipeline.py:239-246)."""
+
+    def __init__(self, weights: dict, cfg: dict = CFG_VAE):
+        self.w = weights
+        self.cfg = cfg
+        self.dtype = weights["encoder.conv_in.weight"].dtype
+
+    def mid_attention(self, x):
+        # same block as the decoder's, under the encoder prefix
+        w = dict((k.replace("encoder.mid_block", "decoder.mid_block"), v) for k, v in self.w.items() if k.startswith("encoder.mid_block.attentions"))
+        saved, self.w = self.w, {**self.w, **w}
+        try:
+            return VAEDecoder.mid_attention(self, x)
+        finally:
+            self.w = saved
+
+    def encode_mean(self, img):
+        """img [B,H,W,8] activation dtype, channels 0..2 in [-1,1] -> latent mean fp32 [B,H/8,W/8,8] (4 valid), NOT yet
+        multiplied by 0.18215."""
+        w = self.w
+        x = ops.conv3x3(img, w["encoder.conv_in.weight"], w["encoder.conv_in.bias"])
+        n = len(self.cfg["block_out_channels"])
+        for i in range(n):
+            for j in range(self.cfg["layers_per_block"]):
+                x = self.resnet(f"encoder.down_blocks.{i}.resnets.{j}", x)
+            if i < n - 1:
+                p = f"encoder.down_blocks.{i}.downsamplers.0.conv"
+                x = ops.conv3x3(x, w[p + ".weight"], w[p + ".bias"], stride=2, pad_lo=0)     # F.pad(0,1,0,1) + stride-2 conv
+        x = self.resnet("encoder.mid_block.resnets.0", x)
+        x = self.mid_attention(x)
+        x = self.resnet("encoder.mid_block.resnets.1", x)
+        x = ops.groupnorm(x, w["encoder.conv_norm_out.weight"], w["encoder.conv_norm_out.bias"], self.cfg["groups"], 1e-6, True)
+        x = ops.conv3x3(x, w["encoder.conv_out.weight"], w["encoder.conv_out.bias"])          # [.., 8] = mean(4) | logvar(4)
+        return ops.linear(x, w["quant_conv.weight"], w["quant_conv.bias"], out_f32=True)
+
+
 def prepare_vae_weights(sd: dict, dtype, device) -> dict:
     """post_quant_conv is a 4->4 1x1 conv: pad it to 8->8 so it runs on the 8-channel latent layout."""
     from .weights import prepare
@@ -82,3 +119,8 @@ def prepare_vae_weights(sd: dict, dtype, device) -> dict:
     bq[:4] = out["post_quant_conv.bias"]
     out["post_quant_conv.weight"], out["post_quant_conv.bias"] = wq, bq
     return out
+
+
+def prepare_vae_encoder_weights(sd: dict, dtype, device) -> dict:
+    from .weights import prepare
+    return prepare(sd, dtype, device)

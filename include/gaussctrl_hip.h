@@ -163,6 +163,7 @@ typedef struct gc_gemm_desc {
     const void *A;
     int64_t lda;
     int B, Hi, Wi, Cin, Ho, Wo, stride, upsample;   /* upsample=1: nearest x2 of the input fused into the loader */
+    int pad_lo;                /* top/left zero padding: 1 (Conv2d padding=1) or 0 (VAE encoder Downsample2D: pad (0,1,0,1), stride 2) */
     const void *W;             /* [N][K] */
     const float *bias;         /* [N] or NULL */
     const float *rowvec;       /* [M / rows_per_batch][ld_rowvec] or NULL (time-embedding add of ResnetBlock2D) */
@@ -225,6 +226,13 @@ int gc_dn_softmax_rows(int dtype, void *s, int64_t M, int64_t N, int64_t ld, flo
 /* CFG combine + DDIM / inverse-DDIM step (eta = 0) + re-pack of the next UNet input (pipeline `cat([latents]*2)`):
  * eps float32 [cfg ? 2f : f][HW][ld_eps], latents float32 [f][HW][4] (updated in place),
  * xin dtype [nrep*f][HW][8].  alpha_t / alpha_prev are the two alphas_cumprod of the step. */
+/* depth2disparity_torch (gaussctrl/gc_pipeline.py:258-266): out[HW][8] (channels 0..2 = 1/(d+1e-5) / max, 3..7 = 0).
+ * max_ws: device uint32[1] scratch. */
+int gc_dn_depth_to_disparity(int dtype, const float *depth, int64_t HW, void *out, unsigned *max_ws, void *stream);
+/* mask compositing of edit_images (gaussctrl/gc_pipeline.py:226-234): out[HW][3] f32 = edited*mask + unedited*(1-mask);
+ * edited f32 [HW][ld_e] (channels-last, 3 used), unedited f32 [HW][3], mask f32 [HW] or NULL (copy). */
+int gc_dn_mask_composite(const float *edited, int ld_e, const float *unedited, const float *mask, float *out, int64_t HW,
+                         void *stream);
 int gc_dn_cfg_ddim_step(int dtype, const float *eps, int ld_eps, int64_t frames, int64_t HW, float guidance, int cfg,
                         float alpha_t, float alpha_prev, float *latents, void *xin, int nrep, void *stream);
 

@@ -345,6 +345,53 @@ def vae_decode(w, z, cfg=VAE_SD):
     return _conv(w, "decoder.conv_out", x)
 
 
+def make_vae_encoder_weights(cfg=VAE_SD, seed=400):
+    I = _Init(seed)
+    boc = cfg["block_out_channels"]; lc = cfg["latent_channels"]
+    I.conv("encoder.conv_in", 3, boc[0], 3)
+    prev = boc[0]
+    for i, cout in enumerate(boc):
+        for j in range(cfg["layers_per_block"]):
+            I.resnet(f"encoder.down_blocks.{i}.resnets.{j}", prev, cout, 0); prev = cout
+        if i < len(boc) - 1:
+            I.conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", cout, cout, 3)
+    I.resnet("encoder.mid_block.resnets.0", boc[-1], boc[-1], 0)
+    a = "encoder.mid_block.attentions.0"
+    I.norm(a + ".group_norm", boc[-1])
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        I.linear(f"{a}.{n}", boc[-1], boc[-1])
+    I.resnet("encoder.mid_block.resnets.1", boc[-1], boc[-1], 0)
+    I.norm("encoder.conv_norm_out", boc[-1]); I.conv("encoder.conv_out", boc[-1], 2 * lc, 3)
+    I.conv("quant_conv", 2 * lc, 2 * lc, 1)
+    return I.w
+
+
+def vae_encode_mean(w, img, cfg=VAE_SD):
+    """AutoencoderKL.encode(img)['latent_dist'].mean (gc_pipeline.py:244) for img in [-1,1], [B,3,H,W]."""
+    g = cfg["groups"]
+    x = _conv(w, "encoder.conv_in", img)
+    n = len(cfg["block_out_channels"])
+    for i in range(n):
+        for j in range(cfg["layers_per_block"]):
+            x = resnet(w, f"encoder.down_blocks.{i}.resnets.{j}", x, None, g, 1e-6)
+        if i < n - 1:
+            x = F.pad(x, (0, 1, 0, 1))                       # diffusers Downsample2D(padding=0) of the VAE encoder
+            x = _conv(w, f"encoder.down_blocks.{i}.downsamplers.0.conv", x, stride=2, pad=0)
+    x = resnet(w, "encoder.mid_block.resnets.0", x, None, g, 1e-6)
+    a = "encoder.mid_block.attentions.0"
+    B, C, H, W = x.shape
+    h = _gn(w, a + ".group_norm", x, g, 1e-6).reshape(B, C, H * W).transpose(1, 2)
+    q = h @ w[a + ".to_q.weight"].T + w[a + ".to_q.bias"]
+    k = h @ w[a + ".to_k.weight"].T + w[a + ".to_k.bias"]
+    v = h @ w[a + ".to_v.weight"].T + w[a + ".to_v.bias"]
+    o = plain_attention(q, k, v, 1) @ w[a + ".to_out.0.weight"].T + w[a + ".to_out.0.bias"]
+    x = x + o.transpose(1, 2).reshape(B, C, H, W)
+    x = resnet(w, "encoder.mid_block.resnets.1", x, None, g, 1e-6)
+    x = F.silu(_gn(w, "encoder.conv_norm_out", x, g, 1e-6))
+    moments = _conv(w, "quant_conv", _conv(w, "encoder.conv_out", x))
+    return moments[:, : cfg["latent_channels"]]
+
+
 # =========================================================================================== scheduler
 class DDIM:
     """DDIMScheduler / DDIMInverseScheduler arithmetic for SD1.x scheduler_config:
