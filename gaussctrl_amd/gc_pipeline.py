@@ -136,8 +136,8 @@ class GaussCtrlPipeline(nn.Module):
         return self.text_encoder(prompt).to(self.device)
 
     def _my_views(self):
-        n = len(self.datamanager.cameras)
-        return [i for i in range(n) if i % self.world_size == self.local_rank]
+        from .dist import shard_views
+        return shard_views(len(self.datamanager.cameras), self.world_size, self.local_rank)
 
     # ------------------------------------------------------------------------------------ :122-157
     @torch.no_grad()
@@ -196,19 +196,13 @@ class GaussCtrlPipeline(nn.Module):
         self.render_reverse([i for i in self.ref_indices if "z_0_image" not in td[i]])
 
     def _allgather_images(self):
-        import torch.distributed as dist
+        from .dist import allgather_view_images
         td = self.datamanager.train_data
-        n = len(td)
-        H, W = td[self._my_views()[0]]["image"].shape[:2]
-        per = (n + self.world_size - 1) // self.world_size
-        mine = torch.zeros(per, H, W, 3, device=self.device)
-        for j, i in enumerate(self._my_views()):
-            mine[j] = td[i]["image"]
-        allb = [torch.empty_like(mine) for _ in range(self.world_size)]
-        dist.all_gather(allb, mine)
-        for r in range(self.world_size):
-            for j, i in enumerate(range(r, n, self.world_size)):
-                td[i]["image"] = allb[r][j]
+        mine = self._my_views()
+        shape = td[mine[0]]["image"].shape
+        allv = allgather_view_images({i: td[i]["image"] for i in mine}, len(td), self.world_size, self.local_rank, shape, self.device)
+        for i, img in allv.items():
+            td[i]["image"] = img
 
     # ------------------------------------------------------------------------------------ :239-274
     @torch.no_grad()
@@ -244,16 +238,8 @@ class GaussCtrlPipeline(nn.Module):
 
     def reduce_gradients(self):
         """world_size > 1: one RCCL all-reduce of the N x 59 fp32 Gaussian gradients (collective 2)."""
-        if self.world_size <= 1:
-            return
-        import torch.distributed as dist
-        grads = [p.grad for p in self._model.parameters() if p.grad is not None]
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat)
-        flat /= self.world_size
-        o = 0
-        for g in grads:
-            g.copy_(flat[o:o + g.numel()].view_as(g)); o += g.numel()
+        from .dist import allreduce_gradients
+        allreduce_gradients(list(self._model.parameters()), self.world_size)
 
     def get_param_groups(self):
         return self._model.get_param_groups()

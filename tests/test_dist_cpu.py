@@ -1,0 +1,47 @@
+"""world_size-2 gloo tests (CPU) of the N>1 logic: view sharding, flat gradient all-reduce, image all-gather."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gaussctrl_amd.dist import allgather_view_images, allreduce_gradients, shard_views
+        n = 7
+        mine = shard_views(n, world, rank)
+        # gradients: each rank holds grad = rank+1 on differently shaped tensors
+        ps = [torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(5, 15, 3)), torch.nn.Parameter(torch.zeros(5, 1))]
+        for p in ps:
+            p.grad = torch.full_like(p, float(rank + 1))
+        ps.append(torch.nn.Parameter(torch.zeros(2)))           # no grad: skipped
+        allreduce_gradients(ps, world)
+        ok_grad = all(torch.allclose(p.grad, torch.full_like(p, sum(range(1, world + 1)) / world)) for p in ps[:3])
+        local = {v: torch.full((4, 6, 3), float(v)) for v in mine}
+        allv = allgather_view_images(local, n, world, rank, (4, 6, 3), "cpu")
+        ok_img = sorted(allv) == list(range(n)) and all(float(allv[v].mean()) == float(v) for v in range(n))
+        ret[rank] = (mine, ok_grad, ok_img)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_view_sharding_partitions():
+    from gaussctrl_amd.dist import shard_views
+    for n in (1, 7, 40, 80):
+        for w in (1, 2, 4, 8):
+            parts = [shard_views(n, w, r) for r in range(w)]
+            assert sorted(sum(parts, [])) == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_gloo_world2_collectives():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, 29000 + os.getpid() % 2000, ret), nprocs=world, join=True)
+    assert ret[0][0] == [0, 2, 4, 6] and ret[1][0] == [1, 3, 5]
+    assert all(ret[r][1] and ret[r][2] for r in range(world))
