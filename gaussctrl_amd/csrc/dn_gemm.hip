@@ -4,27 +4,33 @@
 // /root/reference/gaussctrl/gc_pipeline.py:142-145,209-219.
 //
 // out[m][n] = epilogue( sum_k Act[m][k] * W[n][k] ),  Act = row-major matrix (Linear / 1x1 conv on NHWC)
-// or the on-the-fly im2col of an NHWC tensor (3x3, pad 1, stride 1|2, optional fused nearest x2 upsample).
+// or the on-the-fly im2col of an NHWC tensor (3x3, pad 0|1, stride 1|2, optional fused nearest x2 upsample).
 //
-// CDNA4 mapping: 128(m) x 128(n) x 64(k) workgroup tile, 256 lanes = 4 wave64 in 2x2, each wave a
-// 64x64 sub-tile = 4x4 v_mfma_f32_16x16x32 accumulators (fp32).  Operands are staged global -> VGPR ->
-// LDS (16-byte chunks, XOR-swizzled so every ds_read_b128 fragment read is bank-conflict free), double
-// buffered with the next tile's global loads in flight under the MFMAs (one barrier per k-tile).
-// The MFMA is issued "swapped" (A operand = weights, B operand = activations) so each lane ends up
-// with 4 CONSECUTIVE output channels of one output row: bias / residual / GEGLU are lane-local and the
+// CDNA4 mapping: 128(m) x {128|160}(n) x 64(k) workgroup tile, 256 lanes = 4 wave64 in 2x2, each wave a
+// 64 x {64|80} sub-tile = 4 x {4|5} v_mfma_f32_16x16x32 accumulators (fp32).  160-wide n tiles exist because every
+// SD1.5 channel count (320/640/960/1280/1920/2560) is a multiple of 160 but not of 128.
+// Operands are staged global -> VGPR -> LDS in 16-byte chunks, XOR-swizzled so every ds_read_b128 fragment read is
+// bank-conflict free.  The k loop is software pipelined two tiles deep: while tile t is multiplied out of LDS
+// buffer t&1, tile t+1 sits in one register set (already landed or landing) and tile t+2's global loads are being
+// issued into the other -- the loop is otherwise bound by the ~1 us global->LDS->MFMA dependency chain per k-tile
+// (measured: 22 us for 20 k-tiles on an idle chip).  One barrier per k-tile.
+// The MFMA is issued "swapped" (A operand = weights, B operand = activations) so each lane ends up with 4
+// CONSECUTIVE output channels of one output row: bias / row-vector / residual / SiLU / GEGLU are lane-local and the
 // store is one 8-byte write per accumulator.
+// Small-M / long-K problems (3x3 convs on 16x16 / 8x8 feature maps: 12 / 3 m-tiles, 90-360 k-tiles) are split along K
+// across workgroups (fp32 partial slabs + a small reduce-epilogue kernel) so that all 256 CUs stream the (large) weight
+// matrix together.
 #include "dn_common.h"
 
 namespace {
 using namespace dn;
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BM = 128, BK = 64;
 constexpr int NT = 256;
 
 struct GemmArgs {
     int64_t M, N, K;
     const void *A; int64_t lda;
-    int mode;   // 0 linear, 1 conv3x3
     int B, Hi, Wi, Cin, Ho, Wo, stride, ups, pad;
     const void *W;
     const float *bias;
@@ -34,118 +40,241 @@ struct GemmArgs {
     int act, geglu;
     void *out; int64_t ldc; int out_f32;
     void *out_t; int64_t ldt; int64_t t_batch_stride;
+    int splits; int tiles_per_split;    // split-K: k-tiles [z*tps, min(nk, (z+1)*tps))
+    float *ws;                          // fp32 [M][N] accumulation workspace when splits > 1
 };
 
 // byte offset of 16-byte chunk `c` (0..7) of row `r` inside a [rows][64] 2-byte tile
 __device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
 
-template <class T, bool CONV>
-__global__ __launch_bounds__(NT) void k_gemm(const GemmArgs g)
+// epilogue of one lane's 4 consecutive output channels (n .. n+3) of row m; v = raw accumulators (+ gate for GEGLU)
+template <class T>
+__device__ __forceinline__ void epilogue_store(const GemmArgs &g, int64_t m, int64_t n, int64_t on, float *v, const float *gate)
 {
+    const int64_t bidx = g.rowvec ? m / g.rows_per_batch : 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (g.bias) v[r] += g.bias[n + r];
+        if (g.rowvec) v[r] += g.rowvec[bidx * g.ld_rowvec + n + r];
+    }
+    if (g.geglu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float gt = gate[r];
+            if (g.bias) gt += g.bias[n + 16 + r];
+            v[r] = v[r] * gelu_erf(gt);
+        }
+    }
+    if (g.act == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = silu(v[r]);
+    } else if (g.act == 2) {   // image post-process of pipe(output_type='pt'): (x/2 + 0.5).clamp(0,1)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r] * 0.5f + 0.5f, 0.f), 1.f);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] *= g.out_scale;
+    if (g.residual) {
+        const uint2 rr = *reinterpret_cast<const uint2 *>((const unsigned char *)g.residual + (m * g.ldr + on) * 2);
+        v[0] += T::to_f((unsigned short)(rr.x & 0xffff)); v[1] += T::to_f((unsigned short)(rr.x >> 16));
+        v[2] += T::to_f((unsigned short)(rr.y & 0xffff)); v[3] += T::to_f((unsigned short)(rr.y >> 16));
+    }
+    if (g.out) {
+        if (g.out_f32)
+            *reinterpret_cast<float4 *>((float *)g.out + m * g.ldc + on) = make_float4(v[0], v[1], v[2], v[3]);
+        else
+            *reinterpret_cast<uint2 *>((unsigned char *)g.out + (m * g.ldc + on) * 2) = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
+    }
+    if (g.out_t) {   // transposed copy out_t[b][n][tok] (V operand of the attention kernel)
+        const int64_t b = m / g.rows_per_batch, tok = m - b * g.rows_per_batch;
+        unsigned short *o = (unsigned short *)g.out_t + b * g.t_batch_stride + tok;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[(on + r) * g.ldt] = T::from_f(v[r]);
+    }
+}
+
+// MODE: 0 linear, 1 conv generic (any Cin % 8 == 0), 2 conv fast (Cin % 64 == 0: one tap per k-tile)
+// NTW : n-tiles (of 16) per wave: 4 -> BN = 128, 5 -> BN = 160
+template <class T, int MODE, int NTW>
+__global__ __launch_bounds__(NT, 2) void k_gemm(const GemmArgs g)
+{
+    constexpr int BN = 32 * NTW;
+    constexpr int WCH = BN * 8 / NT;            // W chunks per lane per k-tile (4 | 5)
+    constexpr int STAGE = BM * 128 + BN * 128;  // bytes per LDS stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // layout: [buf][Act 16 KiB | W 16 KiB]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
-    // XCD-aware tile order: consecutive workgroups on one XCD share the activation panel (same m-block)
     const int nbn = (int)((g.N + BN - 1) / BN);
-    // workgroup b runs on XCD b % 8: give each XCD a contiguous run of logical tiles (bijective remap)
+    // workgroup b runs on XCD b % 8: give each XCD a contiguous run of logical tiles (bijective remap) so the
+    // workgroups that share an activation panel share an L2
     const int64_t nwg = gridDim.x, xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
     const int64_t bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
     const int64_t mblk = bid / nbn, nblk = bid % nbn;
     const int64_t m_base = mblk * BM, n_base = nblk * BN;
+    const int nk = (int)((g.K + BK - 1) / BK);
+    const int kt0 = blockIdx.y * g.tiles_per_split, kt1 = min(nk, kt0 + g.tiles_per_split);
+    if (kt0 >= kt1) return;
 
-    // ---- per-thread staging coordinates: 4 chunks of Act and 4 chunks of W per k-tile
+    // ---- per-lane staging coordinates: 4 Act chunks + WCH W chunks per k-tile.  All per-lane address arithmetic is
+    // 32-bit element offsets from the (uniform) tensor bases; for the 3x3 fast path the offset of a chunk is
+    // pixel_offset(lane) + tap_offset(k-tile, uniform): one add and two compares per chunk.
     int a_row[4], a_chunk[4];
-    const unsigned char *a_ptr[4];      // linear: row base pointer (or null if row >= M)
-    int a_b[4], a_y[4], a_x[4];          // conv: output pixel
+    int a_off[4];                 // MODE 0: m*lda + chunk*8 ; MODE 1/2: b*Hi*Wi*Cin (+ chunk*8 [+ (y0*Wi+x0)*Cin when !ups])
+    int a_y[4], a_x[4];           // MODE 1/2: oy*stride - pad, ox*stride - pad
     bool a_ok[4];
-    const unsigned char *w_ptr[4];
-    bool w_ok[4];
+    int w_off[WCH];
+    bool w_ok[WCH];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int q = tid + NT * i;
         a_row[i] = q >> 3; a_chunk[i] = q & 7;
         const int64_t m = m_base + a_row[i];
         a_ok[i] = m < g.M;
-        if (CONV) {
-            const int64_t mm = a_ok[i] ? m : 0;
+        const int mm = a_ok[i] ? (int)m : 0;
+        if (MODE != 0) {
             const int hw = g.Ho * g.Wo;
-            a_b[i] = (int)(mm / hw);
-            const int rem = (int)(mm - (int64_t)a_b[i] * hw);
-            a_y[i] = rem / g.Wo; a_x[i] = rem - a_y[i] * g.Wo;
-            a_ptr[i] = nullptr;
+            const int b = mm / hw;
+            const int rem = mm - b * hw;
+            const int oy = rem / g.Wo;
+            a_y[i] = oy * g.stride - g.pad; a_x[i] = (rem - oy * g.Wo) * g.stride - g.pad;
+            a_off[i] = b * g.Hi * g.Wi * g.Cin + (MODE == 2 ? a_chunk[i] * 8 : 0);
+            if (MODE == 2 && !g.ups) a_off[i] += (a_y[i] * g.Wi + a_x[i]) * g.Cin;
         } else {
-            a_ptr[i] = (const unsigned char *)g.A + (a_ok[i] ? m : 0) * g.lda * 2;
+            a_off[i] = mm * (int)g.lda + a_chunk[i] * 8;
+            a_y[i] = a_x[i] = 0;
         }
-        const int64_t n = n_base + a_row[i];
+    }
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+        const int q = tid + NT * i;
+        const int64_t n = n_base + (q >> 3);
         w_ok[i] = n < g.N;
-        w_ptr[i] = (const unsigned char *)g.W + (w_ok[i] ? n : 0) * g.K * 2;
+        w_off[i] = (w_ok[i] ? (int)n : 0) * (int)g.K + (q & 7) * 8;
     }
     const int Hin = g.ups ? g.Hi * 2 : g.Hi, Win = g.ups ? g.Wi * 2 : g.Wi;
+    const unsigned char *Ab = (const unsigned char *)g.A, *Wb = (const unsigned char *)g.W;
+    const int ktl = kt1 - 1;
+    // loader state (wave-uniform): tap / channel offset of the NEXT k-tile to load (tiles are loaded in order)
+    int ld_tap = 0, ld_ci = 0;
+    if (MODE == 2) { ld_tap = (kt0 * BK) / g.Cin; ld_ci = kt0 * BK - ld_tap * g.Cin; }
 
-    uint4 ra[4], rw[4];
-    auto load_tile = [&](int kt) {
+    // Loads are UNCONDITIONAL (invalid lanes read offset 0 and are zeroed when the tile is written to LDS): no
+    // exec-mask branches around the global loads, so they stay in flight with counted s_waitcnt vmcnt(N).
+    auto load_tile = [&](int kt, uint4 *ra, uint4 *rw, unsigned &mask) __attribute__((always_inline)) {
+        const int kb = kt * BK;
+        int dy_u = 0, dx_u = 0, tap_off = 0;
+        if (MODE == 2) {
+            dy_u = ld_tap / 3; dx_u = ld_tap - dy_u * 3;
+            tap_off = g.ups ? ld_ci : (dy_u * g.Wi + dx_u) * g.Cin + ld_ci;
+            if (kt < ktl) { ld_ci += BK; if (ld_ci >= g.Cin) { ld_ci -= g.Cin; ++ld_tap; } }
+        }
+        unsigned mk = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int64_t k0 = (int64_t)kt * BK + a_chunk[i] * 8;
-            uint4 va = make_uint4(0, 0, 0, 0), vw = make_uint4(0, 0, 0, 0);
-            if (k0 < g.K) {
-                if (CONV) {
-                    const int tap = (int)(k0 / g.Cin);
-                    const int ci = (int)(k0 - (int64_t)tap * g.Cin);
-                    const int dy = tap / 3, dx = tap - dy * 3;
-                    int yi = a_y[i] * g.stride + dy - g.pad, xi = a_x[i] * g.stride + dx - g.pad;
-                    if (a_ok[i] && yi >= 0 && yi < Hin && xi >= 0 && xi < Win) {
-                        if (g.ups) { yi >>= 1; xi >>= 1; }
-                        const int64_t off = (((int64_t)a_b[i] * g.Hi + yi) * g.Wi + xi) * g.Cin + ci;
-                        va = *reinterpret_cast<const uint4 *>((const unsigned char *)g.A + off * 2);
-                    }
-                } else if (a_ok[i]) {
-                    va = *reinterpret_cast<const uint4 *>(a_ptr[i] + k0 * 2);
-                }
-                if (w_ok[i]) vw = *reinterpret_cast<const uint4 *>(w_ptr[i] + k0 * 2);
+            bool ok;
+            int off;
+            if (MODE == 2) {
+                int yi = a_y[i] + dy_u, xi = a_x[i] + dx_u;
+                ok = a_ok[i] && (unsigned)yi < (unsigned)Hin && (unsigned)xi < (unsigned)Win;
+                off = a_off[i] + tap_off;
+                if (g.ups) off += ((yi >> 1) * g.Wi + (xi >> 1)) * g.Cin;
+            } else if (MODE == 1) {
+                const int k0 = kb + a_chunk[i] * 8;
+                const int kc = k0 < (int)g.K ? k0 : 0;
+                const int tap = kc / g.Cin;
+                const int ci = kc - tap * g.Cin;
+                const int dy = tap / 3, dx = tap - dy * 3;
+                int yi = a_y[i] + dy, xi = a_x[i] + dx;
+                ok = a_ok[i] && k0 < (int)g.K && (unsigned)yi < (unsigned)Hin && (unsigned)xi < (unsigned)Win;
+                if (g.ups) { yi >>= 1; xi >>= 1; }
+                off = a_off[i] + (yi * g.Wi + xi) * g.Cin + ci;
+            } else {
+                ok = a_ok[i] && (kb + a_chunk[i] * 8) < (int)g.K;
+                off = a_off[i] + kb;
             }
-            ra[i] = va; rw[i] = vw;
+            ra[i] = *reinterpret_cast<const uint4 *>(Ab + (size_t)(unsigned)((ok ? off : 0) * 2));
+            mk |= (ok ? 1u : 0u) << i;
         }
-    };
-    auto store_tile = [&](int buf) {
-        unsigned char *sa = smem + buf * 32768, *sw = sa + 16384;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<uint4 *>(sa + lds_off(a_row[i], a_chunk[i])) = ra[i];
-            *reinterpret_cast<uint4 *>(sw + lds_off(a_row[i], a_chunk[i])) = rw[i];
+        for (int i = 0; i < WCH; ++i) {
+            const int q = tid + NT * i;
+            const bool ok = w_ok[i] && (kb + (q & 7) * 8) < (int)g.K;
+            rw[i] = *reinterpret_cast<const uint4 *>(Wb + (size_t)(unsigned)((ok ? w_off[i] + kb : 0) * 2));
+            mk |= (ok ? 1u : 0u) << (8 + i);
         }
+        mask = mk;
+    };
+    constexpr unsigned FULL = 0xFu | (((1u << WCH) - 1u) << 8);
+    int sa_off[4], sw_off[WCH];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sa_off[i] = lds_off(a_row[i], a_chunk[i]);
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) { const int q = tid + NT * i; sw_off[i] = BM * 128 + lds_off(q >> 3, q & 7); }
+    auto store_tile = [&](int buf, uint4 *ra, uint4 *rw, unsigned mask) __attribute__((always_inline)) {
+        unsigned char *sa = smem + buf * STAGE;
+        if (!__all(mask == FULL)) {   // border / tail tiles only: zero the lanes that read a clamped address
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {   // value-level masking (a ?: on the arrays would become a pointer select -> scratch)
+                const unsigned km = 0u - ((mask >> i) & 1u);
+                ra[i] = make_uint4(ra[i].x & km, ra[i].y & km, ra[i].z & km, ra[i].w & km);
+            }
+#pragma unroll
+            for (int i = 0; i < WCH; ++i) {
+                const unsigned km = 0u - ((mask >> (8 + i)) & 1u);
+                rw[i] = make_uint4(rw[i].x & km, rw[i].y & km, rw[i].z & km, rw[i].w & km);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4 *>(sa + sa_off[i]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) *reinterpret_cast<uint4 *>(sa + sw_off[i]) = rw[i];
     };
 
-    f32x4 acc[4][4];   // [nt][mt]
+    f32x4 acc[NTW][4];   // [nt][mt]
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < NTW; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = (int)((g.K + BK - 1) / BK);
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
     const int fr = lane & 15, fc = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
-        const unsigned char *sa = smem + buf * 32768, *sw = sa + 16384;
+    // fragment addresses: row = rowbase + 16 t + fr (rowbase % 16 == 0) => the swizzle term ((row >> 1) & 7) does not depend
+    // on t: address(t, ks) = base_ks + t * 2048 -- two VGPRs per operand, everything else is an immediate offset
+    const int swz = (fr >> 1) & 7;
+    const int fx0 = ((fc ^ swz) << 4), fx1 = (((fc + 4) ^ swz) << 4);
+    const int aw0 = BM * 128 + (wn * (16 * NTW) + fr) * 128, aa0 = (wm * 64 + fr) * 128;
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const unsigned char *sb = smem + buf * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            uint4 fw[4], fa[4];
+            const int fx = ks ? fx1 : fx0;
+            uint4 fw[NTW], fa[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                fw[t] = *reinterpret_cast<const uint4 *>(sw + lds_off(wn * 64 + t * 16 + fr, ks * 4 + fc));
-                fa[t] = *reinterpret_cast<const uint4 *>(sa + lds_off(wm * 64 + t * 16 + fr, ks * 4 + fc));
-            }
+            for (int t = 0; t < NTW; ++t) fw[t] = *reinterpret_cast<const uint4 *>(sb + aw0 + fx + t * 2048);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int t = 0; t < 4; ++t) fa[t] = *reinterpret_cast<const uint4 *>(sb + aa0 + fx + t * 2048);
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = T::mfma(fw[nt], fa[mt], acc[nt][mt]);
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
+    };
+
+    // Loads / LDS writes past the last tile are issued anyway (clamped to the last tile, written to the buffer nobody
+    // reads any more): straight-line loop body, no conditionally written register arrays.
+    uint4 raA[4], rwA[WCH], raB[4], rwB[WCH];
+    unsigned mkA = 0, mkB = 0;
+    load_tile(kt0, raA, rwA, mkA);
+    load_tile(min(kt0 + 1, ktl), raB, rwB, mkB);
+    store_tile(0, raA, rwA, mkA);
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; kt += 2) {
+        load_tile(min(kt + 2, ktl), raA, rwA, mkA);
+        compute(0);
+        store_tile(1, raB, rwB, mkB);
+        __syncthreads();
+        if (kt + 1 >= kt1) break;
+        load_tile(min(kt + 3, ktl), raB, rwB, mkB);
+        compute(1);
+        store_tile(0, raA, rwA, mkA);
         __syncthreads();
     }
 
@@ -154,63 +283,102 @@ __global__ __launch_bounds__(NT) void k_gemm(const GemmArgs g)
     for (int mt = 0; mt < 4; ++mt) {
         const int64_t m = m_base + wm * 64 + mt * 16 + fr;
         if (m >= g.M) continue;
-        const int64_t bidx = g.rowvec ? m / g.rows_per_batch : 0;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            if (g.geglu && (nt & 1)) continue;
-            const int64_t n = n_base + wn * 64 + nt * 16 + fc * 4;
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int64_t n = n_base + wn * (16 * NTW) + nt * 16 + fc * 4;
             if (n >= g.N) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float x = acc[nt][mt][r];
-                if (g.bias) x += g.bias[n + r];
-                if (g.rowvec) x += g.rowvec[bidx * g.ld_rowvec + n + r];
-                v[r] = x;
+            if (g.splits > 1) {   // partial sums of this k-slice: plain 16-byte stores into slice blockIdx.y
+                *reinterpret_cast<float4 *>(g.ws + ((int64_t)blockIdx.y * g.M + m) * g.N + n) =
+                    make_float4(acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]);
+                continue;
             }
+            if (g.geglu && (nt & 1)) continue;
+            float v[4] = {acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]};
+            float gate[4] = {0.f, 0.f, 0.f, 0.f};
             int64_t on = n;
-            if (g.geglu) {   // weights are row-permuted in 16-blocks [x | gate]; partner tile = nt + 1
+            if (g.geglu) {   // weights are row-permuted in 16-blocks [x | gate]; partner tile = nt + 1 (NTW is even here)
+                constexpr int NP = NTW - 1;
+                const int np = nt + 1 < NTW ? nt + 1 : NP;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float gt = acc[nt + 1][mt][r];
-                    if (g.bias) gt += g.bias[n + 16 + r];
-                    v[r] = v[r] * gelu_erf(gt);
-                }
-                on = (n_base + wn * 64 + nt * 16) / 2 + fc * 4;
+                for (int r = 0; r < 4; ++r) gate[r] = acc[np][mt][r];
+                on = (n_base + wn * (16 * NTW) + nt * 16) / 2 + fc * 4;
             }
-            if (g.act == 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = silu(v[r]);
-            } else if (g.act == 2) {   // image post-process of pipe(output_type='pt'): (x/2 + 0.5).clamp(0,1)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r] * 0.5f + 0.5f, 0.f), 1.f);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= g.out_scale;
-            if (g.residual) {
-                const uint2 rr = *reinterpret_cast<const uint2 *>((const unsigned char *)g.residual + (m * g.ldr + on) * 2);
-                v[0] += T::to_f((unsigned short)(rr.x & 0xffff)); v[1] += T::to_f((unsigned short)(rr.x >> 16));
-                v[2] += T::to_f((unsigned short)(rr.y & 0xffff)); v[3] += T::to_f((unsigned short)(rr.y >> 16));
-            }
-            if (g.out) {
-                if (g.out_f32) {
-                    *reinterpret_cast<float4 *>((float *)g.out + m * g.ldc + on) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    *reinterpret_cast<uint2 *>((unsigned char *)g.out + (m * g.ldc + on) * 2) =
-                        make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
-                }
-            }
-            if (g.out_t) {   // transposed copy out_t[b][n][tok] (V operand of the attention kernel)
-                const int64_t b = m / g.rows_per_batch, tok = m - b * g.rows_per_batch;
-                unsigned short *o = (unsigned short *)g.out_t + b * g.t_batch_stride + tok;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[(on + r) * g.ldt] = T::from_f(v[r]);
-            }
+            epilogue_store<T>(g, m, n, on, v, gate);
         }
     }
 }
 
+// epilogue of a split-K problem: ws fp32 [M][N] -> out (same epilogue as the fused path; no GEGLU)
+template <class T>
+__global__ __launch_bounds__(256) void k_splitk_epilogue(const GemmArgs g)
+{
+    const int64_t nq = g.N / 4;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < g.M * nq; q += (int64_t)gridDim.x * 256) {
+        const int64_t m = q / nq, n = (q - m * nq) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < g.splits; ++z) {
+            const float4 a = *reinterpret_cast<const float4 *>(g.ws + ((int64_t)z * g.M + m) * g.N + n);
+            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+        }
+        float gate[4] = {0.f, 0.f, 0.f, 0.f};
+        epilogue_store<T>(g, m, n, n, v, gate);
+    }
+}
+
+int choose_splits(int64_t blocks, int nk)
+{
+    // split only long-K / few-tile problems (3x3 convs on 16x16 and 8x8 maps): each slice keeps >= 8 k-tiles and the
+    // fp32 partial slabs ([S][M][N], written once, read once) stay small next to the weight stream
+    if (blocks >= 128 || nk < 32) return 1;
+    int s = (int)((448 + blocks - 1) / blocks);
+    if (s > nk / 8) s = nk / 8;
+    if (s > 16) s = 16;
+    return s < 2 ? 1 : s;
+}
+
+template <class T, int MODE, int NTW>
+void launch(const GemmArgs &g, dim3 grid, hipStream_t s)
+{
+    constexpr size_t lds = 2 * (BM * 128 + 32 * NTW * 128);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_gemm<T, MODE, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_gemm<T, MODE, NTW>), grid, dim3(NT), lds, s, g);
+}
+
+template <class T>
+void dispatch(const GemmArgs &g, int mode, int ntw, dim3 grid, hipStream_t s)
+{
+    if (ntw == 5) {
+        if (mode == 0) launch<T, 0, 5>(g, grid, s); else if (mode == 1) launch<T, 1, 5>(g, grid, s); else launch<T, 2, 5>(g, grid, s);
+    } else {
+        if (mode == 0) launch<T, 0, 4>(g, grid, s); else if (mode == 1) launch<T, 1, 4>(g, grid, s); else launch<T, 2, 4>(g, grid, s);
+    }
+}
+
+void plan(const gc_gemm_desc *d, int *ntw, int *splits, int *tps)
+{
+    // GEGLU pairs tiles (nt, nt+1) inside a wave: needs an even number of n-tiles per wave
+    *ntw = (d->N % 160 == 0 && d->N % 128 != 0 && !d->geglu) ? 5 : 4;
+    const int bn = 32 * *ntw;
+    const int64_t blocks = ((d->M + BM - 1) / BM) * ((d->N + bn - 1) / bn);
+    const int nk = (int)((d->K + BK - 1) / BK);
+    *splits = d->geglu ? 1 : choose_splits(blocks, nk);
+    *tps = (nk + *splits - 1) / *splits;
+    *splits = (nk + *tps - 1) / *tps;
+}
+
 }  // namespace
+
+extern "C" size_t gc_dn_gemm_workspace_bytes(const gc_gemm_desc *d)
+{
+    if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+    int ntw, splits, tps;
+    plan(d, &ntw, &splits, &tps);
+    return splits > 1 ? sizeof(float) * (size_t)splits * (size_t)d->M * (size_t)d->N : 0;
+}
 
 extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
 {
@@ -220,35 +388,37 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
     GC_REQUIRE(d->N % 4 == 0, "N must be a multiple of 4 (pad output channels on the host)");
     GC_REQUIRE(d->dtype == DT_BF16 || d->dtype == DT_F16, "dtype must be 0 (bf16) or 1 (f16)");
     GemmArgs g;
-    g.M = d->M; g.N = d->N; g.K = d->K; g.A = d->A; g.lda = d->lda; g.mode = d->mode;
+    g.M = d->M; g.N = d->N; g.K = d->K; g.A = d->A; g.lda = d->lda;
     g.B = d->B; g.Hi = d->Hi; g.Wi = d->Wi; g.Cin = d->Cin; g.Ho = d->Ho; g.Wo = d->Wo; g.stride = d->stride; g.ups = d->upsample; g.pad = d->pad_lo;
     g.W = d->W; g.bias = d->bias; g.rowvec = d->rowvec; g.ld_rowvec = d->ld_rowvec;
     g.rows_per_batch = d->rows_per_batch > 0 ? d->rows_per_batch : 1;
     g.residual = d->residual; g.ldr = d->ldr; g.out_scale = d->out_scale; g.act = d->act; g.geglu = d->geglu;
     g.out = d->out; g.ldc = d->ldc; g.out_f32 = d->out_f32; g.out_t = d->out_t; g.ldt = d->ldt; g.t_batch_stride = d->t_batch_stride;
+    int mode = 0;
     if (d->mode == 1) {
         GC_REQUIRE(d->Cin % 8 == 0 && d->K == 9 * (int64_t)d->Cin, "conv3x3: K must be 9*Cin with Cin % 8 == 0");
         GC_REQUIRE(d->M == (int64_t)d->B * d->Ho * d->Wo, "conv3x3: M must be B*Ho*Wo");
         GC_REQUIRE(d->pad_lo == 0 || d->pad_lo == 1, "conv3x3: pad_lo must be 0 or 1");
+        mode = (d->Cin % 64 == 0) ? 2 : 1;
     } else {
         GC_REQUIRE(d->lda >= d->K && d->lda % 8 == 0, "linear: lda must be >= K and a multiple of 8");
     }
     if (d->geglu) GC_REQUIRE(d->N % 32 == 0 && !d->out_t, "geglu needs N % 32 == 0");
-    const int64_t nbm = (d->M + BM - 1) / BM, nbn = (d->N + BN - 1) / BN;
-    const dim3 grid((unsigned)(nbm * nbn)), block(NT);
-    const size_t lds = 65536;
+    int ntw, splits, tps;
+    plan(d, &ntw, &splits, &tps);
     hipStream_t s = gc::S(stream);
-#define GC_LAUNCH(T, C)                                                                            \
-    do {                                                                                           \
-        static bool attr_set = false;                                                              \
-        if (!attr_set) {                                                                           \
-            (void)hipFuncSetAttribute((const void *)k_gemm<T, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            attr_set = true;                                                                       \
-        }                                                                                          \
-        hipLaunchKernelGGL((k_gemm<T, C>), grid, block, lds, s, g);                                \
-    } while (0)
-    if (d->dtype == DT_BF16) { if (d->mode == 1) GC_LAUNCH(BF16, true); else GC_LAUNCH(BF16, false); }
-    else { if (d->mode == 1) GC_LAUNCH(F16, true); else GC_LAUNCH(F16, false); }
-#undef GC_LAUNCH
+    if (splits > 1 && (!d->workspace || d->workspace_bytes < sizeof(float) * (size_t)splits * (size_t)d->M * (size_t)d->N)) {
+        splits = 1; tps = (int)((d->K + BK - 1) / BK);      // no workspace: run unsplit
+    }
+    g.splits = splits; g.tiles_per_split = tps; g.ws = (float *)d->workspace;
+    const int bn = 32 * ntw;
+    const int64_t nbm = (d->M + BM - 1) / BM, nbn = (d->N + bn - 1) / bn;
+    const dim3 grid((unsigned)(nbm * nbn), (unsigned)splits);
+    if (d->dtype == DT_BF16) dispatch<BF16>(g, mode, ntw, grid, s); else dispatch<F16>(g, mode, ntw, grid, s);
+    if (splits > 1) {
+        const unsigned eg = (unsigned)std::min<int64_t>((d->M * (d->N / 4) + 255) / 256, 2048);
+        if (d->dtype == DT_BF16) hipLaunchKernelGGL((k_splitk_epilogue<BF16>), dim3(eg), dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((k_splitk_epilogue<F16>), dim3(eg), dim3(256), 0, s, g);
+    }
     return gc::check_launch("gc_dn_gemm");
 }

@@ -21,7 +21,8 @@ class GemmDesc(C.Structure):
                 ("W", C.c_void_p), ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("ld_rowvec", C.c_int64),
                 ("rows_per_batch", C.c_int64), ("residual", C.c_void_p), ("ldr", C.c_int64), ("out_scale", C.c_float),
                 ("act", C.c_int), ("geglu", C.c_int), ("out", C.c_void_p), ("ldc", C.c_int64), ("out_f32", C.c_int),
-                ("out_t", C.c_void_p), ("ldt", C.c_int64), ("t_batch_stride", C.c_int64)]
+                ("out_t", C.c_void_p), ("ldt", C.c_int64), ("t_batch_stride", C.c_int64),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
 class AttnDesc(C.Structure):
@@ -60,6 +61,16 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _run_gemm(d, dev, what):
+    lib = L.lib()
+    wsb = lib.gc_dn_gemm_workspace_bytes(C.byref(d))
+    ws = None
+    if wsb:
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)       # caching allocator: no hipMalloc on the hot path
+        d.workspace = ws.data_ptr(); d.workspace_bytes = wsb
+    L.check(lib.gc_dn_gemm(C.byref(d), _stream()), what)
+
+
 def linear(x, w, bias=None, residual=None, act=0, geglu=False, out_f32=False, scale=1.0, rowvec=None, rows_per_batch=0,
            ld_rowvec=None, out=None, want_out=True, out_t=None, ldt=0, t_batch_stride=0):
     """x [..., K] (last dim contiguous, rows strided by x.stride(-2)) @ w[N,K]^T with fused epilogue."""
@@ -85,7 +96,7 @@ def linear(x, w, bias=None, residual=None, act=0, geglu=False, out_f32=False, sc
         d.out = out.data_ptr(); d.ldc = out.stride(-2); d.out_f32 = int(out_f32)
     if out_t is not None:
         d.out_t = out_t.data_ptr(); d.ldt = ldt; d.t_batch_stride = t_batch_stride
-    L.check(L.lib().gc_dn_gemm(C.byref(d), _stream()), "gc_dn_gemm")
+    _run_gemm(d, x.device, "gc_dn_gemm")
     return out
 
 
@@ -112,7 +123,7 @@ def conv3x3(x, w, bias=None, stride=1, upsample=False, rowvec=None, ld_rowvec=No
         d.residual = residual.data_ptr(); d.ldr = N
     d.out_scale = scale; d.act = act
     d.out = out.data_ptr(); d.ldc = N; d.out_f32 = int(out_f32)
-    L.check(L.lib().gc_dn_gemm(C.byref(d), _stream()), "gc_dn_gemm(conv3x3)")
+    _run_gemm(d, x.device, "gc_dn_gemm(conv3x3)")
     return out
 
 

@@ -180,7 +180,10 @@ typedef struct gc_gemm_desc {
     void *out_t;               /* optional transposed copy [M / rows_per_batch][N][ldt] (V operand of gc_dn_attention) */
     int64_t ldt;
     int64_t t_batch_stride;
+    void *workspace;           /* >= gc_dn_gemm_workspace_bytes(desc) bytes (split-K fp32 accumulator for small-M problems); */
+    size_t workspace_bytes;    /* NULL / too small: the problem runs unsplit */
 } gc_gemm_desc;
+size_t gc_dn_gemm_workspace_bytes(const gc_gemm_desc *desc);
 int gc_dn_gemm(const gc_gemm_desc *desc, void *stream);
 
 /* Fused multi-K/V-set attention = CrossViewAttnProcessor core, gaussctrl/utils.py:86-117 (+ compute_attn :25-37). */

@@ -1,0 +1,15 @@
+import sys, torch
+sys.path.insert(0, '.')
+from gaussctrl_amd.sd import ops
+from gaussctrl_amd.sd.weights import conv3x3_weight
+dt = torch.bfloat16; DEV='cuda:0'; B=6
+which = sys.argv[1] if len(sys.argv) > 1 else 'conv'
+if which == 'conv':
+    H, Cin, Cout = 64, 320, 320
+    x = (torch.randn(B, H, H, Cin, device=DEV)).to(dt); w = conv3x3_weight((torch.randn(Cout, Cin, 3, 3, device=DEV) * (9*Cin) ** -0.5).to(dt), dt); b = torch.randn(Cout, device=DEV)
+    for _ in range(5): ops.conv3x3(x, w, b)
+else:
+    L, C, heads = 4096, 320, 8
+    q = torch.randn(B, L, C, device=DEV).to(dt); k = torch.randn(B, L, C, device=DEV).to(dt); vt = torch.randn(B, C, L, device=DEV).to(dt)
+    for _ in range(3): ops.attention(q, k, vt, heads, [(-1, 0.6)] + [(r, 0.1) for r in range(4)], B // 2, Lk=L)
+torch.cuda.synchronize()
