@@ -34,14 +34,24 @@ struct AttnArgs {
     float scale_log2e;
 };
 
+template <class T> struct One;
+template <> struct One<BF16> { static constexpr unsigned short v = 0x3F80; };
+template <> struct One<F16> { static constexpr unsigned short v = 0x3C00; };
+
 template <class T, int D, int QT>
-__global__ __launch_bounds__(256) void k_attn(const AttnArgs a)
+__global__ __launch_bounds__(256, 2) void k_attn(const AttnArgs a)
 {
     constexpr int DP = (D + 31) / 32 * 32;      // contraction length of QK^T, padded to the MFMA k = 32
     constexpr int DV = (D + 15) / 16 * 16;      // output rows of O^T, padded to the MFMA m = 16
     constexpr int KS = DP / 32, DT = DV / 16;
-    constexpr int KROW = (DP + 8) * 2;          // bytes per key row of the K tile (+16 B pad)
+    constexpr bool SWZ = (DP == 64);            // 128-byte key rows: XOR-swizzled 16-byte chunks (conflict-free ds_read_b128)
+    constexpr int KROW = SWZ ? 128 : (DP + 8) * 2;   // bytes per key row of the K tile
     constexpr int VROW = (64 + 8) * 2;          // bytes per channel row of the V^T tile
+    // When D is not a multiple of 16 the padded V^T row D is filled with ones: O^T row D then accumulates the softmax
+    // denominator sum_k P[q][k] inside the P V MFMAs (same rounding of P as the numerator) -- no VALU adds for l.
+    constexpr bool ONES = (DV > D);
+    constexpr int NKC = 64 * (D / 8), NVC = D * 8;                     // 16-byte chunks per K / V^T tile
+    constexpr int KIT = (NKC + 255) / 256, VIT = (NVC + 255) / 256;
     __shared__ __attribute__((aligned(16))) unsigned char sK[64 * KROW];
     __shared__ __attribute__((aligned(16))) unsigned char sV[DV * VROW];
 
@@ -53,6 +63,10 @@ __global__ __launch_bounds__(256) void k_attn(const AttnArgs a)
     // zero the LDS once: pad columns / pad rows are never written again
     for (int i = tid; i < (int)(sizeof(sK) / 16); i += 256) reinterpret_cast<uint4 *>(sK)[i] = make_uint4(0, 0, 0, 0);
     for (int i = tid; i < (int)(sizeof(sV) / 16); i += 256) reinterpret_cast<uint4 *>(sV)[i] = make_uint4(0, 0, 0, 0);
+    if (ONES) {
+        __syncthreads();
+        if (tid < 64) reinterpret_cast<unsigned short *>(sV + D * VROW)[tid] = One<T>::v;
+    }
 
     // Q fragments (B operand): lane holds Q[q = fr][d = 32*ks + 8*g .. +8]
     uint4 qf[QT][KS];
@@ -68,6 +82,27 @@ __global__ __launch_bounds__(256) void k_attn(const AttnArgs a)
         }
     }
 
+    // per-lane staging coordinates (constant over tiles): element offsets inside a tile, LDS byte offsets
+    int k_go[KIT], k_lo[KIT], k_r[KIT], v_go[VIT], v_lo[VIT], v_c[VIT];
+#pragma unroll
+    for (int j = 0; j < KIT; ++j) {
+        const int c = tid + 256 * j, r = c / (D / 8), cc = c - r * (D / 8);
+        k_r[j] = c < NKC ? r : -1;
+        k_go[j] = c < NKC ? r * (int)a.ldk + cc * 8 : 0;
+        k_lo[j] = SWZ ? r * 128 + ((cc ^ ((r >> 1) & 7)) << 4) : r * KROW + cc * 16;
+    }
+#pragma unroll
+    for (int j = 0; j < VIT; ++j) {
+        const int c = tid + 256 * j, r = c >> 3, cc = c & 7;
+        v_c[j] = c < NVC ? cc * 8 : -1;
+        v_go[j] = c < NVC ? r * (int)a.ldvt + cc * 8 : 0;
+        v_lo[j] = r * VROW + cc * 16;
+    }
+    // K fragment LDS offsets: row = 16 kt + fr, chunk = 4 ks + g
+    int kfo[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kfo[ks] = SWZ ? fr * 128 + (((ks * 4 + g) ^ ((fr >> 1) & 7)) << 4) : fr * KROW + (ks * 32 + g * 8) * 2;
+
     f32x4 otot[DT][QT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
@@ -76,6 +111,7 @@ __global__ __launch_bounds__(256) void k_attn(const AttnArgs a)
 
     const int ntiles = (a.Lk + 63) / 64;
     const int lk8 = (a.Lk + 7) / 8 * 8;
+    const float c2 = a.scale_log2e;
     for (int s = 0; s < a.nsets; ++s) {
         const int kind = a.set_kind[s];
         const unsigned short *Kb, *Vb;
@@ -98,18 +134,38 @@ __global__ __launch_bounds__(256) void k_attn(const AttnArgs a)
         }
         for (int tile = 0; tile < ntiles; ++tile) {
             const int key0 = tile * 64;
-            __syncthreads();   // previous tile fully consumed (also orders the initial zero fill)
-            for (int c = tid; c < 64 * (D / 8); c += 256) {
-                const int r = c / (D / 8), cc = c - r * (D / 8);
-                const int key = key0 + r;
-                const uint4 v = key < a.Lk ? *reinterpret_cast<const uint4 *>(Kb + (int64_t)key * a.ldk + cc * 8) : make_uint4(0, 0, 0, 0);
-                *reinterpret_cast<uint4 *>(sK + r * KROW + cc * 16) = v;
-            }
-            for (int c = tid; c < D * 8; c += 256) {
-                const int r = c >> 3, cc = c & 7;
-                const int key = key0 + cc * 8;
-                const uint4 v = key < lk8 ? *reinterpret_cast<const uint4 *>(Vb + (int64_t)r * a.ldvt + key) : make_uint4(0, 0, 0, 0);
-                *reinterpret_cast<uint4 *>(sV + r * VROW + cc * 16) = v;
+            const bool full = key0 + 64 <= a.Lk;           // wave-uniform: interior tiles skip every bounds test
+            __syncthreads();   // previous tile fully consumed (also orders the initial LDS fill)
+            {
+                const unsigned short *kp = Kb + (int64_t)key0 * a.ldk;
+                const unsigned short *vp = Vb + key0;
+                uint4 kv[KIT], vv[VIT];
+                if (full) {   // interior tile: no bounds tests (lanes without a chunk re-read offset 0 and do not store)
+#pragma unroll
+                    for (int j = 0; j < KIT; ++j) kv[j] = *reinterpret_cast<const uint4 *>(kp + k_go[j]);
+#pragma unroll
+                    for (int j = 0; j < VIT; ++j) vv[j] = *reinterpret_cast<const uint4 *>(vp + v_go[j]);
+                } else {
+                    asm volatile("" ::: "memory");   // keep the wave-uniform branch
+#pragma unroll
+                    for (int j = 0; j < KIT; ++j) {
+                        const bool ok = k_r[j] >= 0 && key0 + k_r[j] < a.Lk;
+                        kv[j] = *reinterpret_cast<const uint4 *>(kp + (ok ? k_go[j] : 0));
+                        if (!ok) kv[j] = make_uint4(0, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int j = 0; j < VIT; ++j) {
+                        const bool ok = v_c[j] >= 0 && key0 + v_c[j] < lk8;
+                        vv[j] = *reinterpret_cast<const uint4 *>(vp + (ok ? v_go[j] : 0));
+                        if (!ok) vv[j] = make_uint4(0, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < KIT; ++j)
+                    if (k_r[j] >= 0) *reinterpret_cast<uint4 *>(sK + k_lo[j]) = kv[j];
+#pragma unroll
+                for (int j = 0; j < VIT; ++j)
+                    if (v_c[j] >= 0) *reinterpret_cast<uint4 *>(sV + v_lo[j]) = vv[j];
             }
             __syncthreads();
 
@@ -123,40 +179,49 @@ __global__ __launch_bounds__(256) void k_attn(const AttnArgs a)
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt) {
-                    const uint4 kf = *reinterpret_cast<const uint4 *>(sK + (kt * 16 + fr) * KROW + (ks * 32 + g * 8) * 2);
+                    const uint4 kf = *reinterpret_cast<const uint4 *>(sK + kfo[ks] + kt * 16 * KROW);
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt) st[kt][qt] = T::mfma(kf, qf[qt][ks], st[kt][qt]);
                 }
-            // ---- online softmax per query row (lane-local + 2 cross-lane steps over g)
-            uint4 pf[QT][2];
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt) {
-                float tmax = -1e30f;
+            if (!full) {   // last, partial tile: mask keys >= Lk (the asm keeps this a real wave-uniform branch)
+                asm volatile("" ::: "memory");
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = key0 + kt * 16 + g * 4 + r;
-                        const float v = key < a.Lk ? st[kt][qt][r] * a.scale_log2e : -1e30f;
-                        st[kt][qt][r] = v;
-                        tmax = fmaxf(tmax, v);
-                    }
+                    for (int r = 0; r < 4; ++r)
+                        if (key0 + kt * 16 + g * 4 + r >= a.Lk) {
+#pragma unroll
+                            for (int qt = 0; qt < QT; ++qt) st[kt][qt][r] = -1e30f;
+                        }
+            }
+            // ---- online softmax per query row (lane-local + 2 cross-lane steps over g); exp2(c2*s - m) in one FMA + v_exp
+            uint4 pf[QT][2];
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                float tmax = fmaxf(fmaxf(st[0][qt][0], st[0][qt][1]), st[0][qt][2]);      // v_max3_f32 chain
+                tmax = fmaxf(fmaxf(tmax, st[0][qt][3]), st[1][qt][0]);
+#pragma unroll
+                for (int kt = 1; kt < 4; ++kt) {
+                    if (kt > 1) tmax = fmaxf(fmaxf(tmax, st[kt - 1][qt][3]), st[kt][qt][0]);
+                    tmax = fmaxf(fmaxf(tmax, st[kt][qt][1]), st[kt][qt][2]);
+                }
+                tmax = fmaxf(tmax, st[3][qt][3]);
                 tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
                 tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-                const float mnew = fmaxf(mrow[qt], tmax);
-                const float alpha = exp2f(mrow[qt] - mnew);
+                const float mnew = fmaxf(mrow[qt], tmax * c2);
+                const float alpha = __builtin_amdgcn_exp2f(mrow[qt] - mnew);
                 mrow[qt] = mnew;
-                float psum = 0.f;
                 float p[4][4];
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float e = exp2f(st[kt][qt][r] - mnew);
-                        p[kt][r] = e;
-                        psum += e;
-                    }
-                lrow[qt] = lrow[qt] * alpha + psum;     // per-lane partial; reduced over g at the end of the set
+                    for (int r = 0; r < 4; ++r) p[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][qt][r], c2, -mnew));
+                if (!ONES) {
+                    float psum = 0.f;
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt) psum += (p[kt][0] + p[kt][1]) + (p[kt][2] + p[kt][3]);
+                    lrow[qt] = lrow[qt] * alpha + psum;   // per-lane partial; reduced over g at the end of the set
+                }
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -182,9 +247,15 @@ __global__ __launch_bounds__(256) void k_attn(const AttnArgs a)
         // ---- fold this set into the weighted total
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
-            float l = lrow[qt];
-            l += __shfl_xor(l, 16, 64);
-            l += __shfl_xor(l, 32, 64);
+            float l;
+            if (ONES) {   // denominator = O^T row D: held by the lane with 16*dt + 4*g + r == D of the same query column
+                constexpr int dt_l = D / 16, g_l = (D % 16) / 4, r_l = D % 4;
+                l = __shfl(os[dt_l][qt][r_l], g_l * 16 + fr, 64);
+            } else {
+                l = lrow[qt];
+                l += __shfl_xor(l, 16, 64);
+                l += __shfl_xor(l, 32, 64);
+            }
             const float inv = a.set_w[s] / l;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)

@@ -46,6 +46,24 @@ __device__ __forceinline__ unsigned pack2(float a, float b)
 {
     return (unsigned)T::from_f(a) | ((unsigned)T::from_f(b) << 16);
 }
+// one v_cvt_pk_bf16_f32 per pair: a 2-vector conversion lets hipcc emit the packed instruction AND pad the
+// VALU-write -> MFMA-read hazard itself (an inline-asm cvt_pk feeding an MFMA operand read stale registers)
+template <>
+__device__ __forceinline__ unsigned pack2<BF16>(float a, float b)
+{
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+    const b2 h = __builtin_convertvector(f2{a, b}, b2);
+    return __builtin_bit_cast(unsigned, h);
+}
+template <>
+__device__ __forceinline__ unsigned pack2<F16>(float a, float b)
+{
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    const h2 h = __builtin_convertvector(f2{a, b}, h2);
+    return __builtin_bit_cast(unsigned, h);
+}
 
 template <class T>
 __device__ __forceinline__ void unpack8(uint4 v, float *f)

@@ -11,5 +11,6 @@ if which == 'conv':
 else:
     L, C, heads = 4096, 320, 8
     q = torch.randn(B, L, C, device=DEV).to(dt); k = torch.randn(B, L, C, device=DEV).to(dt); vt = torch.randn(B, C, L, device=DEV).to(dt)
-    for _ in range(3): ops.attention(q, k, vt, heads, [(-1, 0.6)] + [(r, 0.1) for r in range(4)], B // 2, Lk=L)
+    kr = torch.randn(8, L, C, device=DEV).to(dt); vtr = torch.randn(8, C, L, device=DEV).to(dt)
+    for _ in range(3): ops.attention(q, k, vt, heads, [(-1, 0.6)] + [(r, 0.1) for r in range(4)], B // 2, Lk=L, kref=kr, vtref=vtr, ref_fph=4)
 torch.cuda.synchronize()
