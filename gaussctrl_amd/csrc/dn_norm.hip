@@ -10,75 +10,123 @@ namespace {
 using namespace dn;
 
 // ------------------------------------------------------------------------------------------ GroupNorm
-// stats[b][g] = {sum(x - shift), sum((x - shift)^2)} with shift = x[b, pixel 0, first channel of g]
-// (shifted single pass: no catastrophic cancellation when |mean| >> std).
+// Three streaming kernels, no atomics, 32-bit index arithmetic:
+//   k_gn_partial : per (batch, pixel slab <= 32 per image, channel slice) per-CHANNEL sums of (x - s_c) and (x - s_c)^2 with the
+//                  per-channel shift s_c = x[b, pixel 0, c] (shifted sums: no catastrophic cancellation when |mean| >> std)
+//   k_gn_finalize: per (batch, group): mean / rstd from the shifted channel sums -> per-channel scale a = rstd*gamma, d = beta - mean*a
+//   k_gn_apply   : y = (x * a + d) [SiLU], 16 bytes per lane, coefficients from L1/L2
 template <class T>
-__global__ __launch_bounds__(256) void k_gn_stats(const unsigned short *__restrict__ x, int64_t HW, int C, int G,
-                                                  int nchb, int pix_per_block, float *__restrict__ stats)
+__global__ __launch_bounds__(256) void k_gn_partial(const unsigned short *__restrict__ x, int HW, int C, int nchb,
+                                                    int pix_per_block, float *__restrict__ part)
 {
-    extern __shared__ float sg[];   // [2*G]
-    const int b = blockIdx.z, cpg = C / G;
-    const int lanes = 256 / nchb;                       // pixel lanes per block
+    extern __shared__ float sp[];   // [lanes][nchb][16]
+    const int b = blockIdx.z;
+    const int lanes = 256 / nchb;
     const int tid = threadIdx.x;
-    for (int i = tid; i < 2 * G; i += 256) sg[i] = 0.f;
-    __syncthreads();
     const int cch = tid % nchb, pl = tid / nchb;
     const int c0 = (blockIdx.y * nchb + cch) * 8;
-    const unsigned short *xb = x + (int64_t)b * HW * C;
+    const unsigned short *xb = x + (size_t)b * HW * C;
     if (pl < lanes) {
-        float sh[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sh[j] = T::to_f(xb[((c0 + j) / cpg) * cpg]);
-        float s1[8], s2[8];
+        float sh[8], s1[8], s2[8];
+        unpack8<T>(*reinterpret_cast<const uint4 *>(xb + c0), sh);
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-        const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
-        const int64_t p1 = min(p0 + pix_per_block, HW);
-        for (int64_t p = p0 + pl; p < p1; p += lanes) {
+        const int p0 = blockIdx.x * pix_per_block;
+        const int p1 = min(p0 + pix_per_block, HW);
+        for (int p = p0 + pl; p < p1; p += lanes) {
             float f[8];
-            unpack8<T>(*reinterpret_cast<const uint4 *>(xb + p * C + c0), f);
+            unpack8<T>(*reinterpret_cast<const uint4 *>(xb + (size_t)p * C + c0), f);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float d = f[j] - sh[j]; s1[j] += d; s2[j] += d * d; }
         }
+        float *o = sp + ((size_t)pl * nchb + cch) * 16;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int gi = (c0 + j) / cpg;
-            atomicAdd(&sg[2 * gi], s1[j]);
-            atomicAdd(&sg[2 * gi + 1], s2[j]);
-        }
+        for (int j = 0; j < 8; ++j) { o[2 * j] = s1[j]; o[2 * j + 1] = s2[j]; }
     }
     __syncthreads();
-    // only the groups this y-slice touches are non-zero
-    const int g_lo = (blockIdx.y * nchb * 8) / cpg, g_hi = min(G - 1, ((blockIdx.y + 1) * nchb * 8 - 1) / cpg);
-    for (int i = 2 * g_lo + tid; i <= 2 * g_hi + 1; i += 256) unsafeAtomicAdd(&stats[(int64_t)b * 2 * G + i], sg[i]);
+    if (pl == 0) {
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+        for (int l = 0; l < lanes; ++l) {
+            const float *o = sp + ((size_t)l * nchb + cch) * 16;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] += o[j];
+        }
+        float *dst = part + (((size_t)b * gridDim.x + blockIdx.x) * C + c0) * 2;
+#pragma unroll
+        for (int j = 0; j < 16; j += 4) *reinterpret_cast<float4 *>(dst + j) = make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]);
+    }
+}
+
+// one workgroup per (batch, group): channel c of the group is handled by lanes l = c - g*cpg (+ 256 k)
+template <class T>
+__global__ __launch_bounds__(256) void k_gn_finalize(const unsigned short *__restrict__ x, int HW, int C, int G, int nslab,
+                                                     const float *__restrict__ part, const float *__restrict__ gamma,
+                                                     const float *__restrict__ beta, float eps, float *__restrict__ coef)
+{
+    __shared__ float red[3][4];
+    const int b = blockIdx.x / G, gi = blockIdx.x % G, cpg = C / G, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // every thread: one (channel, slab-subset) share; totals per channel are combined with the channel's shift
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f;        // sum x, sum (x-s)^2 parts folded below
+    float cs1 = 0.f, cs2 = 0.f, sh = 0.f;
+    const int ci = tid % cpg, sub = tid / cpg, nsub = 256 / cpg;   // cpg <= 256
+    if (sub < nsub) {
+        const int c = gi * cpg + ci;
+        sh = T::to_f(x[(size_t)b * HW * C + c]);
+        for (int sl = sub; sl < nslab; sl += nsub) {
+            const float2 v = *reinterpret_cast<const float2 *>(part + (((size_t)b * nslab + sl) * C + c) * 2);
+            cs1 += v.x; cs2 += v.y;
+        }
+        // this share covers n_s pixels (unknown here) -> keep moments about the shift; pixel counts are added in closed form
+        t0 = cs1;                       // sum (x - s_c) over the share
+        t1 = cs2;                       // sum (x - s_c)^2
+        t2 = (sub == 0) ? sh : 0.f;     // s_c counted once per channel
+    }
+    // group mean: mu = (sum_c [S1_c + HW * s_c]) / (HW * cpg)
+    float a0 = wave_sum_f(t0), a2 = wave_sum_f(t2);
+    if (lane == 0) { red[0][wid] = a0; red[2][wid] = a2; }
+    __syncthreads();
+    const float S1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    const float SS = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+    const float n = (float)HW * (float)cpg;
+    const float mu = (S1 + (float)HW * SS) / n;
+    // variance: sum_c [S2_c + 2 (s_c - mu) S1_c + HW (s_c - mu)^2]: the last term once per channel
+    float q = 0.f;
+    if (sub < nsub) {
+        const float dlt = sh - mu;
+        q = t1 + 2.f * dlt * t0 + ((sub == 0) ? (float)HW * dlt * dlt : 0.f);
+    }
+    float aq = wave_sum_f(q);
+    if (lane == 0) red[1][wid] = aq;
+    __syncthreads();
+    const float var = fmaxf((red[1][0] + red[1][1] + red[1][2] + red[1][3]) / n, 0.f);
+    const float rstd = rsqrtf(var + eps);
+    for (int c = gi * cpg + tid; c < (gi + 1) * cpg; c += 256) {
+        const float a = rstd * gamma[c];
+        *reinterpret_cast<float2 *>(coef + ((size_t)b * C + c) * 2) = make_float2(a, beta[c] - mu * a);
+    }
 }
 
 template <class T>
 __global__ __launch_bounds__(256) void k_gn_apply(const unsigned short *__restrict__ x, unsigned short *__restrict__ y,
-                                                  int64_t HW, int C, int G, const float *__restrict__ stats,
-                                                  const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                  float eps, int act, int64_t total_chunks)
+                                                  unsigned HW, unsigned C, const float *__restrict__ coef, int act, unsigned total_chunks)
 {
-    const int cpg = C / G, nch = C / 8;
-    const float inv_n = 1.f / ((float)HW * (float)cpg);
-    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total_chunks; q += (int64_t)gridDim.x * 256) {
-        const int64_t pix = q / nch;
-        const int c0 = (int)(q - pix * nch) * 8;
-        const int64_t b = pix / HW;
-        const unsigned short *xb = x + b * HW * C;
+    const unsigned nch = C / 8, per_img = HW * nch;
+    for (unsigned q = blockIdx.x * 256u + threadIdx.x; q < total_chunks; q += gridDim.x * 256u) {
+        const unsigned b = q / per_img;
+        const unsigned c0 = (q % nch) * 8;
         float f[8];
-        unpack8<T>(*reinterpret_cast<const uint4 *>(x + pix * C + c0), f);
+        unpack8<T>(*reinterpret_cast<const uint4 *>(x + (size_t)q * 8), f);
+        const float4 *cf = reinterpret_cast<const float4 *>(coef + ((size_t)b * C + c0) * 2);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = c0 + j, gi = c / cpg;
-            const float sh = T::to_f(xb[gi * cpg]);
-            const float m1 = stats[(b * G + gi) * 2] * inv_n, m2 = stats[(b * G + gi) * 2 + 1] * inv_n;
-            const float mean = sh + m1, var = fmaxf(m2 - m1 * m1, 0.f);
-            float v = (f[j] - mean) * rsqrtf(var + eps) * gamma[c] + beta[c];
-            if (act) v = silu(v);
-            f[j] = v;
+        for (int j = 0; j < 4; ++j) {
+            const float4 ab = cf[j];
+            float v0 = f[2 * j] * ab.x + ab.y, v1 = f[2 * j + 1] * ab.z + ab.w;
+            if (act) { v0 = silu(v0); v1 = silu(v1); }
+            f[2 * j] = v0; f[2 * j + 1] = v1;
         }
-        *reinterpret_cast<uint4 *>(y + pix * C + c0) = pack8<T>(f);
+        *reinterpret_cast<uint4 *>(y + (size_t)q * 8) = pack8<T>(f);
     }
 }
 
@@ -131,12 +179,12 @@ __global__ __launch_bounds__(256) void k_layernorm(const unsigned short *__restr
 template <class T>
 __global__ __launch_bounds__(256) void k_concat_add(const unsigned short *__restrict__ a, int C1,
                                                     const unsigned short *__restrict__ b, const unsigned short *__restrict__ c,
-                                                    int C2, unsigned short *__restrict__ out, int64_t total_chunks)
+                                                    int C2, unsigned short *__restrict__ out, unsigned total_chunks)
 {
-    const int nch = (C1 + C2) / 8, n1 = C1 / 8;
-    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total_chunks; q += (int64_t)gridDim.x * 256) {
-        const int64_t m = q / nch;
-        const int ch = (int)(q - m * nch);
+    const unsigned nch = (C1 + C2) / 8, n1 = C1 / 8;
+    for (unsigned q = blockIdx.x * 256u + threadIdx.x; q < total_chunks; q += gridDim.x * 256u) {
+        const size_t m = q / nch;
+        const unsigned ch = q - (unsigned)m * nch;
         uint4 v;
         if (ch < n1) v = *reinterpret_cast<const uint4 *>(a + m * C1 + ch * 8);
         else {
@@ -263,6 +311,21 @@ __global__ __launch_bounds__(256) void k_mask_composite(const float *__restrict_
     }
 }
 
+// slab plan of the GroupNorm statistics pass: channel slices of <= 256 16-byte chunks, pixel slabs sized for ~1-2k workgroups
+inline void gn_plan(int64_t B, int64_t HW, int C, int *nslab, int *ppb, int *ny, int *nchb)
+{
+    const int nch = C / 8;
+    int y = 1;
+    while (nch % y != 0 || nch / y > 256) ++y;
+    *ny = y; *nchb = nch / y;
+    const int lanes = 256 / *nchb;
+    // at most 32 slabs per image (keeps the finalize pass tiny), each at least `lanes` pixels
+    int p = (int)((HW + 31) / 32);
+    if (p < lanes) p = lanes;
+    (void)B;
+    *ppb = p; *nslab = (int)((HW + p - 1) / p);
+}
+
 inline unsigned ew_grid(int64_t items) { return (unsigned)std::min<int64_t>((items + 255) / 256, 256 * 8); }
 
 }  // namespace
@@ -276,31 +339,37 @@ inline unsigned ew_grid(int64_t items) { return (unsigned)std::min<int64_t>((ite
 
 extern "C" {
 
+size_t gc_dn_groupnorm_workspace_bytes(int64_t B, int64_t HW, int C)
+{
+    int nslab, ppb, ny, nchb;
+    gn_plan(B, HW, C, &nslab, &ppb, &ny, &nchb);
+    return sizeof(float) * 2 * (size_t)B * (size_t)C * (size_t)(nslab + 1);
+}
+
 int gc_dn_groupnorm(int dtype, const void *x, void *y, int64_t B, int64_t HW, int C, int G, const float *gamma,
                     const float *beta, float eps, int act, float *stats_ws, void *stream)
 {
-    GC_REQUIRE(C % 8 == 0 && C % G == 0 && stats_ws, "groupnorm: C must be a multiple of 8 and of G");
+    GC_REQUIRE(C % 8 == 0 && C % G == 0 && stats_ws, "groupnorm: C must be a multiple of 8 and of G; workspace required");
+    GC_REQUIRE(C / G <= 256 && B * HW * (C / 8) < (int64_t)1 << 31, "groupnorm: group too wide / tensor too large");
     hipStream_t s = gc::S(stream);
-    if (hipMemsetAsync(stats_ws, 0, sizeof(float) * 2 * G * B, s) != hipSuccess) return GC_ELAUNCH;
-    const int nch = C / 8;
-    int ny = 1;
-    while (nch % ny != 0 || nch / ny > 256) ++ny;
-    const int nchb = nch / ny;
+    int nslab, ppb, ny, nchb;
+    gn_plan(B, HW, C, &nslab, &ppb, &ny, &nchb);
+    float *part = stats_ws, *coef = stats_ws + 2 * (size_t)B * C * nslab;
     const int lanes = 256 / nchb;
-    int ppb = 64;                                         // pixels per block: enough blocks to fill the chip
-    while (ppb > lanes && (HW + ppb - 1) / ppb * ny * B < 1024) ppb >>= 1;
-    if (ppb < lanes) ppb = lanes;
-    dim3 grid((unsigned)((HW + ppb - 1) / ppb), ny, (unsigned)B);
-    const size_t lds = sizeof(float) * 2 * G;
+    dim3 grid((unsigned)nslab, ny, (unsigned)B);
+    const size_t lds = sizeof(float) * 16 * (size_t)lanes * nchb;
     DN_DISPATCH(dtype,
-                hipLaunchKernelGGL((k_gn_stats<BF16>), grid, dim3(256), lds, s, (const unsigned short *)x, HW, C, G, nchb, ppb, stats_ws),
-                hipLaunchKernelGGL((k_gn_stats<F16>), grid, dim3(256), lds, s, (const unsigned short *)x, HW, C, G, nchb, ppb, stats_ws));
-    const int64_t chunks = B * HW * nch;
+                hipLaunchKernelGGL((k_gn_partial<BF16>), grid, dim3(256), lds, s, (const unsigned short *)x, (int)HW, C, nchb, ppb, part),
+                hipLaunchKernelGGL((k_gn_partial<F16>), grid, dim3(256), lds, s, (const unsigned short *)x, (int)HW, C, nchb, ppb, part));
+    DN_DISPATCH(dtype,
+                hipLaunchKernelGGL((k_gn_finalize<BF16>), dim3((unsigned)(B * G)), dim3(256), 0, s, (const unsigned short *)x, (int)HW, C, G, nslab, part, gamma, beta, eps, coef),
+                hipLaunchKernelGGL((k_gn_finalize<F16>), dim3((unsigned)(B * G)), dim3(256), 0, s, (const unsigned short *)x, (int)HW, C, G, nslab, part, gamma, beta, eps, coef));
+    const int64_t chunks = B * HW * (C / 8);
     DN_DISPATCH(dtype,
                 hipLaunchKernelGGL((k_gn_apply<BF16>), dim3(ew_grid(chunks)), dim3(256), 0, s, (const unsigned short *)x,
-                                   (unsigned short *)y, HW, C, G, stats_ws, gamma, beta, eps, act, chunks),
+                                   (unsigned short *)y, (unsigned)HW, (unsigned)C, coef, act, (unsigned)chunks),
                 hipLaunchKernelGGL((k_gn_apply<F16>), dim3(ew_grid(chunks)), dim3(256), 0, s, (const unsigned short *)x,
-                                   (unsigned short *)y, HW, C, G, stats_ws, gamma, beta, eps, act, chunks));
+                                   (unsigned short *)y, (unsigned)HW, (unsigned)C, coef, act, (unsigned)chunks));
     return gc::check_launch("gc_dn_groupnorm");
 }
 
@@ -321,9 +390,9 @@ int gc_dn_concat_add(int dtype, const void *a, int C1, const void *b, const void
     const int64_t chunks = M * ((C1 + C2) / 8);
     DN_DISPATCH(dtype,
                 hipLaunchKernelGGL((k_concat_add<BF16>), dim3(ew_grid(chunks)), dim3(256), 0, gc::S(stream), (const unsigned short *)a, C1,
-                                   (const unsigned short *)b, (const unsigned short *)c, C2, (unsigned short *)out, chunks),
+                                   (const unsigned short *)b, (const unsigned short *)c, C2, (unsigned short *)out, (unsigned)chunks),
                 hipLaunchKernelGGL((k_concat_add<F16>), dim3(ew_grid(chunks)), dim3(256), 0, gc::S(stream), (const unsigned short *)a, C1,
-                                   (const unsigned short *)b, (const unsigned short *)c, C2, (unsigned short *)out, chunks));
+                                   (const unsigned short *)b, (const unsigned short *)c, C2, (unsigned short *)out, (unsigned)chunks));
     return gc::check_launch("gc_dn_concat_add");
 }
 

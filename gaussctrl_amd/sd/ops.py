@@ -135,10 +135,11 @@ def groupnorm(x, gamma, beta, groups, eps, silu):
     _gpu(x)
     B, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * Cc)
-    key = (x.device, B, groups)
+    key = (x.device, B, HW, Cc)
     ws = _gn_ws.get(key)
     if ws is None:
-        ws = _gn_ws[key] = torch.empty(2 * groups * B, dtype=torch.float32, device=x.device)
+        nbytes = L.lib().gc_dn_groupnorm_workspace_bytes(C.c_int64(B), C.c_int64(HW), Cc)
+        ws = _gn_ws[key] = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
     y = torch.empty_like(x)
     L.check(L.lib().gc_dn_groupnorm(_dt(x), _p(x), _p(y), C.c_int64(B), C.c_int64(HW), Cc, groups, _p(gamma), _p(beta),
                                     C.c_float(eps), int(silu), _p(ws), _stream()), "gc_dn_groupnorm")

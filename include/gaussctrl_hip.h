@@ -211,7 +211,8 @@ typedef struct gc_attn_desc {
 } gc_attn_desc;
 int gc_dn_attention(const gc_attn_desc *desc, void *stream);
 
-/* GroupNorm(G groups, eps)(+SiLU) on [B][HW][C]; stats_ws: float[2*G*B] scratch. */
+/* GroupNorm(G groups, eps)(+SiLU) on [B][HW][C]; stats_ws: gc_dn_groupnorm_workspace_bytes(B, HW, C) bytes of scratch. */
+size_t gc_dn_groupnorm_workspace_bytes(int64_t B, int64_t HW, int C);
 int gc_dn_groupnorm(int dtype, const void *x, void *y, int64_t B, int64_t HW, int C, int G, const float *gamma,
                     const float *beta, float eps, int act, float *stats_ws, void *stream);
 /* LayerNorm over C on [M][C]. */
