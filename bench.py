@@ -39,7 +39,7 @@ PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0}
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=14)   # one scene of V=40 views at chunk_size 3 = 14 chunks (+ 1 reference trajectory)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--gaussians", type=int, default=1_000_000)
     ap.add_argument("--views", type=int, default=40)
@@ -58,8 +58,17 @@ class GemmProfiler:
         self.rec = []
 
     def wrap(self, ops):
-        self._lin, self._conv = ops.linear, ops.conv3x3
+        self._lin, self._conv, self._att = ops.linear, ops.conv3x3, ops.attention
         prof = self
+
+        def att(q, k, vt, heads, sets, fph, Lk=None, **kw):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = prof._att(q, k, vt, heads, sets, fph, Lk=Lk, **kw)
+            e.record()
+            lk = k.shape[1] if Lk is None else Lk
+            prof.rec.append(("attention", 4.0 * q.shape[0] * q.shape[1] * lk * q.shape[2] * len(sets), s, e))
+            return out
 
         def lin(x, w, *a, **k):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -78,10 +87,10 @@ class GemmProfiler:
             prof.rec.append(("conv3x3", 2.0 * (out.numel() // out.shape[-1]) * w.shape[0] * w.shape[1], s, e))
             return out
 
-        ops.linear, ops.conv3x3 = lin, conv
+        ops.linear, ops.conv3x3, ops.attention = lin, conv, att
 
     def unwrap(self, ops):
-        ops.linear, ops.conv3x3 = self._lin, self._conv
+        ops.linear, ops.conv3x3, ops.attention = self._lin, self._conv, self._att
 
     def summary(self):
         torch.cuda.synchronize()
@@ -214,7 +223,9 @@ def main():
         dom = max(sm.items(), key=lambda kv: kv[1]["ms"])
         kind, d = dom
         ach = d["flop"] / (d["ms"] * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": f"k_gemm<{args.dtype},{'conv3x3' if kind == 'conv3x3' else 'linear'}>",
+        kname = {"conv3x3": f"k_gemm<{args.dtype},conv3x3>", "linear": f"k_gemm<{args.dtype},linear>",
+                 "attention": f"k_attn<{args.dtype}> (multi-K/V-set flash attention)"}[kind]
+        roof = {"bound": "mfma", "kernel": kname,
                 "achieved": round(ach, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
                 "launches": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
@@ -246,9 +257,11 @@ def main():
 
 
 def cpu_baseline(args):
-    """Oracle ("port") timed on the host cores on a bounded sample: ONE CFG ControlNet+UNet cross-view step at the
-    reference's CPU-runnable shape (configs[0]: chunk_size=1 -> f = 4 refs + 1 = 5 frames, batch 10) + one raster
-    fwd+bwd at N=200k; extrapolated to an edited view = 20 steps * step + eval render + train render fwd+bwd."""
+    """Oracle ("port") timed on the host cores on a BOUNDED sample: ONE CFG ControlNet+UNet cross-view step at the
+    reference's CPU-runnable shape (configs[0]: chunk_size=1 -> f = 4 refs + 1 = 5 frames, batch 10) on 32x32 latents,
+    scaled to 64x64 latents by the analytic FLOP ratio (conv / linear terms x4, attention core x16
+    -> x6.28), + one C-oracle raster eval + train fwd+bwd at N=200k scaled linearly to N.  An edited view at chunk_size 1
+    costs the whole f=5 batch for 20 steps."""
     from oracle import raster_c, sd15_torch as sd
     from gaussctrl_amd import synthetic as syn
     cores = os.cpu_count() or 1
@@ -257,12 +270,14 @@ def cpu_baseline(args):
     with torch.no_grad():
         uw = sd.make_unet_weights(sd.SD15, 100); cw = sd.make_controlnet_weights(sd.SD15, 200)
         f = 5
-        lat = torch.randn(f, 4, 64, 64); disp = torch.rand(f, 3, 512, 512)
+        lat = torch.randn(f, 4, 32, 32); disp = torch.rand(f, 3, 256, 256)
         cn, cp = torch.randn(1, 77, 768), torch.randn(1, 77, 768)
         t0 = time.perf_counter()
         sd.denoise_chunk(uw, cw, lat, disp, cn, cp, 5.0, 1, sd.SD15, 20)
-        t_step = time.perf_counter() - t0
+        t32 = time.perf_counter() - t0
     del uw, cw
+    scale = (1293.3 + 479.3) / ((1293.3 - 612.5) / 4 + 612.5 / 16 + (479.3 - 245.1) / 4 + 245.1 / 16)
+    t_step = t32 * scale
     N = 200_000
     P = syn.make_gaussians(N, seed=0)
     c2w = syn.make_cameras(1, seed=1)[0]
@@ -273,10 +288,11 @@ def cpu_baseline(args):
     raster_c.render(P, c2w, K["fx"], K["fy"], K["cx"], K["cy"], 512, 512, bgc, training=False)
     raster_c.render(P, c2w, K["fx"], K["fy"], K["cx"], K["cy"], 512, 512, bgc, training=True, v_rgb=v_rgb)
     t_raster = (time.perf_counter() - t0) * (args.gaussians / N)
-    per_view = 20 * t_step + t_raster            # chunk_size 1: the whole f=5 batch buys ONE edited view
+    per_view = 20 * t_step + t_raster
     return {"value": round(1.0 / per_view, 6), "unit": "views/s", "cores": threads, "kind": "port",
-            "sample": f"1 of 20 CFG ControlNet+UNet cross-view steps at f=5 (batch 10, 64x64 latents) = {t_step:.2f}s x20; "
-                      f"C raster eval + train fwd+bwd at N={N} (1 thread) scaled to N={args.gaussians} = {t_raster:.2f}s; VAE decode not included"}
+            "sample": f"1 of 20 CFG ControlNet+UNet cross-view steps, f=5 (batch 10) on 32x32 latents = {t32:.2f}s, x{scale:.2f} "
+                      f"(analytic FLOP ratio) -> {t_step:.1f}s per 64x64 step, x20 steps; C raster eval + train fwd+bwd at "
+                      f"N={N} (1 thread) scaled to N={args.gaussians} = {t_raster:.2f}s; VAE decode not included"}
 
 
 if __name__ == "__main__":

@@ -39,7 +39,7 @@ struct GemmArgs {
     float out_scale;
     int act, geglu;
     void *out; int64_t ldc; int out_f32;
-    void *out_t; int64_t ldt; int64_t t_batch_stride;
+    void *out_t; int64_t ldt; int64_t t_batch_stride; int64_t t_col0;
     int splits; int tiles_per_split;    // split-K: k-tiles [z*tps, min(nk, (z+1)*tps))
     float *ws;                          // fp32 [M][N] accumulation workspace when splits > 1
 };
@@ -79,17 +79,18 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs &g, int64_t m, int
         v[0] += T::to_f((unsigned short)(rr.x & 0xffff)); v[1] += T::to_f((unsigned short)(rr.x >> 16));
         v[2] += T::to_f((unsigned short)(rr.y & 0xffff)); v[3] += T::to_f((unsigned short)(rr.y >> 16));
     }
-    if (g.out) {
+    const bool to_t = g.out_t && on >= g.t_col0;
+    if (g.out && !(to_t && g.t_col0 > 0)) {
         if (g.out_f32)
             *reinterpret_cast<float4 *>((float *)g.out + m * g.ldc + on) = make_float4(v[0], v[1], v[2], v[3]);
         else
             *reinterpret_cast<uint2 *>((unsigned char *)g.out + (m * g.ldc + on) * 2) = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
     }
-    if (g.out_t) {   // transposed copy out_t[b][n][tok] (V operand of the attention kernel)
+    if (to_t) {   // transposed copy out_t[b][n - t_col0][tok] (V operand of the attention kernel)
         const int64_t b = m / g.rows_per_batch, tok = m - b * g.rows_per_batch;
         unsigned short *o = (unsigned short *)g.out_t + b * g.t_batch_stride + tok;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[(on + r) * g.ldt] = T::from_f(v[r]);
+        for (int r = 0; r < 4; ++r) o[(on - g.t_col0 + r) * g.ldt] = T::from_f(v[r]);
     }
 }
 
@@ -278,32 +279,87 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmArgs g)
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds out[m = m0 + (lane&15)][n = n0 + 4*(lane>>4) + r], r = 0..3
+    // ---- epilogue: lane holds out[m = m0 + (lane&15)][n = n0 + 4*(lane>>4) + r], r = 0..3.
+    // All operand loads of a row (bias once per lane; row-vector + residual per m-tile) are issued together BEFORE they are
+    // used: the naive per-accumulator load->use chain cost ~1 us of latency x 20 accumulators on every launch.
+    const int64_t n_lane = n_base + wn * (16 * NTW) + fc * 4;
+    if (g.splits > 1) {   // partial sums of this k-slice: plain 16-byte stores into slab blockIdx.y
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int64_t m = m_base + wm * 64 + mt * 16 + fr;
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int64_t n = n_lane + nt * 16;
+                if (n < g.N)
+                    *reinterpret_cast<float4 *>(g.ws + ((int64_t)blockIdx.y * g.M + m) * g.N + n) =
+                        make_float4(acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]);
+            }
+        }
+        return;
+    }
+    float4 bia[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int64_t n = n_lane + nt * 16;
+        bia[nt] = (g.bias && n < g.N) ? *reinterpret_cast<const float4 *>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const int64_t m = m_base + wm * 64 + mt * 16 + fr;
         if (m >= g.M) continue;
+        float4 rv[NTW];
+        uint2 rs[NTW];
+        const int64_t bidx = g.rowvec ? m / g.rows_per_batch : 0;
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
-            const int64_t n = n_base + wn * (16 * NTW) + nt * 16 + fc * 4;
+            const int64_t n = n_lane + nt * 16;
+            const bool okn = n < g.N && !(g.geglu && (nt & 1));
+            const int64_t on = g.geglu ? (n_base + wn * (16 * NTW) + nt * 16) / 2 + fc * 4 : n;
+            rv[nt] = (g.rowvec && n < g.N) ? *reinterpret_cast<const float4 *>(g.rowvec + bidx * g.ld_rowvec + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rs[nt] = (g.residual && okn) ? *reinterpret_cast<const uint2 *>((const unsigned char *)g.residual + (m * g.ldr + on) * 2) : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int64_t n = n_lane + nt * 16;
             if (n >= g.N) continue;
-            if (g.splits > 1) {   // partial sums of this k-slice: plain 16-byte stores into slice blockIdx.y
-                *reinterpret_cast<float4 *>(g.ws + ((int64_t)blockIdx.y * g.M + m) * g.N + n) =
-                    make_float4(acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]);
-                continue;
-            }
             if (g.geglu && (nt & 1)) continue;
-            float v[4] = {acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]};
-            float gate[4] = {0.f, 0.f, 0.f, 0.f};
+            float v[4] = {acc[nt][mt][0] + bia[nt].x + rv[nt].x, acc[nt][mt][1] + bia[nt].y + rv[nt].y,
+                          acc[nt][mt][2] + bia[nt].z + rv[nt].z, acc[nt][mt][3] + bia[nt].w + rv[nt].w};
             int64_t on = n;
             if (g.geglu) {   // weights are row-permuted in 16-blocks [x | gate]; partner tile = nt + 1 (NTW is even here)
                 constexpr int NP = NTW - 1;
                 const int np = nt + 1 < NTW ? nt + 1 : NP;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) gate[r] = acc[np][mt][r];
+                v[0] *= gelu_erf(acc[np][mt][0] + bia[np].x); v[1] *= gelu_erf(acc[np][mt][1] + bia[np].y);
+                v[2] *= gelu_erf(acc[np][mt][2] + bia[np].z); v[3] *= gelu_erf(acc[np][mt][3] + bia[np].w);
                 on = (n_base + wn * (16 * NTW) + nt * 16) / 2 + fc * 4;
             }
-            epilogue_store<T>(g, m, n, on, v, gate);
+            if (g.act == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = silu(v[r]);
+            } else if (g.act == 2) {   // image post-process of pipe(output_type='pt'): (x/2 + 0.5).clamp(0,1)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r] * 0.5f + 0.5f, 0.f), 1.f);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= g.out_scale;
+            if (g.residual) {
+                v[0] += T::to_f((unsigned short)(rs[nt].x & 0xffff)); v[1] += T::to_f((unsigned short)(rs[nt].x >> 16));
+                v[2] += T::to_f((unsigned short)(rs[nt].y & 0xffff)); v[3] += T::to_f((unsigned short)(rs[nt].y >> 16));
+            }
+            const bool to_t = g.out_t && on >= g.t_col0;     // fused QKV: columns >= t_col0 (V) go ONLY to the transposed buffer
+            if (g.out && !(to_t && g.t_col0 > 0)) {
+                if (g.out_f32)
+                    *reinterpret_cast<float4 *>((float *)g.out + m * g.ldc + on) = make_float4(v[0], v[1], v[2], v[3]);
+                else
+                    *reinterpret_cast<uint2 *>((unsigned char *)g.out + (m * g.ldc + on) * 2) = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
+            }
+            if (to_t) {   // transposed copy out_t[b][n - t_col0][tok] (V operand of the attention kernel)
+                const int64_t b = m / g.rows_per_batch, tok = m - b * g.rows_per_batch;
+                unsigned short *o = (unsigned short *)g.out_t + b * g.t_batch_stride + tok;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[(on - g.t_col0 + r) * g.ldt] = T::from_f(v[r]);
+            }
         }
     }
 }
@@ -393,7 +449,7 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
     g.W = d->W; g.bias = d->bias; g.rowvec = d->rowvec; g.ld_rowvec = d->ld_rowvec;
     g.rows_per_batch = d->rows_per_batch > 0 ? d->rows_per_batch : 1;
     g.residual = d->residual; g.ldr = d->ldr; g.out_scale = d->out_scale; g.act = d->act; g.geglu = d->geglu;
-    g.out = d->out; g.ldc = d->ldc; g.out_f32 = d->out_f32; g.out_t = d->out_t; g.ldt = d->ldt; g.t_batch_stride = d->t_batch_stride;
+    g.out = d->out; g.ldc = d->ldc; g.out_f32 = d->out_f32; g.out_t = d->out_t; g.ldt = d->ldt; g.t_batch_stride = d->t_batch_stride; g.t_col0 = d->t_col0;
     int mode = 0;
     if (d->mode == 1) {
         GC_REQUIRE(d->Cin % 8 == 0 && d->K == 9 * (int64_t)d->Cin, "conv3x3: K must be 9*Cin with Cin % 8 == 0");

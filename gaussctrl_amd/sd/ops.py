@@ -21,7 +21,7 @@ class GemmDesc(C.Structure):
                 ("W", C.c_void_p), ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("ld_rowvec", C.c_int64),
                 ("rows_per_batch", C.c_int64), ("residual", C.c_void_p), ("ldr", C.c_int64), ("out_scale", C.c_float),
                 ("act", C.c_int), ("geglu", C.c_int), ("out", C.c_void_p), ("ldc", C.c_int64), ("out_f32", C.c_int),
-                ("out_t", C.c_void_p), ("ldt", C.c_int64), ("t_batch_stride", C.c_int64),
+                ("out_t", C.c_void_p), ("ldt", C.c_int64), ("t_batch_stride", C.c_int64), ("t_col0", C.c_int64),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
@@ -72,7 +72,7 @@ def _run_gemm(d, dev, what):
 
 
 def linear(x, w, bias=None, residual=None, act=0, geglu=False, out_f32=False, scale=1.0, rowvec=None, rows_per_batch=0,
-           ld_rowvec=None, out=None, want_out=True, out_t=None, ldt=0, t_batch_stride=0):
+           ld_rowvec=None, out=None, want_out=True, out_t=None, ldt=0, t_batch_stride=0, t_col0=0, out_cols=None):
     """x [..., K] (last dim contiguous, rows strided by x.stride(-2)) @ w[N,K]^T with fused epilogue."""
     _gpu(x, w)
     K = x.shape[-1]
@@ -86,7 +86,7 @@ def linear(x, w, bias=None, residual=None, act=0, geglu=False, out_f32=False, sc
     if rowvec is not None:
         d.rowvec = rowvec.data_ptr(); d.ld_rowvec = rowvec.stride(0) if ld_rowvec is None else ld_rowvec
     d.rows_per_batch = rows_per_batch
-    No = N // 2 if geglu else N
+    No = N // 2 if geglu else (N if out_cols is None else out_cols)
     if residual is not None:
         d.residual = residual.data_ptr(); d.ldr = residual.stride(-2)
     d.out_scale = scale; d.act = act; d.geglu = int(geglu)
@@ -95,7 +95,7 @@ def linear(x, w, bias=None, residual=None, act=0, geglu=False, out_f32=False, sc
             out = torch.empty(x.shape[:-1] + (No,), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
         d.out = out.data_ptr(); d.ldc = out.stride(-2); d.out_f32 = int(out_f32)
     if out_t is not None:
-        d.out_t = out_t.data_ptr(); d.ldt = ldt; d.t_batch_stride = t_batch_stride
+        d.out_t = out_t.data_ptr(); d.ldt = ldt; d.t_batch_stride = t_batch_stride; d.t_col0 = t_col0
     _run_gemm(d, x.device, "gc_dn_gemm")
     return out
 

@@ -68,22 +68,31 @@ class SDNet:
         self.cfg = cfg
         self.name = name
         self.dtype = weights["conv_in.weight"].dtype
+        self._temb_cache = {}
 
     # ---------------------------------------------------------------------------------------- blocks
     def time_embed(self, t: float, device):
-        """-> silu(temb) [1,1280] in the activation dtype (every consumer applies SiLU first)."""
+        """-> {resnet prefix: fp32 row-vector [1, Cout]} = time_emb_proj(silu(time_embedding(t))) for EVERY resnet of the
+        network from one batched GEMM; depends only on t, so it is cached per timestep (20 entries per trajectory)."""
+        key = float(t)
+        hit = self._temb_cache.get(key)
+        if hit is not None:
+            return hit
         w = self.w
         e = timestep_embedding(t, self.cfg["block_out_channels"][0]).to(device).to(self.dtype)
         h = ops.linear(e, w["time_embedding.linear_1.weight"], w["time_embedding.linear_1.bias"], act=1)
-        return ops.linear(h, w["time_embedding.linear_2.weight"], w["time_embedding.linear_2.bias"], act=1)
+        h = ops.linear(h, w["time_embedding.linear_2.weight"], w["time_embedding.linear_2.bias"], act=1)
+        allv = ops.linear(h, w["_temb_all.weight"], w["_temb_all.bias"], out_f32=True)          # [1, sum Cout]
+        out = {n: allv[:, o:o + c] for n, (o, c) in w["_temb_all.index"].items()}
+        if len(self._temb_cache) < 256:
+            self._temb_cache[key] = out
+        return out
 
     def resnet(self, p, x, temb_act, eps=1e-5):
         w = self.w
         g = self.cfg["groups"]
         h = ops.groupnorm(x, w[p + ".norm1.weight"], w[p + ".norm1.bias"], g, eps, True)
-        rv = None
-        if temb_act is not None:
-            rv = ops.linear(temb_act, w[p + ".time_emb_proj.weight"], w[p + ".time_emb_proj.bias"], out_f32=True)
+        rv = None if temb_act is None else temb_act[p]
         h = ops.conv3x3(h, w[p + ".conv1.weight"], w[p + ".conv1.bias"], rowvec=rv, ld_rowvec=0)
         h = ops.groupnorm(h, w[p + ".norm2.weight"], w[p + ".norm2.bias"], g, eps, True)
         sc = x
@@ -96,10 +105,11 @@ class SDNet:
         heads = self.cfg["heads"]
         B, L, Cc = n.shape
         Lp = (L + 7) // 8 * 8
-        q = ops.linear(n, w[p + ".to_q.weight"])
-        k = ops.linear(n, w[p + ".to_k.weight"])
         vt = torch.zeros(B, Cc, Lp, dtype=n.dtype, device=n.device) if Lp != L else torch.empty(B, Cc, Lp, dtype=n.dtype, device=n.device)
-        ops.linear(n, w[p + ".to_v.weight"], want_out=False, rows_per_batch=L, out_t=vt, ldt=Lp, t_batch_stride=Cc * Lp)
+        # one GEMM for Q | K | V: columns [0,2C) -> qk [B,L,2C], columns [2C,3C) -> V^T [B,C,Lp]
+        qk = ops.linear(n, w[p + ".to_qkv.weight"], rows_per_batch=L, out_t=vt, ldt=Lp, t_batch_stride=Cc * Lp, t_col0=2 * Cc,
+                        out_cols=2 * Cc)
+        q, k = qk[..., :Cc], qk[..., Cc:]
         if actx.mode == "plain":
             return ops.attention(q, k, vt, heads, [(-1, 1.0)], actx.f, Lk=L)
         a = actx.coeff

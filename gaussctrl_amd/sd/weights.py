@@ -58,6 +58,20 @@ def prepare(sd: dict, dtype, device) -> dict:
         else:
             out[k] = v.float().contiguous()       # norm affine, linear / 1x1 biases
     for k in list(out.keys()):
+        if k.endswith(".attn1.to_q.weight"):            # fused Q|K|V projection of the self-attention layers
+            a = k[:-len("to_q.weight")]
+            out[a + "to_qkv.weight"] = torch.cat([out[a + "to_q.weight"], out[a + "to_k.weight"], out[a + "to_v.weight"]], 0).contiguous()
+    names = sorted(k[:-len(".time_emb_proj.weight")] for k in out if k.endswith(".time_emb_proj.weight"))
+    if names:                                          # all time-embedding projections of a network as ONE [sum Cout, 1280] GEMM
+        out["_temb_all.weight"] = torch.cat([out[n + ".time_emb_proj.weight"] for n in names], 0).contiguous()
+        out["_temb_all.bias"] = torch.cat([out[n + ".time_emb_proj.bias"] for n in names], 0).contiguous()
+        off = 0
+        idx = {}
+        for n in names:
+            c = out[n + ".time_emb_proj.weight"].shape[0]
+            idx[n] = (off, c); off += c
+        out["_temb_all.index"] = idx
+    for k in list(out.keys()):
         if k.endswith("ff.net.0.proj.weight"):
             b = k[:-6] + "bias"
             out[k], out[b] = geglu_permute(out[k], out[b])

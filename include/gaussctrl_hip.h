@@ -180,6 +180,7 @@ typedef struct gc_gemm_desc {
     void *out_t;               /* optional transposed copy [M / rows_per_batch][N][ldt] (V operand of gc_dn_attention) */
     int64_t ldt;
     int64_t t_batch_stride;
+    int64_t t_col0;            /* fused QKV projection: output columns >= t_col0 are written ONLY to out_t (column n - t_col0); 0 = all columns to both */
     void *workspace;           /* >= gc_dn_gemm_workspace_bytes(desc) bytes (split-K fp32 accumulator for small-M problems); */
     size_t workspace_bytes;    /* NULL / too small: the problem runs unsplit */
 } gc_gemm_desc;

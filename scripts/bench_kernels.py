@@ -6,6 +6,7 @@ from gaussctrl_amd.sd import ops
 from gaussctrl_amd.sd.weights import conv3x3_weight, geglu_permute
 DEV = 'cuda:0'
 what = sys.argv[1] if len(sys.argv) > 1 else 'all'
+if __name__ != '__main__': what = 'none'
 dt = torch.float16 if (len(sys.argv) > 2 and sys.argv[2] == 'f16') else torch.bfloat16
 B = 6
 
@@ -81,4 +82,10 @@ if what in ('norm', 'all'):
         x = rnd(M, C); g = torch.randn(C, device=DEV); bb = torch.randn(C, device=DEV)
         us = timeit(lambda: ops.layernorm(x, g, bb))
         print(f"  layernorm M={M:6d} C={C:5d}: {us:8.1f} us  {M * C * 2 * 2 / us / 1e6:6.2f} TB/s")
+if what == "scan":
+    for K, N in ((320, 320), (1280, 1280), (320, 1280), (1280, 320)):
+        for M in (128, 1536, 6144, 24576, 98304):
+            x = rnd(M, K); w = rnd(N, K, scale=K ** -0.5); b = torch.randn(N, device=DEV)
+            us = timeit(lambda: ops.linear(x, w, b))
+            print(f"  M={M:6d} K={K:5d} N={N:5d}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF/s")
 print("weighted per-UNet-forward totals (us):", {k: round(v) for k, v in tot.items()})
