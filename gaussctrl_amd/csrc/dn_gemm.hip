@@ -304,20 +304,32 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmArgs g)
         const int64_t n = n_lane + nt * 16;
         bia[nt] = (g.bias && n < g.N) ? *reinterpret_cast<const float4 *>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // residual / row-vector operands of ALL four m-tiles are requested before the first one is consumed (one latency, not four)
+    uint2 rs_all[4][NTW];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int64_t m = m_base + wm * 64 + mt * 16 + fr;
+        const bool okm = m < g.M;
+        const int64_t mc = okm ? m : 0;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int64_t n = n_lane + nt * 16;
+            const bool okn = okm && n < g.N && !(g.geglu && (nt & 1));
+            const int64_t on = g.geglu ? (n_base + wn * (16 * NTW) + nt * 16) / 2 + fc * 4 : n;
+            rs_all[mt][nt] = (g.residual && okn) ? *reinterpret_cast<const uint2 *>((const unsigned char *)g.residual + (mc * g.ldr + on) * 2) : make_uint2(0u, 0u);
+        }
+    }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const int64_t m = m_base + wm * 64 + mt * 16 + fr;
         if (m >= g.M) continue;
+        const uint2 *rs = rs_all[mt];
         float4 rv[NTW];
-        uint2 rs[NTW];
         const int64_t bidx = g.rowvec ? m / g.rows_per_batch : 0;
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
             const int64_t n = n_lane + nt * 16;
-            const bool okn = n < g.N && !(g.geglu && (nt & 1));
-            const int64_t on = g.geglu ? (n_base + wn * (16 * NTW) + nt * 16) / 2 + fc * 4 : n;
             rv[nt] = (g.rowvec && n < g.N) ? *reinterpret_cast<const float4 *>(g.rowvec + bidx * g.ld_rowvec + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-            rs[nt] = (g.residual && okn) ? *reinterpret_cast<const uint2 *>((const unsigned char *)g.residual + (m * g.ldr + on) * 2) : make_uint2(0u, 0u);
         }
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
