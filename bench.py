@@ -54,8 +54,9 @@ def parse():
 class GemmProfiler:
     """Brackets every gc_dn_gemm launch with HIP events on the launch stream (one instrumented step)."""
 
-    def __init__(self):
+    def __init__(self, dt="BF16"):
         self.rec = []
+        self.dt = dt
 
     def wrap(self, ops):
         self._lin, self._conv, self._att = ops.linear, ops.conv3x3, ops.attention
@@ -67,7 +68,8 @@ class GemmProfiler:
             out = prof._att(q, k, vt, heads, sets, fph, Lk=Lk, **kw)
             e.record()
             lk = k.shape[1] if Lk is None else Lk
-            prof.rec.append(("attention", 4.0 * q.shape[0] * q.shape[1] * lk * q.shape[2] * len(sets), s, e))
+            qt = 1 if q.shape[2] // heads == 160 else 2
+            prof.rec.append((f"k_attn<{prof.dt},{q.shape[2] // heads},{qt}>", 4.0 * q.shape[0] * q.shape[1] * lk * q.shape[2] * len(sets), s, e))
             return out
 
         def lin(x, w, *a, **k):
@@ -76,7 +78,9 @@ class GemmProfiler:
             out = prof._lin(x, w, *a, **k)
             e.record()
             K = x.shape[-1]
-            prof.rec.append(("linear", 2.0 * (x.numel() // K) * w.shape[0] * K, s, e))
+            N = w.shape[0]
+            ntw = 5 if (N % 160 == 0 and N % 128 != 0 and not k.get("geglu", False)) else 4      # mirrors plan() in dn_gemm.hip
+            prof.rec.append((f"k_gemm<{prof.dt},0,{ntw}>", 2.0 * (x.numel() // K) * N * K, s, e))
             return out
 
         def conv(x, w, *a, **k):
@@ -84,7 +88,10 @@ class GemmProfiler:
             s.record()
             out = prof._conv(x, w, *a, **k)
             e.record()
-            prof.rec.append(("conv3x3", 2.0 * (out.numel() // out.shape[-1]) * w.shape[0] * w.shape[1], s, e))
+            N = w.shape[0]
+            ntw = 5 if (N % 160 == 0 and N % 128 != 0) else 4
+            mode = 2 if x.shape[-1] % 64 == 0 else 1
+            prof.rec.append((f"k_gemm<{prof.dt},{mode},{ntw}>", 2.0 * (out.numel() // out.shape[-1]) * N * w.shape[1], s, e))
             return out
 
         ops.linear, ops.conv3x3, ops.attention = lin, conv, att
@@ -158,10 +165,8 @@ def main():
         stats["M"].append(aux.M)
         return rgb, depth, aux
 
-    def disparity_of(depth):            # gc_pipeline.py:258-266
-        d = 1.0 / (depth + 1e-5)
-        d = d / d.max()
-        return d[None].expand(3, -1, -1)
+    def disparity_of(depth):            # gc_pipeline.py:258-266 as one HIP kernel pair -> [H,W,8] control image (3 channels used)
+        return sdops.depth_to_disparity(depth, dt)
 
     def step(s):
         views = [(s * c + j) % V for j in range(c)]
@@ -213,19 +218,18 @@ def main():
     # ---------------------------------------------------------------- roofline of the dominant kernel (instrumented extra step)
     roof = None
     if args.workload == "edit" and rank == 0:
-        prof = GemmProfiler()
+        prof = GemmProfiler("BF16" if args.dtype == "bf16" else "F16")
         prof.wrap(sdops)
         try:
-            lat = pipe.edit_chunk_cached(z0[:c], torch.rand(c, 3, H, W, device=dev), ctx_neg, ctx_pos, state["bank"])
+            lat = pipe.edit_chunk_cached(z0[:c], torch.rand(c, 3, H, W, device=dev), ctx_neg, ctx_pos, state["bank"])  # noqa: F841
         finally:
             prof.unwrap(sdops)
         sm = prof.summary()
         dom = max(sm.items(), key=lambda kv: kv[1]["ms"])
         kind, d = dom
         ach = d["flop"] / (d["ms"] * 1e-3) / 1e12
-        kname = {"conv3x3": f"k_gemm<{args.dtype},conv3x3>", "linear": f"k_gemm<{args.dtype},linear>",
-                 "attention": f"k_attn<{args.dtype}> (multi-K/V-set flash attention)"}[kind]
-        roof = {"bound": "mfma", "kernel": kname,
+        roof = {"bound": "mfma", "kernel": kind + (" (multi-K/V-set flash attention, dn_attn.hip)" if kind.startswith("k_attn") else
+                                                    " (MFMA GEMM / implicit 3x3 conv <dtype, mode 0=linear 1|2=conv, n-tiles/wave>, dn_gemm.hip)"),
                 "achieved": round(ach, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
                 "launches": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
@@ -235,7 +239,7 @@ def main():
 
     # ---------------------------------------------------------------- CPU baseline (oracle, rank 0, bounded sample)
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
 
     if rank == 0:

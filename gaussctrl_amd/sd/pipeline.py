@@ -80,7 +80,8 @@ class DenoisePipeline:
         lat = latents.permute(0, 2, 3, 1).contiguous().float()            # master copy fp32 [f,h,w,4]
         xin = to_nhwc8(latents, self.dtype)
         xin = torch.cat([xin] * rep, 0).contiguous()                        # cat([latents]*2)
-        cond = to_nhwc8(disparity, self.dtype)
+        # control image: [f,3,H,W] float (reference layout) or already channels-last [f,H,W,8] in the activation dtype
+        cond = disparity if (disparity.dim() == 4 and disparity.shape[-1] == 8 and disparity.dtype == self.dtype) else to_nhwc8(disparity, self.dtype)
         cemb = self.controlnet.cond_embedding(cond)                         # once per chunk
         cemb = torch.cat([cemb] * rep, 0).contiguous() if rep > 1 else cemb
         ts = self.sched.timesteps(self.n, inverse)
