@@ -21,6 +21,7 @@
 // across workgroups (fp32 partial slabs + a small reduce-epilogue kernel) so that all 256 CUs stream the (large) weight
 // matrix together.
 #include "dn_common.h"
+#include <stdlib.h>
 
 namespace {
 using namespace dn;
@@ -41,7 +42,8 @@ struct GemmArgs {
     void *out; int64_t ldc; int out_f32;
     void *out_t; int64_t ldt; int64_t t_batch_stride; int64_t t_col0;
     int splits; int tiles_per_split;    // split-K: k-tiles [z*tps, min(nk, (z+1)*tps))
-    float *ws;                          // fp32 [M][N] accumulation workspace when splits > 1
+    float *ws;                          // fp32 [splits][M][N] partial slabs when splits > 1
+    const void *zeros;                  // >= 16 bytes of zeros (k_gemm8: source of out-of-range / padding lanes)
 };
 
 // byte offset of 16-byte chunk `c` (0..7) of row `r` inside a [rows][64] 2-byte tile
@@ -376,6 +378,236 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmArgs g)
     }
 }
 
+// =====================================================================================================================
+// k_gemm8 -- same 128 x {128,160} x 64 tile, but 8 wave64 (4 x 2, each 32 x {64,80}), operands DMA'd straight into LDS with
+// global_load_lds_dwordx4 (no VGPR staging, no ds_write pass) through a 3-stage ring: tile t is multiplied while t+1 and
+// t+2 are in flight, ONE barrier per k-tile, counted s_waitcnt vmcnt(N) (never 0 in the main loop).  The LDS image is the
+// same XOR-swizzled layout as k_gemm: an LDS-DMA instruction writes wave-uniform-base + lane*16, so the swizzle is applied
+// to the per-lane SOURCE chunk (lane l of row-group g writes slot l&7 of row 8g + (l>>3) and therefore fetches chunk
+// (l&7) ^ ((row>>1)&7)).  Lanes that fall outside the tensor / in the conv padding fetch from a 16-byte zero page.
+// The DMA is issued from inline asm (M0 = LDS base) so hipcc's waitcnt pass does not drain it with vmcnt(0) before every
+// ds_read; ordering is by the explicit vmcnt + s_barrier below.  One workgroup per CU (96-108 KiB LDS), 2 waves per SIMD.
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <class T, int MODE, int NTW>
+__global__ __launch_bounds__(512, 2) void k_gemm8(const GemmArgs g)
+{
+    constexpr int BN = 32 * NTW;
+    constexpr int STAGE = BM * 128 + BN * 128;
+    constexpr int NS = 3;
+    constexpr int AG = BM / 8, WG = BN / 8;           // 8-row groups (one LDS-DMA instruction each)
+    constexpr int AI = AG / 8, WI = (WG + 7) / 8;     // instructions per wave per tile: A 2, W 2|3
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int nbn = (int)((g.N + BN - 1) / BN);
+    const int64_t nwg = gridDim.x, xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int64_t bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
+    const int64_t mblk = bid / nbn, nblk = bid % nbn;
+    const int64_t m_base = mblk * BM, n_base = nblk * BN;
+    const int nk = (int)((g.K + BK - 1) / BK);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+
+    // ---- per-lane DMA coordinates
+    const int lr = lane >> 3, ls = lane & 7;
+    int a_off[AI], a_y[AI], a_x[AI], a_ck[AI];
+    bool a_ok[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int row = (wid + 8 * i) * 8 + lr;
+        a_ck[i] = ls ^ ((row >> 1) & 7);
+        const int64_t m = m_base + row;
+        a_ok[i] = m < g.M;
+        const int mm = a_ok[i] ? (int)m : 0;
+        if (MODE != 0) {
+            const int hw = g.Ho * g.Wo;
+            const int b = mm / hw;
+            const int rem = mm - b * hw;
+            const int oy = rem / g.Wo;
+            a_y[i] = oy * g.stride - g.pad; a_x[i] = (rem - oy * g.Wo) * g.stride - g.pad;
+            a_off[i] = b * g.Hi * g.Wi * g.Cin + (MODE == 2 ? a_ck[i] * 8 : 0);
+            if (MODE == 2 && !g.ups) a_off[i] += (a_y[i] * g.Wi + a_x[i]) * g.Cin;
+        } else {
+            a_off[i] = mm * (int)g.lda + a_ck[i] * 8;
+            a_y[i] = a_x[i] = 0;
+        }
+    }
+    int w_off[WI], w_ck[WI];
+    bool w_ok[WI];
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        const int grp = wid + 8 * i;
+        const int row = grp * 8 + lr;
+        w_ck[i] = ls ^ ((row >> 1) & 7);
+        const int64_t n = n_base + row;
+        w_ok[i] = grp < WG && n < g.N;
+        w_off[i] = (w_ok[i] ? (int)n : 0) * (int)g.K + w_ck[i] * 8;
+    }
+    const int Hin = g.ups ? g.Hi * 2 : g.Hi, Win = g.ups ? g.Wi * 2 : g.Wi;
+    const unsigned char *Ab = (const unsigned char *)g.A, *Wb = (const unsigned char *)g.W;
+    const unsigned char *Zp = (const unsigned char *)g.zeros;
+    int ld_tap = 0, ld_ci = 0;
+
+    auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
+        const int kb = kt * BK;
+        int dy_u = 0, dx_u = 0, tap_off = 0;
+        if (MODE == 2) {
+            dy_u = ld_tap / 3; dx_u = ld_tap - dy_u * 3;
+            tap_off = g.ups ? ld_ci : (dy_u * g.Wi + dx_u) * g.Cin + ld_ci;
+            ld_ci += BK; if (ld_ci >= g.Cin) { ld_ci -= g.Cin; ++ld_tap; }
+        }
+        const unsigned sbase = lds0 + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            bool ok;
+            int off;
+            if (MODE == 2) {
+                int yi = a_y[i] + dy_u, xi = a_x[i] + dx_u;
+                ok = a_ok[i] && (unsigned)yi < (unsigned)Hin && (unsigned)xi < (unsigned)Win;
+                off = a_off[i] + tap_off;
+                if (g.ups) off += ((yi >> 1) * g.Wi + (xi >> 1)) * g.Cin;
+            } else if (MODE == 1) {
+                const int k0 = kb + a_ck[i] * 8;
+                const int kc = k0 < (int)g.K ? k0 : 0;
+                const int tap = kc / g.Cin;
+                const int ci = kc - tap * g.Cin;
+                const int dy = tap / 3, dx = tap - dy * 3;
+                int yi = a_y[i] + dy, xi = a_x[i] + dx;
+                ok = a_ok[i] && k0 < (int)g.K && (unsigned)yi < (unsigned)Hin && (unsigned)xi < (unsigned)Win;
+                if (g.ups) { yi >>= 1; xi >>= 1; }
+                off = a_off[i] + (yi * g.Wi + xi) * g.Cin + ci;
+            } else {
+                ok = a_ok[i] && (kb + a_ck[i] * 8) < (int)g.K;
+                off = a_off[i] + kb;
+            }
+            const unsigned char *src = ok ? Ab + (size_t)(unsigned)(off * 2) : Zp;
+            glds16(src, sbase + (unsigned)((wid + 8 * i) * 1024));
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            if (wid + 8 * i < WG) {    // wave-uniform
+                const bool ok = w_ok[i] && (kb + w_ck[i] * 8) < (int)g.K;
+                const unsigned char *src = ok ? Wb + (size_t)(unsigned)((w_off[i] + kb) * 2) : Zp;
+                glds16(src, sbase + (unsigned)(BM * 128 + (wid + 8 * i) * 1024));
+            }
+        }
+    };
+
+    f32x4 acc[NTW][2];
+#pragma unroll
+    for (int a = 0; a < NTW; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fc = lane >> 4;
+    const int swz = (fr >> 1) & 7;
+    const int fx0 = ((fc ^ swz) << 4), fx1 = (((fc + 4) ^ swz) << 4);
+    const int aw0 = BM * 128 + (wn * (16 * NTW) + fr) * 128, aa0 = (wm * 32 + fr) * 128;
+    auto compute = [&](int stage) __attribute__((always_inline)) {
+        const unsigned char *sb = smem + stage * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int fx = ks ? fx1 : fx0;
+            uint4 fw[NTW], fa[2];
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) fw[t] = *reinterpret_cast<const uint4 *>(sb + aw0 + fx + t * 2048);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) fa[t] = *reinterpret_cast<const uint4 *>(sb + aa0 + fx + t * 2048);
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = T::mfma(fw[nt], fa[mt], acc[nt][mt]);
+        }
+    };
+
+    // instructions this wave issues per tile (wave-uniform): the counted wait leaves exactly one tile in flight
+    const bool w3 = (wid + 16) < WG;     // this wave owns a third W group
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) {               // tile kt+1 may stay in flight; everything older (tile kt) must have landed
+            if (w3) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();    // every wave's part of tile kt is in LDS; every wave finished reading stage (kt+2)%3
+        if (kt + 2 < nk) issue(kt + 2, (kt + 2) % NS);
+        compute(kt % NS);
+    }
+
+    // ---- epilogue (same math as k_gemm; 2 m-tiles per wave)
+    const int64_t n_lane = n_base + wn * (16 * NTW) + fc * 4;
+    float4 bia[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int64_t n = n_lane + nt * 16;
+        bia[nt] = (g.bias && n < g.N) ? *reinterpret_cast<const float4 *>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int64_t m = m_base + wm * 32 + mt * 16 + fr;
+        if (m >= g.M) continue;
+        float4 rv[NTW];
+        uint2 rs[NTW];
+        const int64_t bidx = g.rowvec ? m / g.rows_per_batch : 0;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int64_t n = n_lane + nt * 16;
+            const bool okn = n < g.N && !(g.geglu && (nt & 1));
+            const int64_t on = g.geglu ? (n_base + wn * (16 * NTW) + nt * 16) / 2 + fc * 4 : n;
+            rv[nt] = (g.rowvec && n < g.N) ? *reinterpret_cast<const float4 *>(g.rowvec + bidx * g.ld_rowvec + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rs[nt] = (g.residual && okn) ? *reinterpret_cast<const uint2 *>((const unsigned char *)g.residual + (m * g.ldr + on) * 2) : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int64_t n = n_lane + nt * 16;
+            if (n >= g.N) continue;
+            if (g.geglu && (nt & 1)) continue;
+            float v[4] = {acc[nt][mt][0] + bia[nt].x + rv[nt].x, acc[nt][mt][1] + bia[nt].y + rv[nt].y,
+                          acc[nt][mt][2] + bia[nt].z + rv[nt].z, acc[nt][mt][3] + bia[nt].w + rv[nt].w};
+            int64_t on = n;
+            if (g.geglu) {
+                constexpr int NP = NTW - 1;
+                const int np = nt + 1 < NTW ? nt + 1 : NP;
+                v[0] *= gelu_erf(acc[np][mt][0] + bia[np].x); v[1] *= gelu_erf(acc[np][mt][1] + bia[np].y);
+                v[2] *= gelu_erf(acc[np][mt][2] + bia[np].z); v[3] *= gelu_erf(acc[np][mt][3] + bia[np].w);
+                on = (n_base + wn * (16 * NTW) + nt * 16) / 2 + fc * 4;
+            }
+            if (g.act == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = silu(v[r]);
+            } else if (g.act == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r] * 0.5f + 0.5f, 0.f), 1.f);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= g.out_scale;
+            if (g.residual) {
+                v[0] += T::to_f((unsigned short)(rs[nt].x & 0xffff)); v[1] += T::to_f((unsigned short)(rs[nt].x >> 16));
+                v[2] += T::to_f((unsigned short)(rs[nt].y & 0xffff)); v[3] += T::to_f((unsigned short)(rs[nt].y >> 16));
+            }
+            const bool to_t = g.out_t && on >= g.t_col0;
+            if (g.out && !(to_t && g.t_col0 > 0)) {
+                if (g.out_f32)
+                    *reinterpret_cast<float4 *>((float *)g.out + m * g.ldc + on) = make_float4(v[0], v[1], v[2], v[3]);
+                else
+                    *reinterpret_cast<uint2 *>((unsigned char *)g.out + (m * g.ldc + on) * 2) = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
+            }
+            if (to_t) {
+                const int64_t b = m / g.rows_per_batch, tok = m - b * g.rows_per_batch;
+                unsigned short *o = (unsigned short *)g.out_t + b * g.t_batch_stride + tok;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[(on - g.t_col0 + r) * g.ldt] = T::from_f(v[r]);
+            }
+        }
+    }
+}
+
 // epilogue of a split-K problem: ws fp32 [M][N] -> out (same epilogue as the fused path; no GEGLU)
 template <class T>
 __global__ __launch_bounds__(256) void k_splitk_epilogue(const GemmArgs g)
@@ -414,6 +646,28 @@ void launch(const GemmArgs &g, dim3 grid, hipStream_t s)
         attr_set = true;
     }
     hipLaunchKernelGGL((k_gemm<T, MODE, NTW>), grid, dim3(NT), lds, s, g);
+}
+
+template <class T, int MODE, int NTW>
+void launch8(const GemmArgs &g, dim3 grid, hipStream_t s)
+{
+    constexpr size_t lds = 3 * (BM * 128 + 32 * NTW * 128);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_gemm8<T, MODE, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_gemm8<T, MODE, NTW>), grid, dim3(512), lds, s, g);
+}
+
+template <class T>
+void dispatch8(const GemmArgs &g, int mode, int ntw, dim3 grid, hipStream_t s)
+{
+    if (ntw == 5) {
+        if (mode == 0) launch8<T, 0, 5>(g, grid, s); else if (mode == 1) launch8<T, 1, 5>(g, grid, s); else launch8<T, 2, 5>(g, grid, s);
+    } else {
+        if (mode == 0) launch8<T, 0, 4>(g, grid, s); else if (mode == 1) launch8<T, 1, 4>(g, grid, s); else launch8<T, 2, 4>(g, grid, s);
+    }
 }
 
 template <class T>
@@ -482,6 +736,16 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
     const int bn = 32 * ntw;
     const int64_t nbm = (d->M + BM - 1) / BM, nbn = (d->N + bn - 1) / bn;
     const dim3 grid((unsigned)(nbm * nbn), (unsigned)splits);
+    g.zeros = d->zeros;
+    static const int use8 = [] { const char *e = getenv("GC_GEMM8"); return e ? atoi(e) : 1; }();
+    // LDS-DMA 8-wave kernel (1 workgroup / CU): measured faster than the register-staged kernel (2 workgroups / CU) exactly when
+    // the grid fits one round of single-workgroup CUs (96..256 tiles: 32x32-map convs, the C=640 / 1280 linears); larger grids
+    // run better two-per-CU on k_gemm.  GC_GEMM8=0 disables it, =2 forces it (tests).
+    const int64_t tiles = nbm * nbn;
+    if (use8 && d->zeros && splits == 1 && (use8 == 2 || (tiles >= 96 && tiles <= 256))) {
+        if (d->dtype == DT_BF16) dispatch8<BF16>(g, mode, ntw, grid, s); else dispatch8<F16>(g, mode, ntw, grid, s);
+        return gc::check_launch("gc_dn_gemm");
+    }
     if (d->dtype == DT_BF16) dispatch<BF16>(g, mode, ntw, grid, s); else dispatch<F16>(g, mode, ntw, grid, s);
     if (splits > 1) {
         const unsigned eg = (unsigned)std::min<int64_t>((d->M * (d->N / 4) + 255) / 256, 2048);

@@ -22,7 +22,7 @@ class GemmDesc(C.Structure):
                 ("rows_per_batch", C.c_int64), ("residual", C.c_void_p), ("ldr", C.c_int64), ("out_scale", C.c_float),
                 ("act", C.c_int), ("geglu", C.c_int), ("out", C.c_void_p), ("ldc", C.c_int64), ("out_f32", C.c_int),
                 ("out_t", C.c_void_p), ("ldt", C.c_int64), ("t_batch_stride", C.c_int64), ("t_col0", C.c_int64),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("zeros", C.c_void_p)]
 
 
 class AttnDesc(C.Structure):
@@ -61,8 +61,15 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_zero_page = {}
+
+
 def _run_gemm(d, dev, what):
     lib = L.lib()
+    z = _zero_page.get(dev)
+    if z is None:
+        z = _zero_page[dev] = torch.zeros(64, dtype=torch.uint8, device=dev)
+    d.zeros = z.data_ptr()
     wsb = lib.gc_dn_gemm_workspace_bytes(C.byref(d))
     ws = None
     if wsb:

@@ -183,6 +183,7 @@ typedef struct gc_gemm_desc {
     int64_t t_col0;            /* fused QKV projection: output columns >= t_col0 are written ONLY to out_t (column n - t_col0); 0 = all columns to both */
     void *workspace;           /* >= gc_dn_gemm_workspace_bytes(desc) bytes (split-K fp32 accumulator for small-M problems); */
     size_t workspace_bytes;    /* NULL / too small: the problem runs unsplit */
+    const void *zeros;         /* >= 16 bytes of device zeros: enables the LDS-DMA kernel (padding / out-of-range lanes fetch from it); NULL: register-staged kernel */
 } gc_gemm_desc;
 size_t gc_dn_gemm_workspace_bytes(const gc_gemm_desc *desc);
 int gc_dn_gemm(const gc_gemm_desc *desc, void *stream);
