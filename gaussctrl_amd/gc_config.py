@@ -25,6 +25,6 @@ else:
 
 def build_optimizers(model):
     """Adam per parameter group with the reference's learning rates / eps (gc_config.py:58-87)."""
-    import torch
+    from .train_ops import FusedAdam
     groups = model.get_param_groups()
-    return {name: torch.optim.Adam(params, lr=PARAM_GROUPS[name].lr, eps=PARAM_GROUPS[name].eps) for name, params in groups.items()}
+    return {name: FusedAdam(params, lr=PARAM_GROUPS[name].lr, eps=PARAM_GROUPS[name].eps) for name, params in groups.items()}

@@ -131,16 +131,14 @@ class GaussCtrlModel(nn.Module):
 
     def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, torch.Tensor]:
         """SplatfactoModel.get_loss_dict [recall, SURVEY 8a/A8]: (1-l)*L1 + l*(1-SSIM), l = 0.2."""
+        from .train_ops import l1_ssim_loss
         gt = batch["image"].to(self.device)
-        pred = outputs["rgb"]
-        l1 = (gt - pred).abs().mean()
-        ssim = _ssim(gt.permute(2, 0, 1)[None], pred.permute(2, 0, 1)[None])
-        lam = self.config.ssim_lambda
-        return {"main_loss": (1 - lam) * l1 + lam * (1 - ssim)}
+        return {"main_loss": l1_ssim_loss(outputs["rgb"], gt, self.config.ssim_lambda)}
 
 
 def _ssim(a, b, window=11, sigma=1.5):
-    """pytorch_msssim / torchmetrics-style SSIM with a gaussian 11x11 window (host framework loss; 8f-1 'next')."""
+    """Plain-torch SSIM with a gaussian 11x11 window: NOT on the product path (get_loss_dict uses the fused HIP kernels of
+    train_ops.l1_ssim_loss); kept as the readable definition the GPU test compares against."""
     import torch.nn.functional as F
     coords = torch.arange(window, dtype=a.dtype, device=a.device) - window // 2
     g = torch.exp(-(coords ** 2) / (2 * sigma ** 2)); g = (g / g.sum())

@@ -244,6 +244,20 @@ class GaussCtrlPipeline(nn.Module):
     def get_param_groups(self):
         return self._model.get_param_groups()
 
+    def train_iteration(self, optimizers: dict, step: int):
+        """One splat-optimisation iteration as GaussCtrlTrainer.train_iteration runs it (gc_trainer.py:257-301): zero grads,
+        forward + loss (gc_pipeline.py:276-287), backward, [gradient all-reduce when world_size > 1], Adam steps
+        (gc_config.py:58-87).  Returns (loss, loss_dict, metrics_dict)."""
+        for opt in optimizers.values():
+            opt.zero_grad(set_to_none=True)
+        _, loss_dict, metrics_dict = self.get_train_loss_dict(step)
+        loss = sum(loss_dict.values())
+        loss.backward()
+        self.reduce_gradients()
+        for opt in optimizers.values():
+            opt.step()
+        return loss.detach(), loss_dict, metrics_dict
+
     def forward(self):
         """Not implemented since we only want the parameter saving of the nn module, but not forward()"""
         raise NotImplementedError

@@ -146,6 +146,18 @@ int gc_project_sh_bwd(int64_t N, const float *means, const float *log_scales, co
 int gc_raster_finalize(int64_t num_pixels, float *out_img, float *out_extra, const float *final_Ts,
                        float *alpha, void *stream);
 
+/* Loss + optimiser of the splat optimisation that follows the edit (reference:
+ * SplatfactoModel.get_loss_dict inherited via gaussctrl/gc_pipeline.py:284-285, Adam groups gaussctrl/gc_config.py:58-87,
+ * iteration gaussctrl/gc_trainer.py:257-301). */
+size_t gc_l1_ssim_workspace_bytes(int H, int W, int C);
+/* (1-lambda)*mean|pred-target| + lambda*(1 - mean SSIM_11x11(pred,target)) on float32 [H,W,C]: loss_sums (device float[2]) =
+ * {sum of the SSIM map, sum |pred-target|}; v_pred = grad_scale * d loss / d pred. */
+int gc_l1_ssim_fwd_bwd(const float *pred, const float *target, int H, int W, int C, float lambda_, float grad_scale,
+                       float *loss_sums, float *v_pred, void *workspace, size_t workspace_bytes, void *stream);
+/* torch.optim.Adam step (no weight decay / amsgrad) on one flat float32 tensor; step is the 1-based iteration count. */
+int gc_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
+                 float beta2, float eps, int step, void *stream);
+
 /* ===================================================================================== */
 /* Part B -- ControlNet + UNet denoise step (replaces the diffusers / cuBLAS / cuDNN calls behind  */
 /* gaussctrl/gc_pipeline.py:142-145,209-219 and the attention processor gaussctrl/utils.py:25-133) */

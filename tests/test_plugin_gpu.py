@@ -103,5 +103,39 @@ def test_image2latent_and_pipeline_flow(oracle_c):
     outs, loss_dict, metrics = pipe.get_train_loss_dict(0)
     loss_dict["main_loss"].backward()
     assert torch.isfinite(model.means.grad).all()
+    from gaussctrl_amd.gc_config import build_optimizers
+    opts = build_optimizers(model)
+    assert set(opts) == {"xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation"}
+    before = model.means.detach().clone()
+    losses = [float(pipe.train_iteration(opts, s)[0]) for s in range(6)]
+    assert all(np.isfinite(losses)) and not torch.equal(before, model.means.detach())
     with pytest.raises(NotImplementedError):
         pipe.forward()
+
+
+def test_l1_ssim_loss_and_fused_adam():
+    """fused loss (value + gradient) vs torch autograd of the plain definition; FusedAdam vs torch.optim.Adam."""
+    from gaussctrl_amd.gc_model import _ssim
+    from gaussctrl_amd.train_ops import FusedAdam, l1_ssim_loss
+    g = torch.Generator().manual_seed(0)
+    for (H, W) in ((64, 48), (100, 75), (512, 512)):
+        pred = torch.rand(H, W, 3, generator=g).to(DEV).requires_grad_(True)
+        tgt = torch.rand(H, W, 3, generator=g).to(DEV)
+        ref = 0.8 * (tgt - pred).abs().mean() + 0.2 * (1 - _ssim(tgt.permute(2, 0, 1)[None].double(), pred.permute(2, 0, 1)[None].double()))
+        (gref,) = torch.autograd.grad(ref, pred)
+        pred2 = pred.detach().clone().requires_grad_(True)
+        got = l1_ssim_loss(pred2, tgt, 0.2)
+        (3.0 * got).backward()
+        assert abs(float(got) - float(ref)) < 2e-6 * max(1.0, abs(float(ref)))
+        err = float((pred2.grad / 3.0 - gref).abs().max() / gref.abs().max())
+        assert err < 1e-4, err
+    ps = [torch.randn(1001, 3, generator=g).to(DEV), torch.randn(77, 15, 3, generator=g).to(DEV), torch.randn(5, generator=g).to(DEV)]
+    a = [torch.nn.Parameter(p.clone()) for p in ps]; b = [torch.nn.Parameter(p.clone()) for p in ps]
+    oa = torch.optim.Adam(a, lr=1.6e-4, eps=1e-15); ob = FusedAdam(b, lr=1.6e-4, eps=1e-15)
+    for it in range(4):
+        for x, y in zip(a, b):
+            gr = torch.randn(x.shape, generator=g).to(DEV) * (10.0 ** (it - 2))
+            x.grad = gr.clone(); y.grad = gr.clone()
+        oa.step(); ob.step()
+    for x, y in zip(a, b):
+        assert float((x - y).abs().max()) < 1e-6
