@@ -18,7 +18,8 @@ SYMBOLS = [
     "gc_project_gaussians_fwd", "gc_project_gaussians_bwd", "gc_sh_fwd", "gc_sh_bwd",
     "gc_raster_scan_workspace_bytes", "gc_raster_scan_tiles", "gc_raster_read_count",
     "gc_raster_map_intersects", "gc_raster_pad_intersects", "gc_raster_sort_workspace_bytes",
-    "gc_raster_sort_intersects", "gc_raster_tile_bins", "gc_rasterize_fwd", "gc_rasterize_bwd",
+    "gc_raster_sort_intersects", "gc_raster_tile_bins",
+    "gc_raster_depth_order_workspace_bytes", "gc_raster_depth_order", "gc_raster_bin_workspace_bytes", "gc_raster_bin_tiles", "gc_rasterize_fwd", "gc_rasterize_bwd",
     "gc_project_sh_fwd", "gc_project_sh_bwd", "gc_raster_finalize",
     "gc_l1_ssim_workspace_bytes", "gc_l1_ssim_fwd_bwd", "gc_adam_step",
     "gc_dn_gemm", "gc_dn_gemm_workspace_bytes", "gc_dn_attention", "gc_dn_groupnorm", "gc_dn_groupnorm_workspace_bytes", "gc_dn_layernorm", "gc_dn_concat_add", "gc_dn_axpby",
@@ -44,13 +45,9 @@ def lib() -> C.CDLL:
             if not hasattr(l, s):
                 raise GaussCtrlHipError(f"libgaussctrl_hip.so does not export {s}")
         l.gc_last_error_string.restype = C.c_char_p
-        l.gc_raster_scan_workspace_bytes.restype = C.c_size_t
-        l.gc_raster_sort_workspace_bytes.restype = C.c_size_t
-        l.gc_dn_gemm_workspace_bytes.restype = C.c_size_t
-        l.gc_l1_ssim_workspace_bytes.restype = C.c_size_t
-        l.gc_dn_groupnorm_workspace_bytes.restype = C.c_size_t
         for s in SYMBOLS:
             if s.endswith("_bytes"):
+                getattr(l, s).restype = C.c_size_t
                 continue
             if s not in ("gc_last_error_string",):
                 getattr(l, s).restype = C.c_int

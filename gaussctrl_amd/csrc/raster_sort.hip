@@ -1,0 +1,282 @@
+// raster_sort.hip -- hand-written two-level tile binning for the splat rasterizer (gfx950).
+//
+// Replaces the "sort M 64-bit keys (tile<<32 | depth)" step of gsplat 0.1.3's bin_and_sort_gaussians (reached from
+// /root/reference/gaussctrl/gc_model.py:174-186,191-202) with an equivalent that moves ~4x fewer bytes:
+//
+//   1. stable LSD radix sort of the N Gaussians by depth bits (4 passes x 8 bits over (key32, id32) pairs; culled Gaussians carry
+//      key 0xFFFFFFFF and sink to the end).  Ties keep ascending Gaussian id.
+//   2. tiles-hit gathered in depth order -> scan -> emission offsets; every visible Gaussian emits (tile id, gaussian id) for the
+//      tiles of its box IN DEPTH ORDER.
+//   3. ONE or TWO stable radix passes over the M (tile id, gaussian id) pairs (8 bits each; 1024 tiles -> 2 passes).
+//      Stable-by-tile of a depth-ordered sequence == sort by (tile, depth, id): exactly the order a stable sort of the 64-bit keys gives,
+//      so gaussian_ids_sorted / tile_bins stay bit-identical to the oracle.
+//   4. tile bins from the sorted tile ids; the 64-bit keys are re-assembled only on request (tests / API compatibility).
+//
+// Radix pass = histogram kernel (256 LDS counters / workgroup) -> scan of the [digit][workgroup] table (the wave64 scan of
+// raster_bin.hip) -> scatter kernel with a STABLE in-workgroup rank: 4096 items / workgroup in 16 strided rounds; inside a wave the
+// rank among equal digits comes from 8 ballots (match-any) + popcount; the (round, wave) x digit count table lives in LDS (64 KiB),
+// is prefixed by 256 lanes (one digit each) and seeded with the global digit/workgroup offset.
+#include "common.h"
+
+extern "C" int gc_raster_scan_tiles(int64_t N, const int32_t *in, int32_t *out, int32_t *count_dev, void *workspace,
+                                    size_t workspace_bytes, void *stream);
+extern "C" size_t gc_raster_scan_workspace_bytes(int64_t N);
+
+namespace {
+
+constexpr int TILE = 16;
+constexpr int RT = 256;            // threads
+constexpr int RI = 16;             // items per thread
+constexpr int RB = RT * RI;        // 4096 items per workgroup
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__global__ __launch_bounds__(RT) void k_radix_hist(const uint32_t *__restrict__ keys, int64_t n, int shift, int nblocks,
+                                                   int32_t *__restrict__ hist /* [256][nblocks] */)
+{
+    __shared__ int h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RB;
+#pragma unroll
+    for (int j = 0; j < RI; ++j) {
+        const int64_t i = base + j * RT + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255], 1);
+    }
+    __syncthreads();
+    hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// offs = INCLUSIVE scan of hist ([digit][block] flattened); exclusive offset of (d, b) = offs[d*nb + b] - hist[d*nb + b]
+__global__ __launch_bounds__(RT) void k_radix_scatter(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                      uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int64_t n,
+                                                      int shift, int nblocks, const int32_t *__restrict__ hist,
+                                                      const int32_t *__restrict__ offs)
+{
+    extern __shared__ int tbl[];   // [RI*4][256]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int i = tid; i < RI * 4 * 256; i += RT) tbl[i] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RB;
+    uint32_t k[RI], v[RI];
+    unsigned short rk[RI];        // rank inside the wave among equal digits
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int j = 0; j < RI; ++j) {
+        const int64_t i = base + j * RT + tid;
+        const bool ok = i < n;
+        k[j] = ok ? keys[i] : 0xFFFFFFFFu;
+        v[j] = ok ? vals[i] : 0u;
+        const unsigned d = (k[j] >> shift) & 255;
+        unsigned long long m = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long bal = __ballot((d >> b) & 1);
+            m &= ((d >> b) & 1) ? bal : ~bal;
+        }
+        rk[j] = (unsigned short)__popcll(m & lt);
+        if (ok && (m & lt) == 0) tbl[(j * 4 + wid) * 256 + d] = __popcll(m);     // leader of each digit group writes the count
+    }
+    __syncthreads();
+    {   // lane d: exclusive prefix over the 64 (round, wave) slots of digit d, seeded with the global offset
+        const int d = tid;
+        int run = offs[(int64_t)d * nblocks + blockIdx.x] - hist[(int64_t)d * nblocks + blockIdx.x];
+#pragma unroll 8
+        for (int s = 0; s < RI * 4; ++s) {
+            const int c = tbl[s * 256 + d];
+            tbl[s * 256 + d] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RI; ++j) {
+        const int64_t i = base + j * RT + tid;
+        if (i < n) {
+            const unsigned d = (k[j] >> shift) & 255;
+            const int pos = tbl[(j * 4 + wid) * 256 + d] + rk[j];
+            keys_out[pos] = k[j];
+            vals_out[pos] = v[j];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_depth_keys(int64_t N, const float *__restrict__ depths, const int32_t *__restrict__ radii,
+                                                    uint32_t *__restrict__ keys, uint32_t *__restrict__ ids)
+{
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    keys[i] = radii[i] > 0 ? __float_as_uint(depths[i]) : 0xFFFFFFFFu;
+    ids[i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(256) void k_gather_tiles(int64_t N, const uint32_t *__restrict__ order, const int32_t *__restrict__ nth,
+                                                      int32_t *__restrict__ nth_sorted)
+{
+    int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    nth_sorted[j] = nth[order[j]];
+}
+
+// emission in depth order: pair (tile id, gaussian id) for every tile of the box of order[j]
+__global__ __launch_bounds__(256) void k_emit_sorted(int64_t N, int64_t M_cap, const uint32_t *__restrict__ order,
+                                                     const float *__restrict__ xys, const int32_t *__restrict__ radii,
+                                                     const int32_t *__restrict__ cum_sorted, int tiles_x, int tiles_y,
+                                                     uint32_t *__restrict__ tile_keys, uint32_t *__restrict__ gids)
+{
+    int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    const uint32_t g = order[j];
+    const int r = radii[g];
+    if (r <= 0) return;
+    // same float expressions as the projection kernel / oracle (bit-exact tile box)
+    float tcx = xys[2 * (size_t)g] / (float)TILE, tcy = xys[2 * (size_t)g + 1] / (float)TILE, tr = (float)r / (float)TILE;
+    int minx = clampi((int)(tcx - tr), 0, tiles_x), maxx = clampi((int)(tcx + tr + 1.f), 0, tiles_x);
+    int miny = clampi((int)(tcy - tr), 0, tiles_y), maxy = clampi((int)(tcy + tr + 1.f), 0, tiles_y);
+    int64_t cur = j == 0 ? 0 : cum_sorted[j - 1];
+    for (int ty = miny; ty < maxy; ++ty)
+        for (int tx = minx; tx < maxx; ++tx) {
+            if (cur < M_cap) { tile_keys[cur] = (uint32_t)(ty * tiles_x + tx); gids[cur] = g; }
+            ++cur;
+        }
+}
+
+__global__ __launch_bounds__(256) void k_tile_bins32(int64_t M, int num_tiles, const uint32_t *__restrict__ tkeys,
+                                                     const uint32_t *__restrict__ gids, const float *__restrict__ depths,
+                                                     int32_t *__restrict__ bins, int64_t *__restrict__ keys64, int32_t *__restrict__ ids_out)
+{
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const int t = (int)tkeys[i];
+    const uint32_t g = gids[i];
+    if (ids_out) ids_out[i] = (int32_t)g;
+    if (keys64) keys64[i] = ((int64_t)t << 32) | (int64_t)__float_as_uint(depths[g]);
+    if (i == 0) bins[2 * t] = 0;
+    else {
+        const int tp = (int)tkeys[i - 1];
+        if (tp != t) { bins[2 * tp + 1] = (int32_t)i; bins[2 * t] = (int32_t)i; }
+    }
+    if (i == M - 1) bins[2 * t + 1] = (int32_t)M;
+}
+
+size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// workspace of a run of radix passes over n (key32, val32) pairs: 2 ping-pong pair buffers + digit tables + scan scratch
+struct Plan {
+    size_t off_keys[2], off_vals[2], off_hist, off_offs, off_scan, scan_bytes, off_cnt, total;
+    int nb;
+};
+
+Plan make_plan(int64_t n)
+{
+    Plan p;
+    p.nb = (int)((n + RB - 1) / RB);
+    if (p.nb < 1) p.nb = 1;
+    size_t o = 0;
+    for (int i = 0; i < 2; ++i) { p.off_keys[i] = o; o += al(4 * (size_t)n + 4); p.off_vals[i] = o; o += al(4 * (size_t)n + 4); }
+    p.off_hist = o; o += al(4 * 256 * (size_t)p.nb);
+    p.off_offs = o; o += al(4 * 256 * (size_t)p.nb);
+    const int64_t scan_n = 256 * (int64_t)p.nb > n ? 256 * (int64_t)p.nb : n;
+    p.scan_bytes = al(gc_raster_scan_workspace_bytes(scan_n));
+    p.off_scan = o; o += p.scan_bytes;
+    p.off_cnt = o; o += 256;
+    p.total = o;
+    return p;
+}
+
+void set_attr()
+{
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute((const void *)k_radix_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, RI * 4 * 256 * 4);
+        done = true;
+    }
+}
+
+// one stable 8-bit radix pass
+int radix_pass(const uint32_t *ki, const uint32_t *vi, uint32_t *ko, uint32_t *vo, int64_t n, int shift, const Plan &p,
+               unsigned char *w, hipStream_t s)
+{
+    int32_t *hist = (int32_t *)(w + p.off_hist), *offs = (int32_t *)(w + p.off_offs), *cnt = (int32_t *)(w + p.off_cnt);
+    hipLaunchKernelGGL(k_radix_hist, dim3(p.nb), dim3(RT), 0, s, ki, n, shift, p.nb, hist);
+    int rc = gc_raster_scan_tiles(256 * (int64_t)p.nb, hist, offs, cnt, w + p.off_scan, p.scan_bytes, (void *)s);
+    if (rc != GC_OK) return rc;
+    hipLaunchKernelGGL(k_radix_scatter, dim3(p.nb), dim3(RT), (size_t)RI * 4 * 256 * sizeof(int), s, ki, vi, ko, vo, n, shift,
+                       p.nb, hist, offs);
+    return GC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t gc_raster_depth_order_workspace_bytes(int64_t N) { return make_plan(N > 0 ? N : 1).total + al(4 * (size_t)(N > 0 ? N : 1)); }
+
+/* Phase 1 (no host sync): depth_order[N] = Gaussian ids sorted by (depth bits, id), culled (radii <= 0) last;
+ * cum_sorted[N] = inclusive scan of num_tiles_hit taken in that order; *count_dev = M. */
+int gc_raster_depth_order(int64_t N, const float *depths, const int32_t *radii, const int32_t *num_tiles_hit,
+                          int32_t *depth_order, int32_t *cum_sorted, int32_t *count_dev, void *workspace, size_t workspace_bytes,
+                          void *stream)
+{
+    GC_REQUIRE(N >= 0 && count_dev, "bad arguments");
+    hipStream_t s = gc::S(stream);
+    if (N == 0) return hipMemsetAsync(count_dev, 0, 4, s) == hipSuccess ? GC_OK : GC_ELAUNCH;
+    GC_REQUIRE(depths && radii && num_tiles_hit && depth_order && cum_sorted && workspace, "null pointer");
+    const Plan p = make_plan(N);
+    if (workspace_bytes < gc_raster_depth_order_workspace_bytes(N)) { gc::set_error("gc_raster_depth_order: workspace too small"); return GC_ENOSPC; }
+    set_attr();
+    unsigned char *w = (unsigned char *)workspace;
+    uint32_t *k0 = (uint32_t *)(w + p.off_keys[0]), *v0 = (uint32_t *)(w + p.off_vals[0]);
+    uint32_t *k1 = (uint32_t *)(w + p.off_keys[1]), *v1 = (uint32_t *)(w + p.off_vals[1]);
+    int32_t *nth_s = (int32_t *)(w + p.total);
+    hipLaunchKernelGGL(k_depth_keys, dim3(gc::cdiv(N, 256)), dim3(256), 0, s, N, depths, radii, k0, v0);
+    for (int pass = 0; pass < 4; ++pass) {   // visible depths are > 0: the float bit pattern is monotone
+        const bool odd = pass & 1;
+        uint32_t *vo = pass == 3 ? (uint32_t *)depth_order : (odd ? v0 : v1);
+        int rc = radix_pass(odd ? k1 : k0, odd ? v1 : v0, odd ? k0 : k1, vo, N, 8 * pass, p, w, s);
+        if (rc != GC_OK) return rc;
+    }
+    hipLaunchKernelGGL(k_gather_tiles, dim3(gc::cdiv(N, 256)), dim3(256), 0, s, N, (const uint32_t *)depth_order, num_tiles_hit, nth_s);
+    int rc = gc_raster_scan_tiles(N, nth_s, cum_sorted, count_dev, w + p.off_scan, p.scan_bytes, (void *)s);
+    if (rc != GC_OK) return rc;
+    return gc::check_launch("gc_raster_depth_order");
+}
+
+size_t gc_raster_bin_workspace_bytes(int64_t M) { return make_plan(M > 0 ? M : 1).total; }
+
+/* Phase 2: emit (tile, id) pairs in depth order for the M intersections, stable-sort them by tile, build tile_bins.
+ * gaussian_ids_sorted[M] and tile_bins[T,2] are the rasterizer's inputs; isect_ids_sorted[M] (int64 tile<<32|depth bits) is
+ * optional (NULL to skip). */
+int gc_raster_bin_tiles(int64_t N, int64_t M, const int32_t *depth_order, const int32_t *cum_sorted, const float *xys,
+                        const float *depths, const int32_t *radii, int tiles_x, int tiles_y, int32_t *gaussian_ids_sorted,
+                        int32_t *tile_bins, int64_t *isect_ids_sorted, void *workspace, size_t workspace_bytes, void *stream)
+{
+    GC_REQUIRE(N >= 0 && M >= 0 && tile_bins, "bad arguments");
+    const int num_tiles = tiles_x * tiles_y;
+    hipStream_t s = gc::S(stream);
+    if (hipMemsetAsync(tile_bins, 0, sizeof(int32_t) * 2 * (size_t)num_tiles, s) != hipSuccess) return GC_ELAUNCH;
+    if (M == 0 || N == 0) return GC_OK;
+    GC_REQUIRE(num_tiles <= 65536, "at most 65536 tiles");
+    GC_REQUIRE(depth_order && cum_sorted && xys && depths && radii && gaussian_ids_sorted && workspace, "null pointer");
+    const Plan p = make_plan(M);
+    if (workspace_bytes < p.total) { gc::set_error("gc_raster_bin_tiles: workspace too small"); return GC_ENOSPC; }
+    set_attr();
+    unsigned char *w = (unsigned char *)workspace;
+    uint32_t *k0 = (uint32_t *)(w + p.off_keys[0]), *v0 = (uint32_t *)(w + p.off_vals[0]);
+    uint32_t *k1 = (uint32_t *)(w + p.off_keys[1]), *v1 = (uint32_t *)(w + p.off_vals[1]);
+    hipLaunchKernelGGL(k_emit_sorted, dim3(gc::cdiv(N, 256)), dim3(256), 0, s, N, M, (const uint32_t *)depth_order, xys, radii,
+                       cum_sorted, tiles_x, tiles_y, k0, v0);
+    const int passes = num_tiles <= 256 ? 1 : 2;
+    uint32_t *ks = k0, *vs = v0;
+    for (int pass = 0; pass < passes; ++pass) {
+        uint32_t *ko = ks == k0 ? k1 : k0, *vo = vs == v0 ? v1 : v0;
+        int rc = radix_pass(ks, vs, ko, vo, M, 8 * pass, p, w, s);
+        if (rc != GC_OK) return rc;
+        ks = ko; vs = vo;
+    }
+    hipLaunchKernelGGL(k_tile_bins32, dim3(gc::cdiv(M, 256)), dim3(256), 0, s, M, num_tiles, ks, vs, depths, tile_bins,
+                       isect_ids_sorted, gaussian_ids_sorted);
+    return gc::check_launch("gc_raster_bin_tiles");
+}
+
+}  // extern "C"

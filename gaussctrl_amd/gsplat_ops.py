@@ -134,8 +134,39 @@ def spherical_harmonics(degrees_to_use, viewdirs, coeffs):
 
 
 # --------------------------------------------------------------------------------------------- binning
-def bin_and_sort_gaussians(N, xys, depths, radii, num_tiles_hit, tile_bounds):
-    """cumsum -> map -> sort -> tile bins.  Returns (M, isect_ids_sorted, gaussian_ids_sorted, tile_bins)."""
+def bin_and_sort_gaussians(N, xys, depths, radii, num_tiles_hit, tile_bounds, want_keys=False):
+    """Two-level binning (csrc/raster_sort.hip): depth-sort the Gaussians, emit (tile, id) in depth order, stable radix
+    passes over the tile id, tile bins.  Same gaussian_ids_sorted / tile_bins as gsplat's bin_and_sort_gaussians
+    (reference call sites gc_model.py:174-202).  Returns (M, isect_ids_sorted | None, gaussian_ids_sorted, tile_bins,
+    cum_tiles_hit_in_depth_order).  One 4-byte readback (M)."""
+    lib = L.lib()
+    dev = xys.device
+    st = L.stream_ptr()
+    T = tile_bounds[0] * tile_bounds[1]
+    order = torch.empty(N, dtype=torch.int32, device=dev)
+    cum = torch.empty(N, dtype=torch.int32, device=dev)
+    cnt = torch.empty(1, dtype=torch.int32, device=dev)
+    wb = int(lib.gc_raster_depth_order_workspace_bytes(L.i64(N)))
+    ws = torch.empty(wb, dtype=torch.uint8, device=dev)
+    L.check(lib.gc_raster_depth_order(L.i64(N), L.ptr(depths), L.ptr(radii), L.ptr(num_tiles_hit), L.ptr(order), L.ptr(cum),
+                                      L.ptr(cnt), L.ptr(ws), L.C.c_size_t(wb), st), "gc_raster_depth_order")
+    m_host = L.C.c_int32(0)
+    L.check(lib.gc_raster_read_count(L.ptr(cnt), L.C.byref(m_host), st), "gc_raster_read_count")
+    M = int(m_host.value)
+    bins = torch.empty(T, 2, dtype=torch.int32, device=dev)
+    ids_s = torch.empty(M, dtype=torch.int32, device=dev)
+    keys_s = torch.empty(M, dtype=torch.int64, device=dev) if want_keys else None
+    bb = int(lib.gc_raster_bin_workspace_bytes(L.i64(M)))
+    bws = torch.empty(bb, dtype=torch.uint8, device=dev)
+    L.check(lib.gc_raster_bin_tiles(L.i64(N), L.i64(M), L.ptr(order), L.ptr(cum), L.ptr(xys), L.ptr(depths), L.ptr(radii),
+                                    L.i32(tile_bounds[0]), L.i32(tile_bounds[1]), L.ptr(ids_s), L.ptr(bins), L.ptr(keys_s),
+                                    L.ptr(bws), L.C.c_size_t(bb), st), "gc_raster_bin_tiles")
+    return M, keys_s, ids_s, bins, cum
+
+
+def bin_and_sort_gaussians_keys64(N, xys, depths, radii, num_tiles_hit, tile_bounds):
+    """gsplat-shaped chain: cumsum -> map -> 64-bit key sort -> tile bins (kept for API parity / cross-checks).
+    Returns (M, isect_ids_sorted, gaussian_ids_sorted, tile_bins, cum_tiles_hit)."""
     lib = L.lib()
     dev = xys.device
     st = L.stream_ptr()

@@ -99,6 +99,22 @@ int gc_raster_sort_intersects(int64_t M, int num_tiles, const int64_t *isect_ids
 int gc_raster_tile_bins(int64_t M, int num_tiles, const int64_t *isect_ids_sorted, int32_t *tile_bins,
                         void *stream);
 
+/* Two-level binning (the product path; same outputs as scan+map+sort+tile_bins above, ~4x fewer bytes moved).
+ * Phase 1, no host sync: depth_order[N] = Gaussian ids sorted by (depth bits, id) with culled ones last;
+ * cum_sorted[N] = inclusive scan of num_tiles_hit in that order; *count_dev = M (read it with gc_raster_read_count). */
+size_t gc_raster_depth_order_workspace_bytes(int64_t N);
+int gc_raster_depth_order(int64_t N, const float *depths, const int32_t *radii, const int32_t *num_tiles_hit,
+                          int32_t *depth_order, int32_t *cum_sorted, int32_t *count_dev,
+                          void *workspace, size_t workspace_bytes, void *stream);
+/* Phase 2: emit (tile, id) in depth order, stable radix passes over the tile id only, tile bins.
+ * gaussian_ids_sorted[M], tile_bins[T,2]; isect_ids_sorted[M] (tile<<32 | depth bits) optional (NULL skips it).
+ * Replaces gsplat's map_gaussian_to_intersects + 64-bit key sort + get_tile_bin_edges. */
+size_t gc_raster_bin_workspace_bytes(int64_t M);
+int gc_raster_bin_tiles(int64_t N, int64_t M, const int32_t *depth_order, const int32_t *cum_sorted,
+                        const float *xys, const float *depths, const int32_t *radii, int tiles_x, int tiles_y,
+                        int32_t *gaussian_ids_sorted, int32_t *tile_bins, int64_t *isect_ids_sorted,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
 /* gsplat.rasterize_gaussians forward: RGB (+ optional extra channel, used for the reference's
  * second "depth" pass gc_model.py:191-202, composited in the same sweep) + final_Ts + final_index.
  * colors[N,3], opacities[N], extra[N] or NULL, background[3] (device) ->

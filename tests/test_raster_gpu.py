@@ -90,13 +90,23 @@ def test_bin_and_sort_bit_exact(oracle_c, N, W, H, fx):
     P, c2w, K = _scene(N, W, H, fx)
     o = oracle_c.render(P, c2w, K["fx"], K["fy"], K["cx"], K["cy"], W, H, BG, training=True)
     tb = ((W + 15) // 16, (H + 15) // 16, 1)
-    M, keys, ids, bins, cum = ops.bin_and_sort_gaussians(N, _t(o["xys"]), _t(o["depths"]), _t(o["radii"], torch.int32),
-                                                         _t(o["num_tiles_hit"], torch.int32), tb)
+    args = (N, _t(o["xys"]), _t(o["depths"]), _t(o["radii"], torch.int32), _t(o["num_tiles_hit"], torch.int32), tb)
+    # gsplat-shaped chain (64-bit key sort)
+    M, keys, ids, bins, cum = ops.bin_and_sort_gaussians_keys64(*args)
     assert M == o["M"]
     assert np.array_equal(cum.cpu().numpy(), np.cumsum(o["num_tiles_hit"]).astype(np.int32))
     assert np.array_equal(keys.cpu().numpy(), o["isect_ids_sorted"])
     assert np.array_equal(ids.cpu().numpy(), o["gaussian_ids_sorted"])
     assert np.array_equal(bins.cpu().numpy(), o["tile_bins"])
+    # product path: two-level binning (depth order, then stable tile passes) must give the identical order
+    M2, keys2, ids2, bins2, cum2 = ops.bin_and_sort_gaussians(*args, want_keys=True)
+    assert M2 == o["M"]
+    assert np.array_equal(keys2.cpu().numpy(), o["isect_ids_sorted"])
+    assert np.array_equal(ids2.cpu().numpy(), o["gaussian_ids_sorted"])
+    assert np.array_equal(bins2.cpu().numpy(), o["tile_bins"])
+    assert int(cum2[-1]) == o["M"]
+    M3, keys3, ids3, bins3, _ = ops.bin_and_sort_gaussians(*args)
+    assert keys3 is None and torch.equal(ids3, ids2) and torch.equal(bins3, bins2)
 
 
 @pytest.mark.parametrize("N,W,H,fx,sm", [(5000, 200, 136, 180.0, 0.03), (100000, 512, 512, 540.0, 0.01), (3, 40, 24, 50.0, 0.2)])
