@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgaussctrl_hip.so")
+LIB_PATH = os.environ.get("GC_HIP_LIB") or os.path.join(_HERE, "libgaussctrl_hip.so")   # GC_HIP_LIB: kernel-experiment builds only
 
 # every symbol include/gaussctrl_hip.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [

@@ -17,6 +17,8 @@
 // agree), and the output store is 8 contiguous bytes per accumulator.  V arrives already transposed
 // ([B][C][L], written by the projection GEMM's epilogue) so no transpose happens here.
 #include "dn_common.h"
+#include <cstdlib>
+#include <type_traits>
 
 namespace {
 using namespace dn;
@@ -32,7 +34,20 @@ struct AttnArgs {
     int Lq, Lk, H, f;
     int nsets; int set_kind[5]; float set_w[5];      // kind -1: own frame; -2: frame b / f (shared text K/V); r >= 0: reference r of the half
     float scale_log2e;
+    int nqb;                                         // query blocks per (batch, head)
 };
+
+// 1-D grid, XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the id is remapped
+// bijectively to make the query blocks of one (batch, head) -- which stream the same K / V^T -- land on ONE XCD's L2.
+__device__ __forceinline__ void block_coords(const AttnArgs &a, int QT, int &qblk, int &h, int &b)
+{
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
+    qblk = bid % a.nqb;
+    const int bh = bid / a.nqb;
+    h = bh % a.H; b = bh / a.H;
+}
+
 
 template <class T> struct One;
 template <> struct One<BF16> { static constexpr unsigned short v = 0x3F80; };
@@ -57,8 +72,9 @@ __global__ __launch_bounds__(256, 2) void k_attn(const AttnArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, g = lane >> 4;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q_wave0 = (blockIdx.x * 4 + wid) * (QT * 16);
+    int qblk, h, b;
+    block_coords(a, QT, qblk, h, b);
+    const int q_wave0 = (qblk * 4 + wid) * (QT * 16);
 
     // zero the LDS once: pad columns / pad rows are never written again
     for (int i = tid; i < (int)(sizeof(sK) / 16); i += 256) reinterpret_cast<uint4 *>(sK)[i] = make_uint4(0, 0, 0, 0);
@@ -278,13 +294,423 @@ __global__ __launch_bounds__(256, 2) void k_attn(const AttnArgs a)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// k_attn2: the software-pipelined form of k_attn (same math, same operand layouts in HBM).
+//   * K / V^T tiles travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR staging) into an NST-deep ring, PD = NST-1
+//     tiles ahead, ONE s_barrier per tile and counted s_waitcnt vmcnt(N): the load latency never sits on the critical path.
+//   * (set, tile) pairs are flattened into one sequence of steps; inside a step the QK^T MFMAs of step i+1 are issued beside
+//     the softmax VALU work of step i (a wave issues in order: MFMAs and VALU only overlap when they alternate in ITS stream).
+//   * the MFMA row -> key mapping inside a tile is permuted (key = 32(kt/2) + 8g + 4(kt&1) + r) so that a lane's eight P values
+//     of a 32-key block are eight CONSECUTIVE keys: the V^T fragment is one ds_read_b128 (ds_read2_b64 runs at half rate).
+//   * both tiles use 16-byte-chunk XOR swizzles that are conflict-free for the ds_read_b128 lane groups of gfx950
+//     (searched exhaustively, scripts/lds_swizzle_search.py); pad chunks / the ones-row are DMA'd from constant pages.
+__device__ __attribute__((aligned(16))) unsigned short g_page_zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+__device__ __attribute__((aligned(16))) unsigned short g_page_one_bf16[8] = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+__device__ __attribute__((aligned(16))) unsigned short g_page_one_f16[8] = {0x3C00, 0x3C00, 0x3C00, 0x3C00, 0x3C00, 0x3C00, 0x3C00, 0x3C00};
+template <class T> __device__ __forceinline__ const unsigned char *one_page();
+template <> __device__ __forceinline__ const unsigned char *one_page<BF16>() { return (const unsigned char *)g_page_one_bf16; }
+template <> __device__ __forceinline__ const unsigned char *one_page<F16>() { return (const unsigned char *)g_page_one_f16; }
+
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt()
+{
+    static_assert(N >= 0 && N < 64, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int CPR> __device__ __forceinline__ int swz_k(int row)
+{
+    if (CPR == 8) return (row ^ (row << 1) ^ ((row >> 3) << 2)) & 7;
+    return (row & 1) | (((row >> 3) & 1) << 1);
+}
+__device__ __forceinline__ int swz_v(int row) { return (row ^ (row << 1) ^ (row << 2)) & 7; }
+
+template <class T, int D, int QT, int NST>
+__global__ __launch_bounds__(256, 2) void k_attn2(const AttnArgs a)
+{
+    constexpr int DP = (D + 31) / 32 * 32, KS = DP / 32, CPR = DP / 8;     // K row: CPR 16-byte chunks
+    constexpr int DV = (D + 15) / 16 * 16, DT = DV / 16;
+    constexpr bool ONES = (DV > D);
+    constexpr int VR = (DV + 31) / 32 * 32;                                // V^T rows in LDS (DMA granule: 32 rows = 256 chunks)
+    constexpr int KBYTES = 64 * CPR * 16, VBYTES = VR * 128;
+    constexpr int KI = CPR / 4, VI = VR / 32;                              // LDS-DMA instructions per wave per tile
+    constexpr int PD = NST - 1;                                            // prefetch distance (tiles)
+    constexpr int GRP = KI + VI;
+    static_assert((PD - 1) * GRP < 64, "vmcnt range");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *sK = smem, *sV = smem + NST * KBYTES;
+    const unsigned ldsK = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem, ldsV = ldsK + NST * KBYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    int qblk, h, b;
+    block_coords(a, QT, qblk, h, b);
+    const int q_wave0 = (qblk * 4 + wid) * (QT * 16);
+
+    // Q fragments (B operand): lane holds Q[q = fr][d = 32*ks + 8*g .. +8]
+    uint4 qf[QT][KS];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int q = q_wave0 + qt * 16 + fr;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d = ks * 32 + g * 8;
+            qf[qt][ks] = (q < a.Lq && d + 8 <= D)
+                             ? *reinterpret_cast<const uint4 *>(a.Q + (int64_t)b * a.q_bs + (int64_t)q * a.ldq + h * D + d)
+                             : make_uint4(0, 0, 0, 0);
+        }
+    }
+
+    // ---- LDS-DMA plan of this lane: instruction j of wave w fills chunks [(4j + w) * 64, +64) of the tile image.
+    // A chunk is fetched from the tile's HBM window when key0 < thr (thr folds "row / token inside Lk" and "chunk is real
+    // data"), else from a constant page (zeros; ones for the denominator row of V^T).
+    const unsigned char *zp = (const unsigned char *)g_page_zero;
+    int k_off[KI], k_thr[KI], v_off[VI], v_thr[VI];
+    const unsigned char *v_alt[VI];
+    const int lk8 = (a.Lk + 7) / 8 * 8;
+#pragma unroll
+    for (int j = 0; j < KI; ++j) {
+        const int p = (j * 4 + wid) * 64 + lane, row = p / CPR, lc = (p % CPR) ^ swz_k<CPR>(row);
+        k_off[j] = (row * (int)a.ldk + lc * 8) * 2;
+        k_thr[j] = lc * 8 < D ? a.Lk - row : -1;                 // fetch iff key0 + row < Lk
+    }
+#pragma unroll
+    for (int j = 0; j < VI; ++j) {
+        const int p = (j * 4 + wid) * 64 + lane, row = p >> 3, lc = (p & 7) ^ swz_v(row);
+        v_off[j] = (row * (int)a.ldvt + lc * 8) * 2;
+        v_thr[j] = row < D ? lk8 - lc * 8 : -1;                  // fetch iff key0 + 8 lc < round_up(Lk, 8)
+        v_alt[j] = (ONES && row == D) ? one_page<T>() : zp;
+    }
+
+    const int ntiles = (a.Lk + 63) / 64;
+    const bool ragged = (a.Lk & 63) != 0;
+    const int nsteps = a.nsets * ntiles;
+
+    // per-set K / V^T base addresses, parked in lane s of two VGPR pairs (fetched with v_readlane at set changes)
+    unsigned long long kb_tab = 0, vb_tab = 0;
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        if (s < a.nsets) {
+            const int kind = a.set_kind[s];
+            const unsigned short *Kb, *Vb;
+            if (kind >= 0) {
+                const int kvb = (b / a.f) * a.ref_fph + kind;
+                Kb = a.Kr + (int64_t)kvb * a.kr_bs + h * D;
+                Vb = a.Vtr + (int64_t)kvb * a.vtr_bs + (int64_t)h * D * a.ldvt;
+            } else {
+                const int kvb = kind == -1 ? b : b / a.f;
+                Kb = a.K + (int64_t)kvb * a.k_bs + h * D;
+                Vb = a.Vt + (int64_t)kvb * a.vt_bs + (int64_t)h * D * a.ldvt;
+            }
+            if (lane == s) { kb_tab = (unsigned long long)Kb; vb_tab = (unsigned long long)Vb; }
+        }
+    }
+    auto tab = [&](unsigned long long t, int s) __attribute__((always_inline)) -> const unsigned char * {
+        const unsigned lo = __builtin_amdgcn_readlane((unsigned)t, s), hi = __builtin_amdgcn_readlane((unsigned)(t >> 32), s);
+        return (const unsigned char *)(((unsigned long long)hi << 32) | lo);
+    };
+    // DMA cursors (branch-free): the K stream runs one tile ahead of the V^T stream; both walk the (set, tile) sequence and,
+    // past the end, keep re-loading the last tile (the counted waits need the same number of loads from every wave, every step)
+    struct Cur { const unsigned char *p; int tile, s, slot; };
+    Cur ck, cv;
+    ck.p = tab(kb_tab, 0); ck.tile = 0; ck.s = 0; ck.slot = 0;
+    cv.p = tab(vb_tab, 0); cv.tile = 0; cv.s = 0; cv.slot = 0;
+    auto advance = [&](Cur &c, unsigned long long t, int64_t stride) __attribute__((always_inline)) {
+        c.slot = c.slot + 1 == NST ? 0 : c.slot + 1;
+        const bool wrap = c.tile + 1 == ntiles, last = wrap && c.s + 1 == a.nsets;
+        const int sn = wrap && !last ? c.s + 1 : c.s;
+        const unsigned char *pn = tab(t, sn);
+        c.p = last ? c.p : wrap ? pn : c.p + stride;
+        c.tile = last ? c.tile : wrap ? 0 : c.tile + 1;
+        c.s = sn;
+    };
+    auto issue_k = [&]() __attribute__((always_inline)) {
+        const unsigned dst = ldsK + (unsigned)(ck.slot * KBYTES + wid * 1024);
+        const int key0 = ck.tile * 64;
+#pragma unroll
+        for (int j = 0; j < KI; ++j) glds16(key0 < k_thr[j] ? ck.p + k_off[j] : zp, dst + j * 4096);
+        advance(ck, kb_tab, (int64_t)128 * a.ldk);
+    };
+    auto issue_v = [&]() __attribute__((always_inline)) {
+        const unsigned dst = ldsV + (unsigned)(cv.slot * VBYTES + wid * 1024);
+        const int key0 = cv.tile * 64;
+#pragma unroll
+        for (int j = 0; j < VI; ++j) glds16(key0 < v_thr[j] ? cv.p + v_off[j] : v_alt[j], dst + j * 4096);
+        advance(cv, vb_tab, 128);
+    };
+
+    // fragment read offsets.  K: MFMA row fr of key-subtile kt is key 32(kt/2) + 4(kt&1) + 8(fr/4) + (fr&3); chunk 4ks + g
+    int kfo[KS][2];
+    {
+        const int row0 = 8 * (fr >> 2) + (fr & 3);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int od = 0; od < 2; ++od) {
+                const int row = row0 + 4 * od;
+                kfo[ks][od] = row * (CPR * 16) + (((4 * ks + g) ^ swz_k<CPR>(row)) << 4);
+            }
+    }
+    // V^T: row 16 dt + fr, chunk 4 kb + g (tokens 32 kb + 8 g .. +8)
+    int vfo[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) vfo[kb] = fr * 128 + (((4 * kb + g) ^ swz_v(fr)) << 4);
+
+    f32x4 otot[DT][QT], os[DT][QT];
+    float mrow[QT], lrow[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        mrow[qt] = -1e30f; lrow[qt] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) { otot[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f}; os[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
+    const float c2 = a.scale_log2e;
+
+    // S^T of one tile: st[kt][qt][r] = S[q = fr][key = key0 + 32(kt/2) + 8 g + 4(kt&1) + r]
+    auto qk = [&](f32x4(&st)[4][QT], int stage) __attribute__((always_inline)) {
+        const unsigned char *kb_ = sK + stage * KBYTES;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) st[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const uint4 kf = *reinterpret_cast<const uint4 *>(kb_ + kfo[ks][kt & 1] + (32 * (kt >> 1)) * (CPR * 16));
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) st[kt][qt] = T::mfma(kf, qf[qt][ks], st[kt][qt]);
+            }
+    };
+
+    // one pipeline step: S(i+1) = K(i+1) Q^T  ||  softmax of S(i)  ->  O += V(i)^T P(i)^T
+    // Hand-placed instruction stream: every MFMA is followed by a slice of independent softmax VALU work and the groups are
+    // pinned with sched_barrier(0).  Phase 1: the NQ = 4 KS QT MFMAs of S(i+1) beside the softmax of query tile 0 (and the
+    // head of tile 1); phase 2: P V of query tile 0 beside the rest of tile 1's softmax; phase 3: P V of tile 1.
+    auto body = [&](f32x4(&cur)[4][QT], f32x4(&nxt)[4][QT], int i, int tile, auto part_tag) __attribute__((always_inline)) {
+        constexpr bool PART = decltype(part_tag)::value;
+        wait_vmcnt<(PD - 1) * GRP>();          // K(i+1), V(i) (and everything older) have landed for this wave
+        __builtin_amdgcn_s_barrier();          // ... for every wave; every wave is done with step i-1's buffers
+        issue_k();
+        issue_v();
+        const unsigned char *kb_ = sK + ((i + 1) % NST) * KBYTES;
+        const unsigned char *vb_ = sV + (i % NST) * VBYTES;
+        if (PART) {
+            const int key0 = tile * 64;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (key0 + 32 * (kt >> 1) + 4 * (kt & 1) + 8 * g + r >= a.Lk) {
+#pragma unroll
+                        for (int qt = 0; qt < QT; ++qt) cur[kt][qt][r] = -1e30f;
+                    }
+        }
+        constexpr int NKF = 4 * KS, NQ = NKF * QT, NPV = 2 * DT;      // K fragments, QK MFMAs, PV MFMAs per query tile
+        constexpr int NU = 17;                                        // VALU units per query tile (see unit())
+        float tmax[QT], mnew[QT], alpha[QT], p[QT][4][4];
+        uint4 pf[QT][2], kf[NKF], vf[NPV];
+        auto rd_k = [&](int n) __attribute__((always_inline)) {       // n = ks * 4 + kt
+            const int ks = n >> 2, kt = n & 3;
+            kf[n] = *reinterpret_cast<const uint4 *>(kb_ + kfo[ks][kt & 1] + (32 * (kt >> 1)) * (CPR * 16));
+        };
+        auto rd_v = [&](int n) __attribute__((always_inline)) {       // n = kb * DT + dt
+            const int kb = n / DT, dt = n - kb * DT;
+            vf[n] = *reinterpret_cast<const uint4 *>(vb_ + vfo[kb] + dt * 2048);
+        };
+        auto mma_qk = [&](int m) __attribute__((always_inline)) {     // m = (ks * 4 + kt) * QT + qt
+            const int n = m / QT, qt = m - n * QT, ks = n >> 2, kt = n & 3;
+            if (ks == 0) nxt[kt][qt] = T::mfma(kf[n], qf[qt][ks], f32x4{0.f, 0.f, 0.f, 0.f});
+            else nxt[kt][qt] = T::mfma(kf[n], qf[qt][ks], nxt[kt][qt]);
+        };
+        auto mma_pv = [&](int qt, int n) __attribute__((always_inline)) {
+            const int kb = n / DT, dt = n - kb * DT;
+            os[dt][qt] = T::mfma(vf[n], pf[qt][kb], os[dt][qt]);
+        };
+        // softmax of one query tile in 17 units of 2-6 VALU instructions
+        auto unit = [&](auto qt_, auto u_) __attribute__((always_inline)) {
+            constexpr int qt = decltype(qt_)::value, u = decltype(u_)::value;
+            if constexpr (u == 0) {
+                float t = fmaxf(fmaxf(cur[0][qt][0], cur[0][qt][1]), cur[0][qt][2]);
+                t = fmaxf(fmaxf(t, cur[0][qt][3]), cur[1][qt][0]);
+                t = fmaxf(fmaxf(t, cur[1][qt][1]), cur[1][qt][2]);
+                tmax[qt] = fmaxf(fmaxf(t, cur[1][qt][3]), cur[2][qt][0]);
+            } else if constexpr (u == 1) {
+                float t = fmaxf(fmaxf(tmax[qt], cur[2][qt][1]), cur[2][qt][2]);
+                t = fmaxf(fmaxf(t, cur[2][qt][3]), cur[3][qt][0]);
+                t = fmaxf(fmaxf(t, cur[3][qt][1]), cur[3][qt][2]);
+                tmax[qt] = fmaxf(t, cur[3][qt][3]);
+            } else if constexpr (u == 2) {      // reduce over g (lanes 16 and 32 apart) with the lane-swap instructions: no LDS round trip
+                const unsigned x = __float_as_uint(tmax[qt]);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+                const float t = fmaxf(__uint_as_float(r1[0]), __uint_as_float(r1[1]));
+                const unsigned y = __float_as_uint(t);
+                const auto r2 = __builtin_amdgcn_permlane16_swap(y, y, false, false);
+                tmax[qt] = fmaxf(__uint_as_float(r2[0]), __uint_as_float(r2[1]));
+            } else if constexpr (u == 3) {
+                mnew[qt] = fmaxf(mrow[qt], tmax[qt] * c2);
+                alpha[qt] = __builtin_amdgcn_exp2f(mrow[qt] - mnew[qt]);
+                mrow[qt] = mnew[qt];
+            } else if constexpr (u < 12) {      // 8 units x 2 elements
+                constexpr int e = (u - 4) * 2, kt = e >> 2, r = e & 3;
+                p[qt][kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(cur[kt][qt][r], c2, -mnew[qt]));
+                p[qt][kt][r + 1] = __builtin_amdgcn_exp2f(__builtin_fmaf(cur[kt][qt][r + 1], c2, -mnew[qt]));
+            } else if constexpr (u < 16) {      // 4 units x 2 packed conversions: pf[kb] = (kt = 2kb, r 0..3), (kt = 2kb+1, r 0..3)
+                constexpr int h2 = u - 12, kb = h2 >> 1, od = h2 & 1;
+                const unsigned lo = pack2<T>(p[qt][2 * kb + od][0], p[qt][2 * kb + od][1]);
+                const unsigned hi = pack2<T>(p[qt][2 * kb + od][2], p[qt][2 * kb + od][3]);
+                if constexpr (od == 0) { pf[qt][kb].x = lo; pf[qt][kb].y = hi; } else { pf[qt][kb].z = lo; pf[qt][kb].w = hi; }
+            } else {
+                if constexpr (!ONES) {
+                    float psum = 0.f;
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt) psum += (p[qt][kt][0] + p[qt][kt][1]) + (p[qt][kt][2] + p[qt][kt][3]);
+                    lrow[qt] = lrow[qt] * alpha[qt] + psum;   // per-lane partial; reduced over g at the end of the set
+                }
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) os[dt][qt][r] *= alpha[qt];
+            }
+        };
+        // flat unit stream over the query tiles: unit index x = qt * NU + u
+        constexpr int UT = NU * QT;
+        constexpr int U1 = QT == 1 ? UT : NU + 3;               // units placed beside the QK MFMAs
+        auto units = [&](auto lo_, auto hi_) __attribute__((always_inline)) {
+            constexpr int lo = decltype(lo_)::value, hi = decltype(hi_)::value;
+            static_for<lo, hi>([&](auto x_) __attribute__((always_inline)) {
+                constexpr int x = decltype(x_)::value;
+                unit(std::integral_constant<int, x / NU>{}, std::integral_constant<int, x % NU>{});
+            });
+        };
+        // ---- phase 1
+        rd_k(0);
+        if (NKF > 1) rd_k(1);
+        if (NKF > 2) rd_k(2);
+        units(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});      // max chain first: covers the first fragment reads
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, NQ>([&](auto m_) __attribute__((always_inline)) {
+            constexpr int m = decltype(m_)::value;
+            if constexpr (m % QT == 0 && m / QT + 3 < NKF) rd_k(m / QT + 3);
+            mma_qk(m);
+            units(std::integral_constant<int, 2 + ((U1 - 2) * m) / NQ>{}, std::integral_constant<int, 2 + ((U1 - 2) * (m + 1)) / NQ>{});
+            if constexpr (NQ - m <= NPV) rd_v(NPV - (NQ - m));   // the V^T fragments arrive during the tail of phase 1
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // ---- phase 2 .. : P V per query tile, the next tile's remaining softmax beside it
+        static_for<0, QT>([&](auto qt_) __attribute__((always_inline)) {
+            constexpr int qt = decltype(qt_)::value;
+            constexpr int u_lo = qt == 0 ? U1 : NU * (qt + 1), u_hi = qt + 1 < QT ? NU * (qt + 2) : UT;
+            static_for<0, NPV>([&](auto n_) __attribute__((always_inline)) {
+                constexpr int n = decltype(n_)::value;
+                mma_pv(qt, n);
+                units(std::integral_constant<int, u_lo + ((u_hi - u_lo) * n) / NPV>{}, std::integral_constant<int, u_lo + ((u_hi - u_lo) * (n + 1)) / NPV>{});
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+    };
+
+    auto fold = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            float l;
+            if (ONES) {   // denominator = O^T row D: held by the lane with 16*dt + 4*g + r == D of the same query column
+                constexpr int dt_l = D / 16, g_l = (D % 16) / 4, r_l = D % 4;
+                l = __shfl(os[dt_l][qt][r_l], g_l * 16 + fr, 64);
+            } else {
+                l = lrow[qt];
+                l += __shfl_xor(l, 16, 64);
+                l += __shfl_xor(l, 32, 64);
+            }
+            const float inv = a.set_w[s] / l;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { otot[dt][qt][r] += os[dt][qt][r] * inv; os[dt][qt][r] = 0.f; }
+            mrow[qt] = -1e30f; lrow[qt] = 0.f;
+        }
+    };
+
+    // ---- prologue: K(0) alone, then PD groups {K(j+1), V(j)}
+    issue_k();
+#pragma unroll
+    for (int j = 0; j < PD; ++j) { issue_k(); issue_v(); }
+    wait_vmcnt<PD * GRP>();
+    __builtin_amdgcn_s_barrier();
+    f32x4 sa[4][QT], sb[4][QT];
+    qk(sa, 0);
+
+    int tile = 0, s = 0;
+    auto step = [&](f32x4(&cur)[4][QT], f32x4(&nxt)[4][QT], int i) __attribute__((always_inline)) {
+        if (ragged && tile == ntiles - 1) body(cur, nxt, i, tile, std::true_type{});
+        else body(cur, nxt, i, tile, std::false_type{});
+        if (++tile == ntiles) { fold(s); tile = 0; ++s; }
+    };
+    int i = 0;
+    for (; i + 1 < nsteps; i += 2) { step(sa, sb, i); step(sb, sa, i + 1); }
+    if (i < nsteps) step(sa, sb, i);
+    wait_vmcnt<0>();     // drain the dummy prefetches before the LDS is released
+
+    // ---- store: lane owns O[q = fr][d = 16*dt + 4*g .. +4]
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int q = q_wave0 + qt * 16 + fr;
+        if (q >= a.Lq) continue;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d = dt * 16 + g * 4;
+            if (d + 4 > D) continue;
+            *reinterpret_cast<uint2 *>(a.O + (int64_t)b * a.o_bs + (int64_t)q * a.ldo + h * D + d) =
+                make_uint2(pack2<T>(otot[dt][qt][0], otot[dt][qt][1]), pack2<T>(otot[dt][qt][2], otot[dt][qt][3]));
+        }
+    }
+}
+
+template <class T, int D, int QT, int NST>
+void launch_attn2(const AttnArgs &a, int B, hipStream_t s)
+{
+    constexpr int DP = (D + 31) / 32 * 32, CPR = DP / 8, DV = (D + 15) / 16 * 16, VR = (DV + 31) / 32 * 32;
+    constexpr size_t lds = (size_t)NST * (64 * CPR * 16 + VR * 128);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void *)k_attn2<T, D, QT, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    AttnArgs aa = a;
+    aa.nqb = (a.Lq + 64 * QT - 1) / (64 * QT);
+    dim3 grid((unsigned)(aa.nqb * a.H * B));
+    hipLaunchKernelGGL((k_attn2<T, D, QT, NST>), grid, dim3(256), lds, s, aa);
+}
+
 template <class T>
 int launch_attn(const AttnArgs &a, int D, int B, hipStream_t s)
 {
+    static const int use2 = [] { const char *e = getenv("GC_ATTN2"); return e ? atoi(e) : 0; }();
+    if (use2) {
+        switch (D) {
+        case 40: launch_attn2<T, 40, 2, 3>(a, B, s); return GC_OK;
+        default: break;
+        }
+    }
 #define GC_ATT(DD, QQ)                                                                                  \
     do {                                                                                                \
-        dim3 grid((unsigned)((a.Lq + 64 * QQ - 1) / (64 * QQ)), (unsigned)a.H, (unsigned)B);            \
-        hipLaunchKernelGGL((k_attn<T, DD, QQ>), grid, dim3(256), 0, s, a);                              \
+        AttnArgs aa = a;                                                                                \
+        aa.nqb = (a.Lq + 64 * QQ - 1) / (64 * QQ);                                                      \
+        dim3 grid((unsigned)(aa.nqb * a.H * B));                                                        \
+        hipLaunchKernelGGL((k_attn<T, DD, QQ>), grid, dim3(256), 0, s, aa);                             \
     } while (0)
     switch (D) {
     case 8: GC_ATT(8, 2); break;

@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gaussctrl_amd.sd import ops
 from gaussctrl_amd.sd.weights import conv3x3_weight
 dt = torch.bfloat16; DEV='cuda:0'; B=6

@@ -1,0 +1,85 @@
+// Issue-model microbenchmark for gfx950: how do v_mfma_f32_16x16x32_bf16 and VALU instructions of ONE wave (and of two
+// co-resident waves of a SIMD) overlap?  Prints cycles per MFMA group for several fillers.
+// build: hipcc --offload-arch=gfx950 -O3 -o issue_model issue_model.hip ; run: ./issue_model
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <int NM, int NV, int KIND>
+__global__ __launch_bounds__(1024) void k(float *out, long long *cyc, int iters)
+{
+    f32x4 acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(float)(threadIdx.x + i); b[i] = (__bf16)(float)(i * 3 + 1); }
+    float v[16];
+    for (int i = 0; i < 16; ++i) v[i] = threadIdx.x * 0.001f + i;
+    __syncthreads();
+    long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            if (NM) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[g], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int r = (g * NV + j) & 15;
+                if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v[r]) : "v"(v[(r + 1) & 15]));
+                if (KIND == 1) asm volatile("v_exp_f32 %0, %0" : "+v"(v[r]));
+                if (KIND == 2) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(v[r]) : "v"(v[(r + 1) & 15]), "v"(v[(r + 2) & 15]));
+                if (KIND == 3) { unsigned t; asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(t) : "v"(v[r]), "v"(v[(r + 1) & 15])); v[r] = __uint_as_float(t); }
+                if (KIND == 4) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(*(double *)&v[(2 * r) & 14]) : "v"(*(double *)&v[(2 * r + 2) & 14]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    long long t1 = __builtin_readcyclecounter();
+    float s = 0;
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    for (int i = 0; i < 16; ++i) s += v[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
+}
+
+template <int NM, int NV, int KIND>
+void run(const char *name, int threads)
+{
+    float *out; long long *cyc;
+    hipMalloc(&out, 4 * 512 * 256); hipMalloc(&cyc, 8);
+    const int iters = 200000;
+    k<NM, NV, KIND><<<1, threads>>>(out, cyc, 2000);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    k<NM, NV, KIND><<<1, threads>>>(out, cyc, iters);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    long long h; hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
+    printf("%-20s waves/SIMD=%d : %7.2f ticks, %7.2f ns per group (%d MFMA + %d VALU)\n", name, threads / 256, (double)h / (iters * 8.0), ms * 1e6 / (iters * 8.0), NM, NV);
+    hipFree(out); hipFree(cyc);
+}
+
+int main()
+{
+    // s_memtime counts at 100 MHz on gfx9?  report raw counter units; calibrate with the MFMA-only line (16 clk expected)
+    for (int th : {256, 512, 1024}) {
+        run<1, 0, 0>("mfma only", th);
+        run<0, 4, 0>("4 fma only", th);
+        run<0, 4, 1>("4 exp only", th);
+        run<0, 4, 2>("4 max3 only", th);
+        run<0, 4, 3>("4 cvt_pk only", th);
+        run<0, 4, 4>("4 pk_mul only", th);
+        run<1, 2, 0>("mfma + 2 fma", th);
+        run<1, 3, 0>("mfma + 3 fma", th);
+        run<1, 4, 0>("mfma + 4 fma", th);
+        run<1, 6, 0>("mfma + 6 fma", th);
+        run<1, 8, 0>("mfma + 8 fma", th);
+        run<1, 2, 1>("mfma + 2 exp", th);
+        run<1, 4, 1>("mfma + 4 exp", th);
+        run<1, 4, 2>("mfma + 4 max3", th);
+        run<1, 4, 3>("mfma + 4 cvt_pk", th);
+        run<1, 4, 4>("mfma + 4 pk_mul", th);
+    }
+    return 0;
+}
