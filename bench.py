@@ -143,8 +143,8 @@ def main():
     bg = torch.zeros(3, device=dev)
     pipe = None
     if args.workload == "edit":
-        uw = prepare(arch.random_state_dict(arch.unet_shapes(), 100, dev), dt, dev)
-        cw = prepare(arch.random_state_dict(arch.controlnet_shapes(), 200, dev), dt, dev)
+        uw = prepare(arch.random_state_dict(arch.unet_shapes(), 100, dev), dt, dev, heads=8)
+        cw = prepare(arch.random_state_dict(arch.controlnet_shapes(), 200, dev), dt, dev, heads=8)
         vw = prepare_vae_weights(arch.random_state_dict(arch.vae_decoder_shapes(), 300, dev), dt, dev)
         pipe = DenoisePipeline(uw, cw, vw, nsteps, 5.0)
     g = torch.Generator(device=dev).manual_seed(2 + rank)

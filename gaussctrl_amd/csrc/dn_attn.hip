@@ -53,8 +53,16 @@ template <class T> struct One;
 template <> struct One<BF16> { static constexpr unsigned short v = 0x3F80; };
 template <> struct One<F16> { static constexpr unsigned short v = 0x3C00; };
 
+template <int D> struct SafeLds {
+    static constexpr int DP = (D + 31) / 32 * 32, DV = (D + 15) / 16 * 16;
+    static constexpr int KROW = DP == 64 ? 128 : (DP + 8) * 2, VROW = (64 + 8) * 2;
+    static constexpr int KBYTES = 64 * KROW, VBYTES = DV * VROW;
+};
+
+// The "safe" form: online softmax with a running row maximum (no assumption on the logits).  It is the whole kernel for the
+// head sizes without spare contraction columns and the in-kernel fallback of k_attn3.
 template <class T, int D, int QT>
-__global__ __launch_bounds__(256, 2) void k_attn(const AttnArgs a)
+__device__ __forceinline__ void attn_safe_body(const AttnArgs &a, int qblk, int h, int b, unsigned char *sK, unsigned char *sV)
 {
     constexpr int DP = (D + 31) / 32 * 32;      // contraction length of QK^T, padded to the MFMA k = 32
     constexpr int DV = (D + 15) / 16 * 16;      // output rows of O^T, padded to the MFMA m = 16
@@ -67,18 +75,14 @@ __global__ __launch_bounds__(256, 2) void k_attn(const AttnArgs a)
     constexpr bool ONES = (DV > D);
     constexpr int NKC = 64 * (D / 8), NVC = D * 8;                     // 16-byte chunks per K / V^T tile
     constexpr int KIT = (NKC + 255) / 256, VIT = (NVC + 255) / 256;
-    __shared__ __attribute__((aligned(16))) unsigned char sK[64 * KROW];
-    __shared__ __attribute__((aligned(16))) unsigned char sV[DV * VROW];
-
+    static_assert(KROW == SafeLds<D>::KROW && VROW == SafeLds<D>::VROW && DV == SafeLds<D>::DV, "LDS plan");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, g = lane >> 4;
-    int qblk, h, b;
-    block_coords(a, QT, qblk, h, b);
     const int q_wave0 = (qblk * 4 + wid) * (QT * 16);
 
     // zero the LDS once: pad columns / pad rows are never written again
-    for (int i = tid; i < (int)(sizeof(sK) / 16); i += 256) reinterpret_cast<uint4 *>(sK)[i] = make_uint4(0, 0, 0, 0);
-    for (int i = tid; i < (int)(sizeof(sV) / 16); i += 256) reinterpret_cast<uint4 *>(sV)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < 64 * KROW / 16; i += 256) reinterpret_cast<uint4 *>(sK)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < DV * VROW / 16; i += 256) reinterpret_cast<uint4 *>(sV)[i] = make_uint4(0, 0, 0, 0);
     if (ONES) {
         __syncthreads();
         if (tid < 64) reinterpret_cast<unsigned short *>(sV + D * VROW)[tid] = One<T>::v;
@@ -295,28 +299,66 @@ __global__ __launch_bounds__(256, 2) void k_attn(const AttnArgs a)
 }
 
 
+template <class T, int D, int QT>
+__global__ __launch_bounds__(256, 2) void k_attn(const AttnArgs a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char sK[SafeLds<D>::KBYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char sV[SafeLds<D>::VBYTES];
+    int qblk, h, b;
+    block_coords(a, QT, qblk, h, b);
+    attn_safe_body<T, D, QT>(a, qblk, h, b, sK, sV);
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
-// k_attn2: the software-pipelined form of k_attn (same math, same operand layouts in HBM).
-//   * K / V^T tiles travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR staging) into an NST-deep ring, PD = NST-1
-//     tiles ahead, ONE s_barrier per tile and counted s_waitcnt vmcnt(N): the load latency never sits on the critical path.
-//   * (set, tile) pairs are flattened into one sequence of steps; inside a step the QK^T MFMAs of step i+1 are issued beside
-//     the softmax VALU work of step i (a wave issues in order: MFMAs and VALU only overlap when they alternate in ITS stream).
+// k_attn3: static-offset, software-pipelined form for head sizes with two spare contraction columns (D % 32 != 0: 40, 80).
+//
+// The SIMD issues MFMA and VALU work almost serially (scripts/ubench/issue_model.hip: a v_mfma_16x16x32 costs ~17 clk and
+// hides only ~2 plain VALU; v_exp_f32 costs ~8 clk), and the online softmax of k_attn spends 2/3 of its time in VALU
+// instructions.  Here the softmax bookkeeping moves INTO the QK^T MFMAs:
+//   * Q is pre-multiplied by scale*log2(e) once; contraction column D of every Q row holds -m0 (the row's offset, = the row
+//     maximum over the FIRST key tile of the K/V set) and column D+1 holds -30000.  Column D of a valid key row in LDS is 1,
+//     column D+1 is 1 only for keys >= Lk.  The MFMA therefore returns S' = log2e*scale*q.k - m0 (or <= -30000 for masked keys)
+//     and P = exp2(S') is ONE v_exp_f32 per element: no running maximum, no rescale of O, no masking VALU, no FMA.
+//     (softmax is invariant to the offset; m0 only keeps exp2 in range.)  The softmax denominator comes out of the P V MFMAs
+//     through a row of ones in V^T, as in k_attn.
+//   * If a later tile exceeds m0 by more than the exponent range (P or its sum overflows: the denominator is not a positive
+//     finite number), the workgroup recomputes its rows with the safe online-softmax body.  Results never depend on the data
+//     being "nice"; only the speed does.
+//   * K / V^T tiles travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, SGPR base + lane offset: no VGPR staging, no address
+//     VALU) into an NST-deep ring, PD = NST-1 tiles ahead; ONE s_barrier per tile and counted s_waitcnt vmcnt(N).
+//   * (set, tile) pairs are flattened into one sequence of steps; the QK^T MFMAs of step i+1 are issued between the exp /
+//     convert slices of step i, the P V MFMAs of query tile 0 between those of query tile 1.
 //   * the MFMA row -> key mapping inside a tile is permuted (key = 32(kt/2) + 8g + 4(kt&1) + r) so that a lane's eight P values
 //     of a 32-key block are eight CONSECUTIVE keys: the V^T fragment is one ds_read_b128 (ds_read2_b64 runs at half rate).
 //   * both tiles use 16-byte-chunk XOR swizzles that are conflict-free for the ds_read_b128 lane groups of gfx950
-//     (searched exhaustively, scripts/lds_swizzle_search.py); pad chunks / the ones-row are DMA'd from constant pages.
-__device__ __attribute__((aligned(16))) unsigned short g_page_zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-__device__ __attribute__((aligned(16))) unsigned short g_page_one_bf16[8] = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
-__device__ __attribute__((aligned(16))) unsigned short g_page_one_f16[8] = {0x3C00, 0x3C00, 0x3C00, 0x3C00, 0x3C00, 0x3C00, 0x3C00, 0x3C00};
-template <class T> __device__ __forceinline__ const unsigned char *one_page();
-template <> __device__ __forceinline__ const unsigned char *one_page<BF16>() { return (const unsigned char *)g_page_one_bf16; }
-template <> __device__ __forceinline__ const unsigned char *one_page<F16>() { return (const unsigned char *)g_page_one_f16; }
+//     (exhaustive search: scripts/lds_swizzle_search.py; SQ_LDS_BANK_CONFLICT = 0 measured).
+template <class T> struct Pages;
+__device__ __attribute__((aligned(16))) unsigned short g_pg_e0_bf16[8] = {0x3F80, 0, 0, 0, 0, 0, 0, 0};
+__device__ __attribute__((aligned(16))) unsigned short g_pg_e1_bf16[8] = {0, 0x3F80, 0, 0, 0, 0, 0, 0};
+__device__ __attribute__((aligned(16))) unsigned short g_pg_e0_f16[8] = {0x3C00, 0, 0, 0, 0, 0, 0, 0};
+__device__ __attribute__((aligned(16))) unsigned short g_pg_e1_f16[8] = {0, 0x3C00, 0, 0, 0, 0, 0, 0};
+template <> struct Pages<BF16> {
+    static __device__ __forceinline__ const unsigned char *e0() { return (const unsigned char *)g_pg_e0_bf16; }
+    static __device__ __forceinline__ const unsigned char *e1() { return (const unsigned char *)g_pg_e1_bf16; }
+};
+template <> struct Pages<F16> {
+    static __device__ __forceinline__ const unsigned char *e0() { return (const unsigned char *)g_pg_e0_f16; }
+    static __device__ __forceinline__ const unsigned char *e1() { return (const unsigned char *)g_pg_e1_f16; }
+};
 
-__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst)
+// LDS-DMA of 16 bytes per lane of `mask`: lane l writes LDS[lds_dst + 16 l] (M0 carries the LDS base; this kernel has no other
+// M0 user, so it is not saved).  EXEC is set inside the asm (it is all-ones at every call site): no compiler-made branches, and
+// every wave issues exactly the same number of loads.  Issued from inline asm so that hipcc's waitcnt pass does not drain the
+// loads with vmcnt(0) before every ds_read; ordering is by explicit vmcnt + s_barrier.
+__device__ __forceinline__ void glds16_v(const void *gsrc, unsigned lds_dst, unsigned long long mask)     // 64-bit address per lane
 {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_mov_b64 exec, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\ts_mov_b64 exec, -1"
+                 :: "v"(gsrc), "s"(lds_dst), "s"(mask) : "memory");
+}
+__device__ __forceinline__ void glds16_s(const void *sbase, unsigned voff, unsigned lds_dst, unsigned long long mask)   // uniform base + lane offset
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_mov_b64 exec, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, -1"
+                 :: "v"(voff), "s"(sbase), "s"(lds_dst), "s"(mask) : "memory");
 }
 
 template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&f)
@@ -340,18 +382,20 @@ template <int CPR> __device__ __forceinline__ int swz_k(int row)
 }
 __device__ __forceinline__ int swz_v(int row) { return (row ^ (row << 1) ^ (row << 2)) & 7; }
 
-template <class T, int D, int QT, int NST>
-__global__ __launch_bounds__(256, 2) void k_attn2(const AttnArgs a)
+// RAG: Lk is not a multiple of the 64-key tile.  PRE: Q arrives already multiplied by scale*log2e (folded into the
+// projection weights); otherwise the offset column is kept in raw-logit units and the multiply happens before v_exp_f32.
+template <class T, int D, int QT, int NST, bool RAG, bool PRE>
+__global__ __launch_bounds__(256, 2) void k_attn3(const AttnArgs a)
 {
+    static_assert(D % 8 == 0 && D % 32 != 0, "needs two spare contraction columns");
     constexpr int DP = (D + 31) / 32 * 32, KS = DP / 32, CPR = DP / 8;     // K row: CPR 16-byte chunks
-    constexpr int DV = (D + 15) / 16 * 16, DT = DV / 16;
-    constexpr bool ONES = (DV > D);
-    constexpr int VR = (DV + 31) / 32 * 32;                                // V^T rows in LDS (DMA granule: 32 rows = 256 chunks)
-    constexpr int KBYTES = 64 * CPR * 16, VBYTES = VR * 128;
-    constexpr int KI = CPR / 4, VI = VR / 32;                              // LDS-DMA instructions per wave per tile
+    constexpr int DV = (D + 16) / 16 * 16, DT = DV / 16;                   // V^T rows: D channels, the ones row, zero rows
+    constexpr int KBYTES = 64 * CPR * 16, VBYTES = DV * 128;
+    constexpr int LCS = D / 8, KSS = LCS / 4, GS = LCS % 4;                // the special chunk: columns D (offset) and D+1 (mask)
+    constexpr int KI = CPR / 4;                                            // K DMA instructions per wave per tile (8 rows each)
+    constexpr int VSH = 2 * D, VI = (VSH + 63) / 64;                       // V^T chunks per wave per tile, DMA instructions
     constexpr int PD = NST - 1;                                            // prefetch distance (tiles)
-    constexpr int GRP = KI + VI;
-    static_assert((PD - 1) * GRP < 64, "vmcnt range");
+    constexpr float BIG = 30000.f;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *sK = smem, *sV = smem + NST * KBYTES;
     const unsigned ldsK = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem, ldsV = ldsK + NST * KBYTES;
@@ -362,8 +406,19 @@ __global__ __launch_bounds__(256, 2) void k_attn2(const AttnArgs a)
     int qblk, h, b;
     block_coords(a, QT, qblk, h, b);
     const int q_wave0 = (qblk * 4 + wid) * (QT * 16);
+    const int ntiles = (a.Lk + 63) / 64;
+    const int nsteps = a.nsets * ntiles;
 
-    // Q fragments (B operand): lane holds Q[q = fr][d = 32*ks + 8*g .. +8]
+    // ---- LDS image, written once: zeros, column D of every key row = 1, the ones row of V^T
+    for (int i = tid; i < NST * (KBYTES + VBYTES) / 16; i += 256) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    for (int i = tid; i < NST * 64; i += 256) {
+        const int st = i >> 6, row = i & 63;
+        *reinterpret_cast<unsigned short *>(sK + st * KBYTES + row * (CPR * 16) + ((LCS ^ swz_k<CPR>(row)) << 4)) = One<T>::v;
+    }
+    for (int i = tid; i < NST * 64; i += 256) reinterpret_cast<unsigned short *>(sV + (i >> 6) * VBYTES + D * 128)[i & 63] = One<T>::v;
+
+    // ---- Q fragments (B operand): lane holds Q[q = fr][d = 32*ks + 8*g .. +8]
     uint4 qf[QT][KS];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
@@ -376,31 +431,38 @@ __global__ __launch_bounds__(256, 2) void k_attn2(const AttnArgs a)
                              : make_uint4(0, 0, 0, 0);
         }
     }
+    const float c2 = a.scale_log2e;       // PRE: 1
+    float moff[QT];                       // current offset of each query row (exactly representable in T)
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        moff[qt] = 0.f;
+        if (g == GS) qf[qt][KSS].x = pack2<T>(0.f, -BIG);
+    }
 
-    // ---- LDS-DMA plan of this lane: instruction j of wave w fills chunks [(4j + w) * 64, +64) of the tile image.
-    // A chunk is fetched from the tile's HBM window when key0 < thr (thr folds "row / token inside Lk" and "chunk is real
-    // data"), else from a constant page (zeros; ones for the denominator row of V^T).
-    const unsigned char *zp = (const unsigned char *)g_page_zero;
-    int k_off[KI], k_thr[KI], v_off[VI], v_thr[VI];
-    const unsigned char *v_alt[VI];
-    const int lk8 = (a.Lk + 7) / 8 * 8;
+    // ---- LDS-DMA plan of this lane
+    // K: instruction j of wave w covers chunk slots [(4j + w) * 64, +64) of the tile image (8 key rows); only data chunks load
+    int k_off[KI], k_row[KI];
+    unsigned long long k_msk[KI], k_smk[KI];
 #pragma unroll
     for (int j = 0; j < KI; ++j) {
         const int p = (j * 4 + wid) * 64 + lane, row = p / CPR, lc = (p % CPR) ^ swz_k<CPR>(row);
+        k_row[j] = row;
+        k_msk[j] = __ballot(lc * 8 < D);
+        k_smk[j] = __ballot(lc == LCS);
         k_off[j] = (row * (int)a.ldk + lc * 8) * 2;
-        k_thr[j] = lc * 8 < D ? a.Lk - row : -1;                 // fetch iff key0 + row < Lk
     }
+    // V^T: wave w owns chunk slots [VSH w, VSH (w+1)) of the D x 8 data chunks
+    int v_off[VI], v_tok[VI];
+    unsigned long long v_msk[VI];
 #pragma unroll
     for (int j = 0; j < VI; ++j) {
-        const int p = (j * 4 + wid) * 64 + lane, row = p >> 3, lc = (p & 7) ^ swz_v(row);
+        const int q = j * 64 + lane, p = VSH * wid + q, row = p >> 3, lc = (p & 7) ^ swz_v(row);
+        v_msk[j] = __ballot(q < VSH);
+        v_tok[j] = lc * 8;
         v_off[j] = (row * (int)a.ldvt + lc * 8) * 2;
-        v_thr[j] = row < D ? lk8 - lc * 8 : -1;                  // fetch iff key0 + 8 lc < round_up(Lk, 8)
-        v_alt[j] = (ONES && row == D) ? one_page<T>() : zp;
     }
-
-    const int ntiles = (a.Lk + 63) / 64;
-    const bool ragged = (a.Lk & 63) != 0;
-    const int nsteps = a.nsets * ntiles;
+    const int lk8 = (a.Lk + 7) / 8 * 8;
+    constexpr int GRP = KI * (RAG ? 2 : 1) + VI;          // DMA instructions per wave per step
 
     // per-set K / V^T base addresses, parked in lane s of two VGPR pairs (fetched with v_readlane at set changes)
     unsigned long long kb_tab = 0, vb_tab = 0;
@@ -425,34 +487,38 @@ __global__ __launch_bounds__(256, 2) void k_attn2(const AttnArgs a)
         const unsigned lo = __builtin_amdgcn_readlane((unsigned)t, s), hi = __builtin_amdgcn_readlane((unsigned)(t >> 32), s);
         return (const unsigned char *)(((unsigned long long)hi << 32) | lo);
     };
-    // DMA cursors (branch-free): the K stream runs one tile ahead of the V^T stream; both walk the (set, tile) sequence and,
-    // past the end, keep re-loading the last tile (the counted waits need the same number of loads from every wave, every step)
-    struct Cur { const unsigned char *p; int tile, s, slot; };
+    // DMA cursors: the K stream runs one tile ahead of the V^T stream; both walk the (set, tile) sequence and, past the end,
+    // load the last set's first tile again (the counted waits need the same number of loads from every wave, every step)
+    struct Cur { const unsigned char *p; int tile, s; unsigned dst; };
     Cur ck, cv;
-    ck.p = tab(kb_tab, 0); ck.tile = 0; ck.s = 0; ck.slot = 0;
-    cv.p = tab(vb_tab, 0); cv.tile = 0; cv.s = 0; cv.slot = 0;
-    auto advance = [&](Cur &c, unsigned long long t, int64_t stride) __attribute__((always_inline)) {
-        c.slot = c.slot + 1 == NST ? 0 : c.slot + 1;
-        const bool wrap = c.tile + 1 == ntiles, last = wrap && c.s + 1 == a.nsets;
-        const int sn = wrap && !last ? c.s + 1 : c.s;
-        const unsigned char *pn = tab(t, sn);
-        c.p = last ? c.p : wrap ? pn : c.p + stride;
-        c.tile = last ? c.tile : wrap ? 0 : c.tile + 1;
-        c.s = sn;
-    };
+    ck.p = tab(kb_tab, 0); ck.tile = 0; ck.s = 0; ck.dst = ldsK + wid * 1024;
+    cv.p = tab(vb_tab, 0); cv.tile = 0; cv.s = 0; cv.dst = ldsV + wid * (VSH * 16);
+    const int64_t kstride = (int64_t)128 * a.ldk;
     auto issue_k = [&]() __attribute__((always_inline)) {
-        const unsigned dst = ldsK + (unsigned)(ck.slot * KBYTES + wid * 1024);
-        const int key0 = ck.tile * 64;
+        if (!RAG) {
 #pragma unroll
-        for (int j = 0; j < KI; ++j) glds16(key0 < k_thr[j] ? ck.p + k_off[j] : zp, dst + j * 4096);
-        advance(ck, kb_tab, (int64_t)128 * a.ldk);
+            for (int j = 0; j < KI; ++j) glds16_s(ck.p, (unsigned)k_off[j], ck.dst + j * 4096, k_msk[j]);
+        } else {       // keys >= Lk: the data chunks re-read row 0 of the tile (finite filler), column D+1 = 1 masks them
+            const int lim = a.Lk - ck.tile * 64;
+#pragma unroll
+            for (int j = 0; j < KI; ++j) {
+                const bool ok = k_row[j] < lim;
+                glds16_s(ck.p, (unsigned)(ok ? k_off[j] : k_off[j] - k_row[j] * (int)a.ldk * 2), ck.dst + j * 4096, k_msk[j]);
+                glds16_v(ok ? Pages<T>::e0() : Pages<T>::e1(), ck.dst + j * 4096, k_smk[j]);
+            }
+        }
+        ck.dst = ck.dst + KBYTES == ldsK + wid * 1024 + NST * KBYTES ? ldsK + wid * 1024 : ck.dst + KBYTES;
+        ck.p += kstride;
+        if (++ck.tile == ntiles) { ck.tile = 0; ck.s = ck.s + 1 < a.nsets ? ck.s + 1 : ck.s; ck.p = tab(kb_tab, ck.s); }
     };
     auto issue_v = [&]() __attribute__((always_inline)) {
-        const unsigned dst = ldsV + (unsigned)(cv.slot * VBYTES + wid * 1024);
-        const int key0 = cv.tile * 64;
+        const int lim = lk8 - cv.tile * 64;    // token chunks past round_up(Lk, 8) re-read chunk 0 (their P is exactly 0)
 #pragma unroll
-        for (int j = 0; j < VI; ++j) glds16(key0 < v_thr[j] ? cv.p + v_off[j] : v_alt[j], dst + j * 4096);
-        advance(cv, vb_tab, 128);
+        for (int j = 0; j < VI; ++j)
+            glds16_s(cv.p, (unsigned)(!RAG || v_tok[j] < lim ? v_off[j] : v_off[j] - v_tok[j] * 2), cv.dst + j * 1024, v_msk[j]);
+        cv.dst = cv.dst + VBYTES == ldsV + wid * (VSH * 16) + NST * VBYTES ? ldsV + wid * (VSH * 16) : cv.dst + VBYTES;
+        cv.p += 128;
+        if (++cv.tile == ntiles) { cv.tile = 0; cv.s = cv.s + 1 < a.nsets ? cv.s + 1 : cv.s; cv.p = tab(vb_tab, cv.s); }
     };
 
     // fragment read offsets.  K: MFMA row fr of key-subtile kt is key 32(kt/2) + 4(kt&1) + 8(fr/4) + (fr&3); chunk 4ks + g
@@ -473,58 +539,53 @@ __global__ __launch_bounds__(256, 2) void k_attn2(const AttnArgs a)
     for (int kb = 0; kb < 2; ++kb) vfo[kb] = fr * 128 + (((4 * kb + g) ^ swz_v(fr)) << 4);
 
     f32x4 otot[DT][QT], os[DT][QT];
-    float mrow[QT], lrow[QT];
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        mrow[qt] = -1e30f; lrow[qt] = 0.f;
+    for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) { otot[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f}; os[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    }
-    const float c2 = a.scale_log2e;
+    int bad = 0;
 
-    // S^T of one tile: st[kt][qt][r] = S[q = fr][key = key0 + 32(kt/2) + 8 g + 4(kt&1) + r]
-    auto qk = [&](f32x4(&st)[4][QT], int stage) __attribute__((always_inline)) {
-        const unsigned char *kb_ = sK + stage * KBYTES;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt) st[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                const uint4 kf = *reinterpret_cast<const uint4 *>(kb_ + kfo[ks][kt & 1] + (32 * (kt >> 1)) * (CPR * 16));
-#pragma unroll
-                for (int qt = 0; qt < QT; ++qt) st[kt][qt] = T::mfma(kf, qf[qt][ks], st[kt][qt]);
-            }
-    };
+    constexpr int NKF = 4 * KS, NQ = NKF * QT, NPV = 2 * DT, NU = 8;      // K fragments, QK MFMAs, PV MFMAs / exp units per query tile
 
-    // one pipeline step: S(i+1) = K(i+1) Q^T  ||  softmax of S(i)  ->  O += V(i)^T P(i)^T
-    // Hand-placed instruction stream: every MFMA is followed by a slice of independent softmax VALU work and the groups are
-    // pinned with sched_barrier(0).  Phase 1: the NQ = 4 KS QT MFMAs of S(i+1) beside the softmax of query tile 0 (and the
-    // head of tile 1); phase 2: P V of query tile 0 beside the rest of tile 1's softmax; phase 3: P V of tile 1.
-    auto body = [&](f32x4(&cur)[4][QT], f32x4(&nxt)[4][QT], int i, int tile, auto part_tag) __attribute__((always_inline)) {
-        constexpr bool PART = decltype(part_tag)::value;
+    // one pipeline step.  cur = S'(i) (already holds log2e*scale*q.k - offset); nxt receives S'(i+1)
+    const unsigned char *rk = sK + (NST > 1 ? KBYTES : 0), *rv = sV;     // LDS stages step i reads: K(i+1), V(i)
+    auto body = [&](f32x4(&cur)[4][QT], f32x4(&nxt)[4][QT], auto first_tag) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_tag)::value;
         wait_vmcnt<(PD - 1) * GRP>();          // K(i+1), V(i) (and everything older) have landed for this wave
         __builtin_amdgcn_s_barrier();          // ... for every wave; every wave is done with step i-1's buffers
         issue_k();
         issue_v();
-        const unsigned char *kb_ = sK + ((i + 1) % NST) * KBYTES;
-        const unsigned char *vb_ = sV + (i % NST) * VBYTES;
-        if (PART) {
-            const int key0 = tile * 64;
+        const unsigned char *kb_ = rk, *vb_ = rv;
+        rk = rk + KBYTES == sK + NST * KBYTES ? sK : rk + KBYTES;
+        rv = rv + VBYTES == sV + NST * VBYTES ? sV : rv + VBYTES;
+        if (FIRST) {
+            // first tile of a K/V set: its row maximum becomes the set's offset.  cur was produced with the previous offset.
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+            for (int qt = 0; qt < QT; ++qt) {
+                float t = fmaxf(fmaxf(cur[0][qt][0], cur[0][qt][1]), cur[0][qt][2]);
+                t = fmaxf(fmaxf(t, cur[0][qt][3]), cur[1][qt][0]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (key0 + 32 * (kt >> 1) + 4 * (kt & 1) + 8 * g + r >= a.Lk) {
+                for (int kt = 1; kt < 4; ++kt) {
+                    if (kt > 1) t = fmaxf(fmaxf(t, cur[kt - 1][qt][3]), cur[kt][qt][0]);
+                    t = fmaxf(fmaxf(t, cur[kt][qt][1]), cur[kt][qt][2]);
+                }
+                t = fmaxf(t, cur[3][qt][3]);
+                const unsigned x = __float_as_uint(t);                       // reduce over g with the lane-swap instructions
+                const auto r1 = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+                t = fmaxf(__uint_as_float(r1[0]), __uint_as_float(r1[1]));
+                const unsigned y = __float_as_uint(t);
+                const auto r2 = __builtin_amdgcn_permlane16_swap(y, y, false, false);
+                t = fmaxf(__uint_as_float(r2[0]), __uint_as_float(r2[1]));
+                const float mq = T::to_f(T::from_f(moff[qt] + t));           // new offset, rounded to what the MFMA will see
+                const float dlt = mq - moff[qt];
 #pragma unroll
-                        for (int qt = 0; qt < QT; ++qt) cur[kt][qt][r] = -1e30f;
-                    }
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cur[kt][qt][r] -= dlt;
+                moff[qt] = mq;
+                if (g == GS) qf[qt][KSS].x = pack2<T>(-mq, -BIG);
+            }
         }
-        constexpr int NKF = 4 * KS, NQ = NKF * QT, NPV = 2 * DT;      // K fragments, QK MFMAs, PV MFMAs per query tile
-        constexpr int NU = 17;                                        // VALU units per query tile (see unit())
-        float tmax[QT], mnew[QT], alpha[QT], p[QT][4][4];
         uint4 pf[QT][2], kf[NKF], vf[NPV];
         auto rd_k = [&](int n) __attribute__((always_inline)) {       // n = ks * 4 + kt
             const int ks = n >> 2, kt = n & 3;
@@ -543,55 +604,18 @@ __global__ __launch_bounds__(256, 2) void k_attn2(const AttnArgs a)
             const int kb = n / DT, dt = n - kb * DT;
             os[dt][qt] = T::mfma(vf[n], pf[qt][kb], os[dt][qt]);
         };
-        // softmax of one query tile in 17 units of 2-6 VALU instructions
-        auto unit = [&](auto qt_, auto u_) __attribute__((always_inline)) {
-            constexpr int qt = decltype(qt_)::value, u = decltype(u_)::value;
-            if constexpr (u == 0) {
-                float t = fmaxf(fmaxf(cur[0][qt][0], cur[0][qt][1]), cur[0][qt][2]);
-                t = fmaxf(fmaxf(t, cur[0][qt][3]), cur[1][qt][0]);
-                t = fmaxf(fmaxf(t, cur[1][qt][1]), cur[1][qt][2]);
-                tmax[qt] = fmaxf(fmaxf(t, cur[1][qt][3]), cur[2][qt][0]);
-            } else if constexpr (u == 1) {
-                float t = fmaxf(fmaxf(tmax[qt], cur[2][qt][1]), cur[2][qt][2]);
-                t = fmaxf(fmaxf(t, cur[2][qt][3]), cur[3][qt][0]);
-                t = fmaxf(fmaxf(t, cur[3][qt][1]), cur[3][qt][2]);
-                tmax[qt] = fmaxf(t, cur[3][qt][3]);
-            } else if constexpr (u == 2) {      // reduce over g (lanes 16 and 32 apart) with the lane-swap instructions: no LDS round trip
-                const unsigned x = __float_as_uint(tmax[qt]);
-                const auto r1 = __builtin_amdgcn_permlane32_swap(x, x, false, false);
-                const float t = fmaxf(__uint_as_float(r1[0]), __uint_as_float(r1[1]));
-                const unsigned y = __float_as_uint(t);
-                const auto r2 = __builtin_amdgcn_permlane16_swap(y, y, false, false);
-                tmax[qt] = fmaxf(__uint_as_float(r2[0]), __uint_as_float(r2[1]));
-            } else if constexpr (u == 3) {
-                mnew[qt] = fmaxf(mrow[qt], tmax[qt] * c2);
-                alpha[qt] = __builtin_amdgcn_exp2f(mrow[qt] - mnew[qt]);
-                mrow[qt] = mnew[qt];
-            } else if constexpr (u < 12) {      // 8 units x 2 elements
-                constexpr int e = (u - 4) * 2, kt = e >> 2, r = e & 3;
-                p[qt][kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(cur[kt][qt][r], c2, -mnew[qt]));
-                p[qt][kt][r + 1] = __builtin_amdgcn_exp2f(__builtin_fmaf(cur[kt][qt][r + 1], c2, -mnew[qt]));
-            } else if constexpr (u < 16) {      // 4 units x 2 packed conversions: pf[kb] = (kt = 2kb, r 0..3), (kt = 2kb+1, r 0..3)
-                constexpr int h2 = u - 12, kb = h2 >> 1, od = h2 & 1;
-                const unsigned lo = pack2<T>(p[qt][2 * kb + od][0], p[qt][2 * kb + od][1]);
-                const unsigned hi = pack2<T>(p[qt][2 * kb + od][2], p[qt][2 * kb + od][3]);
-                if constexpr (od == 0) { pf[qt][kb].x = lo; pf[qt][kb].y = hi; } else { pf[qt][kb].z = lo; pf[qt][kb].w = hi; }
-            } else {
-                if constexpr (!ONES) {
-                    float psum = 0.f;
-#pragma unroll
-                    for (int kt = 0; kt < 4; ++kt) psum += (p[qt][kt][0] + p[qt][kt][1]) + (p[qt][kt][2] + p[qt][kt][3]);
-                    lrow[qt] = lrow[qt] * alpha[qt] + psum;   // per-lane partial; reduced over g at the end of the set
-                }
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) os[dt][qt][r] *= alpha[qt];
-            }
+        // softmax numerators of one query tile in 8 units of 2 v_exp_f32 + 1 packed convert; word (kt&1)*2 + (j&1) of
+        // pf[kt>>1] = keys 32(kt>>1) + 8g + 4(kt&1) + {r0, r0+1}
+        auto unit = [&](auto qt_, auto j_) __attribute__((always_inline)) {
+            constexpr int qt = decltype(qt_)::value, j = decltype(j_)::value, kt = j >> 1, r0 = 2 * (j & 1);
+            const float x0 = PRE ? cur[kt][qt][r0] : cur[kt][qt][r0] * c2, x1 = PRE ? cur[kt][qt][r0 + 1] : cur[kt][qt][r0 + 1] * c2;
+            const unsigned w = pack2<T>(__builtin_amdgcn_exp2f(x0), __builtin_amdgcn_exp2f(x1));
+            constexpr int c = (kt & 1) * 2 + (j & 1);
+            if constexpr (c == 0) pf[qt][kt >> 1].x = w;
+            else if constexpr (c == 1) pf[qt][kt >> 1].y = w;
+            else if constexpr (c == 2) pf[qt][kt >> 1].z = w;
+            else pf[qt][kt >> 1].w = w;
         };
-        // flat unit stream over the query tiles: unit index x = qt * NU + u
-        constexpr int UT = NU * QT;
-        constexpr int U1 = QT == 1 ? UT : NU + 3;               // units placed beside the QK MFMAs
         auto units = [&](auto lo_, auto hi_) __attribute__((always_inline)) {
             constexpr int lo = decltype(lo_)::value, hi = decltype(hi_)::value;
             static_for<lo, hi>([&](auto x_) __attribute__((always_inline)) {
@@ -599,74 +623,91 @@ __global__ __launch_bounds__(256, 2) void k_attn2(const AttnArgs a)
                 unit(std::integral_constant<int, x / NU>{}, std::integral_constant<int, x % NU>{});
             });
         };
-        // ---- phase 1
+        constexpr int UT = NU * QT;
+        constexpr int M0 = NQ / QT;                               // QK MFMAs issued before P V of query tile 0 may start
         rd_k(0);
         if (NKF > 1) rd_k(1);
         if (NKF > 2) rd_k(2);
-        units(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});      // max chain first: covers the first fragment reads
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, NQ>([&](auto m_) __attribute__((always_inline)) {
             constexpr int m = decltype(m_)::value;
             if constexpr (m % QT == 0 && m / QT + 3 < NKF) rd_k(m / QT + 3);
+            if constexpr (QT > 1 && m + 2 >= M0 && m + 2 - M0 < NPV) rd_v(m + 2 - M0);
             mma_qk(m);
-            units(std::integral_constant<int, 2 + ((U1 - 2) * m) / NQ>{}, std::integral_constant<int, 2 + ((U1 - 2) * (m + 1)) / NQ>{});
-            if constexpr (NQ - m <= NPV) rd_v(NPV - (NQ - m));   // the V^T fragments arrive during the tail of phase 1
+            units(std::integral_constant<int, (UT * m) / NQ>{}, std::integral_constant<int, (UT * (m + 1)) / NQ>{});
+            if constexpr (QT > 1 && m >= M0 && m - M0 < NPV) {    // P V of query tile 0 between the exps of tile 1
+                __builtin_amdgcn_sched_barrier(0);
+                mma_pv(0, m - M0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         });
-        // ---- phase 2 .. : P V per query tile, the next tile's remaining softmax beside it
+        if constexpr (QT == 1) {
+            static_for<0, NPV>([&](auto n_) __attribute__((always_inline)) { rd_v(decltype(n_)::value); });
+        }
         static_for<0, QT>([&](auto qt_) __attribute__((always_inline)) {
             constexpr int qt = decltype(qt_)::value;
-            constexpr int u_lo = qt == 0 ? U1 : NU * (qt + 1), u_hi = qt + 1 < QT ? NU * (qt + 2) : UT;
-            static_for<0, NPV>([&](auto n_) __attribute__((always_inline)) {
-                constexpr int n = decltype(n_)::value;
-                mma_pv(qt, n);
-                units(std::integral_constant<int, u_lo + ((u_hi - u_lo) * n) / NPV>{}, std::integral_constant<int, u_lo + ((u_hi - u_lo) * (n + 1)) / NPV>{});
+            constexpr int n0 = (qt == 0 && QT > 1) ? (NQ - M0 < NPV ? NQ - M0 : NPV) : 0;    // already issued above
+            static_for<n0, NPV>([&](auto n_) __attribute__((always_inline)) {
+                mma_pv(qt, decltype(n_)::value);
                 __builtin_amdgcn_sched_barrier(0);
             });
         });
     };
 
+    // end of a K/V set: O_total += w / l * O_set; the denominator l is row D of O^T (the ones row of V^T)
     auto fold = [&](int s) __attribute__((always_inline)) {
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
-            float l;
-            if (ONES) {   // denominator = O^T row D: held by the lane with 16*dt + 4*g + r == D of the same query column
-                constexpr int dt_l = D / 16, g_l = (D % 16) / 4, r_l = D % 4;
-                l = __shfl(os[dt_l][qt][r_l], g_l * 16 + fr, 64);
-            } else {
-                l = lrow[qt];
-                l += __shfl_xor(l, 16, 64);
-                l += __shfl_xor(l, 32, 64);
-            }
+            constexpr int dt_l = D / 16, g_l = (D % 16) / 4, r_l = D % 4;
+            const float l = __shfl(os[dt_l][qt][r_l], g_l * 16 + fr, 64);
+            bad |= !(l > 0.f && l < 1e37f);
             const float inv = a.set_w[s] / l;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { otot[dt][qt][r] += os[dt][qt][r] * inv; os[dt][qt][r] = 0.f; }
-            mrow[qt] = -1e30f; lrow[qt] = 0.f;
         }
     };
 
     // ---- prologue: K(0) alone, then PD groups {K(j+1), V(j)}
+    __syncthreads();                 // LDS image complete before the first DMA lands on it
     issue_k();
 #pragma unroll
     for (int j = 0; j < PD; ++j) { issue_k(); issue_v(); }
     wait_vmcnt<PD * GRP>();
     __builtin_amdgcn_s_barrier();
     f32x4 sa[4][QT], sb[4][QT];
-    qk(sa, 0);
+    {
+        const unsigned char *kb_ = sK;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) sa[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const uint4 kf = *reinterpret_cast<const uint4 *>(kb_ + kfo[ks][kt & 1] + (32 * (kt >> 1)) * (CPR * 16));
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) sa[kt][qt] = T::mfma(kf, qf[qt][ks], sa[kt][qt]);
+            }
+    }
 
     int tile = 0, s = 0;
-    auto step = [&](f32x4(&cur)[4][QT], f32x4(&nxt)[4][QT], int i) __attribute__((always_inline)) {
-        if (ragged && tile == ntiles - 1) body(cur, nxt, i, tile, std::true_type{});
-        else body(cur, nxt, i, tile, std::false_type{});
+    auto step = [&](f32x4(&cur)[4][QT], f32x4(&nxt)[4][QT]) __attribute__((always_inline)) {
+        if (tile == 0) body(cur, nxt, std::true_type{});
+        else body(cur, nxt, std::false_type{});
         if (++tile == ntiles) { fold(s); tile = 0; ++s; }
     };
     int i = 0;
-    for (; i + 1 < nsteps; i += 2) { step(sa, sb, i); step(sb, sa, i + 1); }
-    if (i < nsteps) step(sa, sb, i);
-    wait_vmcnt<0>();     // drain the dummy prefetches before the LDS is released
+    for (; i + 1 < nsteps; i += 2) { step(sa, sb); step(sb, sa); }
+    if (i < nsteps) step(sa, sb);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the tail prefetches before the LDS is reused / released
 
+    if (__syncthreads_or(bad)) {      // some row left the exponent range of its first-tile offset: safe recomputation
+        attn_safe_body<T, D, QT>(a, qblk, h, b, smem, smem + SafeLds<D>::KBYTES);
+        return;
+    }
     // ---- store: lane owns O[q = fr][d = 16*dt + 4*g .. +4]
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
@@ -682,26 +723,34 @@ __global__ __launch_bounds__(256, 2) void k_attn2(const AttnArgs a)
     }
 }
 
-template <class T, int D, int QT, int NST>
-void launch_attn2(const AttnArgs &a, int B, hipStream_t s)
+template <class T, int D, int QT, int NST, bool RAG, bool PRE>
+void launch_attn3_(const AttnArgs &a, int B, hipStream_t s)
 {
-    constexpr int DP = (D + 31) / 32 * 32, CPR = DP / 8, DV = (D + 15) / 16 * 16, VR = (DV + 31) / 32 * 32;
-    constexpr size_t lds = (size_t)NST * (64 * CPR * 16 + VR * 128);
+    constexpr int DP = (D + 31) / 32 * 32, CPR = DP / 8, DV = (D + 16) / 16 * 16;
+    constexpr size_t ring = (size_t)NST * (64 * CPR * 16 + DV * 128), safe = SafeLds<D>::KBYTES + SafeLds<D>::VBYTES;
+    constexpr size_t lds = ring > safe ? ring : safe;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)k_attn2<T, D, QT, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    if (!attr) { (void)hipFuncSetAttribute((const void *)k_attn3<T, D, QT, NST, RAG, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
     AttnArgs aa = a;
     aa.nqb = (a.Lq + 64 * QT - 1) / (64 * QT);
     dim3 grid((unsigned)(aa.nqb * a.H * B));
-    hipLaunchKernelGGL((k_attn2<T, D, QT, NST>), grid, dim3(256), lds, s, aa);
+    hipLaunchKernelGGL((k_attn3<T, D, QT, NST, RAG, PRE>), grid, dim3(256), lds, s, aa);
+}
+template <class T, int D, int QT, int NST>
+void launch_attn3(const AttnArgs &a, int B, hipStream_t s)
+{
+    const bool pre = a.scale_log2e == 1.f;
+    if (a.Lk & 63) { if (pre) launch_attn3_<T, D, QT, NST, true, true>(a, B, s); else launch_attn3_<T, D, QT, NST, true, false>(a, B, s); }
+    else { if (pre) launch_attn3_<T, D, QT, NST, false, true>(a, B, s); else launch_attn3_<T, D, QT, NST, false, false>(a, B, s); }
 }
 
 template <class T>
 int launch_attn(const AttnArgs &a, int D, int B, hipStream_t s)
 {
-    static const int use2 = [] { const char *e = getenv("GC_ATTN2"); return e ? atoi(e) : 0; }();
-    if (use2) {
+    static const int fast = [] { const char *e = getenv("GC_ATTN_SAFE"); return e ? !atoi(e) : 1; }();   // GC_ATTN_SAFE=1: online-softmax kernel everywhere
+    if (fast && (int64_t)a.nsets * ((a.Lk + 63) / 64) >= 4) {   // short key streams: the pipeline's fill / LDS set-up does not amortise
         switch (D) {
-        case 40: launch_attn2<T, 40, 2, 3>(a, B, s); return GC_OK;
+        case 40: launch_attn3<T, 40, 2, 3>(a, B, s); return GC_OK;
         default: break;
         }
     }
@@ -748,7 +797,7 @@ extern "C" int gc_dn_attention(const gc_attn_desc *d, void *stream)
     a.ref_fph = d->Kref ? d->ref_frames_per_half : a.f;
     GC_REQUIRE((d->Kref == nullptr) == (d->Vtref == nullptr), "Kref and Vtref must be given together");
     for (int i = 0; i < d->nsets; ++i) GC_REQUIRE(d->set_kind[i] >= -2 && d->set_kind[i] < a.ref_fph, "bad set_kind");
-    a.scale_log2e = d->scale * 1.4426950408889634f;
+    a.scale_log2e = d->q_prescaled ? 1.f : d->scale * 1.4426950408889634f;
     int rc = d->dtype == DT_BF16 ? launch_attn<BF16>(a, d->head_dim, d->batch, gc::S(stream))
              : d->dtype == DT_F16 ? launch_attn<F16>(a, d->head_dim, d->batch, gc::S(stream)) : GC_EINVAL;
     if (rc != GC_OK) return rc;

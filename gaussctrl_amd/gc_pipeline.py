@@ -120,8 +120,8 @@ class GaussCtrlPipeline(nn.Module):
             else:
                 arch.check_state_dict(sd, shapes)
             return sd
-        self.pipe = DenoisePipeline(prepare(get("unet", arch.unet_shapes(), 100), self.dtype, dev),
-                                    prepare(get("controlnet", arch.controlnet_shapes(), 200), self.dtype, dev),
+        self.pipe = DenoisePipeline(prepare(get("unet", arch.unet_shapes(), 100), self.dtype, dev, heads=8),
+                                    prepare(get("controlnet", arch.controlnet_shapes(), 200), self.dtype, dev, heads=8),
                                     prepare_vae_weights(get("vae_decoder", arch.vae_decoder_shapes(), 300), self.dtype, dev),
                                     self.num_inference_steps, self.guidance_scale, self.controlnet_conditioning_scale)
         self.vae_encoder = VAEEncoder(prepare_vae_encoder_weights(get("vae_encoder", arch.vae_encoder_shapes(), 400), self.dtype, dev))

@@ -34,7 +34,7 @@ class AttnDesc(C.Structure):
                 ("Vt", C.c_void_p), ("ldvt", C.c_int64), ("vt_batch_stride", C.c_int64),
                 ("O", C.c_void_p), ("ldo", C.c_int64), ("o_batch_stride", C.c_int64),
                 ("Kref", C.c_void_p), ("kref_batch_stride", C.c_int64), ("Vtref", C.c_void_p),
-                ("vtref_batch_stride", C.c_int64), ("ref_frames_per_half", C.c_int)]
+                ("vtref_batch_stride", C.c_int64), ("ref_frames_per_half", C.c_int), ("q_prescaled", C.c_int)]
 
 
 DT = {torch.bfloat16: 0, torch.float16: 1}
@@ -196,7 +196,7 @@ def softmax_rows_(s, scale):
     return s
 
 
-def attention(q, k, vt, heads, sets, frames_per_half, Lk=None, kref=None, vtref=None, ref_fph=0, scale=None):
+def attention(q, k, vt, heads, sets, frames_per_half, Lk=None, kref=None, vtref=None, ref_fph=0, scale=None, q_prescaled=False):
     """q [B,Lq,C], k [Bk,Lk,C], vt [Bk,C,Lkp] (token-contiguous, zero padded).  sets: [(kind, weight)]:
     kind -1 = own frame, -2 = frame b // frames_per_half, r >= 0 = reference r (bank = kref/vtref or k/vt)."""
     _gpu(q, k, vt)
@@ -210,6 +210,7 @@ def attention(q, k, vt, heads, sets, frames_per_half, Lk=None, kref=None, vtref=
     for i, (kind, w) in enumerate(sets):
         d.set_kind[i] = kind; d.set_weight[i] = w
     d.scale = (D ** -0.5) if scale is None else scale
+    d.q_prescaled = int(q_prescaled)     # Q carries scale*log2(e) already (weights.prepare(..., fold_attn_scale_heads=...))
     d.Q = q.data_ptr(); d.ldq = q.stride(1); d.q_batch_stride = q.stride(0)
     d.K = k.data_ptr(); d.ldk = k.stride(1); d.k_batch_stride = k.stride(0)
     d.Vt = vt.data_ptr(); d.ldvt = vt.stride(1); d.vt_batch_stride = vt.stride(0)

@@ -69,6 +69,7 @@ class SDNet:
         self.name = name
         self.dtype = weights["conv_in.weight"].dtype
         self._temb_cache = {}
+        self.qpre = bool(weights.get("_attn_q_prescaled", False))   # softmax scale folded into the Q weights (weights.prepare(heads=))
 
     # ---------------------------------------------------------------------------------------- blocks
     def time_embed(self, t: float, device):
@@ -111,7 +112,7 @@ class SDNet:
                         out_cols=2 * Cc)
         q, k = qk[..., :Cc], qk[..., Cc:]
         if actx.mode == "plain":
-            return ops.attention(q, k, vt, heads, [(-1, 1.0)], actx.f, Lk=L)
+            return ops.attention(q, k, vt, heads, [(-1, 1.0)], actx.f, Lk=L, q_prescaled=self.qpre)
         a = actx.coeff
         sets = ([(-1, a)] if a != 0.0 else []) + [(r, (1.0 - a) / 4.0) for r in range(4)]    # utils.py:95-102,117
         bank = actx.bank
@@ -119,8 +120,8 @@ class SDNet:
             bank.store[bank.key((actx.net, p))] = (k, vt)            # the batch IS the reference batch [2*4]
         if bank is not None and bank.mode == "use":
             kr, vtr = bank.store[bank.key((actx.net, p))]
-            return ops.attention(q, k, vt, heads, sets, actx.f, Lk=L, kref=kr, vtref=vtr, ref_fph=kr.shape[0] // 2)
-        return ops.attention(q, k, vt, heads, sets, actx.f, Lk=L)
+            return ops.attention(q, k, vt, heads, sets, actx.f, Lk=L, kref=kr, vtref=vtr, ref_fph=kr.shape[0] // 2, q_prescaled=self.qpre)
+        return ops.attention(q, k, vt, heads, sets, actx.f, Lk=L, q_prescaled=self.qpre)
 
     def _text_kv(self, p, ctx, actx: AttnCtx):
         key = (actx.net, p)
@@ -149,7 +150,7 @@ class SDNet:
         q = ops.linear(n, w[t + ".attn2.to_q.weight"])
         k, vt, Lt = self._text_kv(t + ".attn2", ctx, actx)
         # ctx holds one text row per CFG half ([negative || positive]); frame b reads row b // f (kind -2)
-        o = ops.attention(q, k, vt, self.cfg["heads"], [(-2, 1.0)], B // k.shape[0], Lk=Lt)
+        o = ops.attention(q, k, vt, self.cfg["heads"], [(-2, 1.0)], B // k.shape[0], Lk=Lt, q_prescaled=self.qpre)
         h = ops.linear(o, w[t + ".attn2.to_out.0.weight"], w[t + ".attn2.to_out.0.bias"], residual=h)
         n = ops.layernorm(h, w[t + ".norm3.weight"], w[t + ".norm3.bias"])
         ff = ops.linear(n, w[t + ".ff.net.0.proj.weight"], w[t + ".ff.net.0.proj.bias"], geglu=True)

@@ -41,11 +41,18 @@ def geglu_permute(w, b):
     return w[perm].contiguous(), (None if b is None else b[perm].contiguous())
 
 
-def prepare(sd: dict, dtype, device) -> dict:
-    """Generic pass over a diffusers state dict."""
+LOG2E = 1.4426950408889634
+
+
+def prepare(sd: dict, dtype, device, heads=None) -> dict:
+    """Generic pass over a diffusers state dict.  `heads` (attention heads of the network) folds the softmax scale
+    head_dim**-0.5 * log2(e) into the Q projection weights in fp32, before the single rounding to `dtype`: the attention
+    kernel then exponentiates the QK^T MFMA output directly (gc_attn_desc.q_prescaled)."""
     out = {}
     for k, v in sd.items():
         v = v.to(device)
+        if heads and (k.endswith(".attn1.to_q.weight") or k.endswith(".attn2.to_q.weight")):
+            v = v.float() * ((v.shape[0] // heads) ** -0.5 * LOG2E)
         if k.endswith(".weight") and v.dim() == 4:
             if v.shape[-1] == 3:
                 out[k] = conv3x3_weight(v, dtype)
@@ -57,6 +64,7 @@ def prepare(sd: dict, dtype, device) -> dict:
             out[k] = pad_bias(v)
         else:
             out[k] = v.float().contiguous()       # norm affine, linear / 1x1 biases
+    out["_attn_q_prescaled"] = bool(heads)
     for k in list(out.keys()):
         if k.endswith(".attn1.to_q.weight"):            # fused Q|K|V projection of the self-attention layers
             a = k[:-len("to_q.weight")]

@@ -238,6 +238,7 @@ typedef struct gc_attn_desc {
     const void *Kref; int64_t kref_batch_stride;    /* optional cached reference K / V^T (same ldk / ldvt) */
     const void *Vtref; int64_t vtref_batch_stride;
     int ref_frames_per_half;
+    int q_prescaled;                 /* Q is already multiplied by scale*log2(e) (folded into the Q projection weights): `scale` is ignored */
 } gc_attn_desc;
 int gc_dn_attention(const gc_attn_desc *desc, void *stream);
 

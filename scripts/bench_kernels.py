@@ -59,14 +59,14 @@ if what in ('attn', 'all'):
     print(f"--- attention ({dt}) B={B}")
     for (L, C, nsets, Lk, cnt) in [(4096, 320, 5, 4096, 5), (4096, 320, 4, 4096, 2), (1024, 640, 5, 1024, 5), (256, 1280, 5, 256, 5), (64, 1280, 5, 64, 1), (4096, 320, 1, 77, 5), (4096, 320, 1, 4096, 0)]:
         heads = 8
-        q = rnd(B, L, C); Bk = B if Lk == L else 2
+        q = rnd(B, L, C, scale=0.4); Bk = B if Lk == L else 2
         k = rnd(Bk, Lk, C); Lp = (Lk + 7) // 8 * 8
         vt = torch.zeros(Bk, C, Lp, dtype=dt, device=DEV); vt[:, :, :Lk] = rnd(Bk, C, Lk)
         kr = rnd(8, Lk, C); vtr = rnd(8, C, Lp)
         if Lk != L: sets = [(-2, 1.0)]
         elif nsets == 1: sets = [(-1, 1.0)]
         else: sets = ([(-1, 0.6)] if nsets == 5 else []) + [(r, 0.1) for r in range(4)]
-        fn = (lambda: ops.attention(q, k, vt, heads, sets, B // 2, Lk=Lk, kref=kr, vtref=vtr, ref_fph=4)) if (Lk == L and nsets > 1) else (lambda: ops.attention(q, k, vt, heads, sets, B // 2, Lk=Lk))
+        fn = (lambda: ops.attention(q, k, vt, heads, sets, B // 2, Lk=Lk, kref=kr, vtref=vtr, ref_fph=4, q_prescaled=True)) if (Lk == L and nsets > 1) else (lambda: ops.attention(q, k, vt, heads, sets, B // 2, Lk=Lk, q_prescaled=True))
         us = timeit(fn)
         fl = 4.0 * B * L * Lk * C * len(sets)
         tot['attn'] = tot.get('attn', 0) + us * cnt

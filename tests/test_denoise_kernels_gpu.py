@@ -117,7 +117,8 @@ def _ref_attn(q, k, v, heads, scale):
 
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("f,L,heads,D,coeff", [(5, 256, 8, 40, 0.6), (7, 100, 8, 80, 0.6), (5, 64, 8, 160, 0.0), (6, 4, 8, 160, 0.6),
-                                               (5, 1024, 2, 40, 0.6), (5, 70, 2, 8, 0.6)])
+                                               (5, 1024, 2, 40, 0.6), (5, 70, 2, 8, 0.6), (5, 200, 3, 40, 0.6), (5, 64, 2, 40, 0.0),
+                                               (5, 136, 2, 80, 0.6)])
 def test_cross_view_attention(dt, f, L, heads, D, coeff):
     """a*self + (1-a)*mean of the 4 reference attentions (utils.py:86-117) in one fused kernel."""
     from gaussctrl_amd.sd import ops
@@ -137,6 +138,13 @@ def test_cross_view_attention(dt, f, L, heads, D, coeff):
     bank_idx = torch.cat([torch.arange(4), f + torch.arange(4)]).to(DEV)
     got2 = ops.attention(q, k, vt, heads, sets, f, Lk=L, kref=k[bank_idx].contiguous(), vtref=vt[bank_idx].contiguous(), ref_fph=4)
     assert torch.equal(got, got2)
+    # product path: softmax scale * log2(e) already folded into Q (weights.prepare(heads=...)): P = exp2(q'.k)
+    qp = (q.float() * (scale * 1.4426950408889634)).to(dt)
+    refp = coeff * _ref_attn(qp, k, v, heads, float(np.log(2.0)))
+    for r in range(4):
+        idx = torch.arange(B, device=DEV) // f * f + r
+        refp = refp + (1 - coeff) / 4 * _ref_attn(qp, k[idx], v[idx], heads, float(np.log(2.0)))
+    _close(ops.attention(qp, k, vt, heads, sets, f, Lk=L, q_prescaled=True), refp, dt, extra=8.0)
 
 
 @pytest.mark.parametrize("dt", DTS)
@@ -151,6 +159,22 @@ def test_text_attention_and_rescale_branch(dt):
     idx = torch.arange(B, device=DEV) // f
     ref = _ref_attn(q, k[idx], v[idx], heads, D ** -0.5)
     got = ops.attention(q, k, vt, heads, [(-2, 1.0)], f, Lk=Lt)
+    _close(got, ref, dt, extra=8.0)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_attention_offset_overflow_falls_back(dt):
+    """The fast kernel keeps the first key tile's row maximum as a fixed softmax offset; a later key that beats it by far more
+    than the exponent range must trigger the in-kernel safe recomputation (same answer as the online-softmax kernel)."""
+    from gaussctrl_amd.sd import ops
+    f, L, heads, D = 2, 256, 2, 40
+    B, C = 2 * f, heads * D
+    q = _rand((B, L, C), dt, 1.0, 1); k = _rand((B, L, C), dt, 1.0, 2); v = _rand((B, L, C), dt, 1.0, 3)
+    k[:, 200, :] = q[:, 17, :] * 40.0         # logit of (query 17, key 200) ~ 40 * |q|^2 / sqrt(D) ~ 250 >> first-tile maximum
+    vt = v.transpose(1, 2).contiguous()
+    ref = _ref_attn(q, k, v, heads, D ** -0.5)
+    got = ops.attention(q, k, vt, heads, [(-1, 1.0)], f, Lk=L)
+    assert torch.isfinite(got.float()).all()
     _close(got, ref, dt, extra=8.0)
 
 

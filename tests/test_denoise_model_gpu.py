@@ -48,7 +48,7 @@ def test_edit_chunk_matches_oracle(sd15, dt):
     uwr, cwr = _round(uw, dt), _round(cw, dt)
     torch.set_num_threads(torch.get_num_threads())
     ref = sd.denoise_chunk(uwr, cwr, lat, r(disp), r(cn), r(cp), 5.0, steps, sd.SD15, 20)
-    pipe = DenoisePipeline(prepare(uw, dt, DEV), prepare(cw, dt, DEV), None, 20, 5.0)
+    pipe = DenoisePipeline(prepare(uw, dt, DEV, heads=8), prepare(cw, dt, DEV, heads=8), None, 20, 5.0)
     got = pipe.edit_chunk(lat.to(DEV), disp.to(DEV), cn.to(DEV), cp.to(DEV), steps=steps)
     e = _rel(got, ref)
     print(f"edit_chunk {dt}: latent rel L2 err after {steps} steps = {e:.3e}")
@@ -79,7 +79,7 @@ def test_unet_eps_and_inversion_match_oracle(sd15, dt):
         down, mid = sd.controlnet_forward(cwr, x, t, ctx, r(disp), sd.SD15, 1.0, "plain", 0.0)
         eps = sd.unet_forward(uwr, x, t, ctx, down, mid, sd.SD15, "plain", 0.0)
         x = sch.inverse_step(eps, t, x, 20)
-    pipe = DenoisePipeline(prepare(uw, dt, DEV), prepare(cw, dt, DEV), None, 20, 5.0)
+    pipe = DenoisePipeline(prepare(uw, dt, DEV, heads=8), prepare(cw, dt, DEV, heads=8), None, 20, 5.0)
     got = pipe.invert(lat.to(DEV), disp.to(DEV), cp.to(DEV), steps=2)
     e = _rel(got, x)
     print(f"inversion {dt}: rel L2 err {e:.3e}")
