@@ -628,11 +628,12 @@ __global__ __launch_bounds__(256, 2) void k_attn3(const AttnArgs a)
         rd_k(0);
         if (NKF > 1) rd_k(1);
         if (NKF > 2) rd_k(2);
+        if (NKF > 3) rd_k(3);
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, NQ>([&](auto m_) __attribute__((always_inline)) {
             constexpr int m = decltype(m_)::value;
-            if constexpr (m % QT == 0 && m / QT + 3 < NKF) rd_k(m / QT + 3);
-            if constexpr (QT > 1 && m + 2 >= M0 && m + 2 - M0 < NPV) rd_v(m + 2 - M0);
+            if constexpr (m % QT == 0 && m / QT + 4 < NKF) rd_k(m / QT + 4);
+            if constexpr (QT > 1 && m >= 2 && m - 2 < NPV) rd_v(m - 2);      // V^T fragments: far ahead of their MFMAs (LDS latency)
             mma_qk(m);
             units(std::integral_constant<int, (UT * m) / NQ>{}, std::integral_constant<int, (UT * (m + 1)) / NQ>{});
             if constexpr (QT > 1 && m >= M0 && m - M0 < NPV) {    // P V of query tile 0 between the exps of tile 1

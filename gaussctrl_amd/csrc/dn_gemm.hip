@@ -394,14 +394,24 @@ __device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst)
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-template <class T, int MODE, int NTW>
-__global__ __launch_bounds__(512, 2) void k_gemm8(const GemmArgs g)
+// uniform base + 32-bit lane offset form: no per-lane address arithmetic (M0 is not used by anything else in these kernels)
+__device__ __forceinline__ void glds16_s(const void *sbase, unsigned voff, unsigned lds_dst)
 {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
+// MODE 3 (k_gemm8 only): linear with K % 64 == 0 -- rows past M / N re-read the last valid row (their outputs are never stored),
+// so a k-tile's DMA is a uniform base + constant per-lane offset: no VALU at all in the issue path.
+// MT: m-tiles (of 16) per wave: workgroup tile (64 MT) x (32 NTW), waves 4 (M) x 2 (N), wave tile (16 MT) x (16 NTW).
+template <class T, int MODE, int NTW, int MT>
+__global__ __launch_bounds__(512, MT == 2 ? 2 : 1) void k_gemm8(const GemmArgs g)
+{
+    constexpr int BM = 64 * MT;
     constexpr int BN = 32 * NTW;
     constexpr int STAGE = BM * 128 + BN * 128;
     constexpr int NS = 3;
     constexpr int AG = BM / 8, WG = BN / 8;           // 8-row groups (one LDS-DMA instruction each)
-    constexpr int AI = AG / 8, WI = (WG + 7) / 8;     // instructions per wave per tile: A 2, W 2|3
+    constexpr int AI = AG / 8, WI = (WG + 7) / 8;     // instructions per wave per tile: A MT, W 2|3
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -425,7 +435,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const GemmArgs g)
         const int64_t m = m_base + row;
         a_ok[i] = m < g.M;
         const int mm = a_ok[i] ? (int)m : 0;
-        if (MODE != 0) {
+        if (MODE == 1 || MODE == 2) {
             const int hw = g.Ho * g.Wo;
             const int b = mm / hw;
             const int rem = mm - b * hw;
@@ -435,6 +445,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const GemmArgs g)
             if (MODE == 2 && !g.ups) a_off[i] += (a_y[i] * g.Wi + a_x[i]) * g.Cin;
         } else {
             a_off[i] = mm * (int)g.lda + a_ck[i] * 8;
+            if (MODE == 3) a_off[i] = (int)(m < g.M ? m : g.M - 1) * (int)g.lda + a_ck[i] * 8;
             a_y[i] = a_x[i] = 0;
         }
     }
@@ -448,6 +459,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const GemmArgs g)
         const int64_t n = n_base + row;
         w_ok[i] = grp < WG && n < g.N;
         w_off[i] = (w_ok[i] ? (int)n : 0) * (int)g.K + w_ck[i] * 8;
+        if (MODE == 3) w_off[i] = (int)(n < g.N ? n : g.N - 1) * (int)g.K + w_ck[i] * 8;
     }
     const int Hin = g.ups ? g.Hi * 2 : g.Hi, Win = g.ups ? g.Wi * 2 : g.Wi;
     const unsigned char *Ab = (const unsigned char *)g.A, *Wb = (const unsigned char *)g.W;
@@ -463,6 +475,15 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const GemmArgs g)
             ld_ci += BK; if (ld_ci >= g.Cin) { ld_ci -= g.Cin; ++ld_tap; }
         }
         const unsigned sbase = lds0 + stage * STAGE;
+        if (MODE == 3) {
+            const unsigned char *ap = Ab + (size_t)kb * 2, *wp = Wb + (size_t)kb * 2;
+#pragma unroll
+            for (int i = 0; i < AI; ++i) glds16_s(ap, (unsigned)(a_off[i] * 2), sbase + (unsigned)((wid + 8 * i) * 1024));
+#pragma unroll
+            for (int i = 0; i < WI; ++i)
+                if (wid + 8 * i < WG) glds16_s(wp, (unsigned)(w_off[i] * 2), sbase + (unsigned)(BM * 128 + (wid + 8 * i) * 1024));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
             bool ok;
@@ -499,48 +520,69 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const GemmArgs g)
         }
     };
 
-    f32x4 acc[NTW][2];
+    f32x4 acc[NTW][MT];
 #pragma unroll
     for (int a = 0; a < NTW; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fc = lane >> 4;
     const int swz = (fr >> 1) & 7;
     const int fx0 = ((fc ^ swz) << 4), fx1 = (((fc + 4) ^ swz) << 4);
-    const int aw0 = BM * 128 + (wn * (16 * NTW) + fr) * 128, aa0 = (wm * 32 + fr) * 128;
-    auto compute = [&](int stage) __attribute__((always_inline)) {
+    const int aw0 = BM * 128 + (wn * (16 * NTW) + fr) * 128, aa0 = (wm * (16 * MT) + fr) * 128;
+    struct Frag { uint4 w[NTW], a[MT]; };
+    auto load_frag = [&](Frag &f, int stage, int ks) __attribute__((always_inline)) {
         const unsigned char *sb = smem + stage * STAGE;
+        const int fx = ks ? fx1 : fx0;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int fx = ks ? fx1 : fx0;
-            uint4 fw[NTW], fa[2];
+        for (int t = 0; t < NTW; ++t) f.w[t] = *reinterpret_cast<const uint4 *>(sb + aw0 + fx + t * 2048);
 #pragma unroll
-            for (int t = 0; t < NTW; ++t) fw[t] = *reinterpret_cast<const uint4 *>(sb + aw0 + fx + t * 2048);
+        for (int t = 0; t < MT; ++t) f.a[t] = *reinterpret_cast<const uint4 *>(sb + aa0 + fx + t * 2048);
+    };
+    auto mma = [&](const Frag &f) __attribute__((always_inline)) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) fa[t] = *reinterpret_cast<const uint4 *>(sb + aa0 + fx + t * 2048);
+        for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = T::mfma(fw[nt], fa[mt], acc[nt][mt]);
-        }
+            for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = T::mfma(f.w[nt], f.a[mt], acc[nt][mt]);
     };
 
-    // instructions this wave issues per tile (wave-uniform): the counted wait leaves exactly one tile in flight
-    const bool w3 = (wid + 16) < WG;     // this wave owns a third W group
+    // Software pipeline over k-tiles (3 LDS stages, LDS-DMA two tiles ahead; fragment registers double-buffered per k half):
+    //   [ read F1 <- (kt, k-half 1) | MFMAs on F0 = (kt, half 0) ]  wait(tile kt+1 landed) + barrier, DMA tile kt+3 -> stage of kt
+    //   [ read F0 <- (kt+1, half 0) | MFMAs on F1 ]
+    // ONE barrier per k-tile, sitting between two MFMA blocks whose operands are already in registers; every ds_read has a full
+    // MFMA block (16-20 x 16 clk) to land.  Counted vmcnt: tile kt+2 stays in flight across the barrier.
+    const bool w3 = (wid + 16) < WG;     // this wave owns a third W group (instructions per tile are wave-uniform)
+    auto wait_one_tile_in_flight = [&]() __attribute__((always_inline)) {
+        if (w3) { if (AI == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else if (AI == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); }
+        else { if (AI == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else if (AI == 3) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+    };
+    auto wait_two_tiles_in_flight = [&]() __attribute__((always_inline)) {
+        if (w3) { if (AI == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else if (AI == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); }
+        else { if (AI == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else if (AI == 3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
+    };
     issue(0, 0);
     if (nk > 1) issue(1, 1);
+    if (nk > 2) issue(2, 2);
+    if (nk > 2) wait_two_tiles_in_flight(); else if (nk > 1) wait_one_tile_in_flight(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    Frag f0, f1;
+    load_frag(f0, 0, 0);
+    int st = 0;                           // stage of tile kt
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) {               // tile kt+1 may stay in flight; everything older (tile kt) must have landed
-            if (w3) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        load_frag(f1, st, 1);
+        mma(f0);
+        const int st1 = st + 1 == NS ? 0 : st + 1;
+        if (kt + 1 < nk) {
+            if (kt + 2 < nk) wait_one_tile_in_flight(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of stage st are complete
+            __builtin_amdgcn_s_barrier();    // tile kt+1 is in LDS for every wave; every wave finished reading stage st
+            if (kt + 3 < nk) issue(kt + 3, st);
+            load_frag(f0, st1, 0);
         }
-        __builtin_amdgcn_s_barrier();    // every wave's part of tile kt is in LDS; every wave finished reading stage (kt+2)%3
-        if (kt + 2 < nk) issue(kt + 2, (kt + 2) % NS);
-        compute(kt % NS);
+        mma(f1);
+        st = st1;
     }
 
-    // ---- epilogue (same math as k_gemm; 2 m-tiles per wave)
+    // ---- epilogue (same math as k_gemm; MT m-tiles per wave)
     const int64_t n_lane = n_base + wn * (16 * NTW) + fc * 4;
     float4 bia[NTW];
 #pragma unroll
@@ -549,8 +591,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const GemmArgs g)
         bia[nt] = (g.bias && n < g.N) ? *reinterpret_cast<const float4 *>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int64_t m = m_base + wm * 32 + mt * 16 + fr;
+    for (int mt = 0; mt < MT; ++mt) {
+        const int64_t m = m_base + wm * (16 * MT) + mt * 16 + fr;
         if (m >= g.M) continue;
         float4 rv[NTW];
         uint2 rs[NTW];
@@ -648,25 +690,32 @@ void launch(const GemmArgs &g, dim3 grid, hipStream_t s)
     hipLaunchKernelGGL((k_gemm<T, MODE, NTW>), grid, dim3(NT), lds, s, g);
 }
 
-template <class T, int MODE, int NTW>
+template <class T, int MODE, int NTW, int MT>
 void launch8(const GemmArgs &g, dim3 grid, hipStream_t s)
 {
-    constexpr size_t lds = 3 * (BM * 128 + 32 * NTW * 128);
+    constexpr size_t lds = 3 * (64 * MT * 128 + 32 * NTW * 128);
+    static_assert(lds <= 160 * 1024, "LDS ring");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_gemm8<T, MODE, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)k_gemm8<T, MODE, NTW, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_gemm8<T, MODE, NTW>), grid, dim3(512), lds, s, g);
+    hipLaunchKernelGGL((k_gemm8<T, MODE, NTW, MT>), grid, dim3(512), lds, s, g);
 }
 
+template <class T, int NTW, int MT>
+void dispatch8m(const GemmArgs &g, int mode, dim3 grid, hipStream_t s)
+{
+    if (mode == 0) { if (g.K % 64 == 0) launch8<T, 3, NTW, MT>(g, grid, s); else launch8<T, 0, NTW, MT>(g, grid, s); }
+    else if (mode == 1) launch8<T, 1, NTW, MT>(g, grid, s); else launch8<T, 2, NTW, MT>(g, grid, s);
+}
 template <class T>
-void dispatch8(const GemmArgs &g, int mode, int ntw, dim3 grid, hipStream_t s)
+void dispatch8(const GemmArgs &g, int mode, int ntw, int mt, dim3 grid, hipStream_t s)
 {
     if (ntw == 5) {
-        if (mode == 0) launch8<T, 0, 5>(g, grid, s); else if (mode == 1) launch8<T, 1, 5>(g, grid, s); else launch8<T, 2, 5>(g, grid, s);
+        if (mt == 4) dispatch8m<T, 5, 4>(g, mode, grid, s); else if (mt == 3) dispatch8m<T, 5, 3>(g, mode, grid, s); else dispatch8m<T, 5, 2>(g, mode, grid, s);
     } else {
-        if (mode == 0) launch8<T, 0, 4>(g, grid, s); else if (mode == 1) launch8<T, 1, 4>(g, grid, s); else launch8<T, 2, 4>(g, grid, s);
+        if (mt == 4) dispatch8m<T, 4, 4>(g, mode, grid, s); else if (mt == 3) dispatch8m<T, 4, 3>(g, mode, grid, s); else dispatch8m<T, 4, 2>(g, mode, grid, s);
     }
 }
 
@@ -678,6 +727,23 @@ void dispatch(const GemmArgs &g, int mode, int ntw, dim3 grid, hipStream_t s)
     } else {
         if (mode == 0) launch<T, 0, 4>(g, grid, s); else if (mode == 1) launch<T, 1, 4>(g, grid, s); else launch<T, 2, 4>(g, grid, s);
     }
+}
+
+// 8-wave kernel: pick the m-tiles per wave (workgroup rows = 64 MT); 0 = use the 4-wave kernel.  One workgroup per CU, so the
+// grid runs in ceil(tiles / 256) rounds and a tile costs about (MT + 1) units (MT of MFMA work + fill / epilogue): minimise
+// rounds * (MT + 1).  Matches the per-shape sweep in profiles/ (scripts/bench_kernels.py with GC_GEMM_MT=2|3|4).
+int choose_mt(int64_t M, int64_t N, int ntw, bool forced)
+{
+    const int64_t nbn = (N + 32 * ntw - 1) / (32 * ntw);
+    if (((M + 127) / 128) * nbn < 96 && !forced) return 0;      // small problems: 4-wave kernel (+ split-K)
+    int best = 2;
+    int64_t best_cost = -1;
+    for (int mt = 2; mt <= 4; ++mt) {
+        const int64_t tiles = ((M + 64 * mt - 1) / (64 * mt)) * nbn;
+        const int64_t cost = ((tiles + 255) / 256) * (mt + 1);
+        if (best_cost < 0 || cost < best_cost || (cost == best_cost && mt == 4)) { best = mt; best_cost = cost; }
+    }
+    return best;
 }
 
 void plan(const gc_gemm_desc *d, int *ntw, int *splits, int *tps)
@@ -738,13 +804,17 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
     const dim3 grid((unsigned)(nbm * nbn), (unsigned)splits);
     g.zeros = d->zeros;
     static const int use8 = [] { const char *e = getenv("GC_GEMM8"); return e ? atoi(e) : 1; }();
-    // LDS-DMA 8-wave kernel (1 workgroup / CU): measured faster than the register-staged kernel (2 workgroups / CU) exactly when
-    // the grid fits one round of single-workgroup CUs (96..256 tiles: 32x32-map convs, the C=640 / 1280 linears); larger grids
-    // run better two-per-CU on k_gemm.  GC_GEMM8=0 disables it, =2 forces it (tests).
-    const int64_t tiles = nbm * nbn;
-    if (use8 && d->zeros && splits == 1 && (use8 == 2 || (tiles >= 96 && tiles <= 256))) {
-        if (d->dtype == DT_BF16) dispatch8<BF16>(g, mode, ntw, grid, s); else dispatch8<F16>(g, mode, ntw, grid, s);
-        return gc::check_launch("gc_dn_gemm");
+    static const int force_mt = [] { const char *e = getenv("GC_GEMM_MT"); return e ? atoi(e) : 0; }();
+    // 8-wave LDS-DMA kernel (one workgroup per CU, software-pipelined): workgroup tile (64 MT) x (32 NTW).
+    // GC_GEMM8=0 disables it, =2 forces it (tests); GC_GEMM_MT forces MT (experiments).
+    if (use8 && d->zeros && splits == 1) {
+        const int mt = force_mt ? force_mt : choose_mt(d->M, d->N, ntw, use8 == 2);
+        if (mt) {
+            const int64_t nbm8 = (d->M + 64 * mt - 1) / (64 * mt);
+            const dim3 grid8((unsigned)(nbm8 * nbn), 1u);
+            if (d->dtype == DT_BF16) dispatch8<BF16>(g, mode, ntw, mt, grid8, s); else dispatch8<F16>(g, mode, ntw, mt, grid8, s);
+            return gc::check_launch("gc_dn_gemm");
+        }
     }
     if (d->dtype == DT_BF16) dispatch<BF16>(g, mode, ntw, grid, s); else dispatch<F16>(g, mode, ntw, grid, s);
     if (splits > 1) {
