@@ -22,9 +22,18 @@
 // matrix together.
 #include "dn_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 using namespace dn;
+
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 
 constexpr int BM = 128, BK = 64;
 constexpr int NT = 256;
@@ -466,58 +475,61 @@ __global__ __launch_bounds__(512, MT == 2 ? 2 : 1) void k_gemm8(const GemmArgs g
     const unsigned char *Zp = (const unsigned char *)g.zeros;
     int ld_tap = 0, ld_ci = 0;
 
-    auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
-        const int kb = kt * BK;
-        int dy_u = 0, dx_u = 0, tap_off = 0;
+    // DMA of one k-tile, split into per-instruction pieces so that the main loop can place them between MFMAs.
+    struct TileSrc { int kb, dy_u, dx_u, tap_off; unsigned sbase; };
+    auto issue_begin = [&](int kt, int stage) __attribute__((always_inline)) -> TileSrc {
+        TileSrc t;
+        t.kb = kt * BK; t.dy_u = 0; t.dx_u = 0; t.tap_off = 0;
         if (MODE == 2) {
-            dy_u = ld_tap / 3; dx_u = ld_tap - dy_u * 3;
-            tap_off = g.ups ? ld_ci : (dy_u * g.Wi + dx_u) * g.Cin + ld_ci;
+            t.dy_u = ld_tap / 3; t.dx_u = ld_tap - t.dy_u * 3;
+            t.tap_off = g.ups ? ld_ci : (t.dy_u * g.Wi + t.dx_u) * g.Cin + ld_ci;
             ld_ci += BK; if (ld_ci >= g.Cin) { ld_ci -= g.Cin; ++ld_tap; }
         }
-        const unsigned sbase = lds0 + stage * STAGE;
-        if (MODE == 3) {
-            const unsigned char *ap = Ab + (size_t)kb * 2, *wp = Wb + (size_t)kb * 2;
-#pragma unroll
-            for (int i = 0; i < AI; ++i) glds16_s(ap, (unsigned)(a_off[i] * 2), sbase + (unsigned)((wid + 8 * i) * 1024));
-#pragma unroll
-            for (int i = 0; i < WI; ++i)
-                if (wid + 8 * i < WG) glds16_s(wp, (unsigned)(w_off[i] * 2), sbase + (unsigned)(BM * 128 + (wid + 8 * i) * 1024));
-            return;
+        t.sbase = lds0 + stage * STAGE;
+        return t;
+    };
+    auto issue_a = [&](const TileSrc &t, int i) __attribute__((always_inline)) {
+        const unsigned dst = t.sbase + (unsigned)((wid + 8 * i) * 1024);
+        if (MODE == 3) { glds16_s(Ab + (size_t)t.kb * 2, (unsigned)(a_off[i] * 2), dst); return; }
+        bool ok;
+        int off;
+        if (MODE == 2) {
+            int yi = a_y[i] + t.dy_u, xi = a_x[i] + t.dx_u;
+            ok = a_ok[i] && (unsigned)yi < (unsigned)Hin && (unsigned)xi < (unsigned)Win;
+            off = a_off[i] + t.tap_off;
+            if (g.ups) off += ((yi >> 1) * g.Wi + (xi >> 1)) * g.Cin;
+        } else if (MODE == 1) {
+            const int k0 = t.kb + a_ck[i] * 8;
+            const int kc = k0 < (int)g.K ? k0 : 0;
+            const int tap = kc / g.Cin;
+            const int ci = kc - tap * g.Cin;
+            const int dy = tap / 3, dx = tap - dy * 3;
+            int yi = a_y[i] + dy, xi = a_x[i] + dx;
+            ok = a_ok[i] && k0 < (int)g.K && (unsigned)yi < (unsigned)Hin && (unsigned)xi < (unsigned)Win;
+            if (g.ups) { yi >>= 1; xi >>= 1; }
+            off = a_off[i] + (yi * g.Wi + xi) * g.Cin + ci;
+        } else {
+            ok = a_ok[i] && (t.kb + a_ck[i] * 8) < (int)g.K;
+            off = a_off[i] + t.kb;
         }
-#pragma unroll
-        for (int i = 0; i < AI; ++i) {
-            bool ok;
-            int off;
-            if (MODE == 2) {
-                int yi = a_y[i] + dy_u, xi = a_x[i] + dx_u;
-                ok = a_ok[i] && (unsigned)yi < (unsigned)Hin && (unsigned)xi < (unsigned)Win;
-                off = a_off[i] + tap_off;
-                if (g.ups) off += ((yi >> 1) * g.Wi + (xi >> 1)) * g.Cin;
-            } else if (MODE == 1) {
-                const int k0 = kb + a_ck[i] * 8;
-                const int kc = k0 < (int)g.K ? k0 : 0;
-                const int tap = kc / g.Cin;
-                const int ci = kc - tap * g.Cin;
-                const int dy = tap / 3, dx = tap - dy * 3;
-                int yi = a_y[i] + dy, xi = a_x[i] + dx;
-                ok = a_ok[i] && k0 < (int)g.K && (unsigned)yi < (unsigned)Hin && (unsigned)xi < (unsigned)Win;
-                if (g.ups) { yi >>= 1; xi >>= 1; }
-                off = a_off[i] + (yi * g.Wi + xi) * g.Cin + ci;
-            } else {
-                ok = a_ok[i] && (kb + a_ck[i] * 8) < (int)g.K;
-                off = a_off[i] + kb;
-            }
-            const unsigned char *src = ok ? Ab + (size_t)(unsigned)(off * 2) : Zp;
-            glds16(src, sbase + (unsigned)((wid + 8 * i) * 1024));
+        const unsigned char *src = ok ? Ab + (size_t)(unsigned)(off * 2) : Zp;
+        glds16(src, dst);
+    };
+    auto issue_w = [&](const TileSrc &t, int i) __attribute__((always_inline)) {
+        if (wid + 8 * i < WG) {    // wave-uniform
+            const unsigned dst = t.sbase + (unsigned)(BM * 128 + (wid + 8 * i) * 1024);
+            if (MODE == 3) { glds16_s(Wb + (size_t)t.kb * 2, (unsigned)(w_off[i] * 2), dst); return; }
+            const bool ok = w_ok[i] && (t.kb + w_ck[i] * 8) < (int)g.K;
+            const unsigned char *src = ok ? Wb + (size_t)(unsigned)((w_off[i] + t.kb) * 2) : Zp;
+            glds16(src, dst);
         }
+    };
+    auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
+        const TileSrc t = issue_begin(kt, stage);
 #pragma unroll
-        for (int i = 0; i < WI; ++i) {
-            if (wid + 8 * i < WG) {    // wave-uniform
-                const bool ok = w_ok[i] && (kb + w_ck[i] * 8) < (int)g.K;
-                const unsigned char *src = ok ? Wb + (size_t)(unsigned)((w_off[i] + kb) * 2) : Zp;
-                glds16(src, sbase + (unsigned)(BM * 128 + (wid + 8 * i) * 1024));
-            }
-        }
+        for (int i = 0; i < AI; ++i) issue_a(t, i);
+#pragma unroll
+        for (int i = 0; i < WI; ++i) issue_w(t, i);
     };
 
     f32x4 acc[NTW][MT];
@@ -538,16 +550,37 @@ __global__ __launch_bounds__(512, MT == 2 ? 2 : 1) void k_gemm8(const GemmArgs g
 #pragma unroll
         for (int t = 0; t < MT; ++t) f.a[t] = *reinterpret_cast<const uint4 *>(sb + aa0 + fx + t * 2048);
     };
-    auto mma = [&](const Frag &f) __attribute__((always_inline)) {
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = T::mfma(f.w[nt], f.a[mt], acc[nt][mt]);
+    // one MFMA block (NTW x MT MFMAs on the fragments of one k-half).  After the FIRST MFMA the fragment reads of the next
+    // block are issued (the s_waitcnt for this block's operands then never waits behind fresh reads); with DMA = true the LDS-DMA
+    // instructions of a later k-tile (and their address arithmetic) are spread between the remaining MFMAs, where a few VALU /
+    // SALU instructions per MFMA issue for free.
+    constexpr int NMM = NTW * MT, NPC = AI + WI;
+    auto block = [&](const Frag &f, Frag &fn, int st_next, int ks_next, bool load_next, const TileSrc &t, auto dma_tag) __attribute__((always_inline)) {
+        constexpr bool DMA = decltype(dma_tag)::value;
+        static_for<0, NMM>([&](auto m_) __attribute__((always_inline)) {
+            constexpr int m = decltype(m_)::value, nt = m / MT, mt = m % MT;
+            acc[nt][mt] = T::mfma(f.w[nt], f.a[mt], acc[nt][mt]);
+            if constexpr (m == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (load_next) load_frag(fn, st_next, ks_next);
+                __builtin_amdgcn_sched_barrier(0);
+            } else if constexpr (DMA && m >= 2) {
+                // pieces p = 0 .. NPC-1 after MFMA index 2 + p * (NMM - 3) / NPC
+                static_for<0, NPC>([&](auto p_) __attribute__((always_inline)) {
+                    constexpr int pp = decltype(p_)::value;
+                    if constexpr (m == 2 + (pp * (NMM - 3)) / NPC) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (pp < AI) issue_a(t, pp); else issue_w(t, pp - AI);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
+            }
+        });
     };
 
     // Software pipeline over k-tiles (3 LDS stages, LDS-DMA two tiles ahead; fragment registers double-buffered per k half):
-    //   [ read F1 <- (kt, k-half 1) | MFMAs on F0 = (kt, half 0) ]  wait(tile kt+1 landed) + barrier, DMA tile kt+3 -> stage of kt
-    //   [ read F0 <- (kt+1, half 0) | MFMAs on F1 ]
+    //   [ MFMAs on F0 = (kt, half 0) | read F1 <- (kt, half 1) ]  wait(tile kt+1 landed) + barrier
+    //   [ MFMAs on F1 | read F0 <- (kt+1, half 0) | DMA tile kt+3 -> stage of kt ]
     // ONE barrier per k-tile, sitting between two MFMA blocks whose operands are already in registers; every ds_read has a full
     // MFMA block (16-20 x 16 clk) to land.  Counted vmcnt: tile kt+2 stays in flight across the barrier.
     const bool w3 = (wid + 16) < WG;     // this wave owns a third W group (instructions per tile are wave-uniform)
@@ -567,18 +600,23 @@ __global__ __launch_bounds__(512, MT == 2 ? 2 : 1) void k_gemm8(const GemmArgs g
     Frag f0, f1;
     load_frag(f0, 0, 0);
     int st = 0;                           // stage of tile kt
+    TileSrc tnone = {0, 0, 0, 0, 0u};
     for (int kt = 0; kt < nk; ++kt) {
-        load_frag(f1, st, 1);
-        mma(f0);
         const int st1 = st + 1 == NS ? 0 : st + 1;
+        block(f0, f1, st, 1, true, tnone, std::false_type{});
         if (kt + 1 < nk) {
             if (kt + 2 < nk) wait_one_tile_in_flight(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of stage st are complete
             __builtin_amdgcn_s_barrier();    // tile kt+1 is in LDS for every wave; every wave finished reading stage st
-            if (kt + 3 < nk) issue(kt + 3, st);
-            load_frag(f0, st1, 0);
+            if (kt + 3 < nk) {
+                const TileSrc t = issue_begin(kt + 3, st);
+                block(f1, f0, st1, 0, true, t, std::true_type{});
+            } else {
+                block(f1, f0, st1, 0, true, tnone, std::false_type{});
+            }
+        } else {
+            block(f1, f0, st1, 0, false, tnone, std::false_type{});
         }
-        mma(f1);
         st = st1;
     }
 
