@@ -745,6 +745,9 @@ void launch_attn3(const AttnArgs &a, int B, hipStream_t s)
     else { if (pre) launch_attn3_<T, D, QT, NST, false, true>(a, B, s); else launch_attn3_<T, D, QT, NST, false, false>(a, B, s); }
 }
 
+#ifndef ATT80_QT
+#define ATT80_QT 1
+#endif
 template <class T>
 int launch_attn(const AttnArgs &a, int D, int B, hipStream_t s)
 {
@@ -752,6 +755,7 @@ int launch_attn(const AttnArgs &a, int D, int B, hipStream_t s)
     if (fast && (int64_t)a.nsets * ((a.Lk + 63) / 64) >= 4) {   // short key streams: the pipeline's fill / LDS set-up does not amortise
         switch (D) {
         case 40: launch_attn3<T, 40, 2, 3>(a, B, s); return GC_OK;
+        case 80: launch_attn3<T, 80, ATT80_QT, 3>(a, B, s); return GC_OK;
         default: break;
         }
     }

@@ -21,7 +21,12 @@ __global__ __launch_bounds__(1024) void k(float *out, long long *cyc, int iters)
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-            if (NM) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[g], 0, 0, 0);
+            if (NM == 1) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[g], 0, 0, 0);
+            if (NM == 2) {   // 16x16x16 (4 bf16 per lane)
+                typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+                bf16x4 a4 = {a[0], a[1], a[2], a[3]}, b4 = {b[0], b[1], b[2], b[3]};
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(__attribute__((ext_vector_type(4))) short, a4), __builtin_bit_cast(__attribute__((ext_vector_type(4))) short, b4), acc[g], 0, 0, 0);
+            }
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const int r = (g * NV + j) & 15;
@@ -65,6 +70,8 @@ int main()
     // s_memtime counts at 100 MHz on gfx9?  report raw counter units; calibrate with the MFMA-only line (16 clk expected)
     for (int th : {256, 512, 1024}) {
         run<1, 0, 0>("mfma only", th);
+        run<2, 0, 0>("mfma 16x16x16 only", th);
+        run<2, 2, 1>("mfma16 + 2 exp", th);
         run<0, 4, 0>("4 fma only", th);
         run<0, 4, 1>("4 exp only", th);
         run<0, 4, 2>("4 max3 only", th);
