@@ -226,6 +226,29 @@ class GaussCtrlPipeline(nn.Module):
         if mask is not None:
             td["mask_image"] = mask
 
+    # ------------------------------------------------------------------------------------ mid-result cache
+    def save_mid_results(self, root, views=None):
+        """Write depth_npy / z_0 / mask_npy / unedited in the reference's on-disk layout (gc_dataparser_ns.py:408-420)."""
+        from . import midcache
+        td = self.datamanager.train_data
+        for i in (self._my_views() if views is None else views):
+            if "z_0_image" in td[i]:
+                midcache.save_view(root, i, unedited_image=td[i].get("unedited_image"), depth=td[i].get("depth_image"),
+                                   z_0=td[i]["z_0_image"], mask=td[i].get("mask_image"))
+
+    def load_mid_results(self, root, views=None) -> list:
+        """Fill train_data from a scene folder prepared earlier (by this code or by the reference); returns the views found."""
+        from . import midcache
+        td = self.datamanager.train_data
+        found = []
+        for i in (self._my_views() if views is None else views):
+            if midcache.has_view(root, i):
+                d = midcache.load_view(root, i, self.device)
+                d["depth_image"] = d["depth_image"][0]                                   # [H,W] as render_reverse stores it
+                td[i].update(d)
+                found.append(i)
+        return found
+
     # ------------------------------------------------------------------------------------ :276-291
     def get_train_loss_dict(self, step: int):
         camera, batch = self.datamanager.next_train(step)
