@@ -430,7 +430,9 @@ __global__ __launch_bounds__(512, MT == 2 ? 2 : 1) void k_gemm8(const GemmArgs g
     const int64_t bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
     const int64_t mblk = bid / nbn, nblk = bid % nbn;
     const int64_t m_base = mblk * BM, n_base = nblk * BN;
-    const int nk = (int)((g.K + BK - 1) / BK);
+    const int nk_all = (int)((g.K + BK - 1) / BK);
+    const int kt0 = blockIdx.y * g.tiles_per_split;                      // split-K: this workgroup's k-tiles [kt0, kt0 + nk)
+    const int nk = min(nk_all, kt0 + g.tiles_per_split) - kt0;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
 
     // ---- per-lane DMA coordinates
@@ -474,12 +476,13 @@ __global__ __launch_bounds__(512, MT == 2 ? 2 : 1) void k_gemm8(const GemmArgs g
     const unsigned char *Ab = (const unsigned char *)g.A, *Wb = (const unsigned char *)g.W;
     const unsigned char *Zp = (const unsigned char *)g.zeros;
     int ld_tap = 0, ld_ci = 0;
+    if (MODE == 2 && kt0 > 0) { ld_tap = (kt0 * BK) / g.Cin; ld_ci = kt0 * BK - ld_tap * g.Cin; }
 
     // DMA of one k-tile, split into per-instruction pieces so that the main loop can place them between MFMAs.
     struct TileSrc { int kb, dy_u, dx_u, tap_off; unsigned sbase; };
     auto issue_begin = [&](int kt, int stage) __attribute__((always_inline)) -> TileSrc {
         TileSrc t;
-        t.kb = kt * BK; t.dy_u = 0; t.dx_u = 0; t.tap_off = 0;
+        t.kb = (kt0 + kt) * BK; t.dy_u = 0; t.dx_u = 0; t.tap_off = 0;
         if (MODE == 2) {
             t.dy_u = ld_tap / 3; t.dx_u = ld_tap - t.dy_u * 3;
             t.tap_off = g.ups ? ld_ci : (t.dy_u * g.Wi + t.dx_u) * g.Cin + ld_ci;
@@ -622,6 +625,21 @@ __global__ __launch_bounds__(512, MT == 2 ? 2 : 1) void k_gemm8(const GemmArgs g
 
     // ---- epilogue (same math as k_gemm; MT m-tiles per wave)
     const int64_t n_lane = n_base + wn * (16 * NTW) + fc * 4;
+    if (g.splits > 1) {   // partial sums of this k-slice: plain 16-byte stores into slab blockIdx.y
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int64_t m = m_base + wm * (16 * MT) + mt * 16 + fr;
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int64_t n = n_lane + nt * 16;
+                if (n < g.N)
+                    *reinterpret_cast<float4 *>(g.ws + ((int64_t)blockIdx.y * g.M + m) * g.N + n) =
+                        make_float4(acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]);
+            }
+        }
+        return;
+    }
     float4 bia[NTW];
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
@@ -840,21 +858,39 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
     const int bn = 32 * ntw;
     const int64_t nbm = (d->M + BM - 1) / BM, nbn = (d->N + bn - 1) / bn;
     const dim3 grid((unsigned)(nbm * nbn), (unsigned)splits);
+    const int nk_host = (int)((d->K + BK - 1) / BK);
     g.zeros = d->zeros;
     static const int use8 = [] { const char *e = getenv("GC_GEMM8"); return e ? atoi(e) : 1; }();
     static const int force_mt = [] { const char *e = getenv("GC_GEMM_MT"); return e ? atoi(e) : 0; }();
     // 8-wave LDS-DMA kernel (one workgroup per CU, software-pipelined): workgroup tile (64 MT) x (32 NTW).
     // GC_GEMM8=0 disables it, =2 forces it (tests); GC_GEMM_MT forces MT (experiments).
-    if (use8 && d->zeros && splits == 1) {
-        const int mt = force_mt ? force_mt : choose_mt(d->M, d->N, ntw, use8 == 2);
+    bool done = false;
+    if (use8 && d->zeros) {
+        int mt = force_mt ? force_mt : choose_mt(d->M, d->N, ntw, use8 == 2);
+        if (splits > 1 && mode != 0 && !force_mt && use8 != 2) mt = 0;      // small-M convs: 4-wave split-K kernel
+        int s8 = 1, tps8 = nk_host;
+        const int64_t tiles8 = ((d->M + 127) / 128) * nbn;
+        if (mt == 2 && tiles8 <= 128 && mode == 0 && !force_mt && !d->geglu && d->workspace) {
+            // half-filled grid, long K (the 5120 -> 1280 FF projection on 16x16 maps): two k-slices per tile fill the CUs.
+            // (measured: for the 3x3 convs on 16x16 / 8x8 maps the 4-wave split-K kernel stays ahead)
+            s8 = (int)std::min<int64_t>(256 / tiles8, nk_host / 12);
+            if (s8 >= 2 && d->workspace_bytes >= sizeof(float) * (size_t)s8 * (size_t)d->M * (size_t)d->N) {
+                tps8 = (nk_host + s8 - 1) / s8; s8 = (nk_host + tps8 - 1) / tps8;
+            } else s8 = 1;
+        }
+        if (splits > 1 && s8 == 1 && !force_mt && use8 != 2) mt = 0;
         if (mt) {
             const int64_t nbm8 = (d->M + 64 * mt - 1) / (64 * mt);
-            const dim3 grid8((unsigned)(nbm8 * nbn), 1u);
+            const dim3 grid8((unsigned)(nbm8 * nbn), (unsigned)s8);
+            g.splits = s8; g.tiles_per_split = tps8;
             if (d->dtype == DT_BF16) dispatch8<BF16>(g, mode, ntw, mt, grid8, s); else dispatch8<F16>(g, mode, ntw, mt, grid8, s);
-            return gc::check_launch("gc_dn_gemm");
+            splits = s8;
+            done = true;
         }
     }
-    if (d->dtype == DT_BF16) dispatch<BF16>(g, mode, ntw, grid, s); else dispatch<F16>(g, mode, ntw, grid, s);
+    if (!done) {
+        if (d->dtype == DT_BF16) dispatch<BF16>(g, mode, ntw, grid, s); else dispatch<F16>(g, mode, ntw, grid, s);
+    }
     if (splits > 1) {
         const unsigned eg = (unsigned)std::min<int64_t>((d->M * (d->N / 4) + 255) / 256, 2048);
         if (d->dtype == DT_BF16) hipLaunchKernelGGL((k_splitk_epilogue<BF16>), dim3(eg), dim3(256), 0, s, g);

@@ -96,6 +96,16 @@ def test_image2latent_and_pipeline_flow(oracle_c):
     pipe.render_reverse()
     td = pipe.datamanager.train_data
     assert all(t["z_0_image"].shape == (1, 4, H // 8, W // 8) for t in td)
+    # mid-result cache in the reference's on-disk layout: write, then fill a fresh data manager from it
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        pipe.save_mid_results(tmp)
+        dm2 = SimpleDataManager(cams)
+        keep, pipe.datamanager = pipe.datamanager, dm2
+        assert pipe.load_mid_results(tmp) == list(range(V))
+        pipe.datamanager = keep
+        for a, b in zip(td, dm2.train_data):
+            assert torch.equal(a["z_0_image"].float().cpu(), b["z_0_image"].cpu()) and torch.equal(a["depth_image"].cpu(), b["depth_image"].cpu())
     pipe.edit_images()
     for t in td:
         assert t["image"].shape == (H, W, 3) and t["image"].dtype == torch.float32
