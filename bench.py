@@ -68,8 +68,10 @@ class GemmProfiler:
             out = prof._att(q, k, vt, heads, sets, fph, Lk=Lk, **kw)
             e.record()
             lk = k.shape[1] if Lk is None else Lk
-            qt = 1 if q.shape[2] // heads == 160 else 2
-            prof.rec.append((f"k_attn<{prof.dt},{q.shape[2] // heads},{qt}>", 4.0 * q.shape[0] * q.shape[1] * lk * q.shape[2] * len(sets), s, e))
+            D = q.shape[2] // heads
+            fast = D in (40, 80) and len(sets) * ((lk + 63) // 64) >= 4                      # mirrors launch_attn() in dn_attn.hip
+            name = f"k_attn3<{prof.dt},{D},{2 if D == 40 else 1},3>" if fast else f"k_attn<{prof.dt},{D},{1 if D == 160 else 2}>"
+            prof.rec.append((name, 4.0 * q.shape[0] * q.shape[1] * lk * q.shape[2] * len(sets), s, e))
             return out
 
         def lin(x, w, *a, **k):
@@ -80,7 +82,7 @@ class GemmProfiler:
             K = x.shape[-1]
             N = w.shape[0]
             ntw = 5 if (N % 160 == 0 and N % 128 != 0 and not k.get("geglu", False)) else 4      # mirrors plan() in dn_gemm.hip
-            prof.rec.append((f"k_gemm<{prof.dt},0,{ntw}>", 2.0 * (x.numel() // K) * N * K, s, e))
+            prof.rec.append((f"gemm<{prof.dt},linear,BN={32 * ntw}>", 2.0 * (x.numel() // K) * N * K, s, e))
             return out
 
         def conv(x, w, *a, **k):
@@ -91,7 +93,7 @@ class GemmProfiler:
             N = w.shape[0]
             ntw = 5 if (N % 160 == 0 and N % 128 != 0) else 4
             mode = 2 if x.shape[-1] % 64 == 0 else 1
-            prof.rec.append((f"k_gemm<{prof.dt},{mode},{ntw}>", 2.0 * (out.numel() // out.shape[-1]) * N * w.shape[1], s, e))
+            prof.rec.append((f"gemm<{prof.dt},conv3x3{'' if mode == 2 else ' generic'},BN={32 * ntw}>", 2.0 * (out.numel() // out.shape[-1]) * N * w.shape[1], s, e))
             return out
 
         ops.linear, ops.conv3x3, ops.attention = lin, conv, att
@@ -229,7 +231,7 @@ def main():
         kind, d = dom
         ach = d["flop"] / (d["ms"] * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": kind + (" (multi-K/V-set flash attention, dn_attn.hip)" if kind.startswith("k_attn") else
-                                                    " (MFMA GEMM / implicit 3x3 conv <dtype, mode 0=linear 1|2=conv, n-tiles/wave>, dn_gemm.hip)"),
+                                                    " (k_gemm / k_gemm8 MFMA GEMM and implicit 3x3 conv, variant picked per grid, dn_gemm.hip)"),
                 "achieved": round(ach, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
                 "launches": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
