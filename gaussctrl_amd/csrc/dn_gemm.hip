@@ -518,8 +518,9 @@ __global__ __launch_bounds__(512, MT == 2 ? 2 : 1) void k_gemm8(const GemmArgs g
         const unsigned char *src = ok ? Ab + (size_t)(unsigned)(off * 2) : Zp;
         glds16(src, dst);
     };
-    auto issue_w = [&](const TileSrc &t, int i) __attribute__((always_inline)) {
-        if (wid + 8 * i < WG) {    // wave-uniform
+    // has_w(i): W group i of this wave exists (the last group only for the waves with wid + 8 (WI-1) < WG: "w3" waves)
+    auto issue_w = [&](const TileSrc &t, int i, bool has) __attribute__((always_inline)) {
+        if (has) {
             const unsigned dst = t.sbase + (unsigned)(BM * 128 + (wid + 8 * i) * 1024);
             if (MODE == 3) { glds16_s(Wb + (size_t)t.kb * 2, (unsigned)(w_off[i] * 2), dst); return; }
             const bool ok = w_ok[i] && (t.kb + w_ck[i] * 8) < (int)g.K;
@@ -532,7 +533,7 @@ __global__ __launch_bounds__(512, MT == 2 ? 2 : 1) void k_gemm8(const GemmArgs g
 #pragma unroll
         for (int i = 0; i < AI; ++i) issue_a(t, i);
 #pragma unroll
-        for (int i = 0; i < WI; ++i) issue_w(t, i);
+        for (int i = 0; i < WI; ++i) issue_w(t, i, wid + 8 * i < WG);
     };
 
     f32x4 acc[NTW][MT];
@@ -558,8 +559,8 @@ __global__ __launch_bounds__(512, MT == 2 ? 2 : 1) void k_gemm8(const GemmArgs g
     // instructions of a later k-tile (and their address arithmetic) are spread between the remaining MFMAs, where a few VALU /
     // SALU instructions per MFMA issue for free.
     constexpr int NMM = NTW * MT, NPC = AI + WI;
-    auto block = [&](const Frag &f, Frag &fn, int st_next, int ks_next, bool load_next, const TileSrc &t, auto dma_tag) __attribute__((always_inline)) {
-        constexpr bool DMA = decltype(dma_tag)::value;
+    auto block = [&](const Frag &f, Frag &fn, int st_next, int ks_next, bool load_next, const TileSrc &t, auto dma_tag, auto w3_tag) __attribute__((always_inline)) {
+        constexpr bool DMA = decltype(dma_tag)::value, W3 = decltype(w3_tag)::value;
         static_for<0, NMM>([&](auto m_) __attribute__((always_inline)) {
             constexpr int m = decltype(m_)::value, nt = m / MT, mt = m % MT;
             acc[nt][mt] = T::mfma(f.w[nt], f.a[mt], acc[nt][mt]);
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(512, MT == 2 ? 2 : 1) void k_gemm8(const GemmArgs g
                     constexpr int pp = decltype(p_)::value;
                     if constexpr (m == 2 + (pp * (NMM - 3)) / NPC) {
                         __builtin_amdgcn_sched_barrier(0);
-                        if constexpr (pp < AI) issue_a(t, pp); else issue_w(t, pp - AI);
+                        if constexpr (pp < AI) issue_a(t, pp); else issue_w(t, pp - AI, (pp - AI) < WI - 1 || W3 || WG % 8 == 0);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 });
@@ -586,42 +587,51 @@ __global__ __launch_bounds__(512, MT == 2 ? 2 : 1) void k_gemm8(const GemmArgs g
     //   [ MFMAs on F1 | read F0 <- (kt+1, half 0) | DMA tile kt+3 -> stage of kt ]
     // ONE barrier per k-tile, sitting between two MFMA blocks whose operands are already in registers; every ds_read has a full
     // MFMA block (16-20 x 16 clk) to land.  Counted vmcnt: tile kt+2 stays in flight across the barrier.
-    const bool w3 = (wid + 16) < WG;     // this wave owns a third W group (instructions per tile are wave-uniform)
-    auto wait_one_tile_in_flight = [&]() __attribute__((always_inline)) {
-        if (w3) { if (AI == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else if (AI == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); }
-        else { if (AI == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else if (AI == 3) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
-    };
-    auto wait_two_tiles_in_flight = [&]() __attribute__((always_inline)) {
-        if (w3) { if (AI == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else if (AI == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); }
-        else { if (AI == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else if (AI == 3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
-    };
-    issue(0, 0);
-    if (nk > 1) issue(1, 1);
-    if (nk > 2) issue(2, 2);
-    if (nk > 2) wait_two_tiles_in_flight(); else if (nk > 1) wait_one_tile_in_flight(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    const bool w3 = (wid + 8 * (WI - 1)) < WG;     // this wave owns the last W group (instructions per tile are wave-uniform)
     Frag f0, f1;
-    load_frag(f0, 0, 0);
-    int st = 0;                           // stage of tile kt
-    TileSrc tnone = {0, 0, 0, 0, 0u};
-    for (int kt = 0; kt < nk; ++kt) {
-        const int st1 = st + 1 == NS ? 0 : st + 1;
-        block(f0, f1, st, 1, true, tnone, std::false_type{});
-        if (kt + 1 < nk) {
-            if (kt + 2 < nk) wait_one_tile_in_flight(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const TileSrc tnone = {0, 0, 0, 0, 0u};
+    // The whole k loop is instantiated twice (W3 = this wave issues WI / WI-1 W loads per tile) so that the counted waits and the
+    // DMA pieces carry no run-time branches; the steady state (tiles kt+1 .. kt+3 exist) is a branch-free loop, the last three
+    // k-tiles run through the generic tail.
+    auto run = [&](auto w3_tag) __attribute__((always_inline)) {
+        constexpr bool W3 = decltype(w3_tag)::value;
+        constexpr int GRPW = AI + ((W3 || WG % 8 == 0) ? WI : WI - 1);        // LDS-DMA instructions of this wave per k-tile
+        static_assert(2 * GRPW < 64, "vmcnt range");
+        auto wait_tiles = [&](auto n_) __attribute__((always_inline)) {        // n tiles may stay in flight
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(n_)::value * GRPW) : "memory");
+        };
+        issue(0, 0);
+        if (nk > 1) issue(1, 1);
+        if (nk > 2) issue(2, 2);
+        if (nk > 2) wait_tiles(std::integral_constant<int, 2>{}); else if (nk > 1) wait_tiles(std::integral_constant<int, 1>{}); else wait_tiles(std::integral_constant<int, 0>{});
+        __builtin_amdgcn_s_barrier();
+        load_frag(f0, 0, 0);
+        int st = 0, kt = 0;                   // st = stage of tile kt
+        for (; kt + 3 < nk; ++kt) {
+            const int st1 = st + 1 == NS ? 0 : st + 1;
+            block(f0, f1, st, 1, true, tnone, std::false_type{}, w3_tag);
+            wait_tiles(std::integral_constant<int, 1>{});
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of stage st are complete
             __builtin_amdgcn_s_barrier();    // tile kt+1 is in LDS for every wave; every wave finished reading stage st
-            if (kt + 3 < nk) {
-                const TileSrc t = issue_begin(kt + 3, st);
-                block(f1, f0, st1, 0, true, t, std::true_type{});
-            } else {
-                block(f1, f0, st1, 0, true, tnone, std::false_type{});
-            }
-        } else {
-            block(f1, f0, st1, 0, false, tnone, std::false_type{});
+            const TileSrc t = issue_begin(kt + 3, st);
+            block(f1, f0, st1, 0, true, t, std::true_type{}, w3_tag);
+            st = st1;
         }
-        st = st1;
-    }
+        for (; kt < nk; ++kt) {
+            const int st1 = st + 1 == NS ? 0 : st + 1;
+            block(f0, f1, st, 1, true, tnone, std::false_type{}, w3_tag);
+            if (kt + 1 < nk) {
+                if (kt + 2 < nk) wait_tiles(std::integral_constant<int, 1>{}); else wait_tiles(std::integral_constant<int, 0>{});
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                block(f1, f0, st1, 0, true, tnone, std::false_type{}, w3_tag);
+            } else {
+                block(f1, f0, st1, 0, false, tnone, std::false_type{}, w3_tag);
+            }
+            st = st1;
+        }
+    };
+    if (w3) run(std::true_type{}); else run(std::false_type{});
 
     // ---- epilogue (same math as k_gemm; MT m-tiles per wave)
     const int64_t n_lane = n_base + wn * (16 * NTW) + fc * 4;

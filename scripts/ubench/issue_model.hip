@@ -32,6 +32,10 @@ __global__ __launch_bounds__(1024) void k(float *out, long long *cyc, int iters)
                 const int r = (g * NV + j) & 15;
                 if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v[r]) : "v"(v[(r + 1) & 15]));
                 if (KIND == 1) asm volatile("v_exp_f32 %0, %0" : "+v"(v[r]));
+                if (KIND == 5) asm volatile("v_exp_legacy_f32 %0, %0" : "+v"(v[r]));
+                if (KIND == 6) asm volatile("v_exp_f16 %0, %0" : "+v"(v[r]));
+                if (KIND == 7) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(v[r]) : "v"(v[(r + 1) & 15]), "v"(v[(r + 2) & 15]));
+                if (KIND == 8) asm volatile("v_ldexp_f32 %0, %0, %1" : "+v"(v[r]) : "v"(v[(r + 1) & 15]));
                 if (KIND == 2) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(v[r]) : "v"(v[(r + 1) & 15]), "v"(v[(r + 2) & 15]));
                 if (KIND == 3) { unsigned t; asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(t) : "v"(v[r]), "v"(v[(r + 1) & 15])); v[r] = __uint_as_float(t); }
                 if (KIND == 4) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(*(double *)&v[(2 * r) & 14]) : "v"(*(double *)&v[(2 * r + 2) & 14]));
@@ -74,6 +78,12 @@ int main()
         run<2, 2, 1>("mfma16 + 2 exp", th);
         run<0, 4, 0>("4 fma only", th);
         run<0, 4, 1>("4 exp only", th);
+        run<0, 4, 5>("4 exp_legacy only", th);
+        run<0, 4, 6>("4 exp_f16 only", th);
+        run<0, 4, 7>("4 perm_b32 only", th);
+        run<0, 4, 8>("4 ldexp only", th);
+        run<1, 2, 5>("mfma + 2 exp_legacy", th);
+        run<1, 2, 6>("mfma + 2 exp_f16", th);
         run<0, 4, 2>("4 max3 only", th);
         run<0, 4, 3>("4 cvt_pk only", th);
         run<0, 4, 4>("4 pk_mul only", th);
