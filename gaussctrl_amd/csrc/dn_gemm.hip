@@ -416,6 +416,7 @@ template <class T, int MODE, int NTW, int MT>
 __global__ __launch_bounds__(512, MT == 2 ? 2 : 1) void k_gemm8(const GemmArgs g)
 {
     constexpr int BM = 64 * MT;
+    constexpr bool CONVF = MODE == 2 || MODE == 4, UPS = MODE == 4;   // MODE 4 = MODE 2 + fused nearest-x2 upsample
     constexpr int BN = 32 * NTW;
     constexpr int STAGE = BM * 128 + BN * 128;
     constexpr int NS = 3;
@@ -446,14 +447,14 @@ __global__ __launch_bounds__(512, MT == 2 ? 2 : 1) void k_gemm8(const GemmArgs g
         const int64_t m = m_base + row;
         a_ok[i] = m < g.M;
         const int mm = a_ok[i] ? (int)m : 0;
-        if (MODE == 1 || MODE == 2) {
+        if (MODE == 1 || CONVF) {
             const int hw = g.Ho * g.Wo;
             const int b = mm / hw;
             const int rem = mm - b * hw;
             const int oy = rem / g.Wo;
             a_y[i] = oy * g.stride - g.pad; a_x[i] = (rem - oy * g.Wo) * g.stride - g.pad;
-            a_off[i] = b * g.Hi * g.Wi * g.Cin + (MODE == 2 ? a_ck[i] * 8 : 0);
-            if (MODE == 2 && !g.ups) a_off[i] += (a_y[i] * g.Wi + a_x[i]) * g.Cin;
+            a_off[i] = b * g.Hi * g.Wi * g.Cin + (CONVF ? a_ck[i] * 8 : 0);
+            if (MODE == 2) a_off[i] += (a_y[i] * g.Wi + a_x[i]) * g.Cin;
         } else {
             a_off[i] = mm * (int)g.lda + a_ck[i] * 8;
             if (MODE == 3) a_off[i] = (int)(m < g.M ? m : g.M - 1) * (int)g.lda + a_ck[i] * 8;
@@ -472,20 +473,38 @@ __global__ __launch_bounds__(512, MT == 2 ? 2 : 1) void k_gemm8(const GemmArgs g
         w_off[i] = (w_ok[i] ? (int)n : 0) * (int)g.K + w_ck[i] * 8;
         if (MODE == 3) w_off[i] = (int)(n < g.N ? n : g.N - 1) * (int)g.K + w_ck[i] * 8;
     }
-    const int Hin = g.ups ? g.Hi * 2 : g.Hi, Win = g.ups ? g.Wi * 2 : g.Wi;
+    const bool ups = CONVF ? UPS : (g.ups != 0);
+    const int Hin = ups ? g.Hi * 2 : g.Hi, Win = ups ? g.Wi * 2 : g.Wi;
+    // MODE 2: per-lane source pointer of the centre-less tap origin and a 9-bit mask of the taps that fall inside the image
+    const unsigned char *a_ptr[AI];
+    unsigned a_vm[AI];
+    if (MODE == 2) {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            a_ptr[i] = (const unsigned char *)g.A + (int64_t)a_off[i] * 2;
+            unsigned vm = 0;
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                const int yi = a_y[i] + tp / 3, xi = a_x[i] + tp % 3;
+                if (a_ok[i] && (unsigned)yi < (unsigned)Hin && (unsigned)xi < (unsigned)Win) vm |= 1u << tp;
+            }
+            a_vm[i] = vm;
+        }
+    }
     const unsigned char *Ab = (const unsigned char *)g.A, *Wb = (const unsigned char *)g.W;
     const unsigned char *Zp = (const unsigned char *)g.zeros;
     int ld_tap = 0, ld_ci = 0;
-    if (MODE == 2 && kt0 > 0) { ld_tap = (kt0 * BK) / g.Cin; ld_ci = kt0 * BK - ld_tap * g.Cin; }
+    if (CONVF && kt0 > 0) { ld_tap = (kt0 * BK) / g.Cin; ld_ci = kt0 * BK - ld_tap * g.Cin; }
 
     // DMA of one k-tile, split into per-instruction pieces so that the main loop can place them between MFMAs.
-    struct TileSrc { int kb, dy_u, dx_u, tap_off; unsigned sbase; };
+    struct TileSrc { int kb, dy_u, dx_u, tap_off, tap; unsigned sbase; };
     auto issue_begin = [&](int kt, int stage) __attribute__((always_inline)) -> TileSrc {
         TileSrc t;
-        t.kb = (kt0 + kt) * BK; t.dy_u = 0; t.dx_u = 0; t.tap_off = 0;
-        if (MODE == 2) {
+        t.kb = (kt0 + kt) * BK; t.dy_u = 0; t.dx_u = 0; t.tap_off = 0; t.tap = 0;
+        if (CONVF) {
+            t.tap = ld_tap;
             t.dy_u = ld_tap / 3; t.dx_u = ld_tap - t.dy_u * 3;
-            t.tap_off = g.ups ? ld_ci : (t.dy_u * g.Wi + t.dx_u) * g.Cin + ld_ci;
+            t.tap_off = UPS ? ld_ci : (t.dy_u * g.Wi + t.dx_u) * g.Cin + ld_ci;
             ld_ci += BK; if (ld_ci >= g.Cin) { ld_ci -= g.Cin; ++ld_tap; }
         }
         t.sbase = lds0 + stage * STAGE;
@@ -494,13 +513,18 @@ __global__ __launch_bounds__(512, MT == 2 ? 2 : 1) void k_gemm8(const GemmArgs g
     auto issue_a = [&](const TileSrc &t, int i) __attribute__((always_inline)) {
         const unsigned dst = t.sbase + (unsigned)((wid + 8 * i) * 1024);
         if (MODE == 3) { glds16_s(Ab + (size_t)t.kb * 2, (unsigned)(a_off[i] * 2), dst); return; }
+        if (MODE == 2) {     // tap validity from the precomputed mask, address = lane pointer + uniform tap offset
+            const bool okm = (a_vm[i] >> t.tap) & 1u;
+            glds16(okm ? a_ptr[i] + (int64_t)t.tap_off * 2 : Zp, dst);
+            return;
+        }
         bool ok;
         int off;
-        if (MODE == 2) {
+        if (MODE == 4) {
             int yi = a_y[i] + t.dy_u, xi = a_x[i] + t.dx_u;
             ok = a_ok[i] && (unsigned)yi < (unsigned)Hin && (unsigned)xi < (unsigned)Win;
             off = a_off[i] + t.tap_off;
-            if (g.ups) off += ((yi >> 1) * g.Wi + (xi >> 1)) * g.Cin;
+            off += ((yi >> 1) * g.Wi + (xi >> 1)) * g.Cin;
         } else if (MODE == 1) {
             const int k0 = t.kb + a_ck[i] * 8;
             const int kc = k0 < (int)g.K ? k0 : 0;
@@ -522,7 +546,7 @@ __global__ __launch_bounds__(512, MT == 2 ? 2 : 1) void k_gemm8(const GemmArgs g
     auto issue_w = [&](const TileSrc &t, int i, bool has) __attribute__((always_inline)) {
         if (has) {
             const unsigned dst = t.sbase + (unsigned)(BM * 128 + (wid + 8 * i) * 1024);
-            if (MODE == 3) { glds16_s(Wb + (size_t)t.kb * 2, (unsigned)(w_off[i] * 2), dst); return; }
+            if (MODE == 3 || CONVF) { glds16_s(Wb + (size_t)t.kb * 2, (unsigned)(w_off[i] * 2), dst); return; }   // K % 64 == 0: rows past N re-read row 0
             const bool ok = w_ok[i] && (t.kb + w_ck[i] * 8) < (int)g.K;
             const unsigned char *src = ok ? Wb + (size_t)(unsigned)((w_off[i] + t.kb) * 2) : Zp;
             glds16(src, dst);
@@ -589,7 +613,7 @@ __global__ __launch_bounds__(512, MT == 2 ? 2 : 1) void k_gemm8(const GemmArgs g
     // MFMA block (16-20 x 16 clk) to land.  Counted vmcnt: tile kt+2 stays in flight across the barrier.
     const bool w3 = (wid + 8 * (WI - 1)) < WG;     // this wave owns the last W group (instructions per tile are wave-uniform)
     Frag f0, f1;
-    const TileSrc tnone = {0, 0, 0, 0, 0u};
+    const TileSrc tnone = {0, 0, 0, 0, 0, 0u};
     // The whole k loop is instantiated twice (W3 = this wave issues WI / WI-1 W loads per tile) so that the counted waits and the
     // DMA pieces carry no run-time branches; the steady state (tiles kt+1 .. kt+3 exist) is a branch-free loop, the last three
     // k-tiles run through the generic tail.
@@ -773,7 +797,8 @@ template <class T, int NTW, int MT>
 void dispatch8m(const GemmArgs &g, int mode, dim3 grid, hipStream_t s)
 {
     if (mode == 0) { if (g.K % 64 == 0) launch8<T, 3, NTW, MT>(g, grid, s); else launch8<T, 0, NTW, MT>(g, grid, s); }
-    else if (mode == 1) launch8<T, 1, NTW, MT>(g, grid, s); else launch8<T, 2, NTW, MT>(g, grid, s);
+    else if (mode == 1) launch8<T, 1, NTW, MT>(g, grid, s);
+    else if (g.ups) launch8<T, 4, NTW, MT>(g, grid, s); else launch8<T, 2, NTW, MT>(g, grid, s);
 }
 template <class T>
 void dispatch8(const GemmArgs &g, int mode, int ntw, int mt, dim3 grid, hipStream_t s)
@@ -877,18 +902,20 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
     bool done = false;
     if (use8 && d->zeros) {
         int mt = force_mt ? force_mt : choose_mt(d->M, d->N, ntw, use8 == 2);
-        if (splits > 1 && mode != 0 && !force_mt && use8 != 2) mt = 0;      // small-M convs: 4-wave split-K kernel
-        int s8 = 1, tps8 = nk_host;
+        static const int convsplit = [] { const char *e = getenv("GC_GEMM_CONVSPLIT"); return e ? atoi(e) : 1; }();
         const int64_t tiles8 = ((d->M + 127) / 128) * nbn;
-        if (mt == 2 && tiles8 <= 128 && mode == 0 && !force_mt && !d->geglu && d->workspace) {
-            // half-filled grid, long K (the 5120 -> 1280 FF projection on 16x16 maps): two k-slices per tile fill the CUs.
-            // (measured: for the 3x3 convs on 16x16 / 8x8 maps the 4-wave split-K kernel stays ahead)
-            s8 = (int)std::min<int64_t>(256 / tiles8, nk_host / 12);
+        // long-K problems with a part-filled grid (16x16-map convs, the 5120 -> 1280 FF projection): k-slices of >= 12 k-tiles
+        // fill the CUs; GC_GEMM_CONVSPLIT=0 sends such convs back to the 4-wave split-K kernel, =2 also takes the 8x8-map convs
+        const bool small = tiles8 < 96;
+        const bool want_split = !force_mt && use8 != 2 && !d->geglu && d->workspace && tiles8 <= 128 && (mode == 0 ? !small : (convsplit >= (small ? 2 : 1)));
+        int s8 = 1, tps8 = nk_host;
+        if (want_split) {
+            s8 = (int)std::min<int64_t>(small ? (256 + tiles8 - 1) / tiles8 : 256 / tiles8, nk_host / 12);
             if (s8 >= 2 && d->workspace_bytes >= sizeof(float) * (size_t)s8 * (size_t)d->M * (size_t)d->N) {
-                tps8 = (nk_host + s8 - 1) / s8; s8 = (nk_host + tps8 - 1) / tps8;
+                mt = 2; tps8 = (nk_host + s8 - 1) / s8; s8 = (nk_host + tps8 - 1) / tps8;
             } else s8 = 1;
         }
-        if (splits > 1 && s8 == 1 && !force_mt && use8 != 2) mt = 0;
+        if (splits > 1 && s8 == 1 && !force_mt && use8 != 2) mt = 0;      // otherwise: 4-wave split-K kernel as planned
         if (mt) {
             const int64_t nbm8 = (d->M + 64 * mt - 1) / (64 * mt);
             const dim3 grid8((unsigned)(nbm8 * nbn), (unsigned)s8);
