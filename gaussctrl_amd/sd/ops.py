@@ -142,7 +142,7 @@ def groupnorm(x, gamma, beta, groups, eps, silu):
     _gpu(x)
     B, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * Cc)
-    key = (x.device, B, HW, Cc)
+    key = (x.device, B, HW, Cc, torch.cuda.current_stream().cuda_stream)      # scratch is per stream: two networks may run concurrently
     ws = _gn_ws.get(key)
     if ws is None:
         nbytes = L.lib().gc_dn_groupnorm_workspace_bytes(C.c_int64(B), C.c_int64(HW), Cc)

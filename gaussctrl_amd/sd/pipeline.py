@@ -8,6 +8,8 @@ prompt, outside the hot path.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -60,6 +62,14 @@ class DenoisePipeline:
         self.cn_scale = controlnet_conditioning_scale
         self.text_kv = {}          # per-layer text K / V^T cache, valid for one (negative, positive) prompt pair
         self._text_key = None
+        self.two_streams = os.environ.get("GC_DN_STREAMS", "1") != "0"     # ControlNet || UNet encoder on two HIP streams
+        self._side = {}
+
+    def _side_stream(self, dev):
+        st = self._side.get(dev)
+        if st is None:
+            st = self._side[dev] = torch.cuda.Stream(device=dev)
+        return st
 
     def _ctx(self, ctx_neg, ctx_pos):
         ctx = torch.cat([ctx_neg, ctx_pos], 0).to(self.dtype).contiguous() if ctx_neg is not None else ctx_pos.to(self.dtype).contiguous()
@@ -91,8 +101,21 @@ class DenoisePipeline:
                 bank.step = i
             a_cn = AttnCtx(mode, coeff_cn, fph, self.text_kv, bank, "controlnet")
             a_un = AttnCtx(mode, coeff_unet, fph, self.text_kv, bank, "unet")
-            down, mid = self.controlnet.forward(xin, t, ctx, cemb, a_cn, self.cn_scale)
-            eps = self.unet.forward(xin, t, ctx, down, mid, a_un)
+            if self.two_streams:
+                # The ControlNet and the UNet encoder + mid block only share their input: run them on two HIP streams so that
+                # the part-filled grids of the 16x16 / 8x8 layers and every kernel's fill / epilogue phase overlap with the
+                # other network's work; the UNet decoder joins both.
+                main = torch.cuda.current_stream()
+                side = self._side_stream(dev)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    down, mid = self.controlnet.forward(xin, t, ctx, cemb, a_cn, self.cn_scale)
+                x, skips, temb = self.unet.encode(xin, t, ctx, a_un)
+                main.wait_stream(side)
+                eps = self.unet.decode(x, skips, temb, ctx, down, mid, a_un)
+            else:
+                down, mid = self.controlnet.forward(xin, t, ctx, cemb, a_cn, self.cn_scale)
+                eps = self.unet.forward(xin, t, ctx, down, mid, a_un)
             a_from, a_to = self.sched.alphas(t, self.n, inverse)
             ops.cfg_ddim_step(eps, lat, xin, guidance, cfg, a_from, a_to, rep)
         return lat.permute(0, 3, 1, 2).contiguous()

@@ -208,13 +208,18 @@ class ControlNet(SDNet):
 
 
 class UNet(SDNet):
-    def forward(self, xin, t, ctx, down_res, mid_res, actx: AttnCtx):
-        """xin [B,h,w,8] -> eps fp32 [B,h,w,8] (channels 0..3 valid)."""
+    def encode(self, xin, t, ctx, actx: AttnCtx):
+        """conv_in + down blocks + mid block: everything that does not need the ControlNet residuals."""
         w = self.w
-        cfg = self.cfg
         temb_act = self.time_embed(t, xin.device)
         x = ops.conv3x3(xin, w["conv_in.weight"], w["conv_in.bias"])
         x, skips = self.encoder(x, temb_act, ctx, actx)
+        return x, skips, temb_act
+
+    def decode(self, x, skips, temb_act, ctx, down_res, mid_res, actx: AttnCtx):
+        """mid residual add + up blocks + conv_out -> eps fp32 [B,h,w,8] (channels 0..3 valid)."""
+        w = self.w
+        cfg = self.cfg
         if mid_res is not None:
             x = ops.axpby(x, 1.0, mid_res, 1.0)
         n = len(cfg["block_out_channels"])
@@ -232,3 +237,8 @@ class UNet(SDNet):
                 x = ops.conv3x3(x, w[p + ".weight"], w[p + ".bias"], upsample=True)
         x = ops.groupnorm(x, w["conv_norm_out.weight"], w["conv_norm_out.bias"], cfg["groups"], 1e-5, True)
         return ops.conv3x3(x, w["conv_out.weight"], w["conv_out.bias"], out_f32=True)
+
+    def forward(self, xin, t, ctx, down_res, mid_res, actx: AttnCtx):
+        """xin [B,h,w,8] -> eps fp32 [B,h,w,8] (channels 0..3 valid)."""
+        x, skips, temb_act = self.encode(xin, t, ctx, actx)
+        return self.decode(x, skips, temb_act, ctx, down_res, mid_res, actx)
