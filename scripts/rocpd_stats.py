@@ -12,3 +12,15 @@ for n, c, t, mn, mx in rows[: int(sys.argv[2]) if len(sys.argv) > 2 else 40]:
     n = re.sub(r"\(anonymous namespace\)::", "", n)[:90]
     print(f"{n:90s} {c:7d} {t/1e6:10.2f} {t/c/1e3:9.2f} {mn/1e3:8.2f} {mx/1e3:9.2f} {100*t/tot:6.2f}")
 print(f"TOTAL kernel time {tot/1e6:.2f} ms")
+# GPU occupancy in time: union of all kernel intervals over the span from the first to the last kernel
+iv = cur.execute(f"select start, end from {kd} order by start").fetchall()
+if iv:
+    busy, cs, ce = 0, iv[0][0], iv[0][1]
+    for a, b in iv[1:]:
+        if a > ce:
+            busy += ce - cs; cs, ce = a, b
+        else:
+            ce = max(ce, b)
+    busy += ce - cs
+    span = max(b for _, b in iv) - iv[0][0]
+    print(f"kernel-interval union {busy/1e6:.2f} ms of {span/1e6:.2f} ms span ({100.0*busy/span:.1f} % busy); sum of durations / union = {tot/busy:.3f} (stream overlap)")
