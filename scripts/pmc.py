@@ -1,4 +1,5 @@
-"""Collect SQ counters for the kernels matching a regex (rocprofv3 --pmc, one pass per counter group, kernel trace only).
+"""(TCC / FETCH_SIZE groups are deliberately not collected: that pass did not finish within 15 minutes on this pool.)
+Collect SQ counters for the kernels matching a regex (rocprofv3 --pmc, one pass per counter group, kernel trace only).
 usage (on the GPU box): python scripts/pmc.py '<kernel regex>' -- <command ...>"""
 import csv, glob, os, re, subprocess, sys, collections
 SETS = [
@@ -9,10 +10,15 @@ SETS = [
 rx = re.compile(sys.argv[1]); cmd = sys.argv[sys.argv.index("--") + 1:]
 os.environ["TMPDIR"] = "/tmp"
 out = collections.OrderedDict()
+if os.environ.get("PMC_SETS"):
+    SETS = [SETS[int(j)] for j in os.environ["PMC_SETS"].split(",")]
 for i, s in enumerate(SETS):
     d = f"/tmp/pmc_{os.getpid()}_{i}"
-    r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", *s.split(), "--output-format", "csv", "-d", d, "-o", "p", "--"] + cmd,
-                       cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+      r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", *s.split(), "--output-format", "csv", "-d", d, "-o", "p", "--"] + cmd,
+                       cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=int(os.environ.get("PMC_TIMEOUT", "180")))
+    except subprocess.TimeoutExpired:
+        print(f"# set {i} ({s}): timed out"); continue
     files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
     if not files:
         print(f"# set {i}: no counter output (rc={r.returncode})\n" + r.stdout[-600:]); continue
