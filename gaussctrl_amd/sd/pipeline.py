@@ -81,11 +81,9 @@ class DenoisePipeline:
         return self._ctx_tensor
 
     # ---------------------------------------------------------------------------------- core loop
-    def _denoise(self, latents, disparity, ctx, cfg: bool, mode: str, coeff_unet: float, coeff_cn: float,
-                 guidance: float, inverse: bool, steps: int | None, bank: RefBank | None, fph: int):
-        """latents fp32 [f,4,h,w]; disparity fp32 [f,3,H,W].  Returns latents fp32 [f,4,h,w]."""
-        dev = latents.device
-        f = latents.shape[0]
+    def _begin(self, latents, disparity, ctx, cfg: bool, mode: str, coeff_unet: float, coeff_cn: float,
+               guidance: float, inverse: bool, steps: int | None, bank: RefBank | None, fph: int) -> dict:
+        """State of one denoise trajectory (advanced by _advance): latents fp32 [f,4,h,w]; disparity fp32 [f,3,H,W]."""
         rep = 2 if cfg else 1
         lat = latents.permute(0, 2, 3, 1).contiguous().float()            # master copy fp32 [f,h,w,4]
         xin = to_nhwc8(latents, self.dtype)
@@ -96,11 +94,20 @@ class DenoisePipeline:
         cemb = torch.cat([cemb] * rep, 0).contiguous() if rep > 1 else cemb
         ts = self.sched.timesteps(self.n, inverse)
         ts = ts if steps is None else ts[:steps]
-        for i, t in enumerate(ts):
+        return dict(lat=lat, xin=xin, cemb=cemb, ts=ts, i=0, ctx=ctx, cfg=cfg, mode=mode, cu=coeff_unet, cc=coeff_cn, g=guidance,
+                    inverse=inverse, bank=bank, fph=fph, rep=rep, dev=latents.device)
+
+    def _advance(self, st: dict, nsteps: int | None = None) -> bool:
+        """Run up to `nsteps` more DDIM steps of the trajectory (all remaining when None); True when it is complete."""
+        ts, bank, dev = st["ts"], st["bank"], st["dev"]
+        end = len(ts) if nsteps is None else min(len(ts), st["i"] + nsteps)
+        xin, lat, ctx, cemb = st["xin"], st["lat"], st["ctx"], st["cemb"]
+        while st["i"] < end:
+            i = st["i"]; t = ts[i]
             if bank is not None:
                 bank.step = i
-            a_cn = AttnCtx(mode, coeff_cn, fph, self.text_kv, bank, "controlnet")
-            a_un = AttnCtx(mode, coeff_unet, fph, self.text_kv, bank, "unet")
+            a_cn = AttnCtx(st["mode"], st["cc"], st["fph"], self.text_kv, bank, "controlnet")
+            a_un = AttnCtx(st["mode"], st["cu"], st["fph"], self.text_kv, bank, "unet")
             if self.two_streams:
                 # The ControlNet and the UNet encoder + mid block only share their input: run them on two HIP streams so that
                 # the part-filled grids of the 16x16 / 8x8 layers and every kernel's fill / epilogue phase overlap with the
@@ -116,9 +123,17 @@ class DenoisePipeline:
             else:
                 down, mid = self.controlnet.forward(xin, t, ctx, cemb, a_cn, self.cn_scale)
                 eps = self.unet.forward(xin, t, ctx, down, mid, a_un)
-            a_from, a_to = self.sched.alphas(t, self.n, inverse)
-            ops.cfg_ddim_step(eps, lat, xin, guidance, cfg, a_from, a_to, rep)
-        return lat.permute(0, 3, 1, 2).contiguous()
+            a_from, a_to = self.sched.alphas(t, self.n, st["inverse"])
+            ops.cfg_ddim_step(eps, lat, xin, st["g"], st["cfg"], a_from, a_to, st["rep"])
+            st["i"] = i + 1
+        return st["i"] >= len(ts)
+
+    def _denoise(self, latents, disparity, ctx, cfg: bool, mode: str, coeff_unet: float, coeff_cn: float,
+                 guidance: float, inverse: bool, steps: int | None, bank: RefBank | None, fph: int):
+        """Returns latents fp32 [f,4,h,w]."""
+        st = self._begin(latents, disparity, ctx, cfg, mode, coeff_unet, coeff_cn, guidance, inverse, steps, bank, fph)
+        self._advance(st)
+        return st["lat"].permute(0, 3, 1, 2).contiguous()
 
     # ---------------------------------------------------------------------------------- public API
     def edit_chunk(self, latents, disparity, ctx_neg, ctx_pos, steps=None):
@@ -137,6 +152,22 @@ class DenoisePipeline:
                       ref_latents.shape[0])
         bank.mode = "use"
         return bank
+
+    def begin_ref_bank(self, ref_latents, ref_disparity, ctx_neg, ctx_pos, steps=None) -> dict:
+        """Incremental form of build_ref_bank: returns a trajectory; `advance_ref_bank(tr, n)` runs n DDIM steps of it and returns
+        the finished RefBank (else None).  Lets a caller that streams scenes spread the NEXT scene's reference trajectory over the
+        chunks of the current one instead of stalling on it."""
+        ctx = self._ctx(ctx_neg, ctx_pos)
+        bank = RefBank()
+        bank.mode = "record"
+        return self._begin(ref_latents, ref_disparity, ctx, True, "xview", 0.6, 0.0, self.guidance, False, steps, bank,
+                           ref_latents.shape[0])
+
+    def advance_ref_bank(self, tr: dict, nsteps: int | None = None):
+        if self._advance(tr, nsteps):
+            tr["bank"].mode = "use"
+            return tr["bank"]
+        return None
 
     def edit_chunk_cached(self, latents, disparity, ctx_neg, ctx_pos, bank: RefBank, steps=None):
         """Chunk frames only; reference K / V^T come from `bank` (same result as edit_chunk()[4:])."""
