@@ -66,9 +66,11 @@ class DenoisePipeline:
         self._side = {}
 
     def _side_stream(self, dev):
-        st = self._side.get(dev)
+        """the ControlNet stream that pairs with the CURRENT stream (independent trajectories may run on different streams)"""
+        key = (dev, torch.cuda.current_stream().cuda_stream)
+        st = self._side.get(key)
         if st is None:
-            st = self._side[dev] = torch.cuda.Stream(device=dev)
+            st = self._side[key] = torch.cuda.Stream(device=dev)
         return st
 
     def _ctx(self, ctx_neg, ctx_pos):
