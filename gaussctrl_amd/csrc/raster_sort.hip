@@ -31,9 +31,18 @@ constexpr int RB = RT * RI;        // 4096 items per workgroup
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-__global__ __launch_bounds__(RT) void k_radix_hist(const uint32_t *__restrict__ keys, int64_t n, int shift, int nblocks,
-                                                   int32_t *__restrict__ hist /* [256][nblocks] */)
+// n_dev (optional): the item count lives on the device (sync-free binning); `n` is then the capacity it is clamped to
+__device__ __forceinline__ int64_t live_count(int64_t n, const int32_t *n_dev)
 {
+    if (!n_dev) return n;
+    const int64_t m = (int64_t)*n_dev;
+    return m < n ? m : n;
+}
+
+__global__ __launch_bounds__(RT) void k_radix_hist(const uint32_t *__restrict__ keys, int64_t n, const int32_t *__restrict__ n_dev,
+                                                   int shift, int nblocks, int32_t *__restrict__ hist /* [256][nblocks] */)
+{
+    n = live_count(n, n_dev);
     __shared__ int h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
@@ -50,9 +59,10 @@ __global__ __launch_bounds__(RT) void k_radix_hist(const uint32_t *__restrict__ 
 // offs = INCLUSIVE scan of hist ([digit][block] flattened); exclusive offset of (d, b) = offs[d*nb + b] - hist[d*nb + b]
 __global__ __launch_bounds__(RT) void k_radix_scatter(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
                                                       uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int64_t n,
-                                                      int shift, int nblocks, const int32_t *__restrict__ hist,
-                                                      const int32_t *__restrict__ offs)
+                                                      const int32_t *__restrict__ n_dev, int shift, int nblocks,
+                                                      const int32_t *__restrict__ hist, const int32_t *__restrict__ offs)
 {
+    n = live_count(n, n_dev);
     extern __shared__ int tbl[];   // [RI*4][256]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     for (int i = tid; i < RI * 4 * 256; i += RT) tbl[i] = 0;
@@ -141,10 +151,13 @@ __global__ __launch_bounds__(256) void k_emit_sorted(int64_t N, int64_t M_cap, c
         }
 }
 
-__global__ __launch_bounds__(256) void k_tile_bins32(int64_t M, int num_tiles, const uint32_t *__restrict__ tkeys,
+__global__ __launch_bounds__(256) void k_tile_bins32(int64_t M, const int32_t *__restrict__ m_dev, int32_t *__restrict__ overflow,
+                                                     int num_tiles, const uint32_t *__restrict__ tkeys,
                                                      const uint32_t *__restrict__ gids, const float *__restrict__ depths,
                                                      int32_t *__restrict__ bins, int64_t *__restrict__ keys64, int32_t *__restrict__ ids_out)
 {
+    if (m_dev && overflow && blockIdx.x == 0 && threadIdx.x == 0) *overflow = (int64_t)*m_dev > M ? 1 : 0;
+    M = live_count(M, m_dev);
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= M) return;
     const int t = (int)tkeys[i];
@@ -194,15 +207,15 @@ void set_attr()
 }
 
 // one stable 8-bit radix pass
-int radix_pass(const uint32_t *ki, const uint32_t *vi, uint32_t *ko, uint32_t *vo, int64_t n, int shift, const Plan &p,
-               unsigned char *w, hipStream_t s)
+int radix_pass(const uint32_t *ki, const uint32_t *vi, uint32_t *ko, uint32_t *vo, int64_t n, const int32_t *n_dev, int shift,
+               const Plan &p, unsigned char *w, hipStream_t s)
 {
     int32_t *hist = (int32_t *)(w + p.off_hist), *offs = (int32_t *)(w + p.off_offs), *cnt = (int32_t *)(w + p.off_cnt);
-    hipLaunchKernelGGL(k_radix_hist, dim3(p.nb), dim3(RT), 0, s, ki, n, shift, p.nb, hist);
+    hipLaunchKernelGGL(k_radix_hist, dim3(p.nb), dim3(RT), 0, s, ki, n, n_dev, shift, p.nb, hist);
     int rc = gc_raster_scan_tiles(256 * (int64_t)p.nb, hist, offs, cnt, w + p.off_scan, p.scan_bytes, (void *)s);
     if (rc != GC_OK) return rc;
-    hipLaunchKernelGGL(k_radix_scatter, dim3(p.nb), dim3(RT), (size_t)RI * 4 * 256 * sizeof(int), s, ki, vi, ko, vo, n, shift,
-                       p.nb, hist, offs);
+    hipLaunchKernelGGL(k_radix_scatter, dim3(p.nb), dim3(RT), (size_t)RI * 4 * 256 * sizeof(int), s, ki, vi, ko, vo, n, n_dev,
+                       shift, p.nb, hist, offs);
     return GC_OK;
 }
 
@@ -233,7 +246,7 @@ int gc_raster_depth_order(int64_t N, const float *depths, const int32_t *radii, 
     for (int pass = 0; pass < 4; ++pass) {   // visible depths are > 0: the float bit pattern is monotone
         const bool odd = pass & 1;
         uint32_t *vo = pass == 3 ? (uint32_t *)depth_order : (odd ? v0 : v1);
-        int rc = radix_pass(odd ? k1 : k0, odd ? v1 : v0, odd ? k0 : k1, vo, N, 8 * pass, p, w, s);
+        int rc = radix_pass(odd ? k1 : k0, odd ? v1 : v0, odd ? k0 : k1, vo, N, nullptr, 8 * pass, p, w, s);
         if (rc != GC_OK) return rc;
     }
     hipLaunchKernelGGL(k_gather_tiles, dim3(gc::cdiv(N, 256)), dim3(256), 0, s, N, (const uint32_t *)depth_order, num_tiles_hit, nth_s);
@@ -244,22 +257,23 @@ int gc_raster_depth_order(int64_t N, const float *depths, const int32_t *radii, 
 
 size_t gc_raster_bin_workspace_bytes(int64_t M) { return make_plan(M > 0 ? M : 1).total; }
 
-/* Phase 2: emit (tile, id) pairs in depth order for the M intersections, stable-sort them by tile, build tile_bins.
- * gaussian_ids_sorted[M] and tile_bins[T,2] are the rasterizer's inputs; isect_ids_sorted[M] (int64 tile<<32|depth bits) is
- * optional (NULL to skip). */
-int gc_raster_bin_tiles(int64_t N, int64_t M, const int32_t *depth_order, const int32_t *cum_sorted, const float *xys,
-                        const float *depths, const int32_t *radii, int tiles_x, int tiles_y, int32_t *gaussian_ids_sorted,
-                        int32_t *tile_bins, int64_t *isect_ids_sorted, void *workspace, size_t workspace_bytes, void *stream)
+}  // extern "C"
+
+namespace {
+int bin_tiles_impl(int64_t N, int64_t M, const int32_t *m_dev, int32_t *overflow_dev, const int32_t *depth_order,
+                   const int32_t *cum_sorted, const float *xys, const float *depths, const int32_t *radii, int tiles_x, int tiles_y,
+                   int32_t *gaussian_ids_sorted, int32_t *tile_bins, int64_t *isect_ids_sorted, void *workspace,
+                   size_t workspace_bytes, void *stream, const char *what)
 {
-    GC_REQUIRE(N >= 0 && M >= 0 && tile_bins, "bad arguments");
     const int num_tiles = tiles_x * tiles_y;
     hipStream_t s = gc::S(stream);
     if (hipMemsetAsync(tile_bins, 0, sizeof(int32_t) * 2 * (size_t)num_tiles, s) != hipSuccess) return GC_ELAUNCH;
+    if (overflow_dev && hipMemsetAsync(overflow_dev, 0, 4, s) != hipSuccess) return GC_ELAUNCH;
     if (M == 0 || N == 0) return GC_OK;
-    GC_REQUIRE(num_tiles <= 65536, "at most 65536 tiles");
-    GC_REQUIRE(depth_order && cum_sorted && xys && depths && radii && gaussian_ids_sorted && workspace, "null pointer");
+    if (num_tiles > 65536) { gc::set_error("%s: at most 65536 tiles", what); return GC_EINVAL; }
+    if (!(depth_order && cum_sorted && xys && depths && radii && gaussian_ids_sorted && workspace)) { gc::set_error("%s: null pointer", what); return GC_EINVAL; }
     const Plan p = make_plan(M);
-    if (workspace_bytes < p.total) { gc::set_error("gc_raster_bin_tiles: workspace too small"); return GC_ENOSPC; }
+    if (workspace_bytes < p.total) { gc::set_error("%s: workspace too small", what); return GC_ENOSPC; }
     set_attr();
     unsigned char *w = (unsigned char *)workspace;
     uint32_t *k0 = (uint32_t *)(w + p.off_keys[0]), *v0 = (uint32_t *)(w + p.off_vals[0]);
@@ -270,13 +284,42 @@ int gc_raster_bin_tiles(int64_t N, int64_t M, const int32_t *depth_order, const 
     uint32_t *ks = k0, *vs = v0;
     for (int pass = 0; pass < passes; ++pass) {
         uint32_t *ko = ks == k0 ? k1 : k0, *vo = vs == v0 ? v1 : v0;
-        int rc = radix_pass(ks, vs, ko, vo, M, 8 * pass, p, w, s);
+        int rc = radix_pass(ks, vs, ko, vo, M, m_dev, 8 * pass, p, w, s);
         if (rc != GC_OK) return rc;
         ks = ko; vs = vo;
     }
-    hipLaunchKernelGGL(k_tile_bins32, dim3(gc::cdiv(M, 256)), dim3(256), 0, s, M, num_tiles, ks, vs, depths, tile_bins,
-                       isect_ids_sorted, gaussian_ids_sorted);
-    return gc::check_launch("gc_raster_bin_tiles");
+    hipLaunchKernelGGL(k_tile_bins32, dim3(gc::cdiv(M, 256)), dim3(256), 0, s, M, m_dev, overflow_dev, num_tiles, ks, vs, depths,
+                       tile_bins, isect_ids_sorted, gaussian_ids_sorted);
+    return gc::check_launch(what);
+}
+}  // namespace
+
+extern "C" {
+
+/* Phase 2: emit (tile, id) pairs in depth order for the M intersections, stable-sort them by tile, build tile_bins.
+ * gaussian_ids_sorted[M] and tile_bins[T,2] are the rasterizer's inputs; isect_ids_sorted[M] (int64 tile<<32|depth bits) is
+ * optional (NULL to skip). */
+int gc_raster_bin_tiles(int64_t N, int64_t M, const int32_t *depth_order, const int32_t *cum_sorted, const float *xys,
+                        const float *depths, const int32_t *radii, int tiles_x, int tiles_y, int32_t *gaussian_ids_sorted,
+                        int32_t *tile_bins, int64_t *isect_ids_sorted, void *workspace, size_t workspace_bytes, void *stream)
+{
+    GC_REQUIRE(N >= 0 && M >= 0 && tile_bins, "bad arguments");
+    return bin_tiles_impl(N, M, nullptr, nullptr, depth_order, cum_sorted, xys, depths, radii, tiles_x, tiles_y, gaussian_ids_sorted,
+                          tile_bins, isect_ids_sorted, workspace, workspace_bytes, stream, "gc_raster_bin_tiles");
+}
+
+/* Sync-free phase 2: the intersection count stays on the device (count_dev, written by gc_raster_depth_order); every buffer
+ * is sized for the caller's capacity M_cap (gaussian_ids_sorted[M_cap], workspace gc_raster_bin_workspace_bytes(M_cap)), the
+ * kernels clamp to min(*count_dev, M_cap) and *overflow_dev is set to 1 when the frame needed more (the image is then
+ * incomplete: re-run with a larger capacity).  No host round trip: the blocking gc_raster_read_count is not needed. */
+int gc_raster_bin_tiles_dev(int64_t N, int64_t M_cap, const int32_t *count_dev, int32_t *overflow_dev, const int32_t *depth_order,
+                            const int32_t *cum_sorted, const float *xys, const float *depths, const int32_t *radii, int tiles_x,
+                            int tiles_y, int32_t *gaussian_ids_sorted, int32_t *tile_bins, int64_t *isect_ids_sorted,
+                            void *workspace, size_t workspace_bytes, void *stream)
+{
+    GC_REQUIRE(N >= 0 && M_cap >= 0 && tile_bins && count_dev && overflow_dev, "bad arguments");
+    return bin_tiles_impl(N, M_cap, count_dev, overflow_dev, depth_order, cum_sorted, xys, depths, radii, tiles_x, tiles_y,
+                          gaussian_ids_sorted, tile_bins, isect_ids_sorted, workspace, workspace_bytes, stream, "gc_raster_bin_tiles_dev");
 }
 
 }  // extern "C"

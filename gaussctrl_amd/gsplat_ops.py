@@ -134,7 +134,7 @@ def spherical_harmonics(degrees_to_use, viewdirs, coeffs):
 
 
 # --------------------------------------------------------------------------------------------- binning
-def bin_and_sort_gaussians(N, xys, depths, radii, num_tiles_hit, tile_bounds, want_keys=False):
+def bin_and_sort_gaussians(N, xys, depths, radii, num_tiles_hit, tile_bounds, want_keys=False, m_cap=None):
     """Two-level binning (csrc/raster_sort.hip): depth-sort the Gaussians, emit (tile, id) in depth order, stable radix
     passes over the tile id, tile bins.  Same gaussian_ids_sorted / tile_bins as gsplat's bin_and_sort_gaussians
     (reference call sites gc_model.py:174-202).  Returns (M, isect_ids_sorted | None, gaussian_ids_sorted, tile_bins,
@@ -150,10 +150,23 @@ def bin_and_sort_gaussians(N, xys, depths, radii, num_tiles_hit, tile_bounds, wa
     ws = torch.empty(wb, dtype=torch.uint8, device=dev)
     L.check(lib.gc_raster_depth_order(L.i64(N), L.ptr(depths), L.ptr(radii), L.ptr(num_tiles_hit), L.ptr(order), L.ptr(cum),
                                       L.ptr(cnt), L.ptr(ws), L.C.c_size_t(wb), st), "gc_raster_depth_order")
+    bins = torch.empty(T, 2, dtype=torch.int32, device=dev)
+    if m_cap is not None:
+        # sync-free: buffers sized for the caller's capacity, count and overflow flag stay on the device.
+        # Returns M = (count tensor, overflow tensor) instead of a host int.
+        M = int(m_cap)
+        ids_s = torch.empty(M, dtype=torch.int32, device=dev)
+        keys_s = torch.empty(M, dtype=torch.int64, device=dev) if want_keys else None
+        ovf = torch.empty(1, dtype=torch.int32, device=dev)
+        bb = int(lib.gc_raster_bin_workspace_bytes(L.i64(M)))
+        bws = torch.empty(bb, dtype=torch.uint8, device=dev)
+        L.check(lib.gc_raster_bin_tiles_dev(L.i64(N), L.i64(M), L.ptr(cnt), L.ptr(ovf), L.ptr(order), L.ptr(cum), L.ptr(xys),
+                                            L.ptr(depths), L.ptr(radii), L.i32(tile_bounds[0]), L.i32(tile_bounds[1]), L.ptr(ids_s),
+                                            L.ptr(bins), L.ptr(keys_s), L.ptr(bws), L.C.c_size_t(bb), st), "gc_raster_bin_tiles_dev")
+        return (cnt, ovf), keys_s, ids_s, bins, cum
     m_host = L.C.c_int32(0)
     L.check(lib.gc_raster_read_count(L.ptr(cnt), L.C.byref(m_host), st), "gc_raster_read_count")
     M = int(m_host.value)
-    bins = torch.empty(T, 2, dtype=torch.int32, device=dev)
     ids_s = torch.empty(M, dtype=torch.int32, device=dev)
     keys_s = torch.empty(M, dtype=torch.int64, device=dev) if want_keys else None
     bb = int(lib.gc_raster_bin_workspace_bytes(L.i64(M)))
@@ -268,6 +281,7 @@ class RenderAux:
     tile_bins = None
     final_index = None
     isect_ids_sorted = None
+    m_cap = None          # set to an intersection capacity for the sync-free path: M then is (count, overflow) device tensors
 
 
 class _RenderView(torch.autograd.Function):
@@ -295,7 +309,7 @@ class _RenderView(torch.autograd.Function):
             L.i32(sh_degree_to_use), V, P, O, L.f32(cam["fx"]), L.f32(cam["fy"]), L.f32(cam["cx"]), L.f32(cam["cy"]),
             L.i32(H), L.i32(W), L.i32(tb[0]), L.i32(tb[1]), L.f32(0.01), L.ptr(xys), L.ptr(depths), L.ptr(radii),
             L.ptr(conics), L.ptr(nth), L.ptr(rgbs), L.ptr(opac), st), "gc_project_sh_fwd")
-        M, keys_s, ids_s, bins, _ = bin_and_sort_gaussians(N, xys, depths, radii, nth, tb)
+        M, keys_s, ids_s, bins, _ = bin_and_sort_gaussians(N, xys, depths, radii, nth, tb, m_cap=None if aux is None else aux.m_cap)
         bg = _c(background)
         extra = depths if want_depth else None
         img, dep, fT, fi = _rasterize_fwd(H, W, tb, ids_s, bins, xys, conics, rgbs, opac, extra, bg)

@@ -115,6 +115,15 @@ int gc_raster_bin_tiles(int64_t N, int64_t M, const int32_t *depth_order, const 
                         int32_t *gaussian_ids_sorted, int32_t *tile_bins, int64_t *isect_ids_sorted,
                         void *workspace, size_t workspace_bytes, void *stream);
 
+/* Sync-free phase 2 (the "device-side counter + capacity check" convention of the boundary): the intersection count is
+ * read on the device from count_dev (as written by gc_raster_depth_order); buffers are sized for the caller's capacity
+ * M_cap; *overflow_dev = 1 when the frame needed more than M_cap intersections (re-run with a larger capacity).
+ * No host round trip anywhere in the frame. */
+int gc_raster_bin_tiles_dev(int64_t N, int64_t M_cap, const int32_t *count_dev, int32_t *overflow_dev,
+                            const int32_t *depth_order, const int32_t *cum_sorted, const float *xys, const float *depths,
+                            const int32_t *radii, int tiles_x, int tiles_y, int32_t *gaussian_ids_sorted, int32_t *tile_bins,
+                            int64_t *isect_ids_sorted, void *workspace, size_t workspace_bytes, void *stream);
+
 /* gsplat.rasterize_gaussians forward: RGB (+ optional extra channel, used for the reference's
  * second "depth" pass gc_model.py:191-202, composited in the same sweep) + final_Ts + final_index.
  * colors[N,3], opacities[N], extra[N] or NULL, background[3] (device) ->

@@ -107,6 +107,14 @@ def test_bin_and_sort_bit_exact(oracle_c, N, W, H, fx):
     assert int(cum2[-1]) == o["M"]
     M3, keys3, ids3, bins3, _ = ops.bin_and_sort_gaussians(*args)
     assert keys3 is None and torch.equal(ids3, ids2) and torch.equal(bins3, bins2)
+    # sync-free variant: capacity-sized buffers, the count and the overflow flag stay on the device
+    cap = int(o["M"] * 1.3) + 7
+    (cnt, ovf), keys4, ids4, bins4, _ = ops.bin_and_sort_gaussians(*args, want_keys=True, m_cap=cap)
+    assert int(cnt) == o["M"] and int(ovf) == 0
+    assert torch.equal(ids4[:M], ids2) and torch.equal(keys4[:M], keys2) and torch.equal(bins4, bins2)
+    if M > 64:                       # too small a capacity is reported, not silently truncated
+        (cnt5, ovf5), _, _, _, _ = ops.bin_and_sort_gaussians(*args, m_cap=M // 2)
+        assert int(cnt5) == o["M"] and int(ovf5) == 1
 
 
 @pytest.mark.parametrize("N,W,H,fx,sm", [(5000, 200, 136, 180.0, 0.03), (100000, 512, 512, 540.0, 0.01), (3, 40, 24, 50.0, 0.2)])
@@ -171,6 +179,17 @@ def test_fused_render_view(oracle_c, N, W, H, fx, sm, training):
     for k in P:
         _grad_close(tp[k].grad.cpu().numpy(), o["grads"][k], scale)
     _grad_close(aux.xys_grad.cpu().numpy(), o["grads"]["xys"], scale)
+    # sync-free frame (device-side intersection count, capacity-sized buffers): same image, no overflow; grads within atomics noise
+    tq = {k: _t(v).requires_grad_(True) for k, v in P.items()}
+    aux2 = ops.RenderAux(); aux2.m_cap = int(aux.M * 1.25) + 16
+    rgb2, alpha2, depth2 = ops.render_view(tq["means"], tq["scales"], tq["quats"], tq["opacities"], tq["features_dc"],
+                                           tq["features_rest"], cam, _t(BG), not training, 3, aux2)
+    cnt, ovf = aux2.M
+    assert int(cnt) == aux.M and int(ovf) == 0
+    assert torch.equal(rgb2, rgb) and torch.equal(alpha2, alpha)
+    ((rgb2 * _t(v_rgb)).sum() + (alpha2 * _t(v_a)).sum()).backward()
+    for k in P:
+        _grad_close(tq[k].grad.cpu().numpy(), o["grads"][k], scale)
 
 
 def test_psnr_vs_oracle_full_size(oracle_c):
