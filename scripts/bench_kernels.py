@@ -48,7 +48,7 @@ if what in ('linear', 'all'):
     print(f"--- linear ({dt}) B={B}")
     for (L, K, N, geglu, cnt) in [(4096, 320, 320, False, 30), (4096, 320, 2560, True, 5), (4096, 1280, 320, False, 5), (4096, 320, 960, False, 0),
                              (1024, 640, 640, False, 30), (1024, 640, 5120, True, 5), (1024, 2560, 640, False, 5),
-                             (256, 1280, 1280, False, 30), (256, 1280, 10240, True, 5), (256, 5120, 1280, False, 5), (64, 1280, 1280, False, 6), (1, 1280, 1280, False, 22)]:
+                             (256, 1280, 1280, False, 30), (256, 1280, 10240, True, 5), (256, 5120, 1280, False, 5), (64, 1280, 1280, False, 6), (64, 5120, 1280, False, 1), (64, 1280, 10240, True, 1), (1, 1280, 1280, False, 22)]:
         x = rnd(B, L, K); w = rnd(N, K, scale=K ** -0.5); b = torch.randn(N, device=DEV)
         if geglu: w, b = geglu_permute(w, b)
         us = timeit(lambda: ops.linear(x, w, b, geglu=geglu))
