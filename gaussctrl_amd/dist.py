@@ -9,8 +9,11 @@ Collectives:
     (236 / 472 / 944 MB at 1 / 2 / 4 M Gaussians) instead of a per-tensor DDP bucket walk -- xGMI rings are
     per-link bound, so few large messages;
   * all-gather of the edited images at the end of edit_images (3 MB per view) so every rank trains on all views;
-  * the reference K/V bank is REPLICATED in round 1 (every rank runs the 4-view reference trajectory itself: no
-    data-path collective, +4/V_local compute); the pipelined per-step broadcast of the bank is the planned replacement.
+  * the reference K/V bank is REPLICATED by default (every rank runs the 4-view reference trajectory itself: no
+    data-path collective, +4/V_local compute -- SURVEY 8e calls this the validation mode); `broadcast_ref_bank` is the
+    opt-in alternative: the owner rank computes the trajectory once and broadcasts each DDIM step's K / V^T as ONE flat
+    buffer per step (20 messages of ~0.5 GB per scene instead of 920 small ones: ring collectives over xGMI are per-link
+    bound), issued step by step so that a caller can overlap step i's transfer with step i+1's compute.
 These helpers are device-agnostic so the N>1 logic is covered by world_size-2 gloo tests on CPU."""
 from __future__ import annotations
 
@@ -55,3 +58,45 @@ def allgather_view_images(local: dict, n_views: int, world_size: int, rank: int,
         for j, v in enumerate(shard_views(n_views, world_size, r)):
             out[v] = bufs[r][j]
     return out
+
+
+def _bank_steps(store: dict) -> list:
+    return sorted({k[0] for k in store})
+
+
+def broadcast_ref_bank(bank, src: int, world_size: int, rank: int, device=None, steps=None):
+    """Broadcast a RefBank (gaussctrl_amd.sd.unet.RefBank) from rank `src` to every rank, one flat buffer per DDIM step.
+
+    On `src`, `bank` holds {(step, layer): (K [R,L,C] (a column slice of the Q|K buffer), V^T [R,C,Lp])}.  The other ranks pass an
+    empty RefBank and get the same keys; K is re-materialised with the row stride the attention kernel expects (2 C: the bank K
+    is read with the live K's leading dimension).  `steps` restricts the call to some DDIM steps (pipelined use: broadcast step i
+    while step i+1 is being computed)."""
+    if world_size <= 1:
+        return bank
+    import torch.distributed as dist
+    meta = [None]
+    if rank == src:
+        todo = _bank_steps(bank.store) if steps is None else list(steps)
+        meta[0] = [(st, [(key[1], tuple(k.shape), k.stride(1), tuple(vt.shape), str(k.dtype)) for key, (k, vt) in sorted(bank.store.items(), key=lambda kv: str(kv[0])) if key[0] == st])
+                   for st in todo]
+    dist.broadcast_object_list(meta, src=src)
+    for st, layers in meta[0]:
+        n = sum(int(torch.Size(ks).numel()) + int(torch.Size(vs).numel()) for _, ks, _, vs, _ in layers)
+        dtype = getattr(torch, layers[0][4].split(".")[-1])
+        if rank == src:
+            flat = torch.cat([t.reshape(-1) for layer, *_ in layers for t in (bank.store[(st, layer)][0].contiguous(), bank.store[(st, layer)][1])])
+        else:
+            flat = torch.empty(n, dtype=dtype, device=device)
+        dist.broadcast(flat, src=src)
+        if rank != src:
+            o = 0
+            for layer, ks, kstride, vs, _ in layers:
+                nk, nv = int(torch.Size(ks).numel()), int(torch.Size(vs).numel())
+                buf = torch.empty(ks[0], ks[1], kstride, dtype=dtype, device=flat.device)      # row stride of the Q|K buffer
+                k = buf[..., kstride - ks[2]:]
+                k.copy_(flat[o:o + nk].view(ks)); o += nk
+                vt = flat[o:o + nv].view(vs).clone(); o += nv
+                bank.store[(st, layer)] = (k, vt)
+    if rank != src:
+        bank.mode = "use"
+    return bank

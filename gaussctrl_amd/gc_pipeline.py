@@ -75,6 +75,8 @@ class GaussCtrlPipelineConfig:
     # --- additions of this implementation
     dtype: str = "f16"                 # the reference runs fp16 (:101); "bf16" is the throughput default of bench.py
     cache_reference_kv: bool = True
+    ref_bank_owner: int = -1           # world_size > 1: rank that computes the reference trajectory and broadcasts its K / V^T
+                                       # (-1: every rank computes it itself -- no data-path collective)
 
     def setup(self, **kw):
         return GaussCtrlPipeline(self, **kw)
@@ -171,7 +173,16 @@ class GaussCtrlPipeline(nn.Module):
             raise RuntimeError("reference views must be rendered/inverted on every rank (render_reverse with world_size>1 shards "
                                "views; call render_reverse_refs first)")
         ref_disp = torch.stack([self.depth2disparity_torch(td[i]["depth_image"]) for i in self.ref_indices])
-        bank = self.pipe.build_ref_bank(ref_z0, ref_disp, cn, cp) if self.config.cache_reference_kv else None
+        bank = None
+        if self.config.cache_reference_kv:
+            owner = self.config.ref_bank_owner
+            if self.world_size > 1 and owner >= 0:
+                from .dist import broadcast_ref_bank
+                from .sd.unet import RefBank
+                bank = self.pipe.build_ref_bank(ref_z0, ref_disp, cn, cp) if self.local_rank == owner else RefBank()
+                bank = broadcast_ref_bank(bank, owner, self.world_size, self.local_rank, self.device)
+            else:
+                bank = self.pipe.build_ref_bank(ref_z0, ref_disp, cn, cp)
         views = self._my_views()
         for s in range(0, len(views), self.chunk_size):
             chunk = views[s:s + self.chunk_size]

@@ -24,7 +24,26 @@ def _worker(rank, world, port, ret):
         local = {v: torch.full((4, 6, 3), float(v)) for v in mine}
         allv = allgather_view_images(local, n, world, rank, (4, 6, 3), "cpu")
         ok_img = sorted(allv) == list(range(n)) and all(float(allv[v].mean()) == float(v) for v in range(n))
-        ret[rank] = (mine, ok_grad, ok_img)
+        # reference K / V^T bank: owner rank 1 -> everyone, one flat message per DDIM step, K keeps the Q|K row stride
+        from gaussctrl_amd.dist import broadcast_ref_bank
+        from gaussctrl_amd.sd.unet import RefBank
+        bank = RefBank()
+        g = torch.Generator().manual_seed(5)
+        want = {}
+        for st in range(3):
+            for li, (L_, C_) in enumerate([(16, 8), (4, 24)]):
+                qk = torch.randn(8, L_, 2 * C_, generator=g).to(torch.bfloat16)
+                vt = torch.randn(8, C_, L_, generator=g).to(torch.bfloat16)
+                want[(st, ("unet", f"layer{li}"))] = (qk[..., C_:].clone(), vt.clone())
+                if rank == 1:
+                    bank.store[(st, ("unet", f"layer{li}"))] = (qk[..., C_:], vt)
+        if rank == 1:
+            bank.mode = "use"
+        broadcast_ref_bank(bank, 1, world, rank, "cpu")
+        ok_bank = bank.mode == "use" and set(bank.store) == set(want)
+        for key, (k, vt) in bank.store.items():
+            ok_bank = ok_bank and torch.equal(k, want[key][0]) and torch.equal(vt, want[key][1]) and k.stride(1) == 2 * k.shape[2]
+        ret[rank] = (mine, ok_grad, ok_img and ok_bank)
     finally:
         dist.destroy_process_group()
 
