@@ -130,6 +130,46 @@ __global__ __launch_bounds__(256) void k_gn_apply(const unsigned short *__restri
     }
 }
 
+// Small tensors (the 16x16 / 8x8 feature maps: a few MB, L2-resident): ONE launch, one workgroup per (batch, group).
+// Pass 1: sums of (x - s) and (x - s)^2 about the group's first element s; pass 2 (re-read from L2): normalise, affine, SiLU.
+// The three-kernel pipeline above is launch-latency bound there (3 x ~5 us for < 2 us of traffic).
+template <class T>
+__global__ __launch_bounds__(256) void k_gn_small(const unsigned short *__restrict__ x, unsigned short *__restrict__ y, int HW, int C,
+                                                  int G, const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                                  int act)
+{
+    __shared__ float red[2][4];
+    const int b = blockIdx.x / G, gi = blockIdx.x % G, cpg = C / G, hp = cpg / 2;     // hp: 4-byte pairs per pixel of this group
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const unsigned *xb = reinterpret_cast<const unsigned *>(x + ((size_t)b * HW * C + (size_t)gi * cpg));
+    unsigned *yb = reinterpret_cast<unsigned *>(y + ((size_t)b * HW * C + (size_t)gi * cpg));
+    const int n = HW * hp, rowp = C / 2;                                               // pairs in the group; pairs per pixel row
+    const float sh = T::to_f((unsigned short)(xb[0] & 0xffff));
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = tid; i < n; i += 256) {
+        const int p = i / hp, c = i - p * hp;
+        const unsigned u = xb[(size_t)p * rowp + c];
+        const float a = T::to_f((unsigned short)(u & 0xffff)) - sh, d = T::to_f((unsigned short)(u >> 16)) - sh;
+        s1 += a + d; s2 += a * a + d * d;
+    }
+    s1 = wave_sum_f(s1); s2 = wave_sum_f(s2);
+    if (lane == 0) { red[0][wid] = s1; red[1][wid] = s2; }
+    __syncthreads();
+    const float cnt = (float)HW * (float)cpg;
+    const float m1 = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / cnt;           // mean of (x - s)
+    const float var = fmaxf((red[1][0] + red[1][1] + red[1][2] + red[1][3]) / cnt - m1 * m1, 0.f);
+    const float mu = sh + m1, rstd = rsqrtf(var + eps);
+    for (int i = tid; i < n; i += 256) {
+        const int p = i / hp, c = i - p * hp;
+        const unsigned u = xb[(size_t)p * rowp + c];
+        const int ch = gi * cpg + 2 * c;
+        float v0 = (T::to_f((unsigned short)(u & 0xffff)) - mu) * rstd * gamma[ch] + beta[ch];
+        float v1 = (T::to_f((unsigned short)(u >> 16)) - mu) * rstd * gamma[ch + 1] + beta[ch + 1];
+        if (act) { v0 = silu(v0); v1 = silu(v1); }
+        yb[(size_t)p * rowp + c] = pack2<T>(v0, v1);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ LayerNorm
 // one wave64 per token row; exact two-pass in registers (C <= 64*8*4).
 template <class T>
@@ -352,6 +392,14 @@ int gc_dn_groupnorm(int dtype, const void *x, void *y, int64_t B, int64_t HW, in
     GC_REQUIRE(C % 8 == 0 && C % G == 0 && stats_ws, "groupnorm: C must be a multiple of 8 and of G; workspace required");
     GC_REQUIRE(C / G <= 256 && B * HW * (C / 8) < (int64_t)1 << 31, "groupnorm: group too wide / tensor too large");
     hipStream_t s = gc::S(stream);
+    if ((C / G) % 2 == 0 && B * HW * (int64_t)C <= ((int64_t)1 << 20) && B * G >= 64) {      // <= 2 MB (the 8x8 maps): one launch, 5 vs 12 us
+        DN_DISPATCH(dtype,
+                    hipLaunchKernelGGL((k_gn_small<BF16>), dim3((unsigned)(B * G)), dim3(256), 0, s, (const unsigned short *)x,
+                                       (unsigned short *)y, (int)HW, C, G, gamma, beta, eps, act),
+                    hipLaunchKernelGGL((k_gn_small<F16>), dim3((unsigned)(B * G)), dim3(256), 0, s, (const unsigned short *)x,
+                                       (unsigned short *)y, (int)HW, C, G, gamma, beta, eps, act));
+        return gc::check_launch("gc_dn_groupnorm");
+    }
     int nslab, ppb, ny, nchb;
     gn_plan(B, HW, C, &nslab, &ppb, &ny, &nchb);
     float *part = stats_ws, *coef = stats_ws + 2 * (size_t)B * C * nslab;
