@@ -35,3 +35,16 @@ M2, k2, i2, b2, _ = ops.bin_and_sort_gaussians(N, xys, depths, radii, nth, tb, w
 print(f"N={N} M={M} visible={(radii > 0).sum().item()}  equal: ids={torch.equal(i1, i2)} bins={torch.equal(b1, b2)} keys={torch.equal(k1, k2)}")
 print(f"  64-bit key chain (scan+map+rocPRIM sort+bins): {timeit(lambda: ops.bin_and_sort_gaussians_keys64(N, xys, depths, radii, nth, tb)):8.1f} us")
 print(f"  two-level binning (depth order + tile passes): {timeit(lambda: ops.bin_and_sort_gaussians(N, xys, depths, radii, nth, tb)):8.1f} us")
+
+# fused render (project + SH + binning + compositing) forward and forward+backward
+tq = {k: v.clone().requires_grad_(True) for k, v in tp.items()}
+bg = torch.zeros(3, device=dev)
+def fwd():
+    with torch.no_grad():
+        ops.render_view(tq["means"], tq["scales"], tq["quats"], tq["opacities"], tq["features_dc"], tq["features_rest"], cam, bg, True, 3, None)
+def fwdbwd():
+    for p in tq.values(): p.grad = None
+    rgb, alpha, _ = ops.render_view(tq["means"], tq["scales"], tq["quats"], tq["opacities"], tq["features_dc"], tq["features_rest"], cam, bg, False, 3, None)
+    rgb.abs().mean().backward()
+print(f"  eval render (rgb + depth + alpha):             {timeit(fwd, 10):8.1f} us")
+print(f"  train render fwd + bwd:                        {timeit(fwdbwd, 10):8.1f} us")
