@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=14)   # one scene of V=40 views at chunk_size 3 = 14 chunks (+ 1 reference trajectory)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--gaussians", type=int, default=1_000_000)
-    ap.add_argument("--views", type=int, default=40)
+    ap.add_argument("--views", type=int, default=None)     # default: 40 (edit, BASELINE configs[1]) / 256 cameras (raster, configs[4])
     ap.add_argument("--chunk-size", type=int, default=3)
     ap.add_argument("--denoise-steps", type=int, default=20)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
@@ -133,9 +133,11 @@ def main():
     from gaussctrl_amd.sd.weights import prepare
 
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    if args.views is None:
+        args.views = 40 if args.workload == "edit" else 256
     c, V, nsteps = args.chunk_size, args.views, args.denoise_steps
     H = W = 512
-    K = syn.BEAR_INTRINSICS
+    K = syn.BEAR_INTRINSICS if args.workload == "edit" else syn.ROUND_INTRINSICS      # config 5 uses fx=fy=540, cx=cy=256
 
     # ---------------------------------------------------------------- scene, cameras, networks (untimed setup)
     P = syn.make_gaussians(args.gaussians, seed=0)
@@ -145,10 +147,13 @@ def main():
     bg = torch.zeros(3, device=dev)
     pipe = None
     if args.workload == "edit":
-        uw = prepare(arch.random_state_dict(arch.unet_shapes(), 100, dev), dt, dev, heads=8)
-        cw = prepare(arch.random_state_dict(arch.controlnet_shapes(), 200, dev), dt, dev, heads=8)
+        fold_ln = os.environ.get("GC_DN_FOLD_LN", "1") != "0"          # A/B switches of the round-2 normalisation fusions
+        fuse_gn = os.environ.get("GC_DN_FUSE_GN", "1") != "0"
+        uw = prepare(arch.random_state_dict(arch.unet_shapes(), 100, dev), dt, dev, heads=8, fold_ln=fold_ln)
+        cw = prepare(arch.random_state_dict(arch.controlnet_shapes(), 200, dev), dt, dev, heads=8, fold_ln=fold_ln)
         vw = prepare_vae_weights(arch.random_state_dict(arch.vae_decoder_shapes(), 300, dev), dt, dev)
         pipe = DenoisePipeline(uw, cw, vw, nsteps, 5.0)
+        pipe.unet.fuse_stats = pipe.controlnet.fuse_stats = fuse_gn
     g = torch.Generator(device=dev).manual_seed(2 + rank)
     ctx_neg = torch.randn(1, 77, 768, device=dev, generator=g)
     ctx_pos = torch.randn(1, 77, 768, device=dev, generator=g)
@@ -160,6 +165,8 @@ def main():
     state = {"bank": None, "next": None}
 
     syncfree = os.environ.get("GC_BENCH_SYNCFREE", "1") != "0"
+    from gaussctrl_amd.train_ops import l1_ssim_loss
+    raster_target = torch.rand(H, W, 3, device=dev, generator=g)      # raster-only workload: a fixed synthetic target image
 
     def new_aux():
         aux = gops.RenderAux()
@@ -194,7 +201,8 @@ def main():
         x 20 DDIM steps, shared by its chunks) is computed while the PREVIOUS scene is edited, 20 / chunks_per_scene DDIM steps
         per chunk, so every step carries exactly its share of the reference work whatever K is."""
         j = s % chunks_per_scene
-        views = [(s * c + k) % V for k in range(c)]
+        views = list(range(j * c, min(V, (j + 1) * c)))          # the last chunk of a scene is short (40 = 13 x 3 + 1), gc_pipeline.py:190
+        state["views_done"] = state.get("views_done", 0) + len(views)
         if args.workload == "edit":
             if state["bank"] is None:                # the very first scene (setup): its whole reference trajectory at once
                 state["bank"] = pipe.advance_ref_bank(start_ref_trajectory())
@@ -209,7 +217,7 @@ def main():
                 assert done is not None
                 state["bank"], state["next"] = done, None
         else:
-            edited = [None] * c
+            edited = [None] * len(views)
         for p in params.values():
             p.grad = None
         for j, i in enumerate(views):                                                                       # (d)
@@ -217,8 +225,8 @@ def main():
             rgb, alpha, _ = gops.render_view(params["means"], params["scales"], params["quats"], params["opacities"],
                                              params["features_dc"], params["features_rest"], my_cams[i],
                                              torch.rand(3, device=dev), False, 3, aux)
-            target = edited[j].permute(1, 2, 0) if edited[j] is not None else torch.zeros_like(rgb)
-            loss = (rgb - target).abs().mean()
+            target = edited[j].permute(1, 2, 0).contiguous() if edited[j] is not None else raster_target
+            loss = l1_ssim_loss(rgb, target, 0.2)             # the product path's loss (fused L1 + SSIM value and gradient kernels)
             loss.backward()
             note_m(aux)
         if dist is not None:
@@ -237,10 +245,12 @@ def main():
     for _ in range(2 + args.warmup):
         step(g); g += 1
     barrier()
+    v0 = state.get("views_done", 0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(g); g += 1
     barrier()
+    state["views_timed"] = state.get("views_done", 0) - v0
     dt_s = time.perf_counter() - t0
     if dist is not None:
         tt = torch.tensor([dt_s], device=dev, dtype=torch.float64)
@@ -251,7 +261,7 @@ def main():
         ovfs = torch.stack([b for _, b in stats["dev"]]).flatten().cpu()
         assert int(ovfs.max()) == 0, "intersection capacity exceeded in a sync-free frame: raise the capacity margin"
         stats["M"] += [int(v) for v in cnts]
-    views_done = args.steps * c * world
+    views_done = state["views_timed"] * world
     value = views_done / dt_s
 
     # ---------------------------------------------------------------- roofline of the dominant kernel (instrumented extra step)
@@ -279,20 +289,25 @@ def main():
                 "other": {k: {"launches": v["launches"], "ms": round(v["ms"], 2),
                               "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in sm.items() if k != kind}}
 
+    if args.workload == "raster" and rank == 0:
+        roof = raster_roofline(args, step, g, stats, H * W)
+
     # ---------------------------------------------------------------- CPU baseline (oracle, rank 0, bounded sample)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
 
     if rank == 0:
-        out = {"metric": "edited views/sec @512x512 (ControlNet denoise + splat render+bwd)", "value": round(value, 4),
+        metric = ("edited views/sec @512x512 (ControlNet denoise + splat render+bwd)" if args.workload == "edit" else
+                  "raster-only train-render fwd+bwd views/sec @512x512 (BASELINE configs[4])")
+        out = {"metric": metric, "value": round(value, 4),
                "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * dt_s / args.steps, 2), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "vs_baseline": None, "dtype": args.dtype if args.workload == "edit" else "f32", "data": "synthetic",
                "config": {"workload": f"bear-like scene, {V} views/GPU, ref_view_num=4, chunk_size={c}, "
                                       f"{nsteps} DDIM steps, SD1.5+ControlNet-depth shapes (random weights), "
                                       f"{args.gaussians} Gaussians, 512x512" if args.workload == "edit" else
-                                      f"raster-only fwd+bwd, {args.gaussians} Gaussians, 512x512",
+                                      f"raster-only fwd+bwd (+ fused L1+SSIM loss), {args.gaussians} Gaussians, {V} random cameras/GPU, 512x512, fx=fy=540",
                           "views_per_step": c * world, "parallelism": f"views sharded x{world}, reference K/V replicated, grad all-reduce; ControlNet || UNet encoder on 2 HIP streams",
                           "mean_intersections_M": int(np.mean(stats["M"])) if stats["M"] else 0,
                           "ref_trajectory_in_timed_region": bool(args.workload == "edit"),
@@ -301,6 +316,94 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+class LibTimer:
+    """Proxy of the ctypes library handle that brackets every compute entry point with HIP events on the launch stream
+    (instrumented pass of the raster-only workload)."""
+    SKIP = ("gc_last_error_string", "gc_abi_version", "gc_raster_read_count")
+
+    def __init__(self, lib):
+        self._l = lib
+        self.rec = []
+
+    def __getattr__(self, name):
+        f = getattr(self._l, name)
+        if not name.startswith("gc_") or name.endswith("_bytes") or name in self.SKIP:
+            return f
+
+        def timed(*a):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = f(*a)
+            e.record()
+            self.rec.append((name, s, e))
+            return r
+        return timed
+
+
+# algorithmic HBM bytes of one training render (forward + backward) per stage: coefficients of (N Gaussians, M tile
+# intersections, HW pixels) from SURVEY.md 8(d); they add up to N*868 + M*124 + HW*44
+RASTER_STAGES = {
+    "gc_project_sh_fwd": ("k_project_sh_fwd", 280, 0, 0),
+    "gc_raster_depth_order": ("binning: depth keys + 4 radix passes + scan (raster_sort.hip)", 0, 0, 0),      # counted with the next row
+    "gc_raster_bin_tiles_dev": ("binning: emit + 2 tile radix passes + bins (raster_sort.hip)", 0, 44, 0),
+    "gc_raster_bin_tiles": ("binning: emit + 2 tile radix passes + bins (raster_sort.hip)", 0, 44, 0),
+    "gc_rasterize_fwd": ("k_rasterize_fwd", 0, 40, 20),
+    "gc_raster_finalize": ("k_raster_finalize", 0, 0, 0),
+    "gc_l1_ssim_fwd_bwd": ("k_ssim_stats + k_ssim_grad (loss, not in the 8d byte count)", 0, 0, 0),
+    "gc_rasterize_bwd": ("k_rasterize_bwd", 36, 40, 24),
+    "gc_project_sh_bwd": ("k_project_sh_bwd", 552, 0, 0),
+}
+
+
+def raster_roofline(args, step, g, stats, HW):
+    """One instrumented step of the raster-only workload: per-stage HIP-event durations -> achieved algorithmic GB/s per stage
+    and for the whole forward + backward chain; `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes
+    (profiles/r02_raster_traffic.json, FETCH_SIZE / WRITE_SIZE collected in separate passes by scripts/pmc_traffic.py) when the
+    configuration matches, else null."""
+    from gaussctrl_amd import _lib as L
+    real = L.lib()
+    timer = LibTimer(real)
+    n_dev = len(stats["dev"])
+    L._lib = timer
+    try:
+        step(g)
+        torch.cuda.synchronize()
+    finally:
+        L._lib = real
+    Ms = [int(a.item()) for a, _ in stats["dev"][n_dev:]] or stats["M"][-8:]        # intersections of the instrumented views
+    nviews = max(1, sum(1 for n, _, _ in timer.rec if n == "gc_rasterize_bwd"))
+    M = float(np.mean(Ms))
+    N = args.gaussians
+    per = {}
+    for name, s, e in timer.rec:
+        per.setdefault(name, []).append(s.elapsed_time(e) * 1e-3)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r02_raster_traffic.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        traffic = tj.get(str(N))
+    stages, tot_b, tot_s = {}, 0.0, 0.0
+    for name, (label, cn, cm, chw) in RASTER_STAGES.items():
+        if name not in per:
+            continue
+        secs = float(np.mean(per[name]))
+        b = cn * N + cm * M + chw * HW
+        tot_b += b; tot_s += secs
+        stages[name] = {"kernel": label, "avg_us": round(secs * 1e6, 1), "algorithmic_MB": round(b / 1e6, 1),
+                        "GBps": round(b / secs / 1e9, 1) if b else None,
+                        "traffic_MB": None if not traffic or name not in traffic else traffic[name]}
+    dom = max((k for k in stages if stages[k]["GBps"]), key=lambda k: stages[k]["avg_us"])
+    d = stages[dom]
+    ach = d["algorithmic_MB"] * 1e6 / (d["avg_us"] * 1e-6) / 1e9
+    return {"bound": "hbm", "kernel": f"{d['kernel']} ({dom}, dominant stage of the render fwd+bwd chain)", "achieved": round(ach, 1),
+            "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": d["traffic_MB"] and d["traffic_MB"] * 1e6,
+            "avg_launch_us": d["avg_us"], "algorithmic_bytes_per_launch": d["algorithmic_MB"] * 1e6,
+            "chain": {"algorithmic_MB_per_view": round(tot_b / 1e6, 1), "kernel_us_per_view": round(tot_s * 1e6, 1),
+                      "GBps": round(tot_b / tot_s / 1e9, 1), "frac": round(tot_b / tot_s / 8e12, 4), "views_in_sample": nviews,
+                      "N": N, "M_mean": int(M), "formula": "N*868 + M*124 + HW*44 bytes per view (SURVEY.md 8d)"},
+            "stages": stages}
 
 
 def cpu_baseline(args):
@@ -314,6 +417,17 @@ def cpu_baseline(args):
     cores = os.cpu_count() or 1
     threads = min(cores, 64)
     torch.set_num_threads(threads)
+    if args.workload == "raster":
+        N = 200_000
+        P = syn.make_gaussians(N, seed=0)
+        c2w = syn.make_cameras(1, seed=1)[0]
+        K = syn.ROUND_INTRINSICS
+        t0 = time.perf_counter()
+        raster_c.render(P, c2w, K["fx"], K["fy"], K["cx"], K["cy"], 512, 512, np.zeros(3, np.float32), training=True,
+                        v_rgb=np.ones((512, 512, 3), np.float32))
+        t = (time.perf_counter() - t0) * (args.gaussians / N)
+        return {"value": round(1.0 / t, 4), "unit": "views/s", "cores": 1, "kind": "port",
+                "sample": f"C oracle (oracle/raster_ref.c, 1 thread) train render fwd+bwd at N={N} scaled linearly to N={args.gaussians}: {t:.2f}s per view"}
     with torch.no_grad():
         uw = sd.make_unet_weights(sd.SD15, 100); cw = sd.make_controlnet_weights(sd.SD15, 200)
         f = 5

@@ -730,8 +730,8 @@ void launch_attn3_(const AttnArgs &a, int B, hipStream_t s)
     constexpr int DP = (D + 31) / 32 * 32, CPR = DP / 8, DV = (D + 16) / 16 * 16;
     constexpr size_t ring = (size_t)NST * (64 * CPR * 16 + DV * 128), safe = SafeLds<D>::KBYTES + SafeLds<D>::VBYTES;
     constexpr size_t lds = ring > safe ? ring : safe;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)k_attn3<T, D, QT, NST, RAG, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    static gc::AttrOnce once;
+    gc::ensure_dynamic_lds(once, (const void *)k_attn3<T, D, QT, NST, RAG, PRE>, (int)lds);
     AttnArgs aa = a;
     aa.nqb = (a.Lq + 64 * QT - 1) / (64 * QT);
     dim3 grid((unsigned)(aa.nqb * a.H * B));
@@ -749,9 +749,8 @@ void launch_attn3(const AttnArgs &a, int B, hipStream_t s)
 #define ATT80_QT 1
 #endif
 template <class T>
-int launch_attn(const AttnArgs &a, int D, int B, hipStream_t s)
+int launch_attn(const AttnArgs &a, int D, int B, bool fast, hipStream_t s)
 {
-    static const int fast = [] { const char *e = getenv("GC_ATTN_SAFE"); return e ? !atoi(e) : 1; }();   // GC_ATTN_SAFE=1: online-softmax kernel everywhere
     if (fast && (int64_t)a.nsets * ((a.Lk + 63) / 64) >= 4) {   // short key streams: the pipeline's fill / LDS set-up does not amortise
         switch (D) {
         case 40: launch_attn3<T, 40, 2, 3>(a, B, s); return GC_OK;
@@ -803,8 +802,9 @@ extern "C" int gc_dn_attention(const gc_attn_desc *d, void *stream)
     GC_REQUIRE((d->Kref == nullptr) == (d->Vtref == nullptr), "Kref and Vtref must be given together");
     for (int i = 0; i < d->nsets; ++i) GC_REQUIRE(d->set_kind[i] >= -2 && d->set_kind[i] < a.ref_fph, "bad set_kind");
     a.scale_log2e = d->q_prescaled ? 1.f : d->scale * 1.4426950408889634f;
-    int rc = d->dtype == DT_BF16 ? launch_attn<BF16>(a, d->head_dim, d->batch, gc::S(stream))
-             : d->dtype == DT_F16 ? launch_attn<F16>(a, d->head_dim, d->batch, gc::S(stream)) : GC_EINVAL;
+    const bool fast = !(d->kernel_variant & 1);      // kernel_variant bit 0: online-softmax kernel everywhere (tests)
+    int rc = d->dtype == DT_BF16 ? launch_attn<BF16>(a, d->head_dim, d->batch, fast, gc::S(stream))
+             : d->dtype == DT_F16 ? launch_attn<F16>(a, d->head_dim, d->batch, fast, gc::S(stream)) : GC_EINVAL;
     if (rc != GC_OK) return rc;
     return gc::check_launch("gc_dn_attention");
 }

@@ -21,7 +21,6 @@
 // across workgroups (fp32 partial slabs + a small reduce-epilogue kernel) so that all 256 CUs stream the (large) weight
 // matrix together.
 #include "dn_common.h"
-#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -53,16 +52,47 @@ struct GemmArgs {
     int splits; int tiles_per_split;    // split-K: k-tiles [z*tps, min(nk, (z+1)*tps))
     float *ws;                          // fp32 [splits][M][N] partial slabs when splits > 1
     const void *zeros;                  // >= 16 bytes of zeros (k_gemm8: source of out-of-range / padding lanes)
+    // LayerNorm folded into this GEMM (consumer side): Act rows are the UN-normalised x, W carries gamma, and
+    // out = rstd[m] * (acc - mean[m] * colsum[n]) + bias'[n]   with (mean, rstd) from row_stats[m] = (sum x, sum x^2) over the K columns
+    const float *row_stats; int row_stat_slots; const float *colsum; float ln_eps, ln_inv_k;
+    // statistics of THIS GEMM's stored output (producer side):
+    float *out_row_stats;               // [slots][M][2] (sum, sum^2) of each row over one column slab per slot, PLAIN stores (no atomics, no
+                                        // zero-init): slot = wave column (16 NTW wide) of the fused epilogue / 256-column block of the
+                                        // split-K reduce; the consumer adds the slots up  -> LayerNorm folded into the next GEMM
+    float *out_group_stats;             // [M / rows_per_batch][groups][2] per (batch, GroupNorm group), reduced in LDS per workgroup, then
+    int gn_groups, gn_cpg;              // a few float atomics into the zero-initialised buffer     -> gc_dn_groupnorm_apply
 };
+constexpr int GS_SLOTS = 20, GS_MAXG = 32;      // LDS scratch of the group statistics: batches a workgroup tile can touch x groups
+
+// sum over the 16 lanes of a DPP row (lanes 16 j .. 16 j + 15), result in every lane: row_ror 8, 4, 2, 1
+__device__ __forceinline__ float row16_sum(float v)
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+    return v;
+}
 
 // byte offset of 16-byte chunk `c` (0..7) of row `r` inside a [rows][64] 2-byte tile
 __device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
 
 // epilogue of one lane's 4 consecutive output channels (n .. n+3) of row m; v = raw accumulators (+ gate for GEGLU)
+// (split-K reduce kernel) epilogue of 4 consecutive output channels of one row; on return v holds the values as stored
 template <class T>
 __device__ __forceinline__ void epilogue_store(const GemmArgs &g, int64_t m, int64_t n, int64_t on, float *v, const float *gate)
 {
     const int64_t bidx = g.rowvec ? m / g.rows_per_batch : 0;
+    if (g.row_stats) {
+        float2 rs = make_float2(0.f, 0.f);
+        for (int sl = 0; sl < g.row_stat_slots; ++sl) {
+            const float2 t = *reinterpret_cast<const float2 *>(g.row_stats + ((int64_t)sl * g.M + m) * 2);
+            rs.x += t.x; rs.y += t.y;
+        }
+        const float mean = rs.x * g.ln_inv_k, rstd = rsqrtf(fmaxf(rs.y * g.ln_inv_k - mean * mean, 0.f) + g.ln_eps);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = rstd * (v[r] - mean * g.colsum[n + r]);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         if (g.bias) v[r] += g.bias[n + r];
@@ -91,17 +121,219 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs &g, int64_t m, int
         v[2] += T::to_f((unsigned short)(rr.y & 0xffff)); v[3] += T::to_f((unsigned short)(rr.y >> 16));
     }
     const bool to_t = g.out_t && on >= g.t_col0;
+    const uint2 pk = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
     if (g.out && !(to_t && g.t_col0 > 0)) {
         if (g.out_f32)
             *reinterpret_cast<float4 *>((float *)g.out + m * g.ldc + on) = make_float4(v[0], v[1], v[2], v[3]);
         else
-            *reinterpret_cast<uint2 *>((unsigned char *)g.out + (m * g.ldc + on) * 2) = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
+            *reinterpret_cast<uint2 *>((unsigned char *)g.out + (m * g.ldc + on) * 2) = pk;
     }
     if (to_t) {   // transposed copy out_t[b][n - t_col0][tok] (V operand of the attention kernel)
         const int64_t b = m / g.rows_per_batch, tok = m - b * g.rows_per_batch;
         unsigned short *o = (unsigned short *)g.out_t + b * g.t_batch_stride + tok;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[(on - g.t_col0 + r) * g.ldt] = T::from_f(v[r]);
+    }
+    if (!g.out_f32) {
+        v[0] = T::to_f((unsigned short)(pk.x & 0xffff)); v[1] = T::to_f((unsigned short)(pk.x >> 16));
+        v[2] = T::to_f((unsigned short)(pk.y & 0xffff)); v[3] = T::to_f((unsigned short)(pk.y >> 16));
+    }
+}
+
+// The epilogue of one wave's (16 MT) x (16 NTW) accumulator tile, shared by k_gemm (MT = 4) and k_gemm8.
+// Lane (fr = lane & 15, fc = lane >> 4) holds out[m = m_wave + 16 mt + fr][n = n_wave + 16 nt + 4 fc + r], r = 0..3.
+// All operand loads of the tile (bias, LN column sums once; row statistics, row-vector and residual of every m-tile) are issued
+// before the first one is consumed: the naive per-accumulator load -> use chain costs ~1 us of latency per m-tile on every launch.
+template <class T, int NTW, int MT, int NTHREADS>
+__device__ __forceinline__ void wave_epilogue(const GemmArgs &g, f32x4 (&acc)[NTW][MT], int64_t m_base, int64_t m_wave, int64_t n_wave, int lane,
+                                              unsigned char *smem)
+{
+    const int fr = lane & 15, fc = lane >> 4;
+    const int64_t n_lane = n_wave + fc * 4;
+    if (g.splits > 1) {   // partial sums of this k-slice: plain 16-byte stores into slab blockIdx.y
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int64_t m = m_wave + mt * 16 + fr;
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int64_t n = n_lane + nt * 16;
+                if (n < g.N)
+                    *reinterpret_cast<float4 *>(g.ws + ((int64_t)blockIdx.y * g.M + m) * g.N + n) =
+                        make_float4(acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]);
+            }
+        }
+        return;
+    }
+    float4 bia[NTW], csm[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int64_t n = n_lane + nt * 16;
+        bia[nt] = (g.bias && n < g.N) ? *reinterpret_cast<const float4 *>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        csm[nt] = (g.row_stats && n < g.N) ? *reinterpret_cast<const float4 *>(g.colsum + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    uint2 rs_all[MT][NTW];
+    float2 st_all[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int64_t m = m_wave + mt * 16 + fr;
+        const bool okm = m < g.M;
+        const int64_t mc = okm ? m : 0;
+        st_all[mt] = make_float2(0.f, 0.f);
+        if (g.row_stats)
+            for (int sl = 0; sl < g.row_stat_slots; ++sl) {       // the producer left one partial (sum, sum^2) per column slab
+                const float2 t = *reinterpret_cast<const float2 *>(g.row_stats + ((int64_t)sl * g.M + mc) * 2);
+                st_all[mt].x += t.x; st_all[mt].y += t.y;
+            }
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int64_t n = n_lane + nt * 16;
+            const bool okn = okm && n < g.N && !(g.geglu && (nt & 1));
+            const int64_t on = g.geglu ? (n_wave + nt * 16) / 2 + fc * 4 : n;
+            rs_all[mt][nt] = (g.residual && okn) ? *reinterpret_cast<const uint2 *>((const unsigned char *)g.residual + (mc * g.ldr + on) * 2) : make_uint2(0u, 0u);
+        }
+    }
+    // GroupNorm statistics of the output: per-lane channel sums over the wave's rows -> DPP sum over the 16 rows of a tile -> LDS
+    // atomics into [batch slot][group] of the workgroup -> ONE global float atomic per (batch, group) the tile touches.
+    const bool want_cs = g.out_group_stats != nullptr;
+    float *red = reinterpret_cast<float *>(smem);           // [GS_SLOTS][GS_MAXG][2]; the operand tiles in LDS are dead by now
+    const int64_t b0 = want_cs ? m_base / g.rows_per_batch : 0;
+    if (want_cs) {
+        __syncthreads();                                     // every wave has finished reading the last k-tile
+        for (int idx = threadIdx.x; idx < GS_SLOTS * GS_MAXG * 2; idx += NTHREADS) red[idx] = 0.f;
+        __syncthreads();
+    }
+    float cs[NTW][4], css[NTW][4];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { cs[nt][r] = 0.f; css[nt][r] = 0.f; }
+    int64_t cs_b = -1;       // batch of the rows accumulated in cs / css (an m-tile of 16 rows never straddles batches: rows_per_batch % 16 == 0)
+    auto flush_cs = [&]() __attribute__((always_inline)) {
+        float *rb = red + (cs_b - b0) * (GS_MAXG * 2);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int64_t n = n_lane + nt * 16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a = row16_sum(cs[nt][r]), b = row16_sum(css[nt][r]);
+                if (fr == 0 && n + r < g.N) {
+                    const int gi = (int)(n + r) / g.gn_cpg;
+                    __hip_atomic_fetch_add(rb + 2 * gi, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(rb + 2 * gi + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                cs[nt][r] = 0.f; css[nt][r] = 0.f;
+            }
+        }
+    };
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int64_t m = m_wave + mt * 16 + fr;
+        const int64_t m_tile = m_wave + mt * 16;                 // wave-uniform
+        if (m_tile >= g.M) break;
+        const bool okm = m < g.M;
+        if (want_cs) {
+            const int64_t b = m_tile / g.rows_per_batch;
+            if (cs_b >= 0 && b != cs_b) flush_cs();
+            cs_b = b;
+        }
+        const uint2 *rs = rs_all[mt];
+        float mean = 0.f, rstd = 1.f;
+        if (g.row_stats) {
+            mean = st_all[mt].x * g.ln_inv_k;
+            rstd = rsqrtf(fmaxf(st_all[mt].y * g.ln_inv_k - mean * mean, 0.f) + g.ln_eps);
+        }
+        float4 rv[NTW];
+        const int64_t bidx = (g.rowvec && okm) ? m / g.rows_per_batch : 0;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int64_t n = n_lane + nt * 16;
+            rv[nt] = (g.rowvec && n < g.N) ? *reinterpret_cast<const float4 *>(g.rowvec + bidx * g.ld_rowvec + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float rsum = 0.f, rsq = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int64_t n = n_lane + nt * 16;
+            if (n >= g.N) continue;
+            if (g.geglu && (nt & 1)) continue;
+            float a0 = acc[nt][mt][0], a1 = acc[nt][mt][1], a2 = acc[nt][mt][2], a3 = acc[nt][mt][3];
+            if (g.row_stats) {
+                a0 = rstd * (a0 - mean * csm[nt].x); a1 = rstd * (a1 - mean * csm[nt].y);
+                a2 = rstd * (a2 - mean * csm[nt].z); a3 = rstd * (a3 - mean * csm[nt].w);
+            }
+            float v[4] = {a0 + bia[nt].x + rv[nt].x, a1 + bia[nt].y + rv[nt].y, a2 + bia[nt].z + rv[nt].z, a3 + bia[nt].w + rv[nt].w};
+            int64_t on = n;
+            if (g.geglu) {   // weights are row-permuted in 16-blocks [x | gate]; partner tile = nt + 1 (NTW is even here)
+                constexpr int NP = NTW - 1;
+                const int np = nt + 1 < NTW ? nt + 1 : NP;
+                float g0 = acc[np][mt][0], g1 = acc[np][mt][1], g2 = acc[np][mt][2], g3 = acc[np][mt][3];
+                if (g.row_stats) {
+                    g0 = rstd * (g0 - mean * csm[np].x); g1 = rstd * (g1 - mean * csm[np].y);
+                    g2 = rstd * (g2 - mean * csm[np].z); g3 = rstd * (g3 - mean * csm[np].w);
+                }
+                v[0] *= gelu_erf(g0 + bia[np].x); v[1] *= gelu_erf(g1 + bia[np].y);
+                v[2] *= gelu_erf(g2 + bia[np].z); v[3] *= gelu_erf(g3 + bia[np].w);
+                on = (n_wave + nt * 16) / 2 + fc * 4;
+            }
+            if (g.act == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = silu(v[r]);
+            } else if (g.act == 2) {   // image post-process of pipe(output_type='pt'): (x/2 + 0.5).clamp(0,1)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r] * 0.5f + 0.5f, 0.f), 1.f);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= g.out_scale;
+            if (g.residual) {
+                v[0] += T::to_f((unsigned short)(rs[nt].x & 0xffff)); v[1] += T::to_f((unsigned short)(rs[nt].x >> 16));
+                v[2] += T::to_f((unsigned short)(rs[nt].y & 0xffff)); v[3] += T::to_f((unsigned short)(rs[nt].y >> 16));
+            }
+            if (!okm) continue;
+            const bool to_t = g.out_t && on >= g.t_col0;     // fused QKV: columns >= t_col0 (V) go ONLY to the transposed buffer
+            const uint2 pk = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
+            if (g.out && !(to_t && g.t_col0 > 0)) {
+                if (g.out_f32)
+                    *reinterpret_cast<float4 *>((float *)g.out + m * g.ldc + on) = make_float4(v[0], v[1], v[2], v[3]);
+                else
+                    *reinterpret_cast<uint2 *>((unsigned char *)g.out + (m * g.ldc + on) * 2) = pk;
+            }
+            if (to_t) {   // transposed copy out_t[b][n - t_col0][tok] (V operand of the attention kernel)
+                const int64_t b = m / g.rows_per_batch, tok = m - b * g.rows_per_batch;
+                unsigned short *o = (unsigned short *)g.out_t + b * g.t_batch_stride + tok;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[(on - g.t_col0 + r) * g.ldt] = T::from_f(v[r]);
+            }
+            if (g.out_row_stats || want_cs) {     // statistics of the values as STORED (rounded to the activation type)
+                float t[4];
+                if (g.out_f32) { t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3]; }
+                else {
+                    t[0] = T::to_f((unsigned short)(pk.x & 0xffff)); t[1] = T::to_f((unsigned short)(pk.x >> 16));
+                    t[2] = T::to_f((unsigned short)(pk.y & 0xffff)); t[3] = T::to_f((unsigned short)(pk.y >> 16));
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    rsum += t[r]; rsq += t[r] * t[r];
+                    cs[nt][r] += t[r]; css[nt][r] += t[r] * t[r];
+                }
+            }
+        }
+        if (g.out_row_stats && n_wave < g.N) {   // the 4 lanes fc = 0..3 of a row hold disjoint column quads: combine, one plain store per (row, wave column)
+            rsum += __shfl_xor(rsum, 16, 64); rsq += __shfl_xor(rsq, 16, 64);
+            rsum += __shfl_xor(rsum, 32, 64); rsq += __shfl_xor(rsq, 32, 64);
+            const int64_t slot = n_wave / (16 * NTW);
+            if (fc == 0 && okm) *reinterpret_cast<float2 *>(g.out_row_stats + (slot * g.M + m) * 2) = make_float2(rsum, rsq);
+        }
+    }
+    if (want_cs) {
+        if (cs_b >= 0) flush_cs();
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < GS_SLOTS * GS_MAXG * 2; idx += NTHREADS) {
+            const float v = red[idx];
+            if (v != 0.f) {
+                const int sl = idx / (GS_MAXG * 2), rem = idx - sl * (GS_MAXG * 2);
+                unsafeAtomicAdd(g.out_group_stats + ((b0 + sl) * g.gn_groups) * 2 + rem, v);
+            }
+        }
     }
 }
 
@@ -290,101 +522,8 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmArgs g)
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds out[m = m0 + (lane&15)][n = n0 + 4*(lane>>4) + r], r = 0..3.
-    // All operand loads of a row (bias once per lane; row-vector + residual per m-tile) are issued together BEFORE they are
-    // used: the naive per-accumulator load->use chain cost ~1 us of latency x 20 accumulators on every launch.
-    const int64_t n_lane = n_base + wn * (16 * NTW) + fc * 4;
-    if (g.splits > 1) {   // partial sums of this k-slice: plain 16-byte stores into slab blockIdx.y
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int64_t m = m_base + wm * 64 + mt * 16 + fr;
-            if (m >= g.M) continue;
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) {
-                const int64_t n = n_lane + nt * 16;
-                if (n < g.N)
-                    *reinterpret_cast<float4 *>(g.ws + ((int64_t)blockIdx.y * g.M + m) * g.N + n) =
-                        make_float4(acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]);
-            }
-        }
-        return;
-    }
-    float4 bia[NTW];
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-        const int64_t n = n_lane + nt * 16;
-        bia[nt] = (g.bias && n < g.N) ? *reinterpret_cast<const float4 *>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    // residual / row-vector operands of ALL four m-tiles are requested before the first one is consumed (one latency, not four)
-    uint2 rs_all[4][NTW];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int64_t m = m_base + wm * 64 + mt * 16 + fr;
-        const bool okm = m < g.M;
-        const int64_t mc = okm ? m : 0;
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            const int64_t n = n_lane + nt * 16;
-            const bool okn = okm && n < g.N && !(g.geglu && (nt & 1));
-            const int64_t on = g.geglu ? (n_base + wn * (16 * NTW) + nt * 16) / 2 + fc * 4 : n;
-            rs_all[mt][nt] = (g.residual && okn) ? *reinterpret_cast<const uint2 *>((const unsigned char *)g.residual + (mc * g.ldr + on) * 2) : make_uint2(0u, 0u);
-        }
-    }
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int64_t m = m_base + wm * 64 + mt * 16 + fr;
-        if (m >= g.M) continue;
-        const uint2 *rs = rs_all[mt];
-        float4 rv[NTW];
-        const int64_t bidx = g.rowvec ? m / g.rows_per_batch : 0;
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            const int64_t n = n_lane + nt * 16;
-            rv[nt] = (g.rowvec && n < g.N) ? *reinterpret_cast<const float4 *>(g.rowvec + bidx * g.ld_rowvec + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            const int64_t n = n_lane + nt * 16;
-            if (n >= g.N) continue;
-            if (g.geglu && (nt & 1)) continue;
-            float v[4] = {acc[nt][mt][0] + bia[nt].x + rv[nt].x, acc[nt][mt][1] + bia[nt].y + rv[nt].y,
-                          acc[nt][mt][2] + bia[nt].z + rv[nt].z, acc[nt][mt][3] + bia[nt].w + rv[nt].w};
-            int64_t on = n;
-            if (g.geglu) {   // weights are row-permuted in 16-blocks [x | gate]; partner tile = nt + 1 (NTW is even here)
-                constexpr int NP = NTW - 1;
-                const int np = nt + 1 < NTW ? nt + 1 : NP;
-                v[0] *= gelu_erf(acc[np][mt][0] + bia[np].x); v[1] *= gelu_erf(acc[np][mt][1] + bia[np].y);
-                v[2] *= gelu_erf(acc[np][mt][2] + bia[np].z); v[3] *= gelu_erf(acc[np][mt][3] + bia[np].w);
-                on = (n_base + wn * (16 * NTW) + nt * 16) / 2 + fc * 4;
-            }
-            if (g.act == 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = silu(v[r]);
-            } else if (g.act == 2) {   // image post-process of pipe(output_type='pt'): (x/2 + 0.5).clamp(0,1)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r] * 0.5f + 0.5f, 0.f), 1.f);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= g.out_scale;
-            if (g.residual) {
-                v[0] += T::to_f((unsigned short)(rs[nt].x & 0xffff)); v[1] += T::to_f((unsigned short)(rs[nt].x >> 16));
-                v[2] += T::to_f((unsigned short)(rs[nt].y & 0xffff)); v[3] += T::to_f((unsigned short)(rs[nt].y >> 16));
-            }
-            const bool to_t = g.out_t && on >= g.t_col0;     // fused QKV: columns >= t_col0 (V) go ONLY to the transposed buffer
-            if (g.out && !(to_t && g.t_col0 > 0)) {
-                if (g.out_f32)
-                    *reinterpret_cast<float4 *>((float *)g.out + m * g.ldc + on) = make_float4(v[0], v[1], v[2], v[3]);
-                else
-                    *reinterpret_cast<uint2 *>((unsigned char *)g.out + (m * g.ldc + on) * 2) = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
-            }
-            if (to_t) {   // transposed copy out_t[b][n - t_col0][tok] (V operand of the attention kernel)
-                const int64_t b = m / g.rows_per_batch, tok = m - b * g.rows_per_batch;
-                unsigned short *o = (unsigned short *)g.out_t + b * g.t_batch_stride + tok;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[(on - g.t_col0 + r) * g.ldt] = T::from_f(v[r]);
-            }
-        }
-    }
+    // ---- epilogue (shared with k_gemm8): wave tile 64 x (16 NTW)
+    wave_epilogue<T, NTW, 4, NT>(g, acc, m_base, m_base + wm * 64, n_base + wn * (16 * NTW), lane, smem);
 }
 
 // =====================================================================================================================
@@ -657,103 +796,76 @@ __global__ __launch_bounds__(512, MT == 2 ? 2 : 1) void k_gemm8(const GemmArgs g
     };
     if (w3) run(std::true_type{}); else run(std::false_type{});
 
-    // ---- epilogue (same math as k_gemm; MT m-tiles per wave)
-    const int64_t n_lane = n_base + wn * (16 * NTW) + fc * 4;
-    if (g.splits > 1) {   // partial sums of this k-slice: plain 16-byte stores into slab blockIdx.y
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int64_t m = m_base + wm * (16 * MT) + mt * 16 + fr;
-            if (m >= g.M) continue;
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) {
-                const int64_t n = n_lane + nt * 16;
-                if (n < g.N)
-                    *reinterpret_cast<float4 *>(g.ws + ((int64_t)blockIdx.y * g.M + m) * g.N + n) =
-                        make_float4(acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]);
-            }
-        }
-        return;
-    }
-    float4 bia[NTW];
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-        const int64_t n = n_lane + nt * 16;
-        bia[nt] = (g.bias && n < g.N) ? *reinterpret_cast<const float4 *>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int64_t m = m_base + wm * (16 * MT) + mt * 16 + fr;
-        if (m >= g.M) continue;
-        float4 rv[NTW];
-        uint2 rs[NTW];
-        const int64_t bidx = g.rowvec ? m / g.rows_per_batch : 0;
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            const int64_t n = n_lane + nt * 16;
-            const bool okn = n < g.N && !(g.geglu && (nt & 1));
-            const int64_t on = g.geglu ? (n_base + wn * (16 * NTW) + nt * 16) / 2 + fc * 4 : n;
-            rv[nt] = (g.rowvec && n < g.N) ? *reinterpret_cast<const float4 *>(g.rowvec + bidx * g.ld_rowvec + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-            rs[nt] = (g.residual && okn) ? *reinterpret_cast<const uint2 *>((const unsigned char *)g.residual + (m * g.ldr + on) * 2) : make_uint2(0u, 0u);
-        }
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            const int64_t n = n_lane + nt * 16;
-            if (n >= g.N) continue;
-            if (g.geglu && (nt & 1)) continue;
-            float v[4] = {acc[nt][mt][0] + bia[nt].x + rv[nt].x, acc[nt][mt][1] + bia[nt].y + rv[nt].y,
-                          acc[nt][mt][2] + bia[nt].z + rv[nt].z, acc[nt][mt][3] + bia[nt].w + rv[nt].w};
-            int64_t on = n;
-            if (g.geglu) {
-                constexpr int NP = NTW - 1;
-                const int np = nt + 1 < NTW ? nt + 1 : NP;
-                v[0] *= gelu_erf(acc[np][mt][0] + bia[np].x); v[1] *= gelu_erf(acc[np][mt][1] + bia[np].y);
-                v[2] *= gelu_erf(acc[np][mt][2] + bia[np].z); v[3] *= gelu_erf(acc[np][mt][3] + bia[np].w);
-                on = (n_base + wn * (16 * NTW) + nt * 16) / 2 + fc * 4;
-            }
-            if (g.act == 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = silu(v[r]);
-            } else if (g.act == 2) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r] * 0.5f + 0.5f, 0.f), 1.f);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= g.out_scale;
-            if (g.residual) {
-                v[0] += T::to_f((unsigned short)(rs[nt].x & 0xffff)); v[1] += T::to_f((unsigned short)(rs[nt].x >> 16));
-                v[2] += T::to_f((unsigned short)(rs[nt].y & 0xffff)); v[3] += T::to_f((unsigned short)(rs[nt].y >> 16));
-            }
-            const bool to_t = g.out_t && on >= g.t_col0;
-            if (g.out && !(to_t && g.t_col0 > 0)) {
-                if (g.out_f32)
-                    *reinterpret_cast<float4 *>((float *)g.out + m * g.ldc + on) = make_float4(v[0], v[1], v[2], v[3]);
-                else
-                    *reinterpret_cast<uint2 *>((unsigned char *)g.out + (m * g.ldc + on) * 2) = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
-            }
-            if (to_t) {
-                const int64_t b = m / g.rows_per_batch, tok = m - b * g.rows_per_batch;
-                unsigned short *o = (unsigned short *)g.out_t + b * g.t_batch_stride + tok;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[(on - g.t_col0 + r) * g.ldt] = T::from_f(v[r]);
-            }
-        }
-    }
+    // ---- epilogue (shared with k_gemm): wave tile (16 MT) x (16 NTW)
+    wave_epilogue<T, NTW, MT, 512>(g, acc, m_base, m_base + wm * (16 * MT), n_base + wn * (16 * NTW), lane, smem);
 }
 
-// epilogue of a split-K problem: ws fp32 [M][N] -> out (same epilogue as the fused path; no GEGLU)
+// epilogue of a split-K problem: ws fp32 [splits][M][N] -> out (same epilogue as the fused path; no GEGLU).
+// Workgroup = 64 column quads (256 columns) x 4 row lanes over 16 rows of ONE batch, 4 rows per thread with independent loads:
+// coalesced 16-byte slab reads; row statistics by a wave sum (slot = blockIdx.x), group statistics via LDS.
 template <class T>
 __global__ __launch_bounds__(256) void k_splitk_epilogue(const GemmArgs g)
 {
+    __shared__ float red[GS_MAXG * 2];
+    constexpr int RPB = 16;
     const int64_t nq = g.N / 4;
-    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < g.M * nq; q += (int64_t)gridDim.x * 256) {
-        const int64_t m = q / nq, n = (q - m * nq) * 4;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int64_t cq = (int64_t)blockIdx.x * 64 + cl;
+    const int64_t m0 = (int64_t)blockIdx.y * RPB;
+    const bool okc = cq < nq;
+    const int64_t n = (okc ? cq : 0) * 4;
+    if (g.out_group_stats) {
+        if (threadIdx.x < GS_MAXG * 2) red[threadIdx.x] = 0.f;
+        __syncthreads();
+    }
+    float v[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i][0] = 0.f; v[i][1] = 0.f; v[i][2] = 0.f; v[i][3] = 0.f; }
+    if (okc) {
         for (int z = 0; z < g.splits; ++z) {
-            const float4 a = *reinterpret_cast<const float4 *>(g.ws + ((int64_t)z * g.M + m) * g.N + n);
-            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {           // 4 independent 16-byte loads in flight per slab
+                const int64_t m = m0 + rl + 4 * i;
+                if (m < g.M) {
+                    const float4 a = *reinterpret_cast<const float4 *>(g.ws + ((int64_t)z * g.M + m) * g.N + n);
+                    v[i][0] += a.x; v[i][1] += a.y; v[i][2] += a.z; v[i][3] += a.w;
+                }
+            }
         }
-        float gate[4] = {0.f, 0.f, 0.f, 0.f};
-        epilogue_store<T>(g, m, n, n, v, gate);
+    }
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = m0 + rl + 4 * i;          // rl is wave-uniform: every lane of a wave works on the same rows
+        if (m >= g.M) break;
+        if (okc) {
+            float gate[4] = {0.f, 0.f, 0.f, 0.f};
+            epilogue_store<T>(g, m, n, n, v[i], gate);
+        }
+        if (g.out_row_stats) {
+            const float a = wave_sum_f(okc ? (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]) : 0.f);
+            const float b = wave_sum_f(okc ? (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]) : 0.f);
+            if (cl == 0) *reinterpret_cast<float2 *>(g.out_row_stats + ((int64_t)blockIdx.x * g.M + m) * 2) = make_float2(a, b);
+        }
+        if (okc) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { cs[2 * r] += v[i][r]; cs[2 * r + 1] += v[i][r] * v[i][r]; }
+        }
+    }
+    if (g.out_group_stats) {
+        if (okc) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gi = (int)(n + r) / g.gn_cpg;
+                __hip_atomic_fetch_add(red + 2 * gi, cs[2 * r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(red + 2 * gi + 1, cs[2 * r + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < GS_MAXG * 2) {
+            const float t = red[threadIdx.x];
+            if (t != 0.f) unsafeAtomicAdd(g.out_group_stats + (m0 / g.rows_per_batch) * g.gn_groups * 2 + threadIdx.x, t);
+        }
     }
 }
 
@@ -772,11 +884,8 @@ template <class T, int MODE, int NTW>
 void launch(const GemmArgs &g, dim3 grid, hipStream_t s)
 {
     constexpr size_t lds = 2 * (BM * 128 + 32 * NTW * 128);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_gemm<T, MODE, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static gc::AttrOnce once;      // per device, thread-safe (no function-local bool latch)
+    gc::ensure_dynamic_lds(once, (const void *)k_gemm<T, MODE, NTW>, (int)lds);
     hipLaunchKernelGGL((k_gemm<T, MODE, NTW>), grid, dim3(NT), lds, s, g);
 }
 
@@ -785,11 +894,8 @@ void launch8(const GemmArgs &g, dim3 grid, hipStream_t s)
 {
     constexpr size_t lds = 3 * (64 * MT * 128 + 32 * NTW * 128);
     static_assert(lds <= 160 * 1024, "LDS ring");
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_gemm8<T, MODE, NTW, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static gc::AttrOnce once;
+    gc::ensure_dynamic_lds(once, (const void *)k_gemm8<T, MODE, NTW, MT>, (int)lds);
     hipLaunchKernelGGL((k_gemm8<T, MODE, NTW, MT>), grid, dim3(512), lds, s, g);
 }
 
@@ -859,6 +965,59 @@ extern "C" size_t gc_dn_gemm_workspace_bytes(const gc_gemm_desc *d)
     return splits > 1 ? sizeof(float) * (size_t)splits * (size_t)d->M * (size_t)d->N : 0;
 }
 
+namespace {
+// kernel choice of one problem (shared by the launcher and the row-statistics layout query)
+struct Sel { int mode, ntw, splits, tps, mt8; };     // mt8 > 0: 8-wave kernel with MT = mt8; 0: 4-wave kernel
+int select(const gc_gemm_desc *d, Sel *o)
+{
+    int mode = 0;
+    if (d->mode == 1) mode = (d->Cin % 64 == 0) ? 2 : 1;
+    int ntw, splits, tps;
+    plan(d, &ntw, &splits, &tps);
+    if (splits > 1 && (!d->workspace || d->workspace_bytes < sizeof(float) * (size_t)splits * (size_t)d->M * (size_t)d->N)) {
+        splits = 1; tps = (int)((d->K + BK - 1) / BK);      // no workspace: run unsplit
+    }
+    const int bn = 32 * ntw;
+    const int64_t nbn = (d->N + bn - 1) / bn;
+    const int nk_host = (int)((d->K + BK - 1) / BK);
+    // kernel selection overrides travel in the descriptor (tests / experiments); 0 = automatic.  No process-wide state.
+    const int kv = d->kernel_variant;
+    const int force_mt = kv & 7;                                   // 2 | 3 | 4: force the 8-wave kernel's m-tiles per wave
+    const int use8 = (kv & 0x10) ? 0 : ((kv & 0x20) ? 2 : 1);      // 0x10: 4-wave kernel only; 0x20: force the 8-wave kernel
+    const int convsplit = (kv & 0x40) ? 0 : ((kv & 0x80) ? 2 : 1); // 0x40: no k-slices for 16x16-map convs; 0x80: also slice the 8x8-map convs
+    o->mode = mode; o->ntw = ntw; o->splits = splits; o->tps = tps; o->mt8 = 0;
+    // 8-wave LDS-DMA kernel (one workgroup per CU, software-pipelined): workgroup tile (64 MT) x (32 NTW).
+    if (use8 && d->zeros) {
+        int mt = force_mt ? force_mt : choose_mt(d->M, d->N, ntw, use8 == 2);
+        const int64_t tiles8 = ((d->M + 127) / 128) * nbn;
+        // long-K problems with a part-filled grid (16x16-map convs, the 5120 -> 1280 FF projection): k-slices of >= 12 k-tiles
+        // fill the CUs; variant 0x40 sends such convs back to the 4-wave split-K kernel, 0x80 also takes the 8x8-map convs
+        const bool small = tiles8 < 96;
+        if (!mt && mode == 0 && !force_mt) mt = 2;       // small linears: the 8-wave kernel's fill + epilogue is the shorter one (12.6 vs 20.9 us at M = 384)
+        const bool want_split = !force_mt && use8 != 2 && !d->geglu && d->workspace && tiles8 <= 128 && (mode == 0 ? (!small || nk_host >= 24) : (convsplit >= (small ? 2 : 1)));
+        int s8 = 1, tps8 = nk_host;
+        if (want_split) {
+            s8 = (int)std::min<int64_t>(small ? (256 + tiles8 - 1) / tiles8 : 256 / tiles8, nk_host / 12);
+            if (s8 >= 2 && d->workspace_bytes >= sizeof(float) * (size_t)s8 * (size_t)d->M * (size_t)d->N) {
+                mt = 2; tps8 = (nk_host + s8 - 1) / s8; s8 = (nk_host + tps8 - 1) / tps8;
+            } else s8 = 1;
+        }
+        if (splits > 1 && s8 == 1 && !force_mt && use8 != 2) mt = 0;      // otherwise: 4-wave split-K kernel as planned
+        if (mt) { o->mt8 = mt; o->splits = s8; o->tps = tps8; }
+    }
+    return 0;
+}
+}  // namespace
+
+// number of column slabs gc_dn_gemm writes per row into desc->out_row_stats (layout [slots][M][2]) for this problem
+extern "C" int gc_dn_gemm_row_stat_slots(const gc_gemm_desc *d)
+{
+    if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+    Sel sel;
+    select(d, &sel);
+    return sel.splits > 1 ? (int)((d->N / 4 + 63) / 64) : (int)((d->N + 16 * sel.ntw - 1) / (16 * sel.ntw));
+}
+
 extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
 {
     GC_REQUIRE(d && d->W && d->A, "null descriptor / operand");
@@ -873,66 +1032,45 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
     g.rows_per_batch = d->rows_per_batch > 0 ? d->rows_per_batch : 1;
     g.residual = d->residual; g.ldr = d->ldr; g.out_scale = d->out_scale; g.act = d->act; g.geglu = d->geglu;
     g.out = d->out; g.ldc = d->ldc; g.out_f32 = d->out_f32; g.out_t = d->out_t; g.ldt = d->ldt; g.t_batch_stride = d->t_batch_stride; g.t_col0 = d->t_col0;
-    int mode = 0;
+    g.row_stats = d->ln_row_stats; g.row_stat_slots = d->ln_row_stat_slots > 0 ? d->ln_row_stat_slots : 1;
+    g.colsum = d->ln_colsum; g.ln_eps = d->ln_eps; g.ln_inv_k = 1.f / (float)d->K;
+    g.out_row_stats = d->out_row_stats; g.out_group_stats = d->out_group_stats; g.gn_groups = d->gn_groups;
+    g.gn_cpg = d->gn_groups > 0 ? (int)(d->N / d->gn_groups) : 1;
+    GC_REQUIRE((d->ln_row_stats == nullptr) == (d->ln_colsum == nullptr), "ln_row_stats and ln_colsum must be given together");
+    GC_REQUIRE(!d->ln_row_stats || d->mode == 0, "LayerNorm folding applies to linear GEMMs");
+    GC_REQUIRE(!(d->out_row_stats || d->out_group_stats) || (!d->geglu && !d->out_t && d->out), "output statistics need a plain (non-GEGLU, non-transposed) output");
+    GC_REQUIRE(!d->out_group_stats || (g.rows_per_batch % 16 == 0 && d->gn_groups >= 1 && d->gn_groups <= GS_MAXG && d->N % d->gn_groups == 0),
+               "out_group_stats needs rows_per_batch % 16 == 0 and 1 <= gn_groups <= 32 dividing N");
     if (d->mode == 1) {
         GC_REQUIRE(d->Cin % 8 == 0 && d->K == 9 * (int64_t)d->Cin, "conv3x3: K must be 9*Cin with Cin % 8 == 0");
         GC_REQUIRE(d->M == (int64_t)d->B * d->Ho * d->Wo, "conv3x3: M must be B*Ho*Wo");
         GC_REQUIRE(d->pad_lo == 0 || d->pad_lo == 1, "conv3x3: pad_lo must be 0 or 1");
-        mode = (d->Cin % 64 == 0) ? 2 : 1;
     } else {
         GC_REQUIRE(d->lda >= d->K && d->lda % 8 == 0, "linear: lda must be >= K and a multiple of 8");
     }
     if (d->geglu) GC_REQUIRE(d->N % 32 == 0 && !d->out_t, "geglu needs N % 32 == 0");
-    int ntw, splits, tps;
-    plan(d, &ntw, &splits, &tps);
+    const int force_mt = d->kernel_variant & 7;
+    GC_REQUIRE(force_mt == 0 || (force_mt >= 2 && force_mt <= 4), "kernel_variant: MT must be 0, 2, 3 or 4");
+    Sel sel;
+    select(d, &sel);
     hipStream_t s = gc::S(stream);
-    if (splits > 1 && (!d->workspace || d->workspace_bytes < sizeof(float) * (size_t)splits * (size_t)d->M * (size_t)d->N)) {
-        splits = 1; tps = (int)((d->K + BK - 1) / BK);      // no workspace: run unsplit
-    }
-    g.splits = splits; g.tiles_per_split = tps; g.ws = (float *)d->workspace;
-    const int bn = 32 * ntw;
-    const int64_t nbm = (d->M + BM - 1) / BM, nbn = (d->N + bn - 1) / bn;
-    const dim3 grid((unsigned)(nbm * nbn), (unsigned)splits);
-    const int nk_host = (int)((d->K + BK - 1) / BK);
+    g.splits = sel.splits; g.tiles_per_split = sel.tps; g.ws = (float *)d->workspace;
     g.zeros = d->zeros;
-    static const int use8 = [] { const char *e = getenv("GC_GEMM8"); return e ? atoi(e) : 1; }();
-    static const int force_mt = [] { const char *e = getenv("GC_GEMM_MT"); return e ? atoi(e) : 0; }();
-    // 8-wave LDS-DMA kernel (one workgroup per CU, software-pipelined): workgroup tile (64 MT) x (32 NTW).
-    // GC_GEMM8=0 disables it, =2 forces it (tests); GC_GEMM_MT forces MT (experiments).
-    bool done = false;
-    if (use8 && d->zeros) {
-        int mt = force_mt ? force_mt : choose_mt(d->M, d->N, ntw, use8 == 2);
-        static const int convsplit = [] { const char *e = getenv("GC_GEMM_CONVSPLIT"); return e ? atoi(e) : 1; }();
-        const int64_t tiles8 = ((d->M + 127) / 128) * nbn;
-        // long-K problems with a part-filled grid (16x16-map convs, the 5120 -> 1280 FF projection): k-slices of >= 12 k-tiles
-        // fill the CUs; GC_GEMM_CONVSPLIT=0 sends such convs back to the 4-wave split-K kernel, =2 also takes the 8x8-map convs
-        const bool small = tiles8 < 96;
-        if (!mt && mode == 0 && !force_mt) mt = 2;       // small linears: the 8-wave kernel's fill + epilogue is the shorter one (12.6 vs 20.9 us at M = 384)
-        const bool want_split = !force_mt && use8 != 2 && !d->geglu && d->workspace && tiles8 <= 128 && (mode == 0 ? (!small || nk_host >= 24) : (convsplit >= (small ? 2 : 1)));
-        int s8 = 1, tps8 = nk_host;
-        if (want_split) {
-            s8 = (int)std::min<int64_t>(small ? (256 + tiles8 - 1) / tiles8 : 256 / tiles8, nk_host / 12);
-            if (s8 >= 2 && d->workspace_bytes >= sizeof(float) * (size_t)s8 * (size_t)d->M * (size_t)d->N) {
-                mt = 2; tps8 = (nk_host + s8 - 1) / s8; s8 = (nk_host + tps8 - 1) / tps8;
-            } else s8 = 1;
-        }
-        if (splits > 1 && s8 == 1 && !force_mt && use8 != 2) mt = 0;      // otherwise: 4-wave split-K kernel as planned
-        if (mt) {
-            const int64_t nbm8 = (d->M + 64 * mt - 1) / (64 * mt);
-            const dim3 grid8((unsigned)(nbm8 * nbn), (unsigned)s8);
-            g.splits = s8; g.tiles_per_split = tps8;
-            if (d->dtype == DT_BF16) dispatch8<BF16>(g, mode, ntw, mt, grid8, s); else dispatch8<F16>(g, mode, ntw, mt, grid8, s);
-            splits = s8;
-            done = true;
-        }
+    const int bn = 32 * sel.ntw;
+    const int64_t nbn = (d->N + bn - 1) / bn;
+    if (sel.mt8) {
+        const int64_t nbm8 = (d->M + 64 * sel.mt8 - 1) / (64 * sel.mt8);
+        const dim3 grid8((unsigned)(nbm8 * nbn), (unsigned)sel.splits);
+        if (d->dtype == DT_BF16) dispatch8<BF16>(g, sel.mode, sel.ntw, sel.mt8, grid8, s); else dispatch8<F16>(g, sel.mode, sel.ntw, sel.mt8, grid8, s);
+    } else {
+        const int64_t nbm = (d->M + BM - 1) / BM;
+        const dim3 grid((unsigned)(nbm * nbn), (unsigned)sel.splits);
+        if (d->dtype == DT_BF16) dispatch<BF16>(g, sel.mode, sel.ntw, grid, s); else dispatch<F16>(g, sel.mode, sel.ntw, grid, s);
     }
-    if (!done) {
-        if (d->dtype == DT_BF16) dispatch<BF16>(g, mode, ntw, grid, s); else dispatch<F16>(g, mode, ntw, grid, s);
-    }
-    if (splits > 1) {
-        const unsigned eg = (unsigned)std::min<int64_t>((d->M * (d->N / 4) + 255) / 256, 2048);
-        if (d->dtype == DT_BF16) hipLaunchKernelGGL((k_splitk_epilogue<BF16>), dim3(eg), dim3(256), 0, s, g);
-        else hipLaunchKernelGGL((k_splitk_epilogue<F16>), dim3(eg), dim3(256), 0, s, g);
+    if (sel.splits > 1) {
+        const dim3 eg((unsigned)((d->N / 4 + 63) / 64), (unsigned)((d->M + 15) / 16));
+        if (d->dtype == DT_BF16) hipLaunchKernelGGL((k_splitk_epilogue<BF16>), eg, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((k_splitk_epilogue<F16>), eg, dim3(256), 0, s, g);
     }
     return gc::check_launch("gc_dn_gemm");
 }

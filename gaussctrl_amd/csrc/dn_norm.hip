@@ -170,6 +170,123 @@ __global__ __launch_bounds__(256) void k_gn_small(const unsigned short *__restri
     }
 }
 
+// GroupNorm from per-(batch, group) sums that the PRODUCER of x accumulated (GEMM epilogue / k_concat_add_stats):
+// stats[b][g] = (sum x, sum x^2) over the HW pixels and the C/G channels of group g.  ONE launch: every workgroup (blockIdx.y =
+// batch) first turns the batch's G x 2 sums into per-channel coefficients a = rstd_g * gamma_c, d = beta_c - mean_g * a in LDS, then
+// streams its share of the image: y = x * a + d [SiLU], 16 bytes per lane.  Replaces k_gn_partial + k_gn_finalize + k_gn_apply.
+template <class T>
+__global__ __launch_bounds__(256) void k_gn_apply_stats(const unsigned short *__restrict__ x, unsigned short *__restrict__ y, unsigned HW,
+                                                        unsigned C, int G, const float *__restrict__ stats, const float *__restrict__ gamma,
+                                                        const float *__restrict__ beta, float eps, int act)
+{
+    extern __shared__ float coef[];          // [C][2]
+    const unsigned b = blockIdx.y, tid = threadIdx.x, cpg = C / G;
+    const float *sb = stats + (size_t)b * G * 2;
+    const float n = (float)HW * (float)cpg;
+    for (unsigned c = tid; c < C; c += 256) {
+        const unsigned g = c / cpg;
+        const float mu = sb[2 * g] / n;
+        const float rstd = rsqrtf(fmaxf(sb[2 * g + 1] / n - mu * mu, 0.f) + eps);
+        const float a = rstd * gamma[c];
+        coef[2 * c] = a; coef[2 * c + 1] = beta[c] - mu * a;
+    }
+    __syncthreads();
+    const unsigned nch = C / 8, per_img = HW * nch;
+    const unsigned short *xb = x + (size_t)b * per_img * 8;
+    unsigned short *yb = y + (size_t)b * per_img * 8;
+    for (unsigned q = blockIdx.x * 256u + tid; q < per_img; q += gridDim.x * 256u) {
+        const unsigned c0 = (q % nch) * 8;
+        float f[8];
+        unpack8<T>(*reinterpret_cast<const uint4 *>(xb + (size_t)q * 8), f);
+        const float4 *cf = reinterpret_cast<const float4 *>(coef + 2 * c0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 ab = cf[j];
+            float v0 = f[2 * j] * ab.x + ab.y, v1 = f[2 * j + 1] * ab.z + ab.w;
+            if (act) { v0 = silu(v0); v1 = silu(v1); }
+            f[2 * j] = v0; f[2 * j + 1] = v1;
+        }
+        *reinterpret_cast<uint4 *>(yb + (size_t)q * 8) = pack8<T>(f);
+    }
+}
+
+// out[b][p][C1+C2] = [a | b (+ c)] with the per-(batch, group) sums of the OUTPUT accumulated on the way (the input of the next
+// GroupNorm): slab structure of k_gn_partial -- a thread owns one 16-byte channel chunk and walks the pixels of its slab, partial
+// sums are combined over the block's pixel lanes in LDS, one atomic pair per channel per block.
+template <class T>
+__global__ __launch_bounds__(256) void k_concat_add_stats(const unsigned short *__restrict__ a, int C1, const unsigned short *__restrict__ bsrc,
+                                                          const unsigned short *__restrict__ c, int C2, unsigned short *__restrict__ out,
+                                                          int HW, int nchb, int pix_per_block, int G, float *__restrict__ stats)
+{
+    extern __shared__ float sp[];   // [lanes][nchb][16], then [G][2]
+    const int b = blockIdx.z, C = C1 + C2;
+    const int lanes = 256 / nchb;
+    const int tid = threadIdx.x;
+    const int cch = tid % nchb, pl = tid / nchb;
+    const int c0 = (blockIdx.y * nchb + cch) * 8;
+    const size_t row0 = (size_t)b * HW;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    if (pl < lanes) {
+        const int p0 = blockIdx.x * pix_per_block;
+        const int p1 = min(p0 + pix_per_block, HW);
+        for (int p = p0 + pl; p < p1; p += lanes) {
+            const size_t m = row0 + p;
+            uint4 v;
+            float f[8];
+            if (c0 < C1) { v = *reinterpret_cast<const uint4 *>(a + m * C1 + c0); unpack8<T>(v, f); }
+            else {
+                v = *reinterpret_cast<const uint4 *>(bsrc + m * C2 + (c0 - C1));
+                unpack8<T>(v, f);
+                if (c) {
+                    float fc[8];
+                    unpack8<T>(*reinterpret_cast<const uint4 *>(c + m * C2 + (c0 - C1)), fc);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] += fc[j];
+                    v = pack8<T>(f);
+                    unpack8<T>(v, f);        // statistics of the values as stored
+                }
+            }
+            *reinterpret_cast<uint4 *>(out + m * C + c0) = v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s1[j] += f[j]; s2[j] += f[j] * f[j]; }
+        }
+        float *o = sp + ((size_t)pl * nchb + cch) * 16;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { o[2 * j] = s1[j]; o[2 * j + 1] = s2[j]; }
+    }
+    __syncthreads();
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    if (pl == 0) {
+        for (int l = 0; l < lanes; ++l) {
+            const float *o = sp + ((size_t)l * nchb + cch) * 16;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] += o[j];
+        }
+    }
+    __syncthreads();
+    float *grp = sp;                 // [G][2] group sums of this block
+    for (int i = tid; i < 2 * G; i += 256) grp[i] = 0.f;
+    __syncthreads();
+    if (pl == 0) {
+        const int cpg = C / G;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int gi = (c0 + j) / cpg;
+            __hip_atomic_fetch_add(grp + 2 * gi, acc[2 * j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(grp + 2 * gi + 1, acc[2 * j + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * G; i += 256) {
+        const float v = grp[i];
+        if (v != 0.f) unsafeAtomicAdd(stats + (size_t)b * G * 2 + i, v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ LayerNorm
 // one wave64 per token row; exact two-pass in registers (C <= 64*8*4).
 template <class T>
@@ -421,6 +538,27 @@ int gc_dn_groupnorm(int dtype, const void *x, void *y, int64_t B, int64_t HW, in
     return gc::check_launch("gc_dn_groupnorm");
 }
 
+int gc_dn_groupnorm_apply(int dtype, const void *x, void *y, int64_t B, int64_t HW, int C, int G, const float *gamma,
+                          const float *beta, float eps, int act, const float *group_stats, void *stream)
+{
+    const float *chan_stats = group_stats;
+    GC_REQUIRE(C % 8 == 0 && C % G == 0 && chan_stats && gamma && beta, "groupnorm_apply: C must be a multiple of 8 and of G; statistics required");
+    GC_REQUIRE(HW * (int64_t)(C / 8) < (int64_t)1 << 31 && B <= 65535, "groupnorm_apply: tensor too large");
+    const int64_t per_img = HW * (C / 8);
+    // enough workgroups per image to fill the chip, few enough that the coefficient prologue (a few KB from L2 per workgroup) stays small
+    int64_t gx = (per_img + 255) / 256;
+    const int64_t cap = std::max<int64_t>(1, (256 * 4 + B - 1) / B);
+    if (gx > cap) gx = cap;
+    const size_t lds = sizeof(float) * 2 * (size_t)C;
+    dim3 grid((unsigned)gx, (unsigned)B);
+    DN_DISPATCH(dtype,
+                hipLaunchKernelGGL((k_gn_apply_stats<BF16>), grid, dim3(256), lds, gc::S(stream), (const unsigned short *)x, (unsigned short *)y,
+                                   (unsigned)HW, (unsigned)C, G, chan_stats, gamma, beta, eps, act),
+                hipLaunchKernelGGL((k_gn_apply_stats<F16>), grid, dim3(256), lds, gc::S(stream), (const unsigned short *)x, (unsigned short *)y,
+                                   (unsigned)HW, (unsigned)C, G, chan_stats, gamma, beta, eps, act));
+    return gc::check_launch("gc_dn_groupnorm_apply");
+}
+
 int gc_dn_layernorm(int dtype, const void *x, void *y, int64_t M, int C, const float *gamma, const float *beta,
                     float eps, void *stream)
 {
@@ -432,9 +570,26 @@ int gc_dn_layernorm(int dtype, const void *x, void *y, int64_t M, int C, const f
     return gc::check_launch("gc_dn_layernorm");
 }
 
-int gc_dn_concat_add(int dtype, const void *a, int C1, const void *b, const void *c, int C2, void *out, int64_t M, void *stream)
+int gc_dn_concat_add(int dtype, const void *a, int C1, const void *b, const void *c, int C2, void *out, int64_t M, int64_t rows_per_batch,
+                     float *group_stats, int gn_groups, void *stream)
 {
     GC_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0, "concat: channel counts must be multiples of 8");
+    float *chan_stats = group_stats;
+    if (chan_stats) {      // copy + per-(batch, group) sums of the output, added into the caller-zeroed group_stats[B][gn_groups][2]
+        GC_REQUIRE(rows_per_batch > 0 && M % rows_per_batch == 0 && M / rows_per_batch <= 65535, "concat: M must be B * rows_per_batch");
+        GC_REQUIRE(gn_groups >= 1 && gn_groups <= 64 && (C1 + C2) % gn_groups == 0, "concat: gn_groups must divide C1 + C2");
+        int nslab, ppb, ny, nchb;
+        gn_plan(M / rows_per_batch, rows_per_batch, C1 + C2, &nslab, &ppb, &ny, &nchb);
+        const int lanes = 256 / nchb;
+        dim3 grid((unsigned)nslab, ny, (unsigned)(M / rows_per_batch));
+        const size_t lds = sizeof(float) * 16 * (size_t)lanes * nchb;
+        DN_DISPATCH(dtype,
+                    hipLaunchKernelGGL((k_concat_add_stats<BF16>), grid, dim3(256), lds, gc::S(stream), (const unsigned short *)a, C1,
+                                       (const unsigned short *)b, (const unsigned short *)c, C2, (unsigned short *)out, (int)rows_per_batch, nchb, ppb, gn_groups, chan_stats),
+                    hipLaunchKernelGGL((k_concat_add_stats<F16>), grid, dim3(256), lds, gc::S(stream), (const unsigned short *)a, C1,
+                                       (const unsigned short *)b, (const unsigned short *)c, C2, (unsigned short *)out, (int)rows_per_batch, nchb, ppb, gn_groups, chan_stats));
+        return gc::check_launch("gc_dn_concat_add");
+    }
     const int64_t chunks = M * ((C1 + C2) / 8);
     DN_DISPATCH(dtype,
                 hipLaunchKernelGGL((k_concat_add<BF16>), dim3(ew_grid(chunks)), dim3(256), 0, gc::S(stream), (const unsigned short *)a, C1,

@@ -332,7 +332,12 @@ __global__ __launch_bounds__(256) void k_sh_bwd(int64_t N, int K, int n, const f
 // ---------------------------------------------------------------- kernels: fused product path
 // One pass over the 59-float record (236 B/Gaussian read, 48 B written).  Mirrors the reference
 // op-by-op: exp(scales), q/|q| (gc_model.py:144), project, viewdirs (gc_model.py:163-164),
-// SH, clamp(+0.5,min 0) (:167), sigmoid(opacity) (:181).
+// SH, clamp(+0.5,min 0) (:167) -- or sigmoid(features_dc) when config.sh_degree == 0 (:169, n_use = -1) -- and sigmoid(opacity) (:181).
+//
+// HBM access: one lane per Gaussian, but the 45-float features_rest record (180 of the 236 bytes) is NOT read lane-by-lane --
+// a 180-byte lane stride makes every load instruction touch 64 different cache lines (rocprofv3 FETCH_SIZE of the round-1 kernel:
+// 3.6x the algorithmic bytes).  The workgroup's 256 records are one contiguous 46 KB block: it is streamed with 16-byte-per-lane
+// loads into LDS, and each lane then reads ITS record from LDS at a 45-dword stride (odd: bank-conflict free).
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + __expf(-x)); }
 
 template <int K>
@@ -345,44 +350,66 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(int64_t N, Cam cam, int 
                                                         int32_t *__restrict__ tiles_hit, float *__restrict__ rgbs,
                                                         float *__restrict__ opac)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    float p0 = means[3 * i], p1 = means[3 * i + 1], p2 = means[3 * i + 2];
-    float s0 = expf(log_scales[3 * i]), s1 = expf(log_scales[3 * i + 1]), s2 = expf(log_scales[3 * i + 2]);
-    float4 q = *reinterpret_cast<const float4 *>(quats + 4 * i);
-    float qn = sqrtf(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w);
-    q.x = q.x / qn; q.y = q.y / qn; q.z = q.z / qn; q.w = q.w / qn;
+    constexpr int R = (K - 1) * 3;                         // floats of features_rest per Gaussian
+    __shared__ __attribute__((aligned(16))) float srest[R > 0 ? 256 * R : 4];
+    const int tid = threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.x * 256;
+    const int64_t i = i0 + tid;
+    if (R > 0 && n_use > 0) {
+        const int64_t cnt = ((N - i0 < 256 ? N - i0 : 256)) * R;        // floats of this workgroup's block
+        const float *src = f_rest + i0 * R;                              // 256 * R * 4 bytes per block: 16-byte aligned
+        for (int64_t j = tid; j < cnt / 4; j += 256) reinterpret_cast<float4 *>(srest)[j] = reinterpret_cast<const float4 *>(src)[j];
+        for (int64_t j = (cnt / 4) * 4 + tid; j < cnt; j += 256) srest[j] = src[j];
+    }
     Proj o;
-    bool ok = project_one(cam, p0, p1, p2, s0, s1, s2, q.x, q.y, q.z, q.w, o);
-    xys[2 * i] = o.xy[0]; xys[2 * i + 1] = o.xy[1];
-    depths[i] = o.depth; radii[i] = o.radius; tiles_hit[i] = o.tiles_hit;
-    conics[3 * i] = o.conic[0]; conics[3 * i + 1] = o.conic[1]; conics[3 * i + 2] = o.conic[2];
-    opac[i] = sigmoidf(op_logit[i]);
+    bool ok = false;
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+    if (i < N) {
+        p0 = means[3 * i]; p1 = means[3 * i + 1]; p2 = means[3 * i + 2];
+        float s0 = expf(log_scales[3 * i]), s1 = expf(log_scales[3 * i + 1]), s2 = expf(log_scales[3 * i + 2]);
+        float4 q = *reinterpret_cast<const float4 *>(quats + 4 * i);
+        float qn = sqrtf(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w);
+        q.x = q.x / qn; q.y = q.y / qn; q.z = q.z / qn; q.w = q.w / qn;
+        ok = project_one(cam, p0, p1, p2, s0, s1, s2, q.x, q.y, q.z, q.w, o);
+        xys[2 * i] = o.xy[0]; xys[2 * i + 1] = o.xy[1];
+        depths[i] = o.depth; radii[i] = o.radius; tiles_hit[i] = o.tiles_hit;
+        conics[3 * i] = o.conic[0]; conics[3 * i + 1] = o.conic[1]; conics[3 * i + 2] = o.conic[2];
+        opac[i] = sigmoidf(op_logit[i]);
+    }
+    if (R > 0 && n_use > 0) __syncthreads();
+    if (i >= N) return;
     float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-    if (ok) {   // culled Gaussians never reach a tile list: skip their 180-byte SH read
-        float dx = p0 - cam.ox, dy = p1 - cam.oy, dz = p2 - cam.oz;
-        float dn = sqrtf((dx * dx + dy * dy) + dz * dz);
-        dx = dx / dn; dy = dy / dn; dz = dz / dn;
-        float B[16];
-        sh_basis(n_use, dx, dy, dz, B);
-        c0 = B[0] * f_dc[3 * i]; c1 = B[0] * f_dc[3 * i + 1]; c2 = B[0] * f_dc[3 * i + 2];
-        const float *r = f_rest + (size_t)i * (K - 1) * 3;
-        int Ku = (n_use + 1) * (n_use + 1);
+    if (ok) {
+        if (n_use < 0) {          // config.sh_degree == 0: rgbs = sigmoid(features_dc)   (gc_model.py:169)
+            c0 = sigmoidf(f_dc[3 * i]); c1 = sigmoidf(f_dc[3 * i + 1]); c2 = sigmoidf(f_dc[3 * i + 2]);
+        } else {
+            float dx = p0 - cam.ox, dy = p1 - cam.oy, dz = p2 - cam.oz;
+            float dn = sqrtf((dx * dx + dy * dy) + dz * dz);
+            dx = dx / dn; dy = dy / dn; dz = dz / dn;
+            float B[16];
+            sh_basis(n_use, dx, dy, dz, B);
+            c0 = B[0] * f_dc[3 * i]; c1 = B[0] * f_dc[3 * i + 1]; c2 = B[0] * f_dc[3 * i + 2];
+            const float *r = srest + tid * R;
+            int Ku = (n_use + 1) * (n_use + 1);
 #pragma unroll
-        for (int k = 1; k < K; ++k)
-            if (k < Ku) {
-                c0 += B[k] * r[3 * (k - 1)]; c1 += B[k] * r[3 * (k - 1) + 1]; c2 += B[k] * r[3 * (k - 1) + 2];
-            }
-        c0 = fmaxf(c0 + 0.5f, 0.f); c1 = fmaxf(c1 + 0.5f, 0.f); c2 = fmaxf(c2 + 0.5f, 0.f);
+            for (int k = 1; k < K; ++k)
+                if (k < Ku) {
+                    c0 += B[k] * r[3 * (k - 1)]; c1 += B[k] * r[3 * (k - 1) + 1]; c2 += B[k] * r[3 * (k - 1) + 2];
+                }
+            c0 = fmaxf(c0 + 0.5f, 0.f); c1 = fmaxf(c1 + 0.5f, 0.f); c2 = fmaxf(c2 + 0.5f, 0.f);
+        }
     }
     rgbs[3 * i] = c0; rgbs[3 * i + 1] = c1; rgbs[3 * i + 2] = c2;
 }
 
+// Backward of the above.  The colour path needs only the FORWARD colours (rgbs): the clamp(min = 0) mask is rgbs > 0 and the
+// sigmoid mode's derivative is s (1 - s), so the 192-byte SH record is not re-read; the 180-byte features_rest gradient is staged in
+// LDS and written with 16-byte-per-lane stores (a lane-strided 45-float store has the same 64-lines-per-instruction problem).
 template <int K>
 __global__ __launch_bounds__(256) void k_project_sh_bwd(int64_t N, Cam cam, int n_use,
                                                         const float *__restrict__ means, const float *__restrict__ log_scales,
                                                         const float *__restrict__ quats, const float *__restrict__ op_logit,
-                                                        const float *__restrict__ f_dc, const float *__restrict__ f_rest,
+                                                        const float *__restrict__ rgbs,
                                                         const int32_t *__restrict__ radii, const float *__restrict__ conics,
                                                         const float *__restrict__ v_xy, const float *__restrict__ v_conic,
                                                         const float *__restrict__ v_rgbs, const float *__restrict__ v_opac,
@@ -390,56 +417,69 @@ __global__ __launch_bounds__(256) void k_project_sh_bwd(int64_t N, Cam cam, int 
                                                         float *__restrict__ v_quats, float *__restrict__ v_oplogit,
                                                         float *__restrict__ v_dc, float *__restrict__ v_rest)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    float *vr = v_rest + (size_t)i * (K - 1) * 3;
-    if (radii[i] <= 0) {
+    constexpr int R = (K - 1) * 3;
+    __shared__ __attribute__((aligned(16))) float svr[R > 0 ? 256 * R : 4];
+    const int tid = threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.x * 256;
+    const int64_t i = i0 + tid;
+    float *vr = svr + tid * R;
+    if (i < N) {
+        if (radii[i] <= 0) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { v_means[3 * i + k] = 0.f; v_ls[3 * i + k] = 0.f; v_dc[3 * i + k] = 0.f; }
-        *reinterpret_cast<float4 *>(v_quats + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
-        v_oplogit[i] = 0.f;
+            for (int k = 0; k < 3; ++k) { v_means[3 * i + k] = 0.f; v_ls[3 * i + k] = 0.f; v_dc[3 * i + k] = 0.f; }
+            *reinterpret_cast<float4 *>(v_quats + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+            v_oplogit[i] = 0.f;
 #pragma unroll
-        for (int k = 0; k < 3 * (K - 1); ++k) vr[k] = 0.f;
-        return;
-    }
-    float p0 = means[3 * i], p1 = means[3 * i + 1], p2 = means[3 * i + 2];
-    float s0 = expf(log_scales[3 * i]), s1 = expf(log_scales[3 * i + 1]), s2 = expf(log_scales[3 * i + 2]);
-    float4 qr = *reinterpret_cast<const float4 *>(quats + 4 * i);
-    float qn = sqrtf(((qr.x * qr.x + qr.y * qr.y) + qr.z * qr.z) + qr.w * qr.w);
-    float q0 = qr.x / qn, q1 = qr.y / qn, q2 = qr.z / qn, q3 = qr.w / qn;
-    ProjGrad g;
-    project_one_bwd(cam, p0, p1, p2, s0, s1, s2, q0, q1, q2, q3, conics[3 * i], conics[3 * i + 1], conics[3 * i + 2],
-                    v_xy[2 * i], v_xy[2 * i + 1], 0.f, v_conic[3 * i], v_conic[3 * i + 1], v_conic[3 * i + 2], g);
-    v_means[3 * i] = g.vm[0]; v_means[3 * i + 1] = g.vm[1]; v_means[3 * i + 2] = g.vm[2];
-    v_ls[3 * i] = g.vs[0] * s0; v_ls[3 * i + 1] = g.vs[1] * s1; v_ls[3 * i + 2] = g.vs[2] * s2;
-    // outer normalisation q/|q| (gc_model.py:144)
-    float dq = q0 * g.vq[0] + q1 * g.vq[1] + q2 * g.vq[2] + q3 * g.vq[3];
-    *reinterpret_cast<float4 *>(v_quats + 4 * i) =
-        make_float4((g.vq[0] - q0 * dq) / qn, (g.vq[1] - q1 * dq) / qn, (g.vq[2] - q2 * dq) / qn, (g.vq[3] - q3 * dq) / qn);
-    float op = sigmoidf(op_logit[i]);
-    v_oplogit[i] = v_opac[i] * op * (1.f - op);
-    // SH backward with the clamp(+0.5, min 0) mask recomputed from the forward value
-    float dx = p0 - cam.ox, dy = p1 - cam.oy, dz = p2 - cam.oz;
-    float dn = sqrtf((dx * dx + dy * dy) + dz * dz);
-    dx = dx / dn; dy = dy / dn; dz = dz / dn;
-    float B[16];
-    sh_basis(n_use, dx, dy, dz, B);
-    int Ku = (n_use + 1) * (n_use + 1);
-    float c0 = B[0] * f_dc[3 * i], c1 = B[0] * f_dc[3 * i + 1], c2 = B[0] * f_dc[3 * i + 2];
-    const float *r = f_rest + (size_t)i * (K - 1) * 3;
+            for (int k = 0; k < R; ++k) vr[k] = 0.f;
+        } else {
+            float p0 = means[3 * i], p1 = means[3 * i + 1], p2 = means[3 * i + 2];
+            float s0 = expf(log_scales[3 * i]), s1 = expf(log_scales[3 * i + 1]), s2 = expf(log_scales[3 * i + 2]);
+            float4 qr = *reinterpret_cast<const float4 *>(quats + 4 * i);
+            float qn = sqrtf(((qr.x * qr.x + qr.y * qr.y) + qr.z * qr.z) + qr.w * qr.w);
+            float q0 = qr.x / qn, q1 = qr.y / qn, q2 = qr.z / qn, q3 = qr.w / qn;
+            ProjGrad g;
+            project_one_bwd(cam, p0, p1, p2, s0, s1, s2, q0, q1, q2, q3, conics[3 * i], conics[3 * i + 1], conics[3 * i + 2],
+                            v_xy[2 * i], v_xy[2 * i + 1], 0.f, v_conic[3 * i], v_conic[3 * i + 1], v_conic[3 * i + 2], g);
+            v_means[3 * i] = g.vm[0]; v_means[3 * i + 1] = g.vm[1]; v_means[3 * i + 2] = g.vm[2];
+            v_ls[3 * i] = g.vs[0] * s0; v_ls[3 * i + 1] = g.vs[1] * s1; v_ls[3 * i + 2] = g.vs[2] * s2;
+            // outer normalisation q/|q| (gc_model.py:144)
+            float dq = q0 * g.vq[0] + q1 * g.vq[1] + q2 * g.vq[2] + q3 * g.vq[3];
+            *reinterpret_cast<float4 *>(v_quats + 4 * i) =
+                make_float4((g.vq[0] - q0 * dq) / qn, (g.vq[1] - q1 * dq) / qn, (g.vq[2] - q2 * dq) / qn, (g.vq[3] - q3 * dq) / qn);
+            float op = sigmoidf(op_logit[i]);
+            v_oplogit[i] = v_opac[i] * op * (1.f - op);
+            const float r0 = rgbs[3 * i], r1 = rgbs[3 * i + 1], r2 = rgbs[3 * i + 2];
+            if (n_use < 0) {        // d sigmoid(features_dc)
+                v_dc[3 * i] = v_rgbs[3 * i] * r0 * (1.f - r0); v_dc[3 * i + 1] = v_rgbs[3 * i + 1] * r1 * (1.f - r1);
+                v_dc[3 * i + 2] = v_rgbs[3 * i + 2] * r2 * (1.f - r2);
 #pragma unroll
-    for (int k = 1; k < K; ++k)
-        if (k < Ku) {
-            c0 += B[k] * r[3 * (k - 1)]; c1 += B[k] * r[3 * (k - 1) + 1]; c2 += B[k] * r[3 * (k - 1) + 2];
+                for (int k = 0; k < R; ++k) vr[k] = 0.f;
+            } else {
+                float dx = p0 - cam.ox, dy = p1 - cam.oy, dz = p2 - cam.oz;
+                float dn = sqrtf((dx * dx + dy * dy) + dz * dz);
+                dx = dx / dn; dy = dy / dn; dz = dz / dn;
+                float B[16];
+                sh_basis(n_use, dx, dy, dz, B);
+                int Ku = (n_use + 1) * (n_use + 1);
+                // clamp(SH + 0.5, min 0) (gc_model.py:167): the gradient passes where the forward colour is positive
+                float v0 = r0 > 0.f ? v_rgbs[3 * i] : 0.f;
+                float v1 = r1 > 0.f ? v_rgbs[3 * i + 1] : 0.f;
+                float v2 = r2 > 0.f ? v_rgbs[3 * i + 2] : 0.f;
+                v_dc[3 * i] = B[0] * v0; v_dc[3 * i + 1] = B[0] * v1; v_dc[3 * i + 2] = B[0] * v2;
+#pragma unroll
+                for (int k = 1; k < K; ++k) {
+                    float b = k < Ku ? B[k] : 0.f;
+                    vr[3 * (k - 1)] = b * v0; vr[3 * (k - 1) + 1] = b * v1; vr[3 * (k - 1) + 2] = b * v2;
+                }
+            }
         }
-    float v0 = (c0 + 0.5f) >= 0.f ? v_rgbs[3 * i] : 0.f;
-    float v1 = (c1 + 0.5f) >= 0.f ? v_rgbs[3 * i + 1] : 0.f;
-    float v2 = (c2 + 0.5f) >= 0.f ? v_rgbs[3 * i + 2] : 0.f;
-    v_dc[3 * i] = B[0] * v0; v_dc[3 * i + 1] = B[0] * v1; v_dc[3 * i + 2] = B[0] * v2;
-#pragma unroll
-    for (int k = 1; k < K; ++k) {
-        float b = k < Ku ? B[k] : 0.f;
-        vr[3 * (k - 1)] = b * v0; vr[3 * (k - 1) + 1] = b * v1; vr[3 * (k - 1) + 2] = b * v2;
+    }
+    if (R > 0) {
+        __syncthreads();
+        const int64_t cnt = ((N - i0 < 256 ? N - i0 : 256)) * R;
+        float *dst = v_rest + i0 * R;
+        for (int64_t j = tid; j < cnt / 4; j += 256) reinterpret_cast<float4 *>(dst)[j] = reinterpret_cast<const float4 *>(svr)[j];
+        for (int64_t j = (cnt / 4) * 4 + tid; j < cnt; j += 256) dst[j] = svr[j];
     }
 }
 
@@ -535,7 +575,7 @@ int gc_project_sh_fwd(int64_t N, const float *means, const float *log_scales, co
                       int tiles_x, int tiles_y, float clip_thresh, float *xys, float *depths, int32_t *radii,
                       float *conics, int32_t *num_tiles_hit, float *rgbs, float *opac, void *stream)
 {
-    GC_REQUIRE(sh_degree >= 0 && sh_degree <= 3 && degrees_to_use >= 0 && degrees_to_use <= sh_degree, "SH degree must be 0..3");
+    GC_REQUIRE(sh_degree >= 0 && sh_degree <= 3 && degrees_to_use >= -1 && degrees_to_use <= sh_degree, "SH degree must be 0..3 (degrees_to_use -1: sigmoid colour mode)");
     GC_REQUIRE(viewmat && projmat && cam_origin, "camera pointers are host pointers and must not be NULL");
     if (N == 0) return GC_OK;
     Cam cam = make_cam(viewmat, projmat, fx, fy, cx, cy, img_h, img_w, tiles_x, tiles_y, clip_thresh, 1.f, cam_origin);
@@ -545,19 +585,18 @@ int gc_project_sh_fwd(int64_t N, const float *means, const float *log_scales, co
 }
 
 int gc_project_sh_bwd(int64_t N, const float *means, const float *log_scales, const float *quats,
-                      const float *opacity_logits, const float *features_dc, const float *features_rest,
+                      const float *opacity_logits, const float *rgbs,
                       int sh_degree, int degrees_to_use, const float *viewmat, const float *projmat,
                       const float *cam_origin, float fx, float fy, float cx, float cy, int img_h, int img_w,
                       const int32_t *radii, const float *conics, const float *v_xy, const float *v_conic,
                       const float *v_rgbs, const float *v_opac, float *v_means, float *v_log_scales, float *v_quats,
                       float *v_opacity_logits, float *v_features_dc, float *v_features_rest, void *stream)
 {
-    GC_REQUIRE(sh_degree >= 0 && sh_degree <= 3 && degrees_to_use >= 0 && degrees_to_use <= sh_degree, "SH degree must be 0..3");
+    GC_REQUIRE(sh_degree >= 0 && sh_degree <= 3 && degrees_to_use >= -1 && degrees_to_use <= sh_degree, "SH degree must be 0..3 (degrees_to_use -1: sigmoid colour mode)");
     GC_REQUIRE(viewmat && projmat && cam_origin, "camera pointers are host pointers and must not be NULL");
     if (N == 0) return GC_OK;
     Cam cam = make_cam(viewmat, projmat, fx, fy, cx, cy, img_h, img_w, 0, 0, 0.f, 1.f, cam_origin);
-    GC_SH_DISPATCH(k_project_sh_bwd, N, cam, degrees_to_use, means, log_scales, quats, opacity_logits, features_dc,
-                   features_rest, radii, conics, v_xy, v_conic, v_rgbs, v_opac, v_means, v_log_scales, v_quats,
+    GC_SH_DISPATCH(k_project_sh_bwd, N, cam, degrees_to_use, means, log_scales, quats, opacity_logits, rgbs, radii, conics, v_xy, v_conic, v_rgbs, v_opac, v_means, v_log_scales, v_quats,
                    v_opacity_logits, v_features_dc, v_features_rest)
     return gc::check_launch("gc_project_sh_bwd");
 }

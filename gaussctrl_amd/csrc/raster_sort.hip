@@ -199,11 +199,8 @@ Plan make_plan(int64_t n)
 
 void set_attr()
 {
-    static bool done = false;
-    if (!done) {
-        (void)hipFuncSetAttribute((const void *)k_radix_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, RI * 4 * 256 * 4);
-        done = true;
-    }
+    static gc::AttrOnce once;
+    gc::ensure_dynamic_lds(once, (const void *)k_radix_scatter, RI * 4 * 256 * 4);
 }
 
 // one stable 8-bit radix pass

@@ -18,9 +18,11 @@ constexpr int TS = 16;   // output tile
 
 struct Gauss { float w[WIN]; };
 
-// 5 separable 11x11 gaussian blurs in one pass: mu_x, mu_y, E[x^2], E[y^2], E[xy] of one channel plane (zero padding, like
-// conv2d(padding=5)); then the per-pixel SSIM and its partial derivatives w.r.t. (mu_x, E[x^2], E[xy]).
-__global__ __launch_bounds__(256) void k_ssim_stats(const float *__restrict__ x, const float *__restrict__ y, int H, int W, int C,
+// 5 separable 11x11 gaussian blurs in one pass: mu_x, mu_y, E[x^2], E[y^2], E[xy] of one channel plane; then the per-pixel SSIM
+// and its partial derivatives w.r.t. (mu_x, E[x^2], E[xy]).  valid = 1: the SSIM map exists only where the 11x11 window lies inside
+// the image ((H-10) x (W-10) pixels: pytorch_msssim's unpadded convolution, what splatfacto's loss uses); valid = 0: zero-padded
+// 'same' windows on all H x W pixels (conv2d(padding=5), the 3DGS convention).
+__global__ __launch_bounds__(256) void k_ssim_stats(const float *__restrict__ x, const float *__restrict__ y, int H, int W, int C, int valid,
                                                     Gauss gw, float *__restrict__ ssim_sum, float *__restrict__ dmu,
                                                     float *__restrict__ dxx, float *__restrict__ dxy, float *__restrict__ l1_sum)
 {
@@ -52,7 +54,14 @@ __global__ __launch_bounds__(256) void k_ssim_stats(const float *__restrict__ x,
     const int lx = tid & 15, ly = tid >> 4;
     const int gx = tx0 + lx, gy = ty0 + ly;
     float ssim = 0.f, l1 = 0.f;
-    if (gx < W && gy < H) {
+    const bool inside = gx < W && gy < H;
+    const bool has_win = inside && (!valid || (gx >= HALF && gx < W - HALF && gy >= HALF && gy < H - HALF));
+    if (inside && !has_win) {       // no SSIM term for this pixel: zero partials (k_ssim_grad gathers them), L1 still counts
+        const size_t o = ((size_t)gy * W + gx) * C + c;
+        dmu[o] = 0.f; dxx[o] = 0.f; dxy[o] = 0.f;
+        l1 = fabsf(sx[ly + HALF][lx + HALF] - sy[ly + HALF][lx + HALF]);
+    }
+    if (has_win) {
         float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
 #pragma unroll
         for (int k = 0; k < WIN; ++k) {
@@ -87,7 +96,7 @@ __global__ __launch_bounds__(256) void k_ssim_stats(const float *__restrict__ x,
 // v_x = (1-l)/n * sign(x - y) - l/n * ( G*(dmu) + 2 x G*(dxx) + y G*(dxy) )    (G = the same separable window, zero padded)
 __global__ __launch_bounds__(256) void k_ssim_grad(const float *__restrict__ x, const float *__restrict__ y, int H, int W, int C,
                                                    Gauss gw, const float *__restrict__ dmu, const float *__restrict__ dxx,
-                                                   const float *__restrict__ dxy, float lambda_, float inv_n, float scale,
+                                                   const float *__restrict__ dxy, float lambda_, float inv_n, float inv_n_ssim, float scale,
                                                    float *__restrict__ v_x)
 {
     constexpr int TW = TS + 2 * HALF;
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(256) void k_ssim_grad(const float *__restrict__ x, 
     const float xv = x[o], yv = y[o];
     const float dssim = a + 2.f * xv * b + yv * d;
     const float sgn = xv > yv ? 1.f : (xv < yv ? -1.f : 0.f);
-    v_x[o] = scale * ((1.f - lambda_) * inv_n * sgn - lambda_ * inv_n * dssim);
+    v_x[o] = scale * ((1.f - lambda_) * inv_n * sgn - lambda_ * inv_n_ssim * dssim);
 }
 
 // Adam (torch.optim.Adam semantics, no weight decay / amsgrad): one fused pass, 16 bytes per lane per stream.
@@ -163,12 +172,15 @@ extern "C" {
 size_t gc_l1_ssim_workspace_bytes(int H, int W, int C) { return sizeof(float) * (3 * (size_t)H * W * C + 2); }
 
 /* loss = (1-lambda)*mean|x-y| + lambda*(1 - mean SSIM(x,y)); pred x / target y: float32 [H,W,C] channels-last.
+ * valid_window = 1: SSIM averaged over the (H-10) x (W-10) x C pixels with a full window (pytorch_msssim, splatfacto's loss);
+ * 0: zero-padded windows, H x W x C pixels.
  * loss_out: device float[2] = {sum SSIM map, sum |x-y|} (the caller forms the scalar: no host sync here);
  * v_pred: d(loss)/d(pred) * grad_scale, same layout.  workspace >= gc_l1_ssim_workspace_bytes. */
-int gc_l1_ssim_fwd_bwd(const float *pred, const float *target, int H, int W, int C, float lambda_, float grad_scale,
+int gc_l1_ssim_fwd_bwd(const float *pred, const float *target, int H, int W, int C, float lambda_, float grad_scale, int valid_window,
                        float *loss_out, float *v_pred, void *workspace, size_t workspace_bytes, void *stream)
 {
     GC_REQUIRE(pred && target && loss_out && v_pred && workspace, "null argument");
+    GC_REQUIRE(!valid_window || (H > 2 * HALF && W > 2 * HALF), "valid-window SSIM needs an image larger than 11 x 11");
     if (workspace_bytes < gc_l1_ssim_workspace_bytes(H, W, C)) { gc::set_error("gc_l1_ssim_fwd_bwd: workspace too small"); return GC_ENOSPC; }
     hipStream_t s = gc::S(stream);
     const size_t n = (size_t)H * W * C;
@@ -176,8 +188,10 @@ int gc_l1_ssim_fwd_bwd(const float *pred, const float *target, int H, int W, int
     if (hipMemsetAsync(loss_out, 0, 2 * sizeof(float), s) != hipSuccess) return GC_ELAUNCH;
     const Gauss gw = make_window();
     dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, C);
-    hipLaunchKernelGGL(k_ssim_stats, grid, dim3(256), 0, s, pred, target, H, W, C, gw, loss_out, dmu, dxx, dxy, loss_out + 1);
-    hipLaunchKernelGGL(k_ssim_grad, grid, dim3(256), 0, s, pred, target, H, W, C, gw, dmu, dxx, dxy, lambda_, 1.f / (float)n, grad_scale, v_pred);
+    const size_t n_ssim = valid_window ? (size_t)(H - 2 * HALF) * (W - 2 * HALF) * C : n;
+    hipLaunchKernelGGL(k_ssim_stats, grid, dim3(256), 0, s, pred, target, H, W, C, valid_window, gw, loss_out, dmu, dxx, dxy, loss_out + 1);
+    hipLaunchKernelGGL(k_ssim_grad, grid, dim3(256), 0, s, pred, target, H, W, C, gw, dmu, dxx, dxy, lambda_, 1.f / (float)n,
+                       1.f / (float)n_ssim, grad_scale, v_pred);
     return gc::check_launch("gc_l1_ssim_fwd_bwd");
 }
 

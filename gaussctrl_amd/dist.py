@@ -64,39 +64,93 @@ def _bank_steps(store: dict) -> list:
     return sorted({k[0] for k in store})
 
 
+def _step_meta(bank, st: int) -> list:
+    """[(layer key, K shape, K row stride, V^T shape, dtype)] of one DDIM step, in a rank-independent order."""
+    items = sorted(((key, kv) for key, kv in bank.store.items() if key[0] == st), key=lambda kv: str(kv[0]))
+    return [(key[1], tuple(k.shape), k.stride(1), tuple(vt.shape), str(k.dtype)) for key, (k, vt) in items]
+
+
+def _pack_step(bank, st: int, layers: list) -> torch.Tensor:
+    return torch.cat([t.reshape(-1) for layer, *_ in layers for t in (bank.store[(st, layer)][0].contiguous(), bank.store[(st, layer)][1])])
+
+
+def _step_numel(layers: list) -> int:
+    return sum(int(torch.Size(ks).numel()) + int(torch.Size(vs).numel()) for _, ks, _, vs, _ in layers)
+
+
+def _unpack_step(bank, st: int, layers: list, flat: torch.Tensor) -> None:
+    o = 0
+    for layer, ks, kstride, vs, dt in layers:
+        nk, nv = int(torch.Size(ks).numel()), int(torch.Size(vs).numel())
+        buf = torch.empty(ks[0], ks[1], kstride, dtype=flat.dtype, device=flat.device)      # row stride of the Q|K buffer
+        k = buf[..., kstride - ks[2]:]
+        k.copy_(flat[o:o + nk].view(ks)); o += nk
+        vt = flat[o:o + nv].view(vs).clone(); o += nv
+        bank.store[(st, layer)] = (k, vt)
+
+
 def broadcast_ref_bank(bank, src: int, world_size: int, rank: int, device=None, steps=None):
-    """Broadcast a RefBank (gaussctrl_amd.sd.unet.RefBank) from rank `src` to every rank, one flat buffer per DDIM step.
+    """Broadcast a finished RefBank (gaussctrl_amd.sd.unet.RefBank) from rank `src` to every rank, one flat buffer per DDIM step.
 
     On `src`, `bank` holds {(step, layer): (K [R,L,C] (a column slice of the Q|K buffer), V^T [R,C,Lp])}.  The other ranks pass an
     empty RefBank and get the same keys; K is re-materialised with the row stride the attention kernel expects (2 C: the bank K
-    is read with the live K's leading dimension).  `steps` restricts the call to some DDIM steps (pipelined use: broadcast step i
-    while step i+1 is being computed)."""
+    is read with the live K's leading dimension).  `steps` restricts the call to some DDIM steps."""
     if world_size <= 1:
         return bank
     import torch.distributed as dist
     meta = [None]
     if rank == src:
         todo = _bank_steps(bank.store) if steps is None else list(steps)
-        meta[0] = [(st, [(key[1], tuple(k.shape), k.stride(1), tuple(vt.shape), str(k.dtype)) for key, (k, vt) in sorted(bank.store.items(), key=lambda kv: str(kv[0])) if key[0] == st])
-                   for st in todo]
+        meta[0] = [(st, _step_meta(bank, st)) for st in todo]
     dist.broadcast_object_list(meta, src=src)
     for st, layers in meta[0]:
-        n = sum(int(torch.Size(ks).numel()) + int(torch.Size(vs).numel()) for _, ks, _, vs, _ in layers)
         dtype = getattr(torch, layers[0][4].split(".")[-1])
-        if rank == src:
-            flat = torch.cat([t.reshape(-1) for layer, *_ in layers for t in (bank.store[(st, layer)][0].contiguous(), bank.store[(st, layer)][1])])
-        else:
-            flat = torch.empty(n, dtype=dtype, device=device)
+        flat = _pack_step(bank, st, layers) if rank == src else torch.empty(_step_numel(layers), dtype=dtype, device=device)
         dist.broadcast(flat, src=src)
         if rank != src:
-            o = 0
-            for layer, ks, kstride, vs, _ in layers:
-                nk, nv = int(torch.Size(ks).numel()), int(torch.Size(vs).numel())
-                buf = torch.empty(ks[0], ks[1], kstride, dtype=dtype, device=flat.device)      # row stride of the Q|K buffer
-                k = buf[..., kstride - ks[2]:]
-                k.copy_(flat[o:o + nk].view(ks)); o += nk
-                vt = flat[o:o + nv].view(vs).clone(); o += nv
-                bank.store[(st, layer)] = (k, vt)
+            _unpack_step(bank, st, layers, flat)
     if rank != src:
         bank.mode = "use"
+    return bank
+
+
+def broadcast_ref_bank_pipelined(pipe, ref_z0, ref_disp, ctx_neg, ctx_pos, src: int, world_size: int, rank: int, device, n_steps: int):
+    """SURVEY.md 8e collective 1 as a pipeline: the owner advances the 4-view reference trajectory ONE DDIM step at a time and
+    posts step i's K / V^T (one flat message, ~0.5 GB at SD1.5 / 512x512) as an ASYNC broadcast while it computes step i+1; the other
+    ranks post the matching receives up front and unpack as they complete, so the transfer of step i rides under the compute of step
+    i+1 (RCCL runs on its own stream) instead of 20 serial broadcasts after the whole bank exists.  The per-step layout is the same
+    for every step: it travels once, after step 0."""
+    import torch.distributed as dist
+    from .sd.unet import RefBank
+    pending = []
+    if rank == src:
+        tr = pipe.begin_ref_bank(ref_z0, ref_disp, ctx_neg, ctx_pos)
+        bank = tr["bank"]
+        layers = None
+        for i in range(n_steps):
+            done = pipe.advance_ref_bank(tr, 1)
+            if layers is None:
+                layers = _step_meta(bank, 0)
+                dist.broadcast_object_list([layers], src=src)
+            lay_i = [(l, ks, kst, vs, dt) for (l, ks, kst, vs, dt) in layers]
+            flat = _pack_step(bank, i, lay_i)
+            if flat.is_cuda:
+                torch.cuda.current_stream().synchronize()      # the packed buffer is complete before RCCL's stream reads it
+            pending.append((dist.broadcast(flat, src=src, async_op=True), flat))
+        for h, _ in pending:
+            h.wait()
+        assert done is not None
+        return done
+    bank = RefBank()
+    box = [None]
+    dist.broadcast_object_list(box, src=src)
+    layers = box[0]
+    dtype = getattr(torch, layers[0][4].split(".")[-1])
+    for i in range(n_steps):
+        flat = torch.empty(_step_numel(layers), dtype=dtype, device=device)
+        pending.append((dist.broadcast(flat, src=src, async_op=True), flat))
+    for i, (h, flat) in enumerate(pending):
+        h.wait()
+        _unpack_step(bank, i, layers, flat)
+    bank.mode = "use"
     return bank

@@ -18,30 +18,53 @@ from torch import nn
 
 from . import gsplat_ops as ops
 from .camera import camera_to_gsplat
-from .ns_compat import Cameras
+from .ns_compat import HAVE_NERFSTUDIO, Cameras
+
+if HAVE_NERFSTUDIO:  # the reference's bases (gc_model.py:39,52): SplatfactoModelConfig / SplatfactoModel
+    from nerfstudio.models.splatfacto import SplatfactoModel as _ModelBase, SplatfactoModelConfig as _ModelConfigBase  # type: ignore
+else:
+    _ModelBase = nn.Module
+
+    @dataclass
+    class _ModelConfigBase:
+        """the SplatfactoModelConfig fields get_outputs / the loss / the culling callback read [recall nerfstudio 1.0.0]"""
+        sh_degree: int = 3
+        sh_degree_interval: int = 1000
+        background_color: str = "random"
+        ssim_lambda: float = 0.2
+        cull_alpha_thresh: float = 0.1
+        cull_scale_thresh: float = 0.5
+        refine_every: int = 100
+        reset_alpha_every: int = 30
+        stop_split_at: int = 15000
+        continue_cull_post_densification: bool = True
+
+        def setup(self, **kw):
+            return self._target(self, **kw)
 
 
 @dataclass
-class GaussCtrlModelConfig:
-    """gc_model.py:39-50 (+ the splatfacto fields get_outputs reads)."""
-    sh_degree: int = 3
-    sh_degree_interval: int = 1000
-    background_color: str = "random"
-    use_lpips: bool = True          # never read by the reference (no get_loss_dict override)
+class GaussCtrlModelConfig(_ModelConfigBase):
+    """gc_model.py:39-50: the four fields the reference adds (never read: it has no get_loss_dict override)."""
+    _target: type = field(default_factory=lambda: GaussCtrlModel)
+    use_lpips: bool = True
     use_l1: bool = True
     patch_size: int = 32
     lpips_loss_mult: float = 1.0
-    ssim_lambda: float = 0.2
-
-    def setup(self, **kw):
-        return GaussCtrlModel(self, **kw)
 
 
-class GaussCtrlModel(nn.Module):
+class GaussCtrlModel(_ModelBase):
+    """Under nerfstudio: a SplatfactoModel whose get_outputs / get_outputs_for_camera / loss run on the HIP kernels (parameters,
+    densification callbacks, checkpoint keys and param groups are splatfacto's own).  Stand-alone: the same methods on an
+    nn.Module that holds the six splatfacto parameter tensors."""
     config: GaussCtrlModelConfig
 
-    def __init__(self, config: GaussCtrlModelConfig, params: Optional[Dict[str, torch.Tensor]] = None, num_points: int = 0,
-                 device="cuda"):
+    def __init__(self, config: GaussCtrlModelConfig, *args, params: Optional[Dict[str, torch.Tensor]] = None, num_points: int = 0,
+                 device="cuda", **kwargs):
+        if HAVE_NERFSTUDIO:
+            super().__init__(config, *args, **kwargs)         # SplatfactoModel.populate_modules creates the parameters
+            self._aux = ops.RenderAux()
+            return
         super().__init__()
         self.config = config
         k = (config.sh_degree + 1) ** 2 - 1
@@ -71,8 +94,19 @@ class GaussCtrlModel(nn.Module):
         self.crop_box = crop_box
 
     def get_param_groups(self) -> Dict[str, List[nn.Parameter]]:
+        if HAVE_NERFSTUDIO:
+            return super().get_param_groups()
         return {"xyz": [self.means], "features_dc": [self.features_dc], "features_rest": [self.features_rest],
                 "opacity": [self.opacities], "scaling": [self.scales], "rotation": [self.quats]}
+
+    def get_training_callbacks(self, training_callback_attributes):
+        """SplatfactoModel's callbacks (step bookkeeping, after_train, refinement_after) under nerfstudio; stand-alone: the
+        part of refinement_after that still acts after step 30000 (> stop_split_at = 15000): opacity / scale culling every
+        `refine_every` steps [recall nerfstudio 1.0.0 splatfacto.py; SURVEY.md 3.5]."""
+        if HAVE_NERFSTUDIO:
+            return super().get_training_callbacks(training_callback_attributes)
+        from .gc_trainer import CullCallback, StepCallback
+        return [StepCallback(self), CullCallback(self, training_callback_attributes.optimizers)]
 
     # ------------------------------------------------------------------------------------ gc_model.py:57-206
     def get_outputs(self, camera: Cameras) -> Dict[str, Union[torch.Tensor, List]]:
@@ -98,7 +132,8 @@ class GaussCtrlModel(nn.Module):
                                float(camera.fy.reshape(-1)[0]), float(camera.cx.reshape(-1)[0]),
                                float(camera.cy.reshape(-1)[0]), W, H)        # :97-121 on the host
         self.last_size = (H, W)
-        n = min(self.step // self.config.sh_degree_interval, self.config.sh_degree)   # :165
+        # :162-169: SH of degree n (+0.5, clamp) when config.sh_degree > 0, else sigmoid(features_dc) (encoded as n = -1)
+        n = min(self.step // self.config.sh_degree_interval, self.config.sh_degree) if self.config.sh_degree > 0 else -1
         aux = self._aux = ops.RenderAux()
         rgb, alpha, depth = ops.render_view(*p, cam, background, not self.training, n, aux)
         self.xys, self.radii = aux.xys, aux.radii
@@ -134,17 +169,3 @@ class GaussCtrlModel(nn.Module):
         from .train_ops import l1_ssim_loss
         gt = batch["image"].to(self.device)
         return {"main_loss": l1_ssim_loss(outputs["rgb"], gt, self.config.ssim_lambda)}
-
-
-def _ssim(a, b, window=11, sigma=1.5):
-    """Plain-torch SSIM with a gaussian 11x11 window: NOT on the product path (get_loss_dict uses the fused HIP kernels of
-    train_ops.l1_ssim_loss); kept as the readable definition the GPU test compares against."""
-    import torch.nn.functional as F
-    coords = torch.arange(window, dtype=a.dtype, device=a.device) - window // 2
-    g = torch.exp(-(coords ** 2) / (2 * sigma ** 2)); g = (g / g.sum())
-    k = (g[:, None] * g[None, :])[None, None].expand(a.shape[1], 1, window, window)
-    mu = lambda x: F.conv2d(x, k, padding=window // 2, groups=x.shape[1])
-    ma, mb = mu(a), mu(b)
-    va, vb, cab = mu(a * a) - ma * ma, mu(b * b) - mb * mb, mu(a * b) - ma * mb
-    c1, c2 = 0.01 ** 2, 0.03 ** 2
-    return (((2 * ma * mb + c1) * (2 * cab + c2)) / ((ma * ma + mb * mb + c1) * (va + vb + c2))).mean()

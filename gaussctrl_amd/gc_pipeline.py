@@ -23,44 +23,29 @@ from typing import Literal, Optional
 import torch
 from torch import nn
 
+from .gc_datamanager import GaussCtrlDataManager, GaussCtrlDataManagerConfig, SimpleDataManager  # noqa: F401
 from .gc_model import GaussCtrlModel, GaussCtrlModelConfig
-from .ns_compat import Cameras
+from .ns_compat import HAVE_NERFSTUDIO, Cameras
 from .sd import arch, ops as sdops
 from .sd.pipeline import DenoisePipeline, to_nhwc8
 from .sd.vae import VAEEncoder, prepare_vae_encoder_weights, prepare_vae_weights
 from .sd.weights import prepare
 
+if HAVE_NERFSTUDIO:  # the reference's bases (gc_pipeline.py:48,76): VanillaPipelineConfig / VanillaPipeline
+    from nerfstudio.pipelines.base_pipeline import VanillaPipeline as _PipelineBase, VanillaPipelineConfig as _PipelineConfigBase  # type: ignore
+else:
+    _PipelineBase = nn.Module
 
-@dataclass
-class GaussCtrlDataManagerConfig:
-    """gc_datamanager.py:54-66"""
-    subset_num: int = 4
-    sampled_views_every_subset: int = 10
-    load_all: bool = False
-
-
-class SimpleDataManager:
-    """Minimal stand-in for GaussCtrlDataManager (host I/O is out of scope): holds `cameras`
-    and the `train_data` list of dicts the pipeline reads and writes (image, unedited_image, depth_image, z_0_image,
-    mask_image, image_idx) and yields (camera, batch) like next_train (gc_datamanager.py:213-235)."""
-
-    def __init__(self, cameras: Cameras, images=None, seed: int = 0):
-        self.cameras = cameras
-        n = len(cameras)
-        self.train_data = [{"image_idx": i, "image": None if images is None else images[i]} for i in range(n)]
-        self._rng = random.Random(seed)
-        self._unseen = list(range(n))
-
-    def next_train(self, step: int):
-        if not self._unseen:
-            self._unseen = list(range(len(self.cameras)))
-        i = self._unseen.pop(self._rng.randint(0, len(self._unseen) - 1))
-        return self.cameras[i], dict(self.train_data[i])
+    @dataclass
+    class _PipelineConfigBase:
+        def setup(self, **kw):
+            return self._target(self, **kw)
 
 
 @dataclass
-class GaussCtrlPipelineConfig:
+class GaussCtrlPipelineConfig(_PipelineConfigBase):
     """gc_pipeline.py:48-73 (names and defaults kept)."""
+    _target: type = field(default_factory=lambda: GaussCtrlPipeline)
     datamanager: GaussCtrlDataManagerConfig = field(default_factory=GaussCtrlDataManagerConfig)
     model: GaussCtrlModelConfig = field(default_factory=GaussCtrlModelConfig)
     render_rate: int = 500
@@ -73,28 +58,31 @@ class GaussCtrlPipelineConfig:
     ref_view_num: int = 4
     diffusion_ckpt: str = "CompVis/stable-diffusion-v1-4"
     # --- additions of this implementation
+    controlnet_ckpt: str = "lllyasviel/sd-controlnet-depth"      # hard-coded in the reference (:100)
     dtype: str = "f16"                 # the reference runs fp16 (:101); "bf16" is the throughput default of bench.py
     cache_reference_kv: bool = True
-    ref_bank_owner: int = -1           # world_size > 1: rank that computes the reference trajectory and broadcasts its K / V^T
-                                       # (-1: every rank computes it itself -- no data-path collective)
+    ref_bank_owner: int = -1           # world_size > 1: rank that computes the reference trajectory and broadcasts its K / V^T step
+                                       # by step (-1: every rank computes it itself -- no data-path collective)
+    synthetic_weights: bool = False    # True: seeded random SD1.5-shaped weights + hashed prompt embeddings (bench / tests; there
+                                       # are no checkpoints on the build machines).  False: checkpoints are REQUIRED -- no silent fallback.
 
-    def setup(self, **kw):
-        return GaussCtrlPipeline(self, **kw)
 
-
-class GaussCtrlPipeline(nn.Module):
+class GaussCtrlPipeline(_PipelineBase):
     config: GaussCtrlPipelineConfig
 
     def __init__(self, config: GaussCtrlPipelineConfig, device: str, test_mode: Literal["test", "val", "inference"] = "val",
                  world_size: int = 1, local_rank: int = 0, grad_scaler=None, *, datamanager=None, model=None,
                  diffusion_weights: Optional[dict] = None, text_encoder=None, mask_fn=None):
-        super().__init__()
-        self.config = config
+        if HAVE_NERFSTUDIO and datamanager is None:
+            super().__init__(config, device, test_mode, world_size, local_rank)      # builds datamanager + _model from the config tree
+        else:
+            nn.Module.__init__(self)
+            self.config = config
+            self.datamanager = datamanager
+            self._model = model
         self.device = torch.device(device)
         self.test_mode = test_mode
         self.world_size, self.local_rank = world_size, local_rank
-        self.datamanager = datamanager
-        self._model = model
         self.edit_prompt, self.reverse_prompt = config.edit_prompt, config.reverse_prompt
         added_prompt = "best quality, extremely detailed"                                        # :104-107
         self.positive_prompt = self.edit_prompt + ", " + added_prompt
@@ -112,27 +100,52 @@ class GaussCtrlPipeline(nn.Module):
         self.num_inference_steps, self.guidance_scale = config.num_inference_steps, config.guidance_scale
         self.controlnet_conditioning_scale, self.eta, self.chunk_size = 1.0, 0.0, config.chunk_size
         self.dtype = torch.float16 if config.dtype == "f16" else torch.bfloat16
-        w = diffusion_weights or {}
         dev = self.device
+        self.weights_source = {}
+        w = diffusion_weights
+        if w is None and not config.synthetic_weights:                 # the reference's from_pretrained calls (:97-102)
+            from .sd.checkpoint import load_diffusion_weights, load_text_encoder
+            w = load_diffusion_weights(config.diffusion_ckpt, config.controlnet_ckpt)
+            if text_encoder is None:
+                text_encoder = load_text_encoder(config.diffusion_ckpt)
+            self.weights_source = {k: config.controlnet_ckpt if k == "controlnet" else config.diffusion_ckpt for k in w}
+        w = w or {}
 
         def get(name, shapes, seed):
             sd = w.get(name)
-            if sd is None:      # no checkpoint available (no network): seeded random weights of the exact shapes
-                sd = arch.random_state_dict(shapes, seed, dev)
-            else:
-                arch.check_state_dict(sd, shapes)
+            if sd is None:
+                if not config.synthetic_weights:
+                    raise KeyError(f"diffusion_weights has no '{name}' state dict (have {sorted(w)}); seeded random weights are used "
+                                   "only with GaussCtrlPipelineConfig.synthetic_weights=True")
+                self.weights_source[name] = f"synthetic(seed={seed})"
+                return arch.random_state_dict(shapes, seed, dev)
+            arch.check_state_dict(sd, shapes)
+            self.weights_source.setdefault(name, "caller-supplied state dict")
             return sd
         self.pipe = DenoisePipeline(prepare(get("unet", arch.unet_shapes(), 100), self.dtype, dev, heads=8),
                                     prepare(get("controlnet", arch.controlnet_shapes(), 200), self.dtype, dev, heads=8),
                                     prepare_vae_weights(get("vae_decoder", arch.vae_decoder_shapes(), 300), self.dtype, dev),
                                     self.num_inference_steps, self.guidance_scale, self.controlnet_conditioning_scale)
         self.vae_encoder = VAEEncoder(prepare_vae_encoder_weights(get("vae_encoder", arch.vae_encoder_shapes(), 400), self.dtype, dev))
-        self.text_encoder = text_encoder or _hash_text_encoder     # CLIP text tower is outside the hot path
+        if text_encoder is None:
+            if not config.synthetic_weights:
+                raise ValueError("a text_encoder (prompt -> [1,77,768]) is required; the hashed stand-in is used only with "
+                                 "GaussCtrlPipelineConfig.synthetic_weights=True")
+            text_encoder = _hash_text_encoder
+            self.weights_source["text_encoder"] = "synthetic(hash of the prompt)"
+        self.text_encoder = text_encoder                           # CLIP text tower: outside the hot path
         self.mask_fn = mask_fn                                     # LangSAM stand-in: image[H,W,3] -> mask[H,W] (out of scope)
+        print("[gaussctrl_amd] diffusion weights: " + ", ".join(f"{k} <- {v}" for k, v in sorted(self.weights_source.items())))
 
     @property
     def model(self):
-        return self._model
+        return self._model.module if hasattr(self._model, "module") and not isinstance(self._model, GaussCtrlModel) else self._model
+
+    def get_training_callbacks(self, training_callback_attributes):
+        """gc_trainer.py:112-118 asks the pipeline; VanillaPipeline = datamanager callbacks + model callbacks."""
+        if HAVE_NERFSTUDIO and hasattr(_PipelineBase, "get_training_callbacks"):
+            return super().get_training_callbacks(training_callback_attributes)
+        return list(self.model.get_training_callbacks(training_callback_attributes))
 
     def _encode(self, prompt):
         return self.text_encoder(prompt).to(self.device)
@@ -168,19 +181,22 @@ class GaussCtrlPipeline(nn.Module):
         """Chunked cross-view ControlNet denoise of the (local) views; writes train_data[i]['image'] (HWC fp32)."""
         td = self.datamanager.train_data
         cn, cp = self._encode(self.negative_prompts), self._encode(self.positive_prompt)
-        ref_z0 = torch.cat([td[i]["z_0_image"] for i in self.ref_indices], 0) if all("z_0_image" in td[i] for i in self.ref_indices) else None
-        if ref_z0 is None:
-            raise RuntimeError("reference views must be rendered/inverted on every rank (render_reverse with world_size>1 shards "
-                               "views; call render_reverse_refs first)")
-        ref_disp = torch.stack([self.depth2disparity_torch(td[i]["depth_image"]) for i in self.ref_indices])
+        owner = self.config.ref_bank_owner if (self.world_size > 1 and self.config.cache_reference_kv) else -1
+        need_refs = owner < 0 or self.local_rank == owner or not self.config.cache_reference_kv
+        if need_refs:
+            self.render_reverse_refs()        # views are sharded: the 4 reference views may live on other ranks (cheap to redo here)
+        ref_z0 = ref_disp = None
+        if need_refs:
+            ref_z0 = torch.cat([td[i]["z_0_image"] for i in self.ref_indices], 0)
+            ref_disp = torch.stack([self.depth2disparity_torch(td[i]["depth_image"]) for i in self.ref_indices])
         bank = None
         if self.config.cache_reference_kv:
-            owner = self.config.ref_bank_owner
-            if self.world_size > 1 and owner >= 0:
-                from .dist import broadcast_ref_bank
-                from .sd.unet import RefBank
-                bank = self.pipe.build_ref_bank(ref_z0, ref_disp, cn, cp) if self.local_rank == owner else RefBank()
-                bank = broadcast_ref_bank(bank, owner, self.world_size, self.local_rank, self.device)
+            if owner >= 0:
+                # one owner rank runs the 4-view reference trajectory; each DDIM step's K / V^T is broadcast (one flat RCCL message
+                # per step) while the owner already computes the next step (SURVEY.md 8e collective 1)
+                from .dist import broadcast_ref_bank_pipelined
+                bank = broadcast_ref_bank_pipelined(self.pipe, ref_z0, ref_disp, cn, cp, owner, self.world_size, self.local_rank,
+                                                    self.device, self.num_inference_steps)
             else:
                 bank = self.pipe.build_ref_bank(ref_z0, ref_disp, cn, cp)
         views = self._my_views()
@@ -210,7 +226,8 @@ class GaussCtrlPipeline(nn.Module):
         from .dist import allgather_view_images
         td = self.datamanager.train_data
         mine = self._my_views()
-        shape = td[mine[0]]["image"].shape
+        cam = self.datamanager.cameras[0]          # a rank may own no view (V < world_size): the image shape comes from the camera
+        shape = (int(cam.height.reshape(-1)[0]), int(cam.width.reshape(-1)[0]), 3)
         allv = allgather_view_images({i: td[i]["image"] for i in mine}, len(td), self.world_size, self.local_rank, shape, self.device)
         for i, img in allv.items():
             td[i]["image"] = img

@@ -275,6 +275,7 @@ class RenderAux:
     xys = None
     radii = None
     num_tiles_hit = None
+    depths = None
     xys_grad = None
     M = 0
     gaussian_ids_sorted = None
@@ -318,7 +319,7 @@ class _RenderView(torch.autograd.Function):
         L.check(lib.gc_raster_finalize(L.i64(H * W), L.ptr(img), L.ptr(dep), L.ptr(fT), L.ptr(alpha), st),
                 "gc_raster_finalize")
         if aux is not None:
-            aux.xys, aux.radii, aux.num_tiles_hit, aux.M = xys, radii, nth, M
+            aux.xys, aux.radii, aux.num_tiles_hit, aux.M, aux.depths = xys, radii, nth, M, depths
             aux.gaussian_ids_sorted, aux.tile_bins, aux.final_index, aux.isect_ids_sorted = ids_s, bins, fi, keys_s
             aux.xys_grad = None
         ctx.save_for_backward(m, ls, q, op, dc, rest, radii, conics, xys, rgbs, opac, ids_s, bins, bg, fT, fi, pre_clamp)
@@ -345,7 +346,7 @@ class _RenderView(torch.autograd.Function):
         vop = torch.empty(N, device=dev); vdc = torch.empty(N, 3, device=dev)
         vrest = torch.empty(rest.shape, device=dev)
         L.check(L.lib().gc_project_sh_bwd(
-            L.i64(N), L.ptr(m), L.ptr(ls), L.ptr(q), L.ptr(op), L.ptr(dc), L.ptr(rest), L.i32(sh_degree), L.i32(n_use),
+            L.i64(N), L.ptr(m), L.ptr(ls), L.ptr(q), L.ptr(op), L.ptr(rgbs), L.i32(sh_degree), L.i32(n_use),
             V, P, O, L.f32(cam["fx"]), L.f32(cam["fy"]), L.f32(cam["cx"]), L.f32(cam["cy"]), L.i32(H), L.i32(W),
             L.ptr(radii), L.ptr(conics), L.ptr(v_xy), L.ptr(v_conic), L.ptr(v_col), L.ptr(v_op), L.ptr(vm), L.ptr(vls),
             L.ptr(vq), L.ptr(vop), L.ptr(vdc), L.ptr(vrest), L.stream_ptr()), "gc_project_sh_bwd")

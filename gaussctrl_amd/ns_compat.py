@@ -1,13 +1,17 @@
 """nerfstudio surface the plugin needs.  When nerfstudio (pinned 1.0.0 by /root/reference/README.md:53-56) is
-importable its own classes are used; otherwise minimal stand-ins with the same attribute names keep the
-Pipeline / Model classes usable (the build environment has no nerfstudio and no network)."""
+importable the plugin classes SUBCLASS its own bases (Trainer / VanillaPipeline / SplatfactoModel /
+FullImageDatamanager and their configs) so that `ns-train gaussctrl` instantiates them through the usual config tree;
+otherwise minimal stand-ins with the same attribute names keep the Pipeline / Model / Trainer classes usable (the build
+environment has no nerfstudio and no network).  tests/test_plugin_config.py runs the nerfstudio branches against the
+stand-in package tests/fake_nerfstudio."""
 from __future__ import annotations
 
-from dataclasses import dataclass, field
+import math
+from dataclasses import dataclass
 
 import torch
 
-try:  # pragma: no cover - exercised only where nerfstudio is installed
+try:  # pragma: no cover - exercised where nerfstudio (or the test double) is importable
     from nerfstudio.cameras.cameras import Cameras  # type: ignore
     HAVE_NERFSTUDIO = True
 except Exception:  # noqa: BLE001
@@ -69,3 +73,11 @@ PARAM_GROUPS = {
     "rotation": OptimizerSpec(0.001),
     "camera_opt": OptimizerSpec(1e-3, 1e-15, 5e-5, 30000),
 }
+
+
+def exp_decay_lr(step: int, lr_init: float, lr_final: float, max_steps: int) -> float:
+    """nerfstudio ExponentialDecayScheduler (warmup_steps = 0, the reference's settings at gc_config.py:59-66,83-86) [recall
+    nerfstudio 1.0.0 engine/schedulers.py]: log-linear interpolation lr_init -> lr_final over max_steps, constant afterwards.
+    A GaussCtrl run starts from a step-30000 splatfacto checkpoint (gc_trainer.py:75), i.e. at t = 1."""
+    t = min(max(step / max_steps, 0.0), 1.0)
+    return math.exp(math.log(lr_init) * (1.0 - t) + math.log(lr_final) * t)

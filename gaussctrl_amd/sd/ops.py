@@ -22,7 +22,10 @@ class GemmDesc(C.Structure):
                 ("rows_per_batch", C.c_int64), ("residual", C.c_void_p), ("ldr", C.c_int64), ("out_scale", C.c_float),
                 ("act", C.c_int), ("geglu", C.c_int), ("out", C.c_void_p), ("ldc", C.c_int64), ("out_f32", C.c_int),
                 ("out_t", C.c_void_p), ("ldt", C.c_int64), ("t_batch_stride", C.c_int64), ("t_col0", C.c_int64),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("zeros", C.c_void_p)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("zeros", C.c_void_p),
+                ("ln_row_stats", C.c_void_p), ("ln_row_stat_slots", C.c_int), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float),
+                ("out_row_stats", C.c_void_p), ("out_group_stats", C.c_void_p), ("gn_groups", C.c_int),
+                ("kernel_variant", C.c_int)]
 
 
 class AttnDesc(C.Structure):
@@ -34,7 +37,29 @@ class AttnDesc(C.Structure):
                 ("Vt", C.c_void_p), ("ldvt", C.c_int64), ("vt_batch_stride", C.c_int64),
                 ("O", C.c_void_p), ("ldo", C.c_int64), ("o_batch_stride", C.c_int64),
                 ("Kref", C.c_void_p), ("kref_batch_stride", C.c_int64), ("Vtref", C.c_void_p),
-                ("vtref_batch_stride", C.c_int64), ("ref_frames_per_half", C.c_int), ("q_prescaled", C.c_int)]
+                ("vtref_batch_stride", C.c_int64), ("ref_frames_per_half", C.c_int), ("q_prescaled", C.c_int),
+                ("kernel_variant", C.c_int)]
+
+
+def _variant_from_env():
+    """Kernel-selection overrides for tests / experiments.  The library itself holds no such state: they travel in the descriptors
+    (gc_gemm_desc.kernel_variant / gc_attn_desc.kernel_variant); this host layer reads them once from the environment."""
+    import os
+    g = int(os.environ.get("GC_GEMM_MT", "0")) & 7
+    use8 = os.environ.get("GC_GEMM8")
+    if use8 == "0":
+        g |= 0x10
+    elif use8 == "2":
+        g |= 0x20
+    cs = os.environ.get("GC_GEMM_CONVSPLIT")
+    if cs == "0":
+        g |= 0x40
+    elif cs == "2":
+        g |= 0x80
+    return {"gemm": g, "attn": 1 if os.environ.get("GC_ATTN_SAFE", "0") not in ("", "0") else 0}
+
+
+KERNEL_VARIANT = _variant_from_env()
 
 
 DT = {torch.bfloat16: 0, torch.float16: 1}
@@ -64,23 +89,48 @@ def _stream():
 _zero_page = {}
 
 
-def _run_gemm(d, dev, what):
+class RowStats:
+    """(sum, sum^2) of every output row of a GEMM, left by its epilogue as [slots][M][2] partials over column slabs (plain stores: no
+    zero-init); handed to the GEMM that has the following LayerNorm folded in (linear(..., ln=(row_stats, colsum, eps)))."""
+    __slots__ = ("buf", "slots")
+
+    def __init__(self):
+        self.buf, self.slots = None, 0
+
+
+def _run_gemm(d, dev, what, row_stats=None):
     lib = L.lib()
     z = _zero_page.get(dev)
     if z is None:
         z = _zero_page[dev] = torch.zeros(64, dtype=torch.uint8, device=dev)
     d.zeros = z.data_ptr()
+    d.kernel_variant = KERNEL_VARIANT["gemm"]
     wsb = lib.gc_dn_gemm_workspace_bytes(C.byref(d))
     ws = None
     if wsb:
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)       # caching allocator: no hipMalloc on the hot path
         d.workspace = ws.data_ptr(); d.workspace_bytes = wsb
+    if row_stats is not None:                      # the slab count depends on the kernel the library picks for this problem
+        row_stats.slots = int(lib.gc_dn_gemm_row_stat_slots(C.byref(d)))
+        row_stats.buf = torch.empty(row_stats.slots, d.M, 2, dtype=torch.float32, device=dev)
+        d.out_row_stats = row_stats.buf.data_ptr()
     L.check(lib.gc_dn_gemm(C.byref(d), _stream()), what)
 
 
+def _stats_args(d, ln, group_stats):
+    if ln is not None:                          # (RowStats of x, column sums [N] of the gamma-folded weights, eps)
+        d.ln_row_stats = ln[0].buf.data_ptr(); d.ln_row_stat_slots = ln[0].slots; d.ln_colsum = ln[1].data_ptr(); d.ln_eps = ln[2]
+    if group_stats is not None:                 # zeroed fp32 [B, G, 2]
+        d.out_group_stats = group_stats.data_ptr(); d.gn_groups = group_stats.shape[-2]
+
+
 def linear(x, w, bias=None, residual=None, act=0, geglu=False, out_f32=False, scale=1.0, rowvec=None, rows_per_batch=0,
-           ld_rowvec=None, out=None, want_out=True, out_t=None, ldt=0, t_batch_stride=0, t_col0=0, out_cols=None):
-    """x [..., K] (last dim contiguous, rows strided by x.stride(-2)) @ w[N,K]^T with fused epilogue."""
+           ld_rowvec=None, out=None, want_out=True, out_t=None, ldt=0, t_batch_stride=0, t_col0=0, out_cols=None,
+           ln=None, row_stats=None, group_stats=None):
+    """x [..., K] (last dim contiguous, rows strided by x.stride(-2)) @ w[N,K]^T with fused epilogue.
+    ln=(RowStats of x, colsum [N], eps): LayerNorm folded in (w carries gamma, bias carries W beta);
+    row_stats: a RowStats() that receives the per-row (sum, sum^2) partials of the stored output;
+    group_stats: zeroed fp32 [B, G, 2] that receives the per-(batch, GroupNorm group) sums (needs rows_per_batch)."""
     _gpu(x, w)
     K = x.shape[-1]
     M = x.numel() // K
@@ -103,12 +153,13 @@ def linear(x, w, bias=None, residual=None, act=0, geglu=False, out_f32=False, sc
         d.out = out.data_ptr(); d.ldc = out.stride(-2); d.out_f32 = int(out_f32)
     if out_t is not None:
         d.out_t = out_t.data_ptr(); d.ldt = ldt; d.t_batch_stride = t_batch_stride; d.t_col0 = t_col0
-    _run_gemm(d, x.device, "gc_dn_gemm")
+    _stats_args(d, ln, group_stats)
+    _run_gemm(d, x.device, "gc_dn_gemm", row_stats)
     return out
 
 
 def conv3x3(x, w, bias=None, stride=1, upsample=False, rowvec=None, ld_rowvec=None, residual=None, act=0, scale=1.0,
-            out_f32=False, pad_lo=1):
+            out_f32=False, pad_lo=1, group_stats=None):
     """x [B,H,W,Cin] NHWC, w [N, 9*Cin] ((tap, cin) order), pad 1."""
     _gpu(x, w)
     B, H, W_, Cin = x.shape
@@ -130,6 +181,7 @@ def conv3x3(x, w, bias=None, stride=1, upsample=False, rowvec=None, ld_rowvec=No
         d.residual = residual.data_ptr(); d.ldr = N
     d.out_scale = scale; d.act = act
     d.out = out.data_ptr(); d.ldc = N; d.out_f32 = int(out_f32)
+    _stats_args(d, None, group_stats)
     _run_gemm(d, x.device, "gc_dn_gemm(conv3x3)")
     return out
 
@@ -153,6 +205,18 @@ def groupnorm(x, gamma, beta, groups, eps, silu):
     return y
 
 
+def groupnorm_apply(x, group_stats, gamma, beta, groups, eps, silu):
+    """GroupNorm(+SiLU) of x [B,H,W,C] (or [B,HW,C]) from the per-(batch, group) sums [B, G, 2] its producer accumulated: ONE launch."""
+    _gpu(x, group_stats)
+    chan_stats = group_stats
+    B, Cc = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * Cc)
+    y = torch.empty_like(x)
+    L.check(L.lib().gc_dn_groupnorm_apply(_dt(x), _p(x), _p(y), C.c_int64(B), C.c_int64(HW), Cc, groups, _p(gamma), _p(beta),
+                                          C.c_float(eps), int(silu), _p(chan_stats), _stream()), "gc_dn_groupnorm_apply")
+    return y
+
+
 def layernorm(x, gamma, beta, eps=1e-5):
     _gpu(x)
     Cc = x.shape[-1]
@@ -162,14 +226,15 @@ def layernorm(x, gamma, beta, eps=1e-5):
     return y
 
 
-def concat_add(a, b, c=None):
-    """cat([a, b (+ c)], dim=-1) on channels-last tensors."""
+def concat_add(a, b, c=None, group_stats=None):
+    """cat([a, b (+ c)], dim=-1) on channels-last tensors [B, ..., C]; group_stats (zeroed fp32 [B, G, 2]) receives the
+    per-(batch, GroupNorm group) (sum, sum^2) of the output."""
     _gpu(a, b, c)
     C1, C2 = a.shape[-1], b.shape[-1]
     M = a.numel() // C1
     out = torch.empty(a.shape[:-1] + (C1 + C2,), dtype=a.dtype, device=a.device)
-    L.check(L.lib().gc_dn_concat_add(_dt(a), _p(a), C1, _p(b), _p(c), C2, _p(out), C.c_int64(M), _stream()),
-            "gc_dn_concat_add")
+    L.check(L.lib().gc_dn_concat_add(_dt(a), _p(a), C1, _p(b), _p(c), C2, _p(out), C.c_int64(M), C.c_int64(M // a.shape[0]),
+                                     _p(group_stats), 0 if group_stats is None else group_stats.shape[-2], _stream()), "gc_dn_concat_add")
     return out
 
 
@@ -211,6 +276,7 @@ def attention(q, k, vt, heads, sets, frames_per_half, Lk=None, kref=None, vtref=
         d.set_kind[i] = kind; d.set_weight[i] = w
     d.scale = (D ** -0.5) if scale is None else scale
     d.q_prescaled = int(q_prescaled)     # Q carries scale*log2(e) already (weights.prepare(..., fold_attn_scale_heads=...))
+    d.kernel_variant = KERNEL_VARIANT["attn"]
     d.Q = q.data_ptr(); d.ldq = q.stride(1); d.q_batch_stride = q.stride(0)
     d.K = k.data_ptr(); d.ldk = k.stride(1); d.k_batch_stride = k.stride(0)
     d.Vt = vt.data_ptr(); d.ldvt = vt.stride(1); d.vt_batch_stride = vt.stride(0)

@@ -128,22 +128,25 @@ class DenoisePipeline:
             a_from, a_to = self.sched.alphas(t, self.n, st["inverse"])
             ops.cfg_ddim_step(eps, lat, xin, st["g"], st["cfg"], a_from, a_to, st["rep"])
             st["i"] = i + 1
+            if st.get("on_step") is not None:          # parity tests read the latents after every DDIM step
+                st["on_step"](i, lat)
         return st["i"] >= len(ts)
 
     def _denoise(self, latents, disparity, ctx, cfg: bool, mode: str, coeff_unet: float, coeff_cn: float,
-                 guidance: float, inverse: bool, steps: int | None, bank: RefBank | None, fph: int):
-        """Returns latents fp32 [f,4,h,w]."""
+                 guidance: float, inverse: bool, steps: int | None, bank: RefBank | None, fph: int, on_step=None):
+        """Returns latents fp32 [f,4,h,w].  on_step(i, latents fp32 [f,h,w,4]) is called after every DDIM step."""
         st = self._begin(latents, disparity, ctx, cfg, mode, coeff_unet, coeff_cn, guidance, inverse, steps, bank, fph)
+        st["on_step"] = on_step
         self._advance(st)
         return st["lat"].permute(0, 3, 1, 2).contiguous()
 
     # ---------------------------------------------------------------------------------- public API
-    def edit_chunk(self, latents, disparity, ctx_neg, ctx_pos, steps=None):
+    def edit_chunk(self, latents, disparity, ctx_neg, ctx_pos, steps=None, on_step=None):
         """Reference-faithful chunk: `latents` / `disparity` hold the 4 reference frames FIRST, then the chunk
         (gc_pipeline.py:206-219); every frame attends to frames 0..3 of its CFG half."""
         ctx = self._ctx(ctx_neg, ctx_pos)
         return self._denoise(latents, disparity, ctx, True, "xview", 0.6, 0.0, self.guidance, False, steps, None,
-                             latents.shape[0])
+                             latents.shape[0], on_step)
 
     def build_ref_bank(self, ref_latents, ref_disparity, ctx_neg, ctx_pos, steps=None) -> RefBank:
         """Run the 4 reference frames once and keep every layer's K / V^T for every step."""
@@ -171,16 +174,16 @@ class DenoisePipeline:
             return tr["bank"]
         return None
 
-    def edit_chunk_cached(self, latents, disparity, ctx_neg, ctx_pos, bank: RefBank, steps=None):
+    def edit_chunk_cached(self, latents, disparity, ctx_neg, ctx_pos, bank: RefBank, steps=None, on_step=None):
         """Chunk frames only; reference K / V^T come from `bank` (same result as edit_chunk()[4:])."""
         ctx = self._ctx(ctx_neg, ctx_pos)
         return self._denoise(latents, disparity, ctx, True, "xview", 0.6, 0.0, self.guidance, False, steps, bank,
-                             latents.shape[0])
+                             latents.shape[0], on_step)
 
-    def invert(self, latents, disparity, ctx_pos, steps=None):
+    def invert(self, latents, disparity, ctx_pos, steps=None, on_step=None):
         """DDIM inversion with plain attention, guidance 0 -> no CFG batch (gc_pipeline.py:136-145), batched over views."""
         ctx = self._ctx(None, ctx_pos)
-        return self._denoise(latents, disparity, ctx, False, "plain", 0.0, 0.0, 0.0, True, steps, None, latents.shape[0])
+        return self._denoise(latents, disparity, ctx, False, "plain", 0.0, 0.0, 0.0, True, steps, None, latents.shape[0], on_step)
 
     def decode(self, latents):
         """latents fp32 [f,4,h,w] -> images fp32 [f,3,8h,8w] in [0,1] (vae.decode(z/0.18215); (x/2+0.5).clamp(0,1))."""

@@ -34,6 +34,38 @@ def timestep_embedding(t: float, dim: int) -> torch.Tensor:
     return torch.cat([torch.cos(emb), torch.sin(emb)])[None, :]
 
 
+class StatArena:
+    """Per-forward scratch for producer-side normalisation statistics (GEMM epilogues / concat accumulate (sum, sum^2) with float
+    atomics, so the buffers must start at zero): ONE zeroed fp32 buffer per network forward, bump-allocated; `reset()` is a single
+    memset on the launch stream at the start of the forward (the two networks of a denoise step run on two streams: one arena each)."""
+
+    def __init__(self):
+        self.buf = None
+        self.off = 0
+        self.peak = 0
+
+    def reset(self, device):
+        need = max(self.peak, 1 << 16)
+        if self.buf is None or self.buf.numel() < need or self.buf.device != device:
+            self.buf = torch.empty(int(need * 1.25), dtype=torch.float32, device=device)
+        self.buf.zero_()
+        self.off = 0
+
+    def alloc(self, *shape):
+        n = 1
+        for v in shape:
+            n *= int(v)
+        n4 = (n + 3) // 4 * 4
+        if self.off + n4 > self.buf.numel():        # first forward of a new shape: grow (a fresh zeroed buffer; earlier views stay valid)
+            self.peak = max(self.peak, (self.off + n4) * 2)
+            self.buf = torch.zeros(max(self.peak, n4), dtype=torch.float32, device=self.buf.device)
+            self.off = 0
+        v = self.buf[self.off:self.off + n].view(*shape)
+        self.off += n4
+        self.peak = max(self.peak, self.off)
+        return v
+
+
 class RefBank:
     """Cache of the reference frames' per-layer K / V^T for every denoise step.
     mode 'record': layers append their K / V^T of the reference batch; mode 'use': layers read them."""
@@ -70,6 +102,32 @@ class SDNet:
         self.dtype = weights["conv_in.weight"].dtype
         self._temb_cache = {}
         self.qpre = bool(weights.get("_attn_q_prescaled", False))   # softmax scale folded into the Q weights (weights.prepare(heads=))
+        self.ln_folded = bool(weights.get("_ln_folded", False))     # LayerNorms folded into their consumer GEMMs (weights.prepare(fold_ln=))
+        self.fuse_stats = True                                      # GroupNorm statistics from the producing kernel's epilogue
+        self._arenas = {}
+        self.arena = None
+
+    def begin_forward(self, device):
+        """zeroed statistics arena of this forward (one per launch stream: independent trajectories may run on different streams)"""
+        key = torch.cuda.current_stream().cuda_stream
+        a = self._arenas.get(key)
+        if a is None:
+            a = self._arenas[key] = StatArena()
+        a.reset(device)
+        self.arena = a
+
+    def _cs(self, B, C, HW):
+        """zeroed [B, G, 2] buffer for a producer's GroupNorm-group sums; None (stand-alone GroupNorm) when the map is too small for the
+        epilogue's 16-row tiles to stay inside one image (HW % 16 != 0: only the toy test geometries)"""
+        return self.arena.alloc(B, self.cfg["groups"], 2) if (self.fuse_stats and HW % 16 == 0) else None
+
+    def gn(self, x, xs, p, eps, silu):
+        """GroupNorm(+SiLU): one launch when the producer of x left its channel sums (xs), else the three-kernel stand-alone path"""
+        w = self.w
+        g = self.cfg["groups"]
+        if xs is not None:
+            return ops.groupnorm_apply(x, xs, w[p + ".weight"], w[p + ".bias"], g, eps, silu)
+        return ops.groupnorm(x, w[p + ".weight"], w[p + ".bias"], g, eps, silu)
 
     # ---------------------------------------------------------------------------------------- blocks
     def time_embed(self, t: float, device):
@@ -89,27 +147,32 @@ class SDNet:
             self._temb_cache[key] = out
         return out
 
-    def resnet(self, p, x, temb_act, eps=1e-5):
+    def resnet(self, p, x, xs, temb_act, eps=1e-5):
+        """ResnetBlock2D on (x, xs = channel sums of x or None) -> (out, channel sums of out)"""
         w = self.w
-        g = self.cfg["groups"]
-        h = ops.groupnorm(x, w[p + ".norm1.weight"], w[p + ".norm1.bias"], g, eps, True)
+        B, HW = x.shape[0], x.shape[1] * x.shape[2]
+        h = self.gn(x, xs, p + ".norm1", eps, True)
         rv = None if temb_act is None else temb_act[p]
-        h = ops.conv3x3(h, w[p + ".conv1.weight"], w[p + ".conv1.bias"], rowvec=rv, ld_rowvec=0)
-        h = ops.groupnorm(h, w[p + ".norm2.weight"], w[p + ".norm2.bias"], g, eps, True)
+        cout = w[p + ".conv1.weight"].shape[0]
+        hs = self._cs(B, cout, HW)
+        h = ops.conv3x3(h, w[p + ".conv1.weight"], w[p + ".conv1.bias"], rowvec=rv, ld_rowvec=0, group_stats=hs)
+        h = self.gn(h, hs, p + ".norm2", eps, True)
         sc = x
         if (p + ".conv_shortcut.weight") in w:
             sc = ops.linear(x, w[p + ".conv_shortcut.weight"], w[p + ".conv_shortcut.bias"])
-        return ops.conv3x3(h, w[p + ".conv2.weight"], w[p + ".conv2.bias"], residual=sc)
+        os_ = self._cs(B, cout, HW)
+        return ops.conv3x3(h, w[p + ".conv2.weight"], w[p + ".conv2.bias"], residual=sc, group_stats=os_), os_
 
-    def _self_attention(self, p, n, actx: AttnCtx):
+    def _self_attention(self, p, n, actx: AttnCtx, ln=None):
+        """n: LayerNorm-ed tokens, or the raw tokens with ln = (row sums, colsum, eps) when norm1 is folded into the Q|K|V GEMM"""
         w = self.w
         heads = self.cfg["heads"]
         B, L, Cc = n.shape
         Lp = (L + 7) // 8 * 8
         vt = torch.zeros(B, Cc, Lp, dtype=n.dtype, device=n.device) if Lp != L else torch.empty(B, Cc, Lp, dtype=n.dtype, device=n.device)
         # one GEMM for Q | K | V: columns [0,2C) -> qk [B,L,2C], columns [2C,3C) -> V^T [B,C,Lp]
-        qk = ops.linear(n, w[p + ".to_qkv.weight"], rows_per_batch=L, out_t=vt, ldt=Lp, t_batch_stride=Cc * Lp, t_col0=2 * Cc,
-                        out_cols=2 * Cc)
+        qk = ops.linear(n, w[p + ".to_qkv.weight"], w.get(p + ".to_qkv.bias") if ln is not None else None, rows_per_batch=L, out_t=vt,
+                        ldt=Lp, t_batch_stride=Cc * Lp, t_col0=2 * Cc, out_cols=2 * Cc, ln=ln)
         q, k = qk[..., :Cc], qk[..., Cc:]
         if actx.mode == "plain":
             return ops.attention(q, k, vt, heads, [(-1, 1.0)], actx.f, Lk=L, q_prescaled=self.qpre)
@@ -136,46 +199,64 @@ class SDNet:
             actx.text_kv[key] = (k, vt, Lt)
         return actx.text_kv[key]
 
-    def transformer(self, p, x, ctx, actx: AttnCtx):
+    def transformer(self, p, x, xs, ctx, actx: AttnCtx):
+        """Transformer2DModel on (x, xs) -> (out, channel sums of out).  With folded LayerNorms (weights.prepare(fold_ln=True)) the
+        three LayerNorm launches disappear: each producer GEMM leaves the row sums of its output, the consumer GEMM (whose weights
+        carry gamma / beta) normalises in its epilogue -- 11 launches per block instead of 16."""
         w = self.w
         B, H, W_, Cc = x.shape
-        g = self.cfg["groups"]
-        h = ops.groupnorm(x, w[p + ".norm.weight"], w[p + ".norm.bias"], g, 1e-6, False)
-        h = ops.linear(h.view(B, H * W_, Cc), w[p + ".proj_in.weight"], w[p + ".proj_in.bias"])
+        h = self.gn(x, xs, p + ".norm", 1e-6, False)
         t = p + ".transformer_blocks.0"
-        n = ops.layernorm(h, w[t + ".norm1.weight"], w[t + ".norm1.bias"])
-        o = self._self_attention(t + ".attn1", n, actx)
-        h = ops.linear(o, w[t + ".attn1.to_out.0.weight"], w[t + ".attn1.to_out.0.bias"], residual=h)
-        n = ops.layernorm(h, w[t + ".norm2.weight"], w[t + ".norm2.bias"])
-        q = ops.linear(n, w[t + ".attn2.to_q.weight"])
+        fold = self.ln_folded
+        rs = ops.RowStats() if fold else None
+        h = ops.linear(h.view(B, H * W_, Cc), w[p + ".proj_in.weight"], w[p + ".proj_in.bias"], row_stats=rs)
+        if fold:
+            o = self._self_attention(t + ".attn1", h, actx, ln=(rs, w[t + ".attn1.to_qkv.colsum"], 1e-5))
+        else:
+            o = self._self_attention(t + ".attn1", ops.layernorm(h, w[t + ".norm1.weight"], w[t + ".norm1.bias"]), actx)
+        rs = ops.RowStats() if fold else None
+        h = ops.linear(o, w[t + ".attn1.to_out.0.weight"], w[t + ".attn1.to_out.0.bias"], residual=h, row_stats=rs)
+        if fold:
+            q = ops.linear(h, w[t + ".attn2.to_q.weight"], w[t + ".attn2.to_q.bias"], ln=(rs, w[t + ".attn2.to_q.colsum"], 1e-5))
+        else:
+            q = ops.linear(ops.layernorm(h, w[t + ".norm2.weight"], w[t + ".norm2.bias"]), w[t + ".attn2.to_q.weight"])
         k, vt, Lt = self._text_kv(t + ".attn2", ctx, actx)
         # ctx holds one text row per CFG half ([negative || positive]); frame b reads row b // f (kind -2)
         o = ops.attention(q, k, vt, self.cfg["heads"], [(-2, 1.0)], B // k.shape[0], Lk=Lt, q_prescaled=self.qpre)
-        h = ops.linear(o, w[t + ".attn2.to_out.0.weight"], w[t + ".attn2.to_out.0.bias"], residual=h)
-        n = ops.layernorm(h, w[t + ".norm3.weight"], w[t + ".norm3.bias"])
-        ff = ops.linear(n, w[t + ".ff.net.0.proj.weight"], w[t + ".ff.net.0.proj.bias"], geglu=True)
+        rs = ops.RowStats() if fold else None
+        h = ops.linear(o, w[t + ".attn2.to_out.0.weight"], w[t + ".attn2.to_out.0.bias"], residual=h, row_stats=rs)
+        if fold:
+            ff = ops.linear(h, w[t + ".ff.net.0.proj.weight"], w[t + ".ff.net.0.proj.bias"], geglu=True,
+                            ln=(rs, w[t + ".ff.net.0.proj.colsum"], 1e-5))
+        else:
+            ff = ops.linear(ops.layernorm(h, w[t + ".norm3.weight"], w[t + ".norm3.bias"]), w[t + ".ff.net.0.proj.weight"],
+                            w[t + ".ff.net.0.proj.bias"], geglu=True)
         h = ops.linear(ff, w[t + ".ff.net.2.weight"], w[t + ".ff.net.2.bias"], residual=h)
-        out = ops.linear(h, w[p + ".proj_out.weight"], w[p + ".proj_out.bias"], residual=x.view(B, H * W_, Cc))
-        return out.view(B, H, W_, Cc)
+        os_ = self._cs(B, Cc, H * W_)
+        out = ops.linear(h, w[p + ".proj_out.weight"], w[p + ".proj_out.bias"], residual=x.view(B, H * W_, Cc), rows_per_batch=H * W_,
+                         group_stats=os_)
+        return out.view(B, H, W_, Cc), os_
 
-    def encoder(self, x, temb_act, ctx, actx):
+    def encoder(self, x, xs, temb_act, ctx, actx):
+        """(x, xs = channel sums of x) -> (mid-block output, its channel sums, skip tensors)"""
         cfg = self.cfg
         skips = [x]
         n = len(cfg["block_out_channels"])
         for i in range(n):
             for j in range(cfg["layers_per_block"]):
-                x = self.resnet(f"down_blocks.{i}.resnets.{j}", x, temb_act)
+                x, xs = self.resnet(f"down_blocks.{i}.resnets.{j}", x, xs, temb_act)
                 if cfg["attn_levels"][i]:
-                    x = self.transformer(f"down_blocks.{i}.attentions.{j}", x, ctx, actx)
+                    x, xs = self.transformer(f"down_blocks.{i}.attentions.{j}", x, xs, ctx, actx)
                 skips.append(x)
             if i < n - 1:
                 p = f"down_blocks.{i}.downsamplers.0.conv"
-                x = ops.conv3x3(x, self.w[p + ".weight"], self.w[p + ".bias"], stride=2)
+                xs = self._cs(x.shape[0], self.w[p + ".weight"].shape[0], (x.shape[1] // 2) * (x.shape[2] // 2))
+                x = ops.conv3x3(x, self.w[p + ".weight"], self.w[p + ".bias"], stride=2, group_stats=xs)
                 skips.append(x)
-        x = self.resnet("mid_block.resnets.0", x, temb_act)
-        x = self.transformer("mid_block.attentions.0", x, ctx, actx)
-        x = self.resnet("mid_block.resnets.1", x, temb_act)
-        return x, skips
+        x, xs = self.resnet("mid_block.resnets.0", x, xs, temb_act)
+        x, xs = self.transformer("mid_block.attentions.0", x, xs, ctx, actx)
+        x, xs = self.resnet("mid_block.resnets.1", x, xs, temb_act)
+        return x, xs, skips
 
 
 class ControlNet(SDNet):
@@ -192,9 +273,11 @@ class ControlNet(SDNet):
     def forward(self, xin, t, ctx, cond_emb, actx: AttnCtx, conditioning_scale=1.0):
         """xin [B,h,w,8] -> (12 down residuals, mid residual), all [B,*,*,C] channels-last."""
         w = self.w
+        self.begin_forward(xin.device)
         temb_act = self.time_embed(t, xin.device)
-        x = ops.conv3x3(xin, w["conv_in.weight"], w["conv_in.bias"], residual=cond_emb)
-        x, skips = self.encoder(x, temb_act, ctx, actx)
+        xs = self._cs(xin.shape[0], w["conv_in.weight"].shape[0], xin.shape[1] * xin.shape[2])
+        x = ops.conv3x3(xin, w["conv_in.weight"], w["conv_in.bias"], residual=cond_emb, group_stats=xs)
+        x, _, skips = self.encoder(x, xs, temb_act, ctx, actx)
         down = []
         for n, s in enumerate(skips):
             B, H, W_, Cc = s.shape
@@ -211,9 +294,11 @@ class UNet(SDNet):
     def encode(self, xin, t, ctx, actx: AttnCtx):
         """conv_in + down blocks + mid block: everything that does not need the ControlNet residuals."""
         w = self.w
+        self.begin_forward(xin.device)
         temb_act = self.time_embed(t, xin.device)
-        x = ops.conv3x3(xin, w["conv_in.weight"], w["conv_in.bias"])
-        x, skips = self.encoder(x, temb_act, ctx, actx)
+        xs = self._cs(xin.shape[0], w["conv_in.weight"].shape[0], xin.shape[1] * xin.shape[2])
+        x = ops.conv3x3(xin, w["conv_in.weight"], w["conv_in.bias"], group_stats=xs)
+        x, _, skips = self.encoder(x, xs, temb_act, ctx, actx)
         return x, skips, temb_act
 
     def decode(self, x, skips, temb_act, ctx, down_res, mid_res, actx: AttnCtx):
@@ -228,14 +313,15 @@ class UNet(SDNet):
             for j in range(cfg["layers_per_block"] + 1):
                 s = skips.pop()
                 r = down_res.pop() if down_res is not None else None
-                x = ops.concat_add(x, s, r)                  # cat([x, skip + controlnet residual])
-                x = self.resnet(f"up_blocks.{i}.resnets.{j}", x, temb_act)
+                xs = self._cs(x.shape[0], x.shape[-1] + s.shape[-1], 16)     # the concat kernel has no tile constraint
+                x = ops.concat_add(x, s, r, group_stats=xs)   # cat([x, skip + controlnet residual]) + its channel sums
+                x, xs = self.resnet(f"up_blocks.{i}.resnets.{j}", x, xs, temb_act)
                 if rev_attn[i]:
-                    x = self.transformer(f"up_blocks.{i}.attentions.{j}", x, ctx, actx)
+                    x, xs = self.transformer(f"up_blocks.{i}.attentions.{j}", x, xs, ctx, actx)
             if i < n - 1:
                 p = f"up_blocks.{i}.upsamplers.0.conv"
                 x = ops.conv3x3(x, w[p + ".weight"], w[p + ".bias"], upsample=True)
-        x = ops.groupnorm(x, w["conv_norm_out.weight"], w["conv_norm_out.bias"], cfg["groups"], 1e-5, True)
+        x = self.gn(x, xs, "conv_norm_out", 1e-5, True)
         return ops.conv3x3(x, w["conv_out.weight"], w["conv_out.bias"], out_f32=True)
 
     def forward(self, xin, t, ctx, down_res, mid_res, actx: AttnCtx):

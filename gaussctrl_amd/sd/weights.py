@@ -44,10 +44,11 @@ def geglu_permute(w, b):
 LOG2E = 1.4426950408889634
 
 
-def prepare(sd: dict, dtype, device, heads=None) -> dict:
+def prepare(sd: dict, dtype, device, heads=None, fold_ln=True) -> dict:
     """Generic pass over a diffusers state dict.  `heads` (attention heads of the network) folds the softmax scale
     head_dim**-0.5 * log2(e) into the Q projection weights in fp32, before the single rounding to `dtype`: the attention
-    kernel then exponentiates the QK^T MFMA output directly (gc_attn_desc.q_prescaled)."""
+    kernel then exponentiates the QK^T MFMA output directly (gc_attn_desc.q_prescaled).  fold_ln folds the three LayerNorms of every
+    transformer block into the GEMMs that consume them (norm1 -> Q|K|V, norm2 -> attn2.to_q, norm3 -> GEGLU projection)."""
     out = {}
     for k, v in sd.items():
         v = v.to(device)
@@ -65,10 +66,23 @@ def prepare(sd: dict, dtype, device, heads=None) -> dict:
         else:
             out[k] = v.float().contiguous()       # norm affine, linear / 1x1 biases
     out["_attn_q_prescaled"] = bool(heads)
+    out["_ln_folded"] = bool(fold_ln)
     for k in list(out.keys()):
         if k.endswith(".attn1.to_q.weight"):            # fused Q|K|V projection of the self-attention layers
             a = k[:-len("to_q.weight")]
-            out[a + "to_qkv.weight"] = torch.cat([out[a + "to_q.weight"], out[a + "to_k.weight"], out[a + "to_v.weight"]], 0).contiguous()
+            t = a[:-len("attn1.")]                       # "...transformer_blocks.0."
+            if fold_ln:
+                # LayerNorm folded into the GEMM that consumes it (gc_gemm_desc.ln_*): W' = W diag(gamma) rounded ONCE from fp32,
+                # bias' = b + W beta, colsum = sum_k W'[n][k] of the ROUNDED weights (the epilogue subtracts mean * colsum exactly)
+                qkv32 = torch.cat([_f32(sd, out, a + "to_q.weight", heads, device), _f32(sd, out, a + "to_k.weight", None, device),
+                                   _f32(sd, out, a + "to_v.weight", None, device)], 0)
+                _fold_ln(out, a + "to_qkv", qkv32, None, out[t + "norm1.weight"], out[t + "norm1.bias"], dtype)
+                q2 = _f32(sd, out, t + "attn2.to_q.weight", heads, device)
+                _fold_ln(out, t + "attn2.to_q", q2, None, out[t + "norm2.weight"], out[t + "norm2.bias"], dtype)
+                ff = sd[t + "ff.net.0.proj.weight"].to(device).float()
+                _fold_ln(out, t + "ff.net.0.proj", ff, out[t + "ff.net.0.proj.bias"], out[t + "norm3.weight"], out[t + "norm3.bias"], dtype)
+            else:
+                out[a + "to_qkv.weight"] = torch.cat([out[a + "to_q.weight"], out[a + "to_k.weight"], out[a + "to_v.weight"]], 0).contiguous()
     names = sorted(k[:-len(".time_emb_proj.weight")] for k in out if k.endswith(".time_emb_proj.weight"))
     if names:                                          # all time-embedding projections of a network as ONE [sum Cout, 1280] GEMM
         out["_temb_all.weight"] = torch.cat([out[n + ".time_emb_proj.weight"] for n in names], 0).contiguous()
@@ -83,4 +97,23 @@ def prepare(sd: dict, dtype, device, heads=None) -> dict:
         if k.endswith("ff.net.0.proj.weight"):
             b = k[:-6] + "bias"
             out[k], out[b] = geglu_permute(out[k], out[b])
+            if fold_ln:
+                out[k[:-6] + "colsum"] = out[k].float().sum(1).contiguous()      # of the rounded, permuted rows
     return out
+
+
+def _f32(sd, out, key, heads, device):
+    """fp32 master of a projection weight (with the softmax scale folded into Q rows when `heads` is given)."""
+    v = sd[key].to(device).float()
+    if heads:
+        v = v * ((v.shape[0] // heads) ** -0.5 * LOG2E)
+    return v
+
+
+def _fold_ln(out, name, w32, bias, gamma, beta, dtype):
+    """y = LN(x) W^T + b  ==  rstd (x W'^T - mean colsum) + b'   with W' = W diag(gamma), b' = b + W beta."""
+    wf = (w32 * gamma.float()[None, :]).to(dtype).contiguous()
+    out[name + ".weight"] = wf
+    out[name + ".colsum"] = wf.float().sum(1).contiguous()
+    b2 = w32 @ beta.float()
+    out[name + ".bias"] = (b2 if bias is None else bias.float() + b2).contiguous()

@@ -56,3 +56,13 @@ def make_cameras(v: int, seed: int = 1, rmin: float = 2.0, rmax: float = 3.0) ->
         tgt = g.uniform(-0.2, 0.2, size=3)
         out.append(look_at_c2w(d * rad, tgt))
     return np.stack(out, 0)
+
+
+def elliptical_mask(h: int, w: int, soft: bool = False) -> np.ndarray:
+    """Synthetic stand-in for a LangSAM object mask (BASELINE configs[3]): an axis-aligned ellipse covering the
+    image centre, [H,W] float32 in {0,1} (or with a smooth 0..1 rim when `soft`)."""
+    y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+    r = ((x - 0.5 * w) / (0.32 * w)) ** 2 + ((y - 0.47 * h) / (0.40 * h)) ** 2
+    if soft:
+        return np.clip((1.15 - r) / 0.3, 0.0, 1.0).astype(np.float32)
+    return (r <= 1.0).astype(np.float32)

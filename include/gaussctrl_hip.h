@@ -10,7 +10,8 @@
  *   - the caller owns every buffer (including workspaces); the library allocates nothing, frees
  *     nothing and keeps no pointer after return.  Launches go only to `stream`; no hidden
  *     device-wide synchronisation (gc_raster_read_count is the single documented blocking call).
- *   - re-entrant: all state is in the arguments.
+ *   - re-entrant: all state is in the arguments (kernel-selection overrides are descriptor fields, not environment
+ *     variables; the only process-wide state is a per-(kernel, device) "attribute already set" bit, updated atomically).
  *   - all float tensors are contiguous float32 unless a name says bf16.
  *
  * Each block cites the reference interface it replaces (paths under /root/reference/).
@@ -147,7 +148,8 @@ int gc_rasterize_bwd(int img_h, int img_w, int tiles_x, int tiles_y, int64_t N,
  * exp(scales), quat normalisation, projection, view directions, SH(+0.5, clamp min 0), sigmoid(opacity)
  * in ONE pass over the 59-float parameter record.
  * means[N,3] log_scales[N,3] quats[N,4] opacity_logits[N] features_dc[N,3] features_rest[N,K-1,3]
- * cam_origin[3] (host floats) -> xys depths radii conics num_tiles_hit rgbs[N,3] opac[N]. */
+ * cam_origin[3] (host floats) -> xys depths radii conics num_tiles_hit rgbs[N,3] opac[N].
+ * degrees_to_use = -1 selects the config.sh_degree == 0 colour of gc_model.py:169: rgbs = sigmoid(features_dc). */
 int gc_project_sh_fwd(int64_t N, const float *means, const float *log_scales, const float *quats,
                       const float *opacity_logits, const float *features_dc, const float *features_rest,
                       int sh_degree, int degrees_to_use, const float *viewmat, const float *projmat,
@@ -156,9 +158,10 @@ int gc_project_sh_fwd(int64_t N, const float *means, const float *log_scales, co
                       float *xys, float *depths, int32_t *radii, float *conics, int32_t *num_tiles_hit,
                       float *rgbs, float *opac, void *stream);
 
-/* Fused backward: v_xy,v_conic,v_rgbs,v_opac -> gradients of the six leaf tensors. */
+/* Fused backward: v_xy,v_conic,v_rgbs,v_opac -> gradients of the six leaf tensors.  rgbs[N,3] = the colours gc_project_sh_fwd
+ * produced (the clamp mask is rgbs > 0, the sigmoid mode's derivative rgbs (1 - rgbs): the SH record is not read again). */
 int gc_project_sh_bwd(int64_t N, const float *means, const float *log_scales, const float *quats,
-                      const float *opacity_logits, const float *features_dc, const float *features_rest,
+                      const float *opacity_logits, const float *rgbs,
                       int sh_degree, int degrees_to_use, const float *viewmat, const float *projmat,
                       const float *cam_origin, float fx, float fy, float cx, float cy, int img_h, int img_w,
                       const int32_t *radii, const float *conics,
@@ -176,9 +179,11 @@ int gc_raster_finalize(int64_t num_pixels, float *out_img, float *out_extra, con
  * iteration gaussctrl/gc_trainer.py:257-301). */
 size_t gc_l1_ssim_workspace_bytes(int H, int W, int C);
 /* (1-lambda)*mean|pred-target| + lambda*(1 - mean SSIM_11x11(pred,target)) on float32 [H,W,C]: loss_sums (device float[2]) =
- * {sum of the SSIM map, sum |pred-target|}; v_pred = grad_scale * d loss / d pred. */
+ * {sum of the SSIM map, sum |pred-target|}; v_pred = grad_scale * d loss / d pred.
+ * valid_window = 1: unpadded windows, SSIM mean over (H-10)(W-10)C (pytorch_msssim.SSIM as splatfacto calls it); 0: zero-padded
+ * windows, mean over HWC. */
 int gc_l1_ssim_fwd_bwd(const float *pred, const float *target, int H, int W, int C, float lambda_, float grad_scale,
-                       float *loss_sums, float *v_pred, void *workspace, size_t workspace_bytes, void *stream);
+                       int valid_window, float *loss_sums, float *v_pred, void *workspace, size_t workspace_bytes, void *stream);
 /* torch.optim.Adam step (no weight decay / amsgrad) on one flat float32 tensor; step is the 1-based iteration count. */
 int gc_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
                  float beta2, float eps, int step, void *stream);
@@ -221,8 +226,22 @@ typedef struct gc_gemm_desc {
     void *workspace;           /* >= gc_dn_gemm_workspace_bytes(desc) bytes (split-K fp32 accumulator for small-M problems); */
     size_t workspace_bytes;    /* NULL / too small: the problem runs unsplit */
     const void *zeros;         /* >= 16 bytes of device zeros: enables the LDS-DMA kernel (padding / out-of-range lanes fetch from it); NULL: register-staged kernel */
+    /* LayerNorm folded into the GEMM (mode 0): A holds the UN-normalised rows x, W = W0 * diag(gamma), bias = b0 + W0 beta and */
+    /* out = rstd[m] * (acc - mean[m] * ln_colsum[n]) + bias[n], (mean, rstd) from sum_slots ln_row_stats[slot][m] = (sum_k x, sum_k x^2). */
+    const float *ln_row_stats; /* [ln_row_stat_slots][M][2] or NULL: what the GEMM that produced A left in its out_row_stats */
+    int ln_row_stat_slots;     /* gc_dn_gemm_row_stat_slots(producer's descriptor) */
+    const float *ln_colsum;    /* [N] = sum_k W[n][k] (of the rounded weights) */
+    float ln_eps;
+    /* statistics of the STORED output (NULL: not wanted): */
+    float *out_row_stats;      /* [gc_dn_gemm_row_stat_slots(desc)][M][2]: per row, (sum, sum of squares) over one column slab per slot; */
+                               /* plain stores (no atomics, no zero-init needed) -> ln_row_stats of a following GEMM */
+    float *out_group_stats;    /* [M / rows_per_batch][gn_groups][2]: per (batch, GroupNorm group of N / gn_groups channels) sums, ADDED with */
+    int gn_groups;             /* float atomics (caller zero-fills) -> gc_dn_groupnorm_apply; needs rows_per_batch % 16 == 0, gn_groups <= 32 */
+    int kernel_variant;        /* 0 = automatic.  Overrides for tests / experiments: bits 0-2 force the 8-wave kernel's m-tiles per wave (2,3,4); */
+                               /* 0x10 4-wave kernel only; 0x20 force the 8-wave kernel; 0x40 no k-slices for part-filled conv grids; 0x80 slice 8x8-map convs too */
 } gc_gemm_desc;
 size_t gc_dn_gemm_workspace_bytes(const gc_gemm_desc *desc);
+int gc_dn_gemm_row_stat_slots(const gc_gemm_desc *desc);   /* column slabs per row this problem writes to out_row_stats (with desc->workspace set) */
 int gc_dn_gemm(const gc_gemm_desc *desc, void *stream);
 
 /* Fused multi-K/V-set attention = CrossViewAttnProcessor core, gaussctrl/utils.py:86-117 (+ compute_attn :25-37). */
@@ -248,6 +267,7 @@ typedef struct gc_attn_desc {
     const void *Vtref; int64_t vtref_batch_stride;
     int ref_frames_per_half;
     int q_prescaled;                 /* Q is already multiplied by scale*log2(e) (folded into the Q projection weights): `scale` is ignored */
+    int kernel_variant;              /* 0 = automatic; bit 0: online-softmax kernel for every shape (tests) */
 } gc_attn_desc;
 int gc_dn_attention(const gc_attn_desc *desc, void *stream);
 
@@ -255,12 +275,18 @@ int gc_dn_attention(const gc_attn_desc *desc, void *stream);
 size_t gc_dn_groupnorm_workspace_bytes(int64_t B, int64_t HW, int C);
 int gc_dn_groupnorm(int dtype, const void *x, void *y, int64_t B, int64_t HW, int C, int G, const float *gamma,
                     const float *beta, float eps, int act, float *stats_ws, void *stream);
+/* GroupNorm(+SiLU) from producer-side statistics: group_stats[B][G][2] = per (batch, group) (sum, sum of squares) over the HW pixels and
+ * the C / G channels of the group, accumulated by the kernel that wrote x (gc_gemm_desc.out_group_stats, gc_dn_concat_add).
+ * One launch instead of three. */
+int gc_dn_groupnorm_apply(int dtype, const void *x, void *y, int64_t B, int64_t HW, int C, int G, const float *gamma,
+                          const float *beta, float eps, int act, const float *group_stats, void *stream);
 /* LayerNorm over C on [M][C]. */
 int gc_dn_layernorm(int dtype, const void *x, void *y, int64_t M, int C, const float *gamma, const float *beta,
                     float eps, void *stream);
-/* out[M][C1+C2] = [a | b (+ c)] : skip concat of the up blocks with the ControlNet residual add folded in. */
+/* out[M][C1+C2] = [a | b (+ c)] : skip concat of the up blocks with the ControlNet residual add folded in.
+ * group_stats (optional, caller-zeroed [M / rows_per_batch][gn_groups][2]): per (batch, GroupNorm group) (sum, sum of squares) of `out`. */
 int gc_dn_concat_add(int dtype, const void *a, int C1, const void *b, const void *c, int C2, void *out, int64_t M,
-                     void *stream);
+                     int64_t rows_per_batch, float *group_stats, int gn_groups, void *stream);
 /* out = act(a*sa + b*sb) over n elements (b may be NULL). */
 int gc_dn_axpby(int dtype, const void *a, float sa, const void *b, float sb, int act, void *out, int64_t n, void *stream);
 /* float32 -> dtype with optional SiLU (time-embedding vectors). */

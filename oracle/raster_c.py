@@ -187,8 +187,12 @@ def render(params, c2w, fx, fy, cx, cy, W, H, background, training, sh_degree_to
         return {"rgb": np.broadcast_to(bg, (H, W, 3)).copy()}
     vd = means - np.asarray(c2w, np.float32)[:3, 3]
     vd = (vd / np.linalg.norm(vd, axis=-1, keepdims=True)).astype(np.float32)
-    sh = spherical_harmonics(sh_degree_to_use, vd, coeffs)
-    rgbs = np.maximum(sh + np.float32(0.5), 0).astype(np.float32)
+    if sh_degree_to_use < 0:           # config.sh_degree == 0: rgbs = sigmoid(colors[:, 0, :])   (gc_model.py:169)
+        sh = None
+        rgbs = _sigmoid(coeffs[:, 0, :]).astype(np.float32)
+    else:
+        sh = spherical_harmonics(sh_degree_to_use, vd, coeffs)
+        rgbs = np.maximum(sh + np.float32(0.5), 0).astype(np.float32)
     opac = _sigmoid(op_logit).astype(np.float32)
     cum, keys, ids, bins = bin_and_sort(xys, depths, radii, nth, tb)
     img, dep, fT, fi = rasterize_fwd(xys, conics, rgbs, opac, ids, bins, H, W, tb, bg, extra=None if training else depths)
@@ -207,8 +211,12 @@ def render(params, c2w, fx, fy, cx, cy, W, H, background, training, sh_degree_to
         v_img = _f32(v_rgb) * (img <= 1.0)                      # clamp(max=1) backward (gc_model.py:188)
         v_xy, v_conic, v_col, v_op = rasterize_bwd(xys, conics, rgbs, opac, ids, bins, H, W, tb, bg, fT, fi, v_img,
                                                    None if v_alpha is None else _f32(v_alpha).reshape(H, W))
-        v_sh = v_col * ((sh + np.float32(0.5)) >= 0)            # clamp(min=0) backward (gc_model.py:167)
-        v_coeffs = spherical_harmonics_bwd(sh_degree_to_use, vd, K, v_sh)
+        if sh is None:
+            v_coeffs = np.zeros_like(coeffs)
+            v_coeffs[:, 0, :] = v_col * rgbs * (1 - rgbs)
+        else:
+            v_sh = v_col * ((sh + np.float32(0.5)) >= 0)            # clamp(min=0) backward (gc_model.py:167)
+            v_coeffs = spherical_harmonics_bwd(sh_degree_to_use, vd, K, v_sh)
         vm, vs, vq = project_gaussians_bwd(means, scales, 1.0, qn, V[:3], full, fx, fy, cx, cy, H, W, radii, conics,
                                            v_xy, None, v_conic)
         # chain through exp(scales), quat normalisation (gc_model.py:142-144), sigmoid (gc_model.py:181)

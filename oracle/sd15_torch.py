@@ -173,11 +173,20 @@ def _heads(t, h):
     return t.reshape(b, l, h, c // h).permute(0, 2, 1, 3)          # [B,H,L,D]
 
 
+ATTN_IMPL = "explicit"      # "explicit": materialised softmax(q k^T s) v, the form the reference executes (utils.py:25-37);
+                            # "sdpa": torch's fused CPU kernel of the same function, used only by the full-geometry fixture
+                            # generator (tests/golden/make_fullgeom_golden.py) where L = 4096 makes the explicit form take
+                            # hours; tests/test_oracle_sd.py checks the two agree on the reference-generated goldens.
+
+
 def plain_attention(q, k, v, heads):
     """softmax(q k^T / sqrt(d)) v -- diffusers AttnProcessor / get_attention_scores."""
     qh, kh, vh = _heads(q, heads), _heads(k, heads), _heads(v, heads)
-    s = (qh @ kh.transpose(-1, -2)) * (qh.shape[-1] ** -0.5)
-    o = s.softmax(-1) @ vh
+    if ATTN_IMPL == "sdpa":
+        o = F.scaled_dot_product_attention(qh, kh, vh)
+    else:
+        s = (qh @ kh.transpose(-1, -2)) * (qh.shape[-1] ** -0.5)
+        o = s.softmax(-1) @ vh
     b, h, l, d = o.shape
     return o.permute(0, 2, 1, 3).reshape(b, l, h * d)
 
@@ -429,10 +438,11 @@ class DDIM:
 
 
 def denoise_chunk(unet_w, cn_w, latents, disparity, ctx_neg, ctx_pos, guidance, steps, cfg=SD15, num_steps_total=None,
-                  mode="xview"):
+                  mode="xview", trace=None):
     """The 20-step loop inside pipe() as edit_images drives it (gc_pipeline.py:209-219):
     latents [f,4,h,w] with the 4 reference frames FIRST, disparity [f,3,8h,8w], text [1,77,768] each.
-    `steps` = how many of the `num_steps_total` DDIM steps to run (tests run a prefix)."""
+    `steps` = how many of the `num_steps_total` DDIM steps to run (tests run a prefix); `trace` (a list) receives the
+    latents after every step."""
     n = num_steps_total or steps
     sch = DDIM()
     f = latents.shape[0]
@@ -445,6 +455,8 @@ def denoise_chunk(unet_w, cn_w, latents, disparity, ctx_neg, ctx_pos, guidance, 
         eps = unet_forward(unet_w, xin, t, ctx, down, mid, cfg, mode, 0.6)
         eu, ec = eps.chunk(2)
         x = sch.step(eu + guidance * (ec - eu), t, x, n)
+        if trace is not None:
+            trace.append(x.clone())
     return x
 
 
@@ -465,3 +477,25 @@ def mask_composite(edited, unedited_hwc, mask):
     """gc_pipeline.py:226-234: edited [3,H,W], unedited [H,W,3], mask [H,W] -> [H,W,3] fp32."""
     out = edited * mask[None] + unedited_hwc.permute(2, 0, 1) * (1 - mask)[None]
     return out.permute(1, 2, 0).to(torch.float32)
+
+
+# =========================================================================================== loss (row A8)
+def ssim(a, b, window=11, sigma=1.5, valid=True):
+    """SSIM of [B,C,H,W] images in [0,1] with a gaussian 11x11 window (sigma 1.5), C1 = 0.01^2, C2 = 0.03^2.
+    valid=True restates pytorch_msssim.SSIM(data_range=1.0, size_average=True) -- the module SplatfactoModel.get_loss_dict calls
+    [recall nerfstudio 1.0.0 splatfacto.py / pytorch_msssim ssim.py: separable UNPADDED gaussian filter, sigma products with
+    compensation 1.0, mean over the (H-10) x (W-10) map]; valid=False is the zero-padded 'same' variant of the 3DGS code base."""
+    coords = torch.arange(window, dtype=a.dtype, device=a.device) - window // 2
+    g = torch.exp(-(coords ** 2) / (2 * sigma ** 2)); g = (g / g.sum())
+    k = (g[:, None] * g[None, :])[None, None].expand(a.shape[1], 1, window, window)
+    mu = lambda x: F.conv2d(x, k, padding=0 if valid else window // 2, groups=x.shape[1])
+    ma, mb = mu(a), mu(b)
+    va, vb, cab = mu(a * a) - ma * ma, mu(b * b) - mb * mb, mu(a * b) - ma * mb
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    return (((2 * ma * mb + c1) * (2 * cab + c2)) / ((ma * ma + mb * mb + c1) * (va + vb + c2))).mean()
+
+
+def splat_loss(pred_hwc, gt_hwc, ssim_lambda=0.2, valid=True):
+    """SplatfactoModel.get_loss_dict main loss: (1 - l) * L1 + l * (1 - SSIM) (inherited by the reference, gc_pipeline.py:284-285)."""
+    l1 = (gt_hwc - pred_hwc).abs().mean()
+    return (1 - ssim_lambda) * l1 + ssim_lambda * (1 - ssim(gt_hwc.permute(2, 0, 1)[None], pred_hwc.permute(2, 0, 1)[None], valid=valid))

@@ -1,0 +1,107 @@
+"""Generates the full-geometry denoise fixtures tests/golden/fullgeom_*.npz with the CPU fp32 oracle
+(oracle/sd15_torch.py) at the geometry bench.py measures: 64x64 latents (512x512 images), SD1.5 /
+sd-controlnet-depth / VAE shapes, f = 4 reference + 3 chunk frames (CFG batch 14), all 20 DDIM steps.
+
+The oracle needs ~20 min of 8 host cores for the f=7 trajectory, so it is run ONCE here and the GPU box only
+loads the .npz (data: per-step latents / decoded image; inputs and weights are re-created from the seeds below with
+CPU torch generators, which are deterministic across machines).
+
+Weights and the 2-byte inputs (disparity, text embeddings) are rounded to bf16 before the fp32 run.  bf16 values are
+exactly representable in f16 inside f16's normal range (weights below 6e-5 in magnitude lose at most 3e-8 absolute),
+so ONE fixture serves both the bf16 and the f16 GPU runs.
+
+Attention uses oracle.sd15_torch.ATTN_IMPL = "sdpa" (torch's fused CPU kernel of softmax(q k^T s) v; the explicit
+form would materialise 5 x [14*8, 4096, 4096] fp32 tensors per layer); tests/test_oracle_sd.py pins both forms
+against the reference-generated goldens.
+
+usage: python tests/golden/make_fullgeom_golden.py [edit7|vae|invert|edit12 ...]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from oracle import sd15_torch as sd  # noqa: E402
+
+SEED_UNET, SEED_CN, SEED_VAE = 100, 200, 300
+
+
+def bf16r(x):
+    return x.to(torch.bfloat16).float()
+
+
+def inputs(f, h, seed):
+    """same recipe as tests/test_denoise_model_gpu.py::_inputs"""
+    g = torch.Generator().manual_seed(seed)
+    lat = torch.randn(f, 4, h, h, generator=g)
+    disp = torch.rand(f, 3, 8 * h, 8 * h, generator=g)
+    cn = torch.randn(1, 77, 768, generator=g); cp = torch.randn(1, 77, 768, generator=g)
+    return lat, disp, cn, cp
+
+
+def weights():
+    uw = {k: bf16r(v) for k, v in sd.make_unet_weights(sd.SD15, SEED_UNET).items()}
+    cw = {k: bf16r(v) for k, v in sd.make_controlnet_weights(sd.SD15, SEED_CN).items()}
+    return uw, cw
+
+
+def edit(f, h, steps, seed, name):
+    uw, cw = weights()
+    lat, disp, cn, cp = inputs(f, h, seed)
+    trace = []
+    t0 = time.time()
+    with torch.no_grad():
+        sd.denoise_chunk(uw, cw, lat, bf16r(disp), bf16r(cn), bf16r(cp), 5.0, steps, sd.SD15, 20, trace=trace)
+    np.savez_compressed(os.path.join(HERE, name), lat_steps=torch.stack(trace).numpy(),
+                        meta=np.array([f, h, steps, seed, SEED_UNET, SEED_CN], np.int64))
+    print(f"{name}: {time.time() - t0:.0f}s", flush=True)
+
+
+def invert(f, h, steps, seed, name):
+    """DDIM inversion: plain attention, guidance 0 -> no CFG batch (gc_pipeline.py:136-145)."""
+    uw, cw = weights()
+    lat, disp, cn, cp = inputs(f, h, seed)
+    sch = sd.DDIM()
+    x = lat.clone()
+    ctx = bf16r(cp).expand(f, -1, -1)
+    trace = []
+    t0 = time.time()
+    with torch.no_grad():
+        for t in sch.timesteps(20, inverse=True)[:steps]:
+            down, mid = sd.controlnet_forward(cw, x, t, ctx, bf16r(disp), sd.SD15, 1.0, "plain", 0.0)
+            eps = sd.unet_forward(uw, x, t, ctx, down, mid, sd.SD15, "plain", 0.0)
+            x = sch.inverse_step(eps, t, x, 20)
+            trace.append(x.clone())
+    np.savez_compressed(os.path.join(HERE, name), lat_steps=torch.stack(trace).numpy(),
+                        meta=np.array([f, h, steps, seed, SEED_UNET, SEED_CN], np.int64))
+    print(f"{name}: {time.time() - t0:.0f}s", flush=True)
+
+
+def vae(h, seed, name):
+    vw = {k: bf16r(v) for k, v in sd.make_vae_decoder_weights(sd.VAE_SD, SEED_VAE).items()}
+    z = torch.randn(1, 4, h, h, generator=torch.Generator().manual_seed(seed))
+    t0 = time.time()
+    with torch.no_grad():
+        img = sd.postprocess_image(sd.vae_decode(vw, bf16r(z / 0.18215), sd.VAE_SD))
+    np.savez_compressed(os.path.join(HERE, name), image=img.numpy(), meta=np.array([1, h, seed, SEED_VAE], np.int64))
+    print(f"{name}: {time.time() - t0:.0f}s", flush=True)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(int(os.environ.get("GC_GOLDEN_THREADS", "7")))
+    sd.ATTN_IMPL = "sdpa"
+    what = sys.argv[1:] or ["vae", "edit7", "invert", "edit12"]
+    for w in what:
+        if w == "vae":
+            vae(64, 1, "fullgeom_vae_h64.npz")
+        elif w == "edit7":       # BASELINE configs[1]: chunk_size 3 -> f = 7, CFG batch 14, all 20 steps
+            edit(7, 64, 20, 2, "fullgeom_edit_f7_h64.npz")
+        elif w == "invert":      # render_reverse's inversion, 3 views batched, all 20 steps
+            invert(3, 64, 20, 5, "fullgeom_invert_f3_h64.npz")
+        elif w == "edit12":      # BASELINE configs[3]: chunk_size 8 -> f = 12, CFG batch 24 (2 of 20 steps)
+            edit(12, 64, 2, 7, "fullgeom_edit_f12_h64.npz")

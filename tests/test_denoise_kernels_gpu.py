@@ -199,3 +199,103 @@ def test_elementwise_and_ddim(dt):
     ops.cfg_ddim_step(eps, lat, xin, gs, True, a_t, a_p, 2)
     assert torch.allclose(lat, want, atol=2e-5)
     _close(xin[:f, ..., :4], want, dt); assert torch.equal(xin[:f], xin[f:]); assert float(xin[..., 4:].abs().max()) == 0
+
+
+# ------------------------------------------------------------------------------------------- fused normalisation (round 2)
+def _sums(t):
+    t = t.double()
+    return torch.stack([t.sum(-1), (t * t).sum(-1)], -1)
+
+
+def _group_sums(out_bln, G):
+    """[B, L, N] -> [B, G, 2] (sum, sum^2) over the L rows and the N / G channels of each group"""
+    B, L, N = out_bln.shape
+    return _sums(out_bln.double().reshape(B, L, G, N // G).permute(0, 2, 1, 3).reshape(B, G, -1))
+
+
+def _stats_close(got, ref):
+    err = (got.double().cpu() - ref.cpu()).abs()
+    assert float((err / (ref.cpu().abs() + 1e-3 * ref.abs().max().cpu())).max()) < 2e-5, float(err.max())
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("B,L,N,K", [(2, 256, 320, 320), (6, 4096, 320, 320), (3, 64, 1280, 1280), (2, 1024, 640, 640), (2, 80, 320, 5120),
+                                     (6, 256, 1280, 5120)])
+def test_linear_output_statistics(dt, B, L, N, K):
+    """producer side: (sum, sum^2) of the STORED output per row (slab partials -> LayerNorm fold) and per (batch, GroupNorm group)
+    (-> GroupNorm apply), left by the GEMM epilogue (every k_gemm8 / k_gemm / split-K variant via test_gemm_variants_gpu)."""
+    from gaussctrl_amd.sd import ops
+    x = _rand((B, L, K), dt, 1.0, 1); w = _rand((N, K), dt, K ** -0.5, 2)
+    b = torch.randn(N, device=DEV); r = (_rand((B, L, N), dt, 1.0, 3).float() + 1.5).to(dt)
+    rs = ops.RowStats(); gs = torch.zeros(B, 32, 2, device=DEV)
+    out = ops.linear(x, w, b, residual=r, rows_per_batch=L, row_stats=rs, group_stats=gs)
+    _close(out, x.double() @ w.double().T + b.double() + r.double(), dt)
+    assert rs.buf.shape == (rs.slots, B * L, 2) and rs.slots >= 1
+    _stats_close(rs.buf.sum(0), _sums(out.view(B * L, N)))
+    _stats_close(gs, _group_sums(out, 32))
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride", [(6, 64, 64, 320, 320, 1), (2, 32, 32, 640, 640, 1), (3, 16, 16, 1280, 1280, 1),
+                                                   (2, 32, 32, 320, 320, 2), (14, 8, 8, 1280, 1280, 1), (2, 16, 16, 64, 96, 1)])
+def test_conv_output_group_statistics(dt, B, H, W, Cin, Cout, stride):
+    from gaussctrl_amd.sd import ops
+    from gaussctrl_amd.sd.weights import conv3x3_weight
+    x = _rand((B, H, W, Cin), dt, 1.0, 1)
+    w = conv3x3_weight(_rand((Cout, Cin, 3, 3), dt, (9 * Cin) ** -0.5, 2), dt)
+    b = torch.randn(Cout, device=DEV); rv = torch.randn(B, Cout, device=DEV)
+    gs = torch.zeros(B, 32, 2, device=DEV)
+    out = ops.conv3x3(x, w, b, stride=stride, rowvec=rv, group_stats=gs)
+    _stats_close(gs, _group_sums(out.reshape(B, -1, Cout), 32))
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("M,N,K,geglu", [(512, 960, 320, False), (24576, 960, 320, False), (300, 1280, 1280, False), (1024, 2560, 320, True),
+                                         (384, 10240, 1280, True)])
+def test_linear_layernorm_folded(dt, M, N, K, geglu):
+    """consumer side: y = LN(x) W^T + b computed as rstd (x W'^T - mean colsum) + b' from the row sums the PRODUCER of x left
+    (here: an identity-free producer GEMM x = x0 W0^T so that the slab layout is the real one); reference = torch layer_norm +
+    matmul in fp64 on the same rounded x and the UNfolded weights."""
+    from gaussctrl_amd.sd import ops
+    from gaussctrl_amd.sd.weights import _fold_ln, geglu_permute
+    x0 = _rand((M, 256), dt, 1.0, 1); w0 = _rand((K, 256), dt, 256 ** -0.5 * 1.7, 5); b0 = torch.full((K,), 0.4, device=DEV)
+    rs = ops.RowStats()
+    x = ops.linear(x0, w0, b0, row_stats=rs)                                   # producer: leaves the row sums of x
+    w32 = torch.randn(N, K, generator=torch.Generator().manual_seed(2)).to(DEV) * K ** -0.5
+    b = torch.randn(N, device=DEV); gamma = 1 + 0.2 * torch.randn(K, device=DEV); beta = 0.3 * torch.randn(K, device=DEV)
+    ln = F.layer_norm(x.double(), (K,), gamma.double(), beta.double(), 1e-5)
+    ref = ln @ w32.double().T + b.double()
+    o = {}
+    _fold_ln(o, "w", w32, b, gamma, beta, dt)
+    wf, bf = o["w.weight"], o["w.bias"]
+    if geglu:
+        hid, gate = ref.chunk(2, dim=-1)
+        ref = hid * F.gelu(gate)
+        wf, bf = geglu_permute(wf, bf)
+    colsum = wf.float().sum(1).contiguous()
+    got = ops.linear(x, wf, bf, geglu=geglu, ln=(rs, colsum, 1e-5))
+    _close(got, ref, dt, extra=3.0)          # + one rounding of gamma-folded weights instead of one of the normalised activations
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("B,HW,C,G", [(2, 256, 320, 32), (3, 64, 1280, 32), (2, 112, 2560, 32), (6, 4096, 320, 32), (2, 36, 960, 32), (1, 16, 1920, 32)])
+def test_groupnorm_apply_from_statistics(dt, B, HW, C, G):
+    from gaussctrl_amd.sd import ops
+    x = (_rand((B, HW, C), dt, 1.0, 1).float() * 2 + 1.0).to(dt)
+    gamma = torch.randn(C, device=DEV); beta = torch.randn(C, device=DEV)
+    gs = _group_sums(x, G).float().contiguous()
+    ref = F.group_norm(x.double().transpose(1, 2), G, gamma.double(), beta.double(), 1e-6).transpose(1, 2)
+    _close(ops.groupnorm_apply(x, gs, gamma, beta, G, 1e-6, False), ref, dt, extra=2.0)
+    _close(ops.groupnorm_apply(x, gs, gamma, beta, G, 1e-6, True), F.silu(ref), dt, extra=2.0)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("B,HW,C1,C2", [(2, 256, 640, 320), (3, 64, 1280, 1280), (6, 1024, 320, 320), (2, 100, 1280, 640)])
+def test_concat_add_with_statistics(dt, B, HW, C1, C2):
+    from gaussctrl_amd.sd import ops
+    a = _rand((B, HW, C1), dt, 1.0, 1); b = _rand((B, HW, C2), dt, 1.0, 2); c = _rand((B, HW, C2), dt, 1.0, 3)
+    for cc in (c, None):
+        gs = torch.zeros(B, 32, 2, device=DEV)
+        out = ops.concat_add(a, b, cc, group_stats=gs)
+        assert torch.equal(out, ops.concat_add(a, b, cc))
+        _stats_close(gs, _group_sums(out, 32))

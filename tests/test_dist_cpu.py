@@ -43,7 +43,37 @@ def _worker(rank, world, port, ret):
         ok_bank = bank.mode == "use" and set(bank.store) == set(want)
         for key, (k, vt) in bank.store.items():
             ok_bank = ok_bank and torch.equal(k, want[key][0]) and torch.equal(vt, want[key][1]) and k.stride(1) == 2 * k.shape[2]
-        ret[rank] = (mine, ok_grad, ok_img and ok_bank)
+        # pipelined variant: the owner advances the reference trajectory one DDIM step at a time and posts each step's K / V^T as an
+        # async broadcast; a stand-in pipe records deterministic K / V^T per step (the real one needs the GPU)
+        from gaussctrl_amd.dist import broadcast_ref_bank_pipelined
+
+        class FakePipe:
+            def begin_ref_bank(self, *a):
+                b = RefBank(); b.mode = "record"
+                return {"bank": b, "i": 0}
+
+            def advance_ref_bank(self, tr, n):
+                st = tr["i"]
+                for li, (L_, C_) in enumerate([(16, 8), (4, 24)]):
+                    qk, vt = want2[(st, ("unet", f"layer{li}"))]
+                    tr["bank"].store[(st, ("unet", f"layer{li}"))] = (qk[..., C_:], vt)
+                tr["i"] += 1
+                if tr["i"] == 3:
+                    tr["bank"].mode = "use"
+                    return tr["bank"]
+                return None
+        g2 = torch.Generator().manual_seed(9)
+        want2 = {}
+        for st in range(3):
+            for li, (L_, C_) in enumerate([(16, 8), (4, 24)]):
+                want2[(st, ("unet", f"layer{li}"))] = (torch.randn(8, L_, 2 * C_, generator=g2).to(torch.bfloat16),
+                                                       torch.randn(8, C_, L_, generator=g2).to(torch.bfloat16))
+        bank2 = broadcast_ref_bank_pipelined(FakePipe(), None, None, None, None, 0, world, rank, "cpu", 3)
+        ok_pipe = bank2.mode == "use" and set(bank2.store) == set(want2)
+        for key, (k, vt) in bank2.store.items():
+            C_ = vt.shape[1]
+            ok_pipe = ok_pipe and torch.equal(k, want2[key][0][..., C_:]) and torch.equal(vt, want2[key][1]) and k.stride(1) == 2 * C_
+        ret[rank] = (mine, ok_grad, ok_img and ok_bank and ok_pipe)
     finally:
         dist.destroy_process_group()
 

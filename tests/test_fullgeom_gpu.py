@@ -1,0 +1,153 @@
+"""GPU parity at the geometry bench.py measures: 64x64 latents (512x512 images), full SD1.5 / sd-controlnet-depth / VAE
+shapes, f = 4 reference + 3 chunk frames (CFG batch 14) -- the k_attn3<.,40,..> L = 4096 grids and the 256-tile k_gemm8 grids
+that carry the timed step -- through ALL 20 DDIM steps, in both activation dtypes, against fixtures the CPU fp32 oracle produced
+once in the build container (tests/golden/make_fullgeom_golden.py; the GPU box only loads the .npz).
+
+Bars.  north_star: "UNet latents within 1e-3 rel fp16" -- the f16 relative L2 error of the latents stays <= 1e-3 after every
+one of the 20 steps.  bf16 carries 3 fewer mantissa bits (8x the rounding unit), its bar is 8e-3 on the same curve (measured
+curve printed by the test and recorded in DESIGN.md section 2)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+BAR = {torch.float16: 1e-3, torch.bfloat16: 8e-3}
+
+
+def _rel(a, b):
+    a = a.double().cpu(); b = b.double().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+def _inputs(f, h, seed):
+    g = torch.Generator().manual_seed(seed)
+    lat = torch.randn(f, 4, h, h, generator=g)
+    disp = torch.rand(f, 3, 8 * h, 8 * h, generator=g)
+    cn = torch.randn(1, 77, 768, generator=g); cp = torch.randn(1, 77, 768, generator=g)
+    r = lambda x: x.to(torch.bfloat16).float()          # the fixture rounds the 2-byte inputs to bf16 (exact in f16 too)
+    return lat, r(disp), r(cn), r(cp)
+
+
+@pytest.fixture(scope="module")
+def nets():
+    """fp32 weights of the fixture (seeded CPU generators), rounded to bf16 like the generator did; prepared per dtype on demand."""
+    from oracle import sd15_torch as sd
+    from gaussctrl_amd.sd.weights import prepare
+    r = lambda w: {k: v.to(torch.bfloat16).float() for k, v in w.items()}
+    uw, cw = r(sd.make_unet_weights(sd.SD15, 100)), r(sd.make_controlnet_weights(sd.SD15, 200))
+    cache = {}
+
+    def get(dt):
+        if dt not in cache:
+            cache.clear()
+            cache[dt] = (prepare(uw, dt, DEV, heads=8), prepare(cw, dt, DEV, heads=8))
+        return cache[dt]
+    return get
+
+
+def _curve(trace, ref, sl=slice(None)):
+    return [_rel(t[sl], torch.tensor(ref[i][sl])) for i, t in enumerate(trace)]
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_edit_f7_h64_all_20_steps(nets, dt):
+    """BASELINE configs[1] geometry: in-batch references (reference order, gc_pipeline.py:206-219) AND the cached-reference
+    product path, every DDIM step compared with the oracle trajectory."""
+    from gaussctrl_amd.sd.pipeline import DenoisePipeline
+    z = np.load(os.path.join(GOLD, "fullgeom_edit_f7_h64.npz"))
+    ref = z["lat_steps"]                                            # [20, 7, 4, 64, 64]
+    f, h, steps, seed = [int(v) for v in z["meta"][:4]]
+    lat, disp, cn, cp = _inputs(f, h, seed)
+    uw, cw = nets(dt)
+    pipe = DenoisePipeline(uw, cw, None, 20, 5.0)
+    trace = []
+    on = lambda i, l: trace.append(l.permute(0, 3, 1, 2).float().cpu())
+    pipe.edit_chunk(lat.to(DEV), disp.to(DEV), cn.to(DEV), cp.to(DEV), steps=steps, on_step=on)
+    assert len(trace) == steps == 20
+    cur = _curve(trace, ref)
+    print(f"\nedit f=7 h=64 {dt}: rel L2 error of the latents per DDIM step (in-batch references):\n  " +
+          " ".join(f"{e:.2e}" for e in cur))
+    assert max(cur) <= BAR[dt], (max(cur), cur)
+    # product path: reference K / V^T from the bank, chunk frames only
+    bank = pipe.build_ref_bank(lat[:4].to(DEV), disp[:4].to(DEV), cn.to(DEV), cp.to(DEV))
+    trace_c = []
+    pipe.edit_chunk_cached(lat[4:].to(DEV), disp[4:].to(DEV), cn.to(DEV), cp.to(DEV), bank,
+                           on_step=lambda i, l: trace_c.append(l.permute(0, 3, 1, 2).float().cpu()))
+    cur_c = [_rel(t, torch.tensor(ref[i][4:])) for i, t in enumerate(trace_c)]
+    print(f"edit f=7 h=64 {dt}: cached-reference path, chunk frames vs oracle:\n  " + " ".join(f"{e:.2e}" for e in cur_c))
+    assert max(cur_c) <= BAR[dt], (max(cur_c), cur_c)
+    d = _rel(trace_c[-1], trace[-1][4:])
+    print(f"cached vs in-batch after 20 steps: {d:.2e}")
+    assert d <= BAR[dt]
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_invert_f3_h64_all_20_steps(nets, dt):
+    """render_reverse's DDIM inversion (plain attention, no CFG, batched views; gc_pipeline.py:136-145) at full size."""
+    from gaussctrl_amd.sd.pipeline import DenoisePipeline
+    z = np.load(os.path.join(GOLD, "fullgeom_invert_f3_h64.npz"))
+    ref = z["lat_steps"]
+    f, h, steps, seed = [int(v) for v in z["meta"][:4]]
+    lat, disp, cn, cp = _inputs(f, h, seed)
+    uw, cw = nets(dt)
+    pipe = DenoisePipeline(uw, cw, None, 20, 5.0)
+    trace = []
+    pipe.invert(lat.to(DEV), disp.to(DEV), cp.to(DEV), steps=steps,
+                on_step=lambda i, l: trace.append(l.permute(0, 3, 1, 2).float().cpu()))
+    cur = _curve(trace, ref)
+    print(f"\ninversion f=3 h=64 {dt}: rel L2 per step:\n  " + " ".join(f"{e:.2e}" for e in cur))
+    assert max(cur) <= BAR[dt], (max(cur), cur)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_edit_f12_h64_config4_geometry(nets, dt):
+    """BASELINE configs[3] geometry: chunk_size 8 -> f = 12 frames, CFG batch 24 (first 2 of 20 steps)."""
+    from gaussctrl_amd.sd.pipeline import DenoisePipeline
+    path = os.path.join(GOLD, "fullgeom_edit_f12_h64.npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated")
+    z = np.load(path)
+    ref = z["lat_steps"]
+    f, h, steps, seed = [int(v) for v in z["meta"][:4]]
+    lat, disp, cn, cp = _inputs(f, h, seed)
+    uw, cw = nets(dt)
+    pipe = DenoisePipeline(uw, cw, None, 20, 5.0)
+    trace = []
+    pipe.edit_chunk(lat.to(DEV), disp.to(DEV), cn.to(DEV), cp.to(DEV), steps=steps,
+                    on_step=lambda i, l: trace.append(l.permute(0, 3, 1, 2).float().cpu()))
+    cur = _curve(trace, ref)
+    print(f"\nedit f=12 h=64 {dt}: " + " ".join(f"{e:.2e}" for e in cur))
+    assert max(cur) <= BAR[dt], cur
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_vae_decode_h64(dt):
+    """vae.decode(z / 0.18215) -> (x/2 + 0.5).clamp(0,1) at 64x64 latents (512x512 image; L = 4096, D = 512 mid-block
+    attention), against the oracle's fp32 decode of the same (bf16-rounded) weights.
+    Bars, from the measured errors (MI355X, round 2: f16 rel L2 5.3e-4 / mean abs 2.1e-4 / max abs 3.6e-3; bf16 4.2e-3 / 1.7e-3 /
+    2.1e-2): the same relative-L2 bars as the latents (f16 1e-3 = north_star's, bf16 8e-3), plus per-pixel limits in 8-bit levels of
+    the [0,1] image: f16 every pixel within ONE level (1/255); bf16 (8 mantissa bits through ~30 convolutions) mean error within
+    one level and isolated worst pixels within 8 levels.  Round 1 asserted only max <= 1/255 on an 8x8 latent, where the tail of
+    the error distribution is never sampled; the 2e-3 figure it first tried was a guess, not a derived bar."""
+    from oracle import sd15_torch as sd
+    from gaussctrl_amd.sd.pipeline import to_nhwc8
+    from gaussctrl_amd.sd.vae import VAEDecoder, prepare_vae_weights
+    z = np.load(os.path.join(GOLD, "fullgeom_vae_h64.npz"))
+    ref = torch.tensor(z["image"])
+    _, h, seed, wseed = [int(v) for v in z["meta"]]
+    vw = {k: v.to(torch.bfloat16).float() for k, v in sd.make_vae_decoder_weights(sd.VAE_SD, wseed).items()}
+    lat = torch.randn(1, 4, h, h, generator=torch.Generator().manual_seed(seed))
+    zin = (lat / 0.18215).to(torch.bfloat16).float()
+    dec = VAEDecoder(prepare_vae_weights(vw, dt, DEV))
+    got = dec.decode(to_nhwc8(zin.to(DEV), dt), postprocess=True)[..., :3].permute(0, 3, 1, 2).cpu()
+    err = (got - ref).abs()
+    print(f"\nvae decode h=64 {dt}: max abs {float(err.max()):.3e}  mean abs {float(err.mean()):.3e}  rel L2 {_rel(got, ref):.3e}")
+    assert _rel(got, ref) <= BAR[dt]
+    if dt == torch.float16:
+        assert float(err.max()) <= 1.0 / 255.0, float(err.max())
+    else:
+        assert float(err.mean()) <= 1.0 / 255.0 and float(err.max()) <= 8.0 / 255.0, (float(err.mean()), float(err.max()))

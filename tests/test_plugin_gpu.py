@@ -125,20 +125,21 @@ def test_image2latent_and_pipeline_flow(oracle_c):
 
 def test_l1_ssim_loss_and_fused_adam():
     """fused loss (value + gradient) vs torch autograd of the plain definition; FusedAdam vs torch.optim.Adam."""
-    from gaussctrl_amd.gc_model import _ssim
+    from oracle import sd15_torch as sd            # the checker: pytorch_msssim-equivalent SSIM (valid windows) and the padded variant
     from gaussctrl_amd.train_ops import FusedAdam, l1_ssim_loss
     g = torch.Generator().manual_seed(0)
     for (H, W) in ((64, 48), (100, 75), (512, 512)):
-        pred = torch.rand(H, W, 3, generator=g).to(DEV).requires_grad_(True)
-        tgt = torch.rand(H, W, 3, generator=g).to(DEV)
-        ref = 0.8 * (tgt - pred).abs().mean() + 0.2 * (1 - _ssim(tgt.permute(2, 0, 1)[None].double(), pred.permute(2, 0, 1)[None].double()))
-        (gref,) = torch.autograd.grad(ref, pred)
-        pred2 = pred.detach().clone().requires_grad_(True)
-        got = l1_ssim_loss(pred2, tgt, 0.2)
-        (3.0 * got).backward()
-        assert abs(float(got) - float(ref)) < 2e-6 * max(1.0, abs(float(ref)))
-        err = float((pred2.grad / 3.0 - gref).abs().max() / gref.abs().max())
-        assert err < 1e-4, err
+        for valid in (True, False):
+            pred = torch.rand(H, W, 3, generator=g).to(DEV).requires_grad_(True)
+            tgt = torch.rand(H, W, 3, generator=g).to(DEV)
+            ref = sd.splat_loss(pred.double(), tgt.double(), 0.2, valid=valid)
+            (gref,) = torch.autograd.grad(ref, pred)
+            pred2 = pred.detach().clone().requires_grad_(True)
+            got = l1_ssim_loss(pred2, tgt, 0.2, valid_window=valid)
+            (3.0 * got).backward()
+            assert abs(float(got) - float(ref)) < 2e-6 * max(1.0, abs(float(ref))), (H, W, valid, float(got), float(ref))
+            err = float((pred2.grad / 3.0 - gref).abs().max() / gref.abs().max())
+            assert err < 1e-4, (H, W, valid, err)
     ps = [torch.randn(1001, 3, generator=g).to(DEV), torch.randn(77, 15, 3, generator=g).to(DEV), torch.randn(5, generator=g).to(DEV)]
     a = [torch.nn.Parameter(p.clone()) for p in ps]; b = [torch.nn.Parameter(p.clone()) for p in ps]
     oa = torch.optim.Adam(a, lr=1.6e-4, eps=1e-15); ob = FusedAdam(b, lr=1.6e-4, eps=1e-15)
@@ -149,3 +150,27 @@ def test_l1_ssim_loss_and_fused_adam():
         oa.step(); ob.step()
     for x, y in zip(a, b):
         assert float((x - y).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("H,W,C", [(512, 512, 8), (96, 130, 3)])
+def test_mask_composite_with_real_mask(H, W, C):
+    """gc_pipeline.py:226-234 with a mask: edited * mask + unedited * (1 - mask) -> HWC fp32, bit-comparable arithmetic (one
+    mul-add pair in fp32).  Mask = the synthetic elliptical LangSAM stand-in of BASELINE configs[3] and a soft
+    (non-binary) variant; the no-mask call must return the edited image unchanged."""
+    from oracle import sd15_torch as sd
+    from gaussctrl_amd import synthetic as syn
+    from gaussctrl_amd.sd import ops as sdops
+    g = torch.Generator().manual_seed(11)
+    edited = torch.rand(H, W, C, generator=g)               # decoder output, channels-last (channels >= 3 padded to 8)
+    unedited = torch.rand(H, W, 3, generator=g)
+    for mask in (syn.elliptical_mask(H, W), syn.elliptical_mask(H, W, soft=True)):
+        mask = torch.tensor(mask)
+        ref = sd.mask_composite(edited[..., :3].permute(2, 0, 1), unedited, mask)
+        got = sdops.mask_composite(edited.to(DEV).contiguous(), unedited.to(DEV), mask.to(DEV)).cpu()
+        assert got.shape == (H, W, 3) and got.dtype == torch.float32
+        assert float((got - ref).abs().max()) <= 1.2e-7          # fp32 mul/add vs fma contraction: <= 1 ulp of values in [0,1]
+        inside = mask == 1.0
+        if bool(inside.any()):
+            assert torch.equal(got[inside], edited[..., :3][inside])
+    got0 = sdops.mask_composite(edited.to(DEV).contiguous()).cpu()
+    assert torch.equal(got0, edited[..., :3])

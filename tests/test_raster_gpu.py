@@ -225,3 +225,107 @@ def test_empty_and_all_culled():
     assert bool((depth == 1000.0).all())
     rgb.sum().backward()
     assert float(tp["means"].grad.abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------- BASELINE configs 3 and 5
+def _full_parity(oracle_c, P, c2w, K, training, seed=5):
+    """fused product render (fwd [+ depth] + bwd to the six leaf tensors) vs the C oracle at full size."""
+    from gaussctrl_amd import gsplat_ops as ops
+    from gaussctrl_amd.camera import camera_to_gsplat
+    W, H = K["W"], K["H"]
+    g = np.random.default_rng(seed)
+    v_rgb = g.normal(size=(H, W, 3)).astype(np.float32); v_a = g.normal(size=(H, W)).astype(np.float32)
+    o = oracle_c.render(P, c2w, K["fx"], K["fy"], K["cx"], K["cy"], W, H, BG, training=training, v_rgb=v_rgb, v_alpha=v_a)
+    cam = camera_to_gsplat(c2w, K["fx"], K["fy"], K["cx"], K["cy"], W, H)
+    tp = {k: _t(v).requires_grad_(True) for k, v in P.items()}
+    aux = ops.RenderAux()
+    rgb, alpha, depth = ops.render_view(tp["means"], tp["scales"], tp["quats"], tp["opacities"], tp["features_dc"],
+                                        tp["features_rest"], cam, _t(BG), not training, 3, aux)
+    _img_close(rgb.detach().cpu().numpy(), o["rgb"])
+    _img_close(alpha.detach().cpu().numpy(), o["accumulation"][..., 0])
+    mse = float(((rgb.detach().cpu().numpy().astype(np.float64) - o["rgb"]) ** 2).mean())
+    assert 10 * math.log10(1.0 / max(mse, 1e-20)) >= 45.0
+    assert (aux.radii.cpu().numpy() != o["radii"]).mean() < 1e-4
+    assert abs(aux.M - o["M"]) <= max(4, 1e-4 * o["M"])
+    if not training:
+        d = depth.cpu().numpy(); od = o["depth"][..., 0]
+        far = (od == 1000.0)
+        assert np.array_equal(far, d == 1000.0)
+        _img_close(np.where(far, 0, d), np.where(far, 0, od))
+    ((rgb * _t(v_rgb)).sum() + (alpha * _t(v_a)).sum()).backward()
+    scale = max(np.abs(o["grads"][k]).max() for k in P)
+    for k in P:
+        _grad_close(tp[k].grad.cpu().numpy(), o["grads"][k], scale)
+    return aux.M
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_config3_garden_2m(oracle_c, training):
+    """BASELINE configs[2]: garden intrinsics (/root/reference/data/garden/transforms.json), ~2 M Gaussians."""
+    P = syn.make_gaussians(2_000_000, seed=0)
+    c2w = syn.make_cameras(3, seed=11)[2]
+    M = _full_parity(oracle_c, P, c2w, syn.GARDEN_INTRINSICS, training)
+    print(f"config 3: M = {M}")
+
+
+def test_config5_raster_4m(oracle_c):
+    """BASELINE configs[4]: 4 M random Gaussians, random 512x512 cameras (fx=fy=540, cx=cy=256): one camera against the C
+    oracle (image, depth, leaf gradients), further cameras through size-independent properties of the binning and the
+    compositing: tile bins partition [0, M), keys sorted, tiles inside the image, alpha = 1 - T."""
+    from gaussctrl_amd import gsplat_ops as ops
+    from gaussctrl_amd.camera import camera_to_gsplat
+    N = 4_000_000
+    P = syn.make_gaussians(N, seed=0)
+    cams = syn.make_cameras(256, seed=1)
+    K = syn.ROUND_INTRINSICS
+    M = _full_parity(oracle_c, P, cams[17], K, True)
+    print(f"config 5: M = {M}")
+    tp = {k: _t(v) for k, v in P.items()}
+    W, H = K["W"], K["H"]
+    tb = ((W + 15) // 16, (H + 15) // 16, 1)
+    T = tb[0] * tb[1]
+    for ci in (0, 100, 255):
+        cam = camera_to_gsplat(cams[ci], K["fx"], K["fy"], K["cx"], K["cy"], W, H)
+        aux = ops.RenderAux()
+        rgb, alpha, depth = ops.render_view(tp["means"], tp["scales"], tp["quats"], tp["opacities"], tp["features_dc"],
+                                            tp["features_rest"], cam, _t(BG), True, 3, aux)
+        assert bool(torch.isfinite(rgb).all()) and float(alpha.min()) >= 0.0 and float(alpha.max()) <= 1.0
+        nth = aux.num_tiles_hit
+        Mi, keys, ids, bins, cum = ops.bin_and_sort_gaussians(N, aux.xys, aux.depths, aux.radii, nth, tb, want_keys=True)
+        assert Mi == aux.M == int(nth.sum())
+        k = keys.cpu().numpy()
+        assert np.all(k[1:] >= k[:-1])                                    # tile-major, depth-minor order
+        b = bins.cpu().numpy().astype(np.int64)
+        tiles = (k >> 32).astype(np.int64)
+        assert tiles.min() >= 0 and tiles.max() < T
+        nz = b[:, 1] > b[:, 0]
+        assert int((b[nz, 1] - b[nz, 0]).sum()) == Mi                     # bins partition [0, M)
+        starts = np.sort(b[nz, 0]); ends = np.sort(b[nz, 1])
+        assert starts[0] == 0 and ends[-1] == Mi and np.array_equal(starts[1:], ends[:-1])
+        idn = ids.cpu().numpy()
+        assert idn.min() >= 0 and idn.max() < N
+        # every intersection's Gaussian is visible and its depth is the key's low word
+        dbits = aux.depths.cpu().numpy().view(np.int32)[idn[:: max(1, Mi // 100000)]]
+        assert np.array_equal(dbits.astype(np.int64), (k[:: max(1, Mi // 100000)] & 0xFFFFFFFF))
+
+
+def test_sh_degree0_sigmoid_colour(oracle_c):
+    """config.sh_degree == 0 branch of the reference (gc_model.py:169): rgbs = sigmoid(features_dc), no SH (K = 1)."""
+    from gaussctrl_amd import gsplat_ops as ops
+    from gaussctrl_amd.camera import camera_to_gsplat
+    N, W, H = 30000, 160, 128
+    P = syn.make_gaussians(N, seed=4, sh_degree=0, scale_mean=0.02)
+    assert P["features_rest"].shape == (N, 0, 3)
+    c2w = syn.make_cameras(1, seed=6)[0]
+    g = np.random.default_rng(3)
+    v_rgb = g.normal(size=(H, W, 3)).astype(np.float32)
+    o = oracle_c.render(P, c2w, 150.0, 151.0, 80.3, 63.1, W, H, BG, training=True, sh_degree_to_use=-1, v_rgb=v_rgb)
+    cam = camera_to_gsplat(c2w, 150.0, 151.0, 80.3, 63.1, W, H)
+    tp = {k: _t(v).requires_grad_(True) for k, v in P.items()}
+    rgb, alpha, _ = ops.render_view(tp["means"], tp["scales"], tp["quats"], tp["opacities"], tp["features_dc"], tp["features_rest"],
+                                    cam, _t(BG), False, -1, None)
+    _img_close(rgb.detach().cpu().numpy(), o["rgb"])
+    (rgb * _t(v_rgb)).sum().backward()
+    scale = max(np.abs(o["grads"][k]).max() for k in ("means", "scales", "quats", "opacities", "features_dc"))
+    for k in ("means", "scales", "quats", "opacities", "features_dc"):
+        _grad_close(tp[k].grad.cpu().numpy(), o["grads"][k], scale)
