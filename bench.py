@@ -33,7 +33,7 @@ import torch
 
 UNET_GFLOP_XVIEW = 1293.3      # per sample-forward, SURVEY.md Appendix B (analytic, 2*MAC)
 CN_GFLOP_XVIEW = 430.0         # ControlNet with the weight-0 self term skipped
-PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0}
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "fp8": 2500.0}      # fp8 run: the dominant kernel (attention) still computes in bf16
 
 
 def parse():
@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--views", type=int, default=None)     # default: 40 (edit, BASELINE configs[1]) / 256 cameras (raster, configs[4])
     ap.add_argument("--chunk-size", type=int, default=3)
     ap.add_argument("--denoise-steps", type=int, default=20)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "fp8"])     # fp8: e4m3 resnet convs on the block-scaled MFMA, bf16 elsewhere
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="edit", choices=["edit", "raster"])
     return ap.parse_args()
@@ -132,7 +132,7 @@ def main():
     from gaussctrl_amd.sd.vae import prepare_vae_weights
     from gaussctrl_amd.sd.weights import prepare
 
-    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    dt = torch.float16 if args.dtype == "f16" else torch.bfloat16
     if args.views is None:
         args.views = 40 if args.workload == "edit" else 256
     c, V, nsteps = args.chunk_size, args.views, args.denoise_steps
@@ -149,8 +149,13 @@ def main():
     if args.workload == "edit":
         fold_ln = os.environ.get("GC_DN_FOLD_LN", "1") != "0"          # A/B switches of the round-2 normalisation fusions
         fuse_gn = os.environ.get("GC_DN_FUSE_GN", "1") != "0"
-        uw = prepare(arch.random_state_dict(arch.unet_shapes(), 100, dev), dt, dev, heads=8, fold_ln=fold_ln)
-        cw = prepare(arch.random_state_dict(arch.controlnet_shapes(), 200, dev), dt, dev, heads=8, fold_ln=fold_ln)
+        usd, csd = arch.random_state_dict(arch.unet_shapes(), 100, dev), arch.random_state_dict(arch.controlnet_shapes(), 200, dev)
+        uw = prepare(usd, dt, dev, heads=8, fold_ln=fold_ln)
+        cw = prepare(csd, dt, dev, heads=8, fold_ln=fold_ln)
+        if args.dtype == "fp8":
+            from gaussctrl_amd.sd.weights import add_fp8_convs
+            add_fp8_convs(uw, usd, dev); add_fp8_convs(cw, csd, dev)
+        del usd, csd
         vw = prepare_vae_weights(arch.random_state_dict(arch.vae_decoder_shapes(), 300, dev), dt, dev)
         pipe = DenoisePipeline(uw, cw, vw, nsteps, 5.0)
         pipe.unet.fuse_stats = pipe.controlnet.fuse_stats = fuse_gn
@@ -267,7 +272,7 @@ def main():
     # ---------------------------------------------------------------- roofline of the dominant kernel (instrumented extra step)
     roof = None
     if args.workload == "edit" and rank == 0:
-        prof = GemmProfiler("BF16" if args.dtype == "bf16" else "F16")
+        prof = GemmProfiler("F16" if args.dtype == "f16" else "BF16")
         prof.wrap(sdops)
         two = pipe.two_streams
         pipe.two_streams = False          # HIP events bracket one kernel only when nothing else shares the GPU: single stream here

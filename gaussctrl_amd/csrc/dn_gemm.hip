@@ -1,873 +1,10 @@
-// dn_gemm.hip -- bf16/f16 MFMA GEMM and implicit-GEMM 3x3 convolution for the SD1.5 UNet / ControlNet /
-// VAE blocks (gfx950).  Replaces the cuBLAS / cuDNN calls diffusers issues for every Linear and Conv2d
-// of UNet2DConditionModel / ControlNetModel / AutoencoderKL reached from
-// /root/reference/gaussctrl/gc_pipeline.py:142-145,209-219.
-//
-// out[m][n] = epilogue( sum_k Act[m][k] * W[n][k] ),  Act = row-major matrix (Linear / 1x1 conv on NHWC)
-// or the on-the-fly im2col of an NHWC tensor (3x3, pad 0|1, stride 1|2, optional fused nearest x2 upsample).
-//
-// CDNA4 mapping: 128(m) x {128|160}(n) x 64(k) workgroup tile, 256 lanes = 4 wave64 in 2x2, each wave a
-// 64 x {64|80} sub-tile = 4 x {4|5} v_mfma_f32_16x16x32 accumulators (fp32).  160-wide n tiles exist because every
-// SD1.5 channel count (320/640/960/1280/1920/2560) is a multiple of 160 but not of 128.
-// Operands are staged global -> VGPR -> LDS in 16-byte chunks, XOR-swizzled so every ds_read_b128 fragment read is
-// bank-conflict free.  The k loop is software pipelined two tiles deep: while tile t is multiplied out of LDS
-// buffer t&1, tile t+1 sits in one register set (already landed or landing) and tile t+2's global loads are being
-// issued into the other -- the loop is otherwise bound by the ~1 us global->LDS->MFMA dependency chain per k-tile
-// (measured: 22 us for 20 k-tiles on an idle chip).  One barrier per k-tile.
-// The MFMA is issued "swapped" (A operand = weights, B operand = activations) so each lane ends up with 4
-// CONSECUTIVE output channels of one output row: bias / row-vector / residual / SiLU / GEGLU are lane-local and the
-// store is one 8-byte write per accumulator.
-// Small-M / long-K problems (3x3 convs on 16x16 / 8x8 feature maps: 12 / 3 m-tiles, 90-360 k-tiles) are split along K
-// across workgroups (fp32 partial slabs + a small reduce-epilogue kernel) so that all 256 CUs stream the (large) weight
-// matrix together.
-#include "dn_common.h"
-#include <type_traits>
+// dn_gemm.hip -- host side of the bf16 / f16 / fp8 MFMA GEMM and implicit-GEMM 3x3 convolution of the SD1.5 UNet / ControlNet / VAE
+// blocks (gfx950): problem validation, kernel selection, launches.  The kernels live in dn_gemm_kernels.h and are instantiated in
+// three translation units that compile in parallel: dn_gemm_plain.hip (lean epilogue), dn_gemm_fuse.hip (fused-normalisation
+// epilogue), dn_gemm_fp8.hip (e4m3 operands on the block-scaled MFMA).  Reference call sites: see dn_gemm_kernels.h.
+#include "dn_gemm_kernels.h"
 
 namespace {
-using namespace dn;
-
-template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&f)
-{
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-constexpr int BM = 128, BK = 64;
-constexpr int NT = 256;
-
-struct GemmArgs {
-    int64_t M, N, K;
-    const void *A; int64_t lda;
-    int B, Hi, Wi, Cin, Ho, Wo, stride, ups, pad;
-    const void *W;
-    const float *bias;
-    const float *rowvec; int64_t ld_rowvec; int64_t rows_per_batch;
-    const void *residual; int64_t ldr;
-    float out_scale;
-    int act, geglu;
-    void *out; int64_t ldc; int out_f32;
-    void *out_t; int64_t ldt; int64_t t_batch_stride; int64_t t_col0;
-    int splits; int tiles_per_split;    // split-K: k-tiles [z*tps, min(nk, (z+1)*tps))
-    float *ws;                          // fp32 [splits][M][N] partial slabs when splits > 1
-    const void *zeros;                  // >= 16 bytes of zeros (k_gemm8: source of out-of-range / padding lanes)
-    // LayerNorm folded into this GEMM (consumer side): Act rows are the UN-normalised x, W carries gamma, and
-    // out = rstd[m] * (acc - mean[m] * colsum[n]) + bias'[n]   with (mean, rstd) from row_stats[m] = (sum x, sum x^2) over the K columns
-    const float *row_stats; int row_stat_slots; const float *colsum; float ln_eps, ln_inv_k;
-    // statistics of THIS GEMM's stored output (producer side):
-    float *out_row_stats;               // [slots][M][2] (sum, sum^2) of each row over one column slab per slot, PLAIN stores (no atomics, no
-                                        // zero-init): slot = wave column (16 NTW wide) of the fused epilogue / 256-column block of the
-                                        // split-K reduce; the consumer adds the slots up  -> LayerNorm folded into the next GEMM
-    float *out_group_stats;             // [M / rows_per_batch][groups][2] per (batch, GroupNorm group), reduced in LDS per workgroup, then
-    int gn_groups, gn_cpg;              // a few float atomics into the zero-initialised buffer     -> gc_dn_groupnorm_apply
-};
-constexpr int GS_SLOTS = 20, GS_MAXG = 32;      // LDS scratch of the group statistics: batches a workgroup tile can touch x groups
-
-// sum over the 16 lanes of a DPP row (lanes 16 j .. 16 j + 15), result in every lane: row_ror 8, 4, 2, 1
-__device__ __forceinline__ float row16_sum(float v)
-{
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
-    return v;
-}
-
-// byte offset of 16-byte chunk `c` (0..7) of row `r` inside a [rows][64] 2-byte tile
-__device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
-
-// epilogue of one lane's 4 consecutive output channels (n .. n+3) of row m; v = raw accumulators (+ gate for GEGLU)
-// (split-K reduce kernel) epilogue of 4 consecutive output channels of one row; on return v holds the values as stored
-template <class T>
-__device__ __forceinline__ void epilogue_store(const GemmArgs &g, int64_t m, int64_t n, int64_t on, float *v, const float *gate)
-{
-    const int64_t bidx = g.rowvec ? m / g.rows_per_batch : 0;
-    if (g.row_stats) {
-        float2 rs = make_float2(0.f, 0.f);
-        for (int sl = 0; sl < g.row_stat_slots; ++sl) {
-            const float2 t = *reinterpret_cast<const float2 *>(g.row_stats + ((int64_t)sl * g.M + m) * 2);
-            rs.x += t.x; rs.y += t.y;
-        }
-        const float mean = rs.x * g.ln_inv_k, rstd = rsqrtf(fmaxf(rs.y * g.ln_inv_k - mean * mean, 0.f) + g.ln_eps);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = rstd * (v[r] - mean * g.colsum[n + r]);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        if (g.bias) v[r] += g.bias[n + r];
-        if (g.rowvec) v[r] += g.rowvec[bidx * g.ld_rowvec + n + r];
-    }
-    if (g.geglu) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float gt = gate[r];
-            if (g.bias) gt += g.bias[n + 16 + r];
-            v[r] = v[r] * gelu_erf(gt);
-        }
-    }
-    if (g.act == 1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = silu(v[r]);
-    } else if (g.act == 2) {   // image post-process of pipe(output_type='pt'): (x/2 + 0.5).clamp(0,1)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r] * 0.5f + 0.5f, 0.f), 1.f);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] *= g.out_scale;
-    if (g.residual) {
-        const uint2 rr = *reinterpret_cast<const uint2 *>((const unsigned char *)g.residual + (m * g.ldr + on) * 2);
-        v[0] += T::to_f((unsigned short)(rr.x & 0xffff)); v[1] += T::to_f((unsigned short)(rr.x >> 16));
-        v[2] += T::to_f((unsigned short)(rr.y & 0xffff)); v[3] += T::to_f((unsigned short)(rr.y >> 16));
-    }
-    const bool to_t = g.out_t && on >= g.t_col0;
-    const uint2 pk = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
-    if (g.out && !(to_t && g.t_col0 > 0)) {
-        if (g.out_f32)
-            *reinterpret_cast<float4 *>((float *)g.out + m * g.ldc + on) = make_float4(v[0], v[1], v[2], v[3]);
-        else
-            *reinterpret_cast<uint2 *>((unsigned char *)g.out + (m * g.ldc + on) * 2) = pk;
-    }
-    if (to_t) {   // transposed copy out_t[b][n - t_col0][tok] (V operand of the attention kernel)
-        const int64_t b = m / g.rows_per_batch, tok = m - b * g.rows_per_batch;
-        unsigned short *o = (unsigned short *)g.out_t + b * g.t_batch_stride + tok;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[(on - g.t_col0 + r) * g.ldt] = T::from_f(v[r]);
-    }
-    if (!g.out_f32) {
-        v[0] = T::to_f((unsigned short)(pk.x & 0xffff)); v[1] = T::to_f((unsigned short)(pk.x >> 16));
-        v[2] = T::to_f((unsigned short)(pk.y & 0xffff)); v[3] = T::to_f((unsigned short)(pk.y >> 16));
-    }
-}
-
-// The epilogue of one wave's (16 MT) x (16 NTW) accumulator tile, shared by k_gemm (MT = 4) and k_gemm8.
-// Lane (fr = lane & 15, fc = lane >> 4) holds out[m = m_wave + 16 mt + fr][n = n_wave + 16 nt + 4 fc + r], r = 0..3.
-// All operand loads of the tile (bias, LN column sums once; row statistics, row-vector and residual of every m-tile) are issued
-// before the first one is consumed: the naive per-accumulator load -> use chain costs ~1 us of latency per m-tile on every launch.
-template <class T, int NTW, int MT, int NTHREADS>
-__device__ __forceinline__ void wave_epilogue(const GemmArgs &g, f32x4 (&acc)[NTW][MT], int64_t m_base, int64_t m_wave, int64_t n_wave, int lane,
-                                              unsigned char *smem)
-{
-    const int fr = lane & 15, fc = lane >> 4;
-    const int64_t n_lane = n_wave + fc * 4;
-    if (g.splits > 1) {   // partial sums of this k-slice: plain 16-byte stores into slab blockIdx.y
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int64_t m = m_wave + mt * 16 + fr;
-            if (m >= g.M) continue;
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) {
-                const int64_t n = n_lane + nt * 16;
-                if (n < g.N)
-                    *reinterpret_cast<float4 *>(g.ws + ((int64_t)blockIdx.y * g.M + m) * g.N + n) =
-                        make_float4(acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]);
-            }
-        }
-        return;
-    }
-    float4 bia[NTW], csm[NTW];
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-        const int64_t n = n_lane + nt * 16;
-        bia[nt] = (g.bias && n < g.N) ? *reinterpret_cast<const float4 *>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-        csm[nt] = (g.row_stats && n < g.N) ? *reinterpret_cast<const float4 *>(g.colsum + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    uint2 rs_all[MT][NTW];
-    float2 st_all[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int64_t m = m_wave + mt * 16 + fr;
-        const bool okm = m < g.M;
-        const int64_t mc = okm ? m : 0;
-        st_all[mt] = make_float2(0.f, 0.f);
-        if (g.row_stats)
-            for (int sl = 0; sl < g.row_stat_slots; ++sl) {       // the producer left one partial (sum, sum^2) per column slab
-                const float2 t = *reinterpret_cast<const float2 *>(g.row_stats + ((int64_t)sl * g.M + mc) * 2);
-                st_all[mt].x += t.x; st_all[mt].y += t.y;
-            }
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            const int64_t n = n_lane + nt * 16;
-            const bool okn = okm && n < g.N && !(g.geglu && (nt & 1));
-            const int64_t on = g.geglu ? (n_wave + nt * 16) / 2 + fc * 4 : n;
-            rs_all[mt][nt] = (g.residual && okn) ? *reinterpret_cast<const uint2 *>((const unsigned char *)g.residual + (mc * g.ldr + on) * 2) : make_uint2(0u, 0u);
-        }
-    }
-    // GroupNorm statistics of the output: per-lane channel sums over the wave's rows -> DPP sum over the 16 rows of a tile -> LDS
-    // atomics into [batch slot][group] of the workgroup -> ONE global float atomic per (batch, group) the tile touches.
-    const bool want_cs = g.out_group_stats != nullptr;
-    float *red = reinterpret_cast<float *>(smem);           // [GS_SLOTS][GS_MAXG][2]; the operand tiles in LDS are dead by now
-    const int64_t b0 = want_cs ? m_base / g.rows_per_batch : 0;
-    if (want_cs) {
-        __syncthreads();                                     // every wave has finished reading the last k-tile
-        for (int idx = threadIdx.x; idx < GS_SLOTS * GS_MAXG * 2; idx += NTHREADS) red[idx] = 0.f;
-        __syncthreads();
-    }
-    float cs[NTW][4], css[NTW][4];
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { cs[nt][r] = 0.f; css[nt][r] = 0.f; }
-    int64_t cs_b = -1;       // batch of the rows accumulated in cs / css (an m-tile of 16 rows never straddles batches: rows_per_batch % 16 == 0)
-    auto flush_cs = [&]() __attribute__((always_inline)) {
-        float *rb = red + (cs_b - b0) * (GS_MAXG * 2);
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            const int64_t n = n_lane + nt * 16;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float a = row16_sum(cs[nt][r]), b = row16_sum(css[nt][r]);
-                if (fr == 0 && n + r < g.N) {
-                    const int gi = (int)(n + r) / g.gn_cpg;
-                    __hip_atomic_fetch_add(rb + 2 * gi, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(rb + 2 * gi + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                cs[nt][r] = 0.f; css[nt][r] = 0.f;
-            }
-        }
-    };
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int64_t m = m_wave + mt * 16 + fr;
-        const int64_t m_tile = m_wave + mt * 16;                 // wave-uniform
-        if (m_tile >= g.M) break;
-        const bool okm = m < g.M;
-        if (want_cs) {
-            const int64_t b = m_tile / g.rows_per_batch;
-            if (cs_b >= 0 && b != cs_b) flush_cs();
-            cs_b = b;
-        }
-        const uint2 *rs = rs_all[mt];
-        float mean = 0.f, rstd = 1.f;
-        if (g.row_stats) {
-            mean = st_all[mt].x * g.ln_inv_k;
-            rstd = rsqrtf(fmaxf(st_all[mt].y * g.ln_inv_k - mean * mean, 0.f) + g.ln_eps);
-        }
-        float4 rv[NTW];
-        const int64_t bidx = (g.rowvec && okm) ? m / g.rows_per_batch : 0;
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            const int64_t n = n_lane + nt * 16;
-            rv[nt] = (g.rowvec && n < g.N) ? *reinterpret_cast<const float4 *>(g.rowvec + bidx * g.ld_rowvec + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        float rsum = 0.f, rsq = 0.f;
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            const int64_t n = n_lane + nt * 16;
-            if (n >= g.N) continue;
-            if (g.geglu && (nt & 1)) continue;
-            float a0 = acc[nt][mt][0], a1 = acc[nt][mt][1], a2 = acc[nt][mt][2], a3 = acc[nt][mt][3];
-            if (g.row_stats) {
-                a0 = rstd * (a0 - mean * csm[nt].x); a1 = rstd * (a1 - mean * csm[nt].y);
-                a2 = rstd * (a2 - mean * csm[nt].z); a3 = rstd * (a3 - mean * csm[nt].w);
-            }
-            float v[4] = {a0 + bia[nt].x + rv[nt].x, a1 + bia[nt].y + rv[nt].y, a2 + bia[nt].z + rv[nt].z, a3 + bia[nt].w + rv[nt].w};
-            int64_t on = n;
-            if (g.geglu) {   // weights are row-permuted in 16-blocks [x | gate]; partner tile = nt + 1 (NTW is even here)
-                constexpr int NP = NTW - 1;
-                const int np = nt + 1 < NTW ? nt + 1 : NP;
-                float g0 = acc[np][mt][0], g1 = acc[np][mt][1], g2 = acc[np][mt][2], g3 = acc[np][mt][3];
-                if (g.row_stats) {
-                    g0 = rstd * (g0 - mean * csm[np].x); g1 = rstd * (g1 - mean * csm[np].y);
-                    g2 = rstd * (g2 - mean * csm[np].z); g3 = rstd * (g3 - mean * csm[np].w);
-                }
-                v[0] *= gelu_erf(g0 + bia[np].x); v[1] *= gelu_erf(g1 + bia[np].y);
-                v[2] *= gelu_erf(g2 + bia[np].z); v[3] *= gelu_erf(g3 + bia[np].w);
-                on = (n_wave + nt * 16) / 2 + fc * 4;
-            }
-            if (g.act == 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = silu(v[r]);
-            } else if (g.act == 2) {   // image post-process of pipe(output_type='pt'): (x/2 + 0.5).clamp(0,1)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r] * 0.5f + 0.5f, 0.f), 1.f);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= g.out_scale;
-            if (g.residual) {
-                v[0] += T::to_f((unsigned short)(rs[nt].x & 0xffff)); v[1] += T::to_f((unsigned short)(rs[nt].x >> 16));
-                v[2] += T::to_f((unsigned short)(rs[nt].y & 0xffff)); v[3] += T::to_f((unsigned short)(rs[nt].y >> 16));
-            }
-            if (!okm) continue;
-            const bool to_t = g.out_t && on >= g.t_col0;     // fused QKV: columns >= t_col0 (V) go ONLY to the transposed buffer
-            const uint2 pk = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
-            if (g.out && !(to_t && g.t_col0 > 0)) {
-                if (g.out_f32)
-                    *reinterpret_cast<float4 *>((float *)g.out + m * g.ldc + on) = make_float4(v[0], v[1], v[2], v[3]);
-                else
-                    *reinterpret_cast<uint2 *>((unsigned char *)g.out + (m * g.ldc + on) * 2) = pk;
-            }
-            if (to_t) {   // transposed copy out_t[b][n - t_col0][tok] (V operand of the attention kernel)
-                const int64_t b = m / g.rows_per_batch, tok = m - b * g.rows_per_batch;
-                unsigned short *o = (unsigned short *)g.out_t + b * g.t_batch_stride + tok;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[(on - g.t_col0 + r) * g.ldt] = T::from_f(v[r]);
-            }
-            if (g.out_row_stats || want_cs) {     // statistics of the values as STORED (rounded to the activation type)
-                float t[4];
-                if (g.out_f32) { t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3]; }
-                else {
-                    t[0] = T::to_f((unsigned short)(pk.x & 0xffff)); t[1] = T::to_f((unsigned short)(pk.x >> 16));
-                    t[2] = T::to_f((unsigned short)(pk.y & 0xffff)); t[3] = T::to_f((unsigned short)(pk.y >> 16));
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    rsum += t[r]; rsq += t[r] * t[r];
-                    cs[nt][r] += t[r]; css[nt][r] += t[r] * t[r];
-                }
-            }
-        }
-        if (g.out_row_stats && n_wave < g.N) {   // the 4 lanes fc = 0..3 of a row hold disjoint column quads: combine, one plain store per (row, wave column)
-            rsum += __shfl_xor(rsum, 16, 64); rsq += __shfl_xor(rsq, 16, 64);
-            rsum += __shfl_xor(rsum, 32, 64); rsq += __shfl_xor(rsq, 32, 64);
-            const int64_t slot = n_wave / (16 * NTW);
-            if (fc == 0 && okm) *reinterpret_cast<float2 *>(g.out_row_stats + (slot * g.M + m) * 2) = make_float2(rsum, rsq);
-        }
-    }
-    if (want_cs) {
-        if (cs_b >= 0) flush_cs();
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < GS_SLOTS * GS_MAXG * 2; idx += NTHREADS) {
-            const float v = red[idx];
-            if (v != 0.f) {
-                const int sl = idx / (GS_MAXG * 2), rem = idx - sl * (GS_MAXG * 2);
-                unsafeAtomicAdd(g.out_group_stats + ((b0 + sl) * g.gn_groups) * 2 + rem, v);
-            }
-        }
-    }
-}
-
-// MODE: 0 linear, 1 conv generic (any Cin % 8 == 0), 2 conv fast (Cin % 64 == 0: one tap per k-tile)
-// NTW : n-tiles (of 16) per wave: 4 -> BN = 128, 5 -> BN = 160
-template <class T, int MODE, int NTW>
-__global__ __launch_bounds__(NT, 2) void k_gemm(const GemmArgs g)
-{
-    constexpr int BN = 32 * NTW;
-    constexpr int WCH = BN * 8 / NT;            // W chunks per lane per k-tile (4 | 5)
-    constexpr int STAGE = BM * 128 + BN * 128;  // bytes per LDS stage
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
-    const int nbn = (int)((g.N + BN - 1) / BN);
-    // workgroup b runs on XCD b % 8: give each XCD a contiguous run of logical tiles (bijective remap) so the
-    // workgroups that share an activation panel share an L2
-    const int64_t nwg = gridDim.x, xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
-    const int64_t bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
-    const int64_t mblk = bid / nbn, nblk = bid % nbn;
-    const int64_t m_base = mblk * BM, n_base = nblk * BN;
-    const int nk = (int)((g.K + BK - 1) / BK);
-    const int kt0 = blockIdx.y * g.tiles_per_split, kt1 = min(nk, kt0 + g.tiles_per_split);
-    if (kt0 >= kt1) return;
-
-    // ---- per-lane staging coordinates: 4 Act chunks + WCH W chunks per k-tile.  All per-lane address arithmetic is
-    // 32-bit element offsets from the (uniform) tensor bases; for the 3x3 fast path the offset of a chunk is
-    // pixel_offset(lane) + tap_offset(k-tile, uniform): one add and two compares per chunk.
-    int a_row[4], a_chunk[4];
-    int a_off[4];                 // MODE 0: m*lda + chunk*8 ; MODE 1/2: b*Hi*Wi*Cin (+ chunk*8 [+ (y0*Wi+x0)*Cin when !ups])
-    int a_y[4], a_x[4];           // MODE 1/2: oy*stride - pad, ox*stride - pad
-    bool a_ok[4];
-    int w_off[WCH];
-    bool w_ok[WCH];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int q = tid + NT * i;
-        a_row[i] = q >> 3; a_chunk[i] = q & 7;
-        const int64_t m = m_base + a_row[i];
-        a_ok[i] = m < g.M;
-        const int mm = a_ok[i] ? (int)m : 0;
-        if (MODE != 0) {
-            const int hw = g.Ho * g.Wo;
-            const int b = mm / hw;
-            const int rem = mm - b * hw;
-            const int oy = rem / g.Wo;
-            a_y[i] = oy * g.stride - g.pad; a_x[i] = (rem - oy * g.Wo) * g.stride - g.pad;
-            a_off[i] = b * g.Hi * g.Wi * g.Cin + (MODE == 2 ? a_chunk[i] * 8 : 0);
-            if (MODE == 2 && !g.ups) a_off[i] += (a_y[i] * g.Wi + a_x[i]) * g.Cin;
-        } else {
-            a_off[i] = mm * (int)g.lda + a_chunk[i] * 8;
-            a_y[i] = a_x[i] = 0;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < WCH; ++i) {
-        const int q = tid + NT * i;
-        const int64_t n = n_base + (q >> 3);
-        w_ok[i] = n < g.N;
-        w_off[i] = (w_ok[i] ? (int)n : 0) * (int)g.K + (q & 7) * 8;
-    }
-    const int Hin = g.ups ? g.Hi * 2 : g.Hi, Win = g.ups ? g.Wi * 2 : g.Wi;
-    const unsigned char *Ab = (const unsigned char *)g.A, *Wb = (const unsigned char *)g.W;
-    const int ktl = kt1 - 1;
-    // loader state (wave-uniform): tap / channel offset of the NEXT k-tile to load (tiles are loaded in order)
-    int ld_tap = 0, ld_ci = 0;
-    if (MODE == 2) { ld_tap = (kt0 * BK) / g.Cin; ld_ci = kt0 * BK - ld_tap * g.Cin; }
-
-    // Loads are UNCONDITIONAL (invalid lanes read offset 0 and are zeroed when the tile is written to LDS): no
-    // exec-mask branches around the global loads, so they stay in flight with counted s_waitcnt vmcnt(N).
-    auto load_tile = [&](int kt, uint4 *ra, uint4 *rw, unsigned &mask) __attribute__((always_inline)) {
-        const int kb = kt * BK;
-        int dy_u = 0, dx_u = 0, tap_off = 0;
-        if (MODE == 2) {
-            dy_u = ld_tap / 3; dx_u = ld_tap - dy_u * 3;
-            tap_off = g.ups ? ld_ci : (dy_u * g.Wi + dx_u) * g.Cin + ld_ci;
-            if (kt < ktl) { ld_ci += BK; if (ld_ci >= g.Cin) { ld_ci -= g.Cin; ++ld_tap; } }
-        }
-        unsigned mk = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            bool ok;
-            int off;
-            if (MODE == 2) {
-                int yi = a_y[i] + dy_u, xi = a_x[i] + dx_u;
-                ok = a_ok[i] && (unsigned)yi < (unsigned)Hin && (unsigned)xi < (unsigned)Win;
-                off = a_off[i] + tap_off;
-                if (g.ups) off += ((yi >> 1) * g.Wi + (xi >> 1)) * g.Cin;
-            } else if (MODE == 1) {
-                const int k0 = kb + a_chunk[i] * 8;
-                const int kc = k0 < (int)g.K ? k0 : 0;
-                const int tap = kc / g.Cin;
-                const int ci = kc - tap * g.Cin;
-                const int dy = tap / 3, dx = tap - dy * 3;
-                int yi = a_y[i] + dy, xi = a_x[i] + dx;
-                ok = a_ok[i] && k0 < (int)g.K && (unsigned)yi < (unsigned)Hin && (unsigned)xi < (unsigned)Win;
-                if (g.ups) { yi >>= 1; xi >>= 1; }
-                off = a_off[i] + (yi * g.Wi + xi) * g.Cin + ci;
-            } else {
-                ok = a_ok[i] && (kb + a_chunk[i] * 8) < (int)g.K;
-                off = a_off[i] + kb;
-            }
-            ra[i] = *reinterpret_cast<const uint4 *>(Ab + (size_t)(unsigned)((ok ? off : 0) * 2));
-            mk |= (ok ? 1u : 0u) << i;
-        }
-#pragma unroll
-        for (int i = 0; i < WCH; ++i) {
-            const int q = tid + NT * i;
-            const bool ok = w_ok[i] && (kb + (q & 7) * 8) < (int)g.K;
-            rw[i] = *reinterpret_cast<const uint4 *>(Wb + (size_t)(unsigned)((ok ? w_off[i] + kb : 0) * 2));
-            mk |= (ok ? 1u : 0u) << (8 + i);
-        }
-        mask = mk;
-    };
-    constexpr unsigned FULL = 0xFu | (((1u << WCH) - 1u) << 8);
-    int sa_off[4], sw_off[WCH];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) sa_off[i] = lds_off(a_row[i], a_chunk[i]);
-#pragma unroll
-    for (int i = 0; i < WCH; ++i) { const int q = tid + NT * i; sw_off[i] = BM * 128 + lds_off(q >> 3, q & 7); }
-    auto store_tile = [&](int buf, uint4 *ra, uint4 *rw, unsigned mask) __attribute__((always_inline)) {
-        unsigned char *sa = smem + buf * STAGE;
-        if (!__all(mask == FULL)) {   // border / tail tiles only: zero the lanes that read a clamped address
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {   // value-level masking (a ?: on the arrays would become a pointer select -> scratch)
-                const unsigned km = 0u - ((mask >> i) & 1u);
-                ra[i] = make_uint4(ra[i].x & km, ra[i].y & km, ra[i].z & km, ra[i].w & km);
-            }
-#pragma unroll
-            for (int i = 0; i < WCH; ++i) {
-                const unsigned km = 0u - ((mask >> (8 + i)) & 1u);
-                rw[i] = make_uint4(rw[i].x & km, rw[i].y & km, rw[i].z & km, rw[i].w & km);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4 *>(sa + sa_off[i]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < WCH; ++i) *reinterpret_cast<uint4 *>(sa + sw_off[i]) = rw[i];
-    };
-
-    f32x4 acc[NTW][4];   // [nt][mt]
-#pragma unroll
-    for (int a = 0; a < NTW; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int fr = lane & 15, fc = lane >> 4;
-    // fragment addresses: row = rowbase + 16 t + fr (rowbase % 16 == 0) => the swizzle term ((row >> 1) & 7) does not depend
-    // on t: address(t, ks) = base_ks + t * 2048 -- two VGPRs per operand, everything else is an immediate offset
-    const int swz = (fr >> 1) & 7;
-    const int fx0 = ((fc ^ swz) << 4), fx1 = (((fc + 4) ^ swz) << 4);
-    const int aw0 = BM * 128 + (wn * (16 * NTW) + fr) * 128, aa0 = (wm * 64 + fr) * 128;
-    auto compute = [&](int buf) __attribute__((always_inline)) {
-        const unsigned char *sb = smem + buf * STAGE;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int fx = ks ? fx1 : fx0;
-            uint4 fw[NTW], fa[4];
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) fw[t] = *reinterpret_cast<const uint4 *>(sb + aw0 + fx + t * 2048);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) fa[t] = *reinterpret_cast<const uint4 *>(sb + aa0 + fx + t * 2048);
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = T::mfma(fw[nt], fa[mt], acc[nt][mt]);
-        }
-    };
-
-    // Loads / LDS writes past the last tile are issued anyway (clamped to the last tile, written to the buffer nobody
-    // reads any more): straight-line loop body, no conditionally written register arrays.
-    uint4 raA[4], rwA[WCH], raB[4], rwB[WCH];
-    unsigned mkA = 0, mkB = 0;
-    load_tile(kt0, raA, rwA, mkA);
-    load_tile(min(kt0 + 1, ktl), raB, rwB, mkB);
-    store_tile(0, raA, rwA, mkA);
-    __syncthreads();
-    for (int kt = kt0; kt < kt1; kt += 2) {
-        load_tile(min(kt + 2, ktl), raA, rwA, mkA);
-        compute(0);
-        store_tile(1, raB, rwB, mkB);
-        __syncthreads();
-        if (kt + 1 >= kt1) break;
-        load_tile(min(kt + 3, ktl), raB, rwB, mkB);
-        compute(1);
-        store_tile(0, raA, rwA, mkA);
-        __syncthreads();
-    }
-
-    // ---- epilogue (shared with k_gemm8): wave tile 64 x (16 NTW)
-    wave_epilogue<T, NTW, 4, NT>(g, acc, m_base, m_base + wm * 64, n_base + wn * (16 * NTW), lane, smem);
-}
-
-// =====================================================================================================================
-// k_gemm8 -- same 128 x {128,160} x 64 tile, but 8 wave64 (4 x 2, each 32 x {64,80}), operands DMA'd straight into LDS with
-// global_load_lds_dwordx4 (no VGPR staging, no ds_write pass) through a 3-stage ring: tile t is multiplied while t+1 and
-// t+2 are in flight, ONE barrier per k-tile, counted s_waitcnt vmcnt(N) (never 0 in the main loop).  The LDS image is the
-// same XOR-swizzled layout as k_gemm: an LDS-DMA instruction writes wave-uniform-base + lane*16, so the swizzle is applied
-// to the per-lane SOURCE chunk (lane l of row-group g writes slot l&7 of row 8g + (l>>3) and therefore fetches chunk
-// (l&7) ^ ((row>>1)&7)).  Lanes that fall outside the tensor / in the conv padding fetch from a 16-byte zero page.
-// The DMA is issued from inline asm (M0 = LDS base) so hipcc's waitcnt pass does not drain it with vmcnt(0) before every
-// ds_read; ordering is by the explicit vmcnt + s_barrier below.  One workgroup per CU (96-108 KiB LDS), 2 waves per SIMD.
-__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-
-// uniform base + 32-bit lane offset form: no per-lane address arithmetic (M0 is not used by anything else in these kernels)
-__device__ __forceinline__ void glds16_s(const void *sbase, unsigned voff, unsigned lds_dst)
-{
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
-}
-
-// MODE 3 (k_gemm8 only): linear with K % 64 == 0 -- rows past M / N re-read the last valid row (their outputs are never stored),
-// so a k-tile's DMA is a uniform base + constant per-lane offset: no VALU at all in the issue path.
-// MT: m-tiles (of 16) per wave: workgroup tile (64 MT) x (32 NTW), waves 4 (M) x 2 (N), wave tile (16 MT) x (16 NTW).
-template <class T, int MODE, int NTW, int MT>
-__global__ __launch_bounds__(512, MT == 2 ? 2 : 1) void k_gemm8(const GemmArgs g)
-{
-    constexpr int BM = 64 * MT;
-    constexpr bool CONVF = MODE == 2 || MODE == 4, UPS = MODE == 4;   // MODE 4 = MODE 2 + fused nearest-x2 upsample
-    constexpr int BN = 32 * NTW;
-    constexpr int STAGE = BM * 128 + BN * 128;
-    constexpr int NS = 3;
-    constexpr int AG = BM / 8, WG = BN / 8;           // 8-row groups (one LDS-DMA instruction each)
-    constexpr int AI = AG / 8, WI = (WG + 7) / 8;     // instructions per wave per tile: A MT, W 2|3
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 1, wn = wid & 1;
-    const int nbn = (int)((g.N + BN - 1) / BN);
-    const int64_t nwg = gridDim.x, xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
-    const int64_t bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
-    const int64_t mblk = bid / nbn, nblk = bid % nbn;
-    const int64_t m_base = mblk * BM, n_base = nblk * BN;
-    const int nk_all = (int)((g.K + BK - 1) / BK);
-    const int kt0 = blockIdx.y * g.tiles_per_split;                      // split-K: this workgroup's k-tiles [kt0, kt0 + nk)
-    const int nk = min(nk_all, kt0 + g.tiles_per_split) - kt0;
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
-
-    // ---- per-lane DMA coordinates
-    const int lr = lane >> 3, ls = lane & 7;
-    int a_off[AI], a_y[AI], a_x[AI], a_ck[AI];
-    bool a_ok[AI];
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-        const int row = (wid + 8 * i) * 8 + lr;
-        a_ck[i] = ls ^ ((row >> 1) & 7);
-        const int64_t m = m_base + row;
-        a_ok[i] = m < g.M;
-        const int mm = a_ok[i] ? (int)m : 0;
-        if (MODE == 1 || CONVF) {
-            const int hw = g.Ho * g.Wo;
-            const int b = mm / hw;
-            const int rem = mm - b * hw;
-            const int oy = rem / g.Wo;
-            a_y[i] = oy * g.stride - g.pad; a_x[i] = (rem - oy * g.Wo) * g.stride - g.pad;
-            a_off[i] = b * g.Hi * g.Wi * g.Cin + (CONVF ? a_ck[i] * 8 : 0);
-            if (MODE == 2) a_off[i] += (a_y[i] * g.Wi + a_x[i]) * g.Cin;
-        } else {
-            a_off[i] = mm * (int)g.lda + a_ck[i] * 8;
-            if (MODE == 3) a_off[i] = (int)(m < g.M ? m : g.M - 1) * (int)g.lda + a_ck[i] * 8;
-            a_y[i] = a_x[i] = 0;
-        }
-    }
-    int w_off[WI], w_ck[WI];
-    bool w_ok[WI];
-#pragma unroll
-    for (int i = 0; i < WI; ++i) {
-        const int grp = wid + 8 * i;
-        const int row = grp * 8 + lr;
-        w_ck[i] = ls ^ ((row >> 1) & 7);
-        const int64_t n = n_base + row;
-        w_ok[i] = grp < WG && n < g.N;
-        w_off[i] = (w_ok[i] ? (int)n : 0) * (int)g.K + w_ck[i] * 8;
-        if (MODE == 3) w_off[i] = (int)(n < g.N ? n : g.N - 1) * (int)g.K + w_ck[i] * 8;
-    }
-    const bool ups = CONVF ? UPS : (g.ups != 0);
-    const int Hin = ups ? g.Hi * 2 : g.Hi, Win = ups ? g.Wi * 2 : g.Wi;
-    // MODE 2: per-lane source pointer of the centre-less tap origin and a 9-bit mask of the taps that fall inside the image
-    const unsigned char *a_ptr[AI];
-    unsigned a_vm[AI];
-    if (MODE == 2) {
-#pragma unroll
-        for (int i = 0; i < AI; ++i) {
-            a_ptr[i] = (const unsigned char *)g.A + (int64_t)a_off[i] * 2;
-            unsigned vm = 0;
-#pragma unroll
-            for (int tp = 0; tp < 9; ++tp) {
-                const int yi = a_y[i] + tp / 3, xi = a_x[i] + tp % 3;
-                if (a_ok[i] && (unsigned)yi < (unsigned)Hin && (unsigned)xi < (unsigned)Win) vm |= 1u << tp;
-            }
-            a_vm[i] = vm;
-        }
-    }
-    const unsigned char *Ab = (const unsigned char *)g.A, *Wb = (const unsigned char *)g.W;
-    const unsigned char *Zp = (const unsigned char *)g.zeros;
-    int ld_tap = 0, ld_ci = 0;
-    if (CONVF && kt0 > 0) { ld_tap = (kt0 * BK) / g.Cin; ld_ci = kt0 * BK - ld_tap * g.Cin; }
-
-    // DMA of one k-tile, split into per-instruction pieces so that the main loop can place them between MFMAs.
-    struct TileSrc { int kb, dy_u, dx_u, tap_off, tap; unsigned sbase; };
-    auto issue_begin = [&](int kt, int stage) __attribute__((always_inline)) -> TileSrc {
-        TileSrc t;
-        t.kb = (kt0 + kt) * BK; t.dy_u = 0; t.dx_u = 0; t.tap_off = 0; t.tap = 0;
-        if (CONVF) {
-            t.tap = ld_tap;
-            t.dy_u = ld_tap / 3; t.dx_u = ld_tap - t.dy_u * 3;
-            t.tap_off = UPS ? ld_ci : (t.dy_u * g.Wi + t.dx_u) * g.Cin + ld_ci;
-            ld_ci += BK; if (ld_ci >= g.Cin) { ld_ci -= g.Cin; ++ld_tap; }
-        }
-        t.sbase = lds0 + stage * STAGE;
-        return t;
-    };
-    auto issue_a = [&](const TileSrc &t, int i) __attribute__((always_inline)) {
-        const unsigned dst = t.sbase + (unsigned)((wid + 8 * i) * 1024);
-        if (MODE == 3) { glds16_s(Ab + (size_t)t.kb * 2, (unsigned)(a_off[i] * 2), dst); return; }
-        if (MODE == 2) {     // tap validity from the precomputed mask, address = lane pointer + uniform tap offset
-            const bool okm = (a_vm[i] >> t.tap) & 1u;
-            glds16(okm ? a_ptr[i] + (int64_t)t.tap_off * 2 : Zp, dst);
-            return;
-        }
-        bool ok;
-        int off;
-        if (MODE == 4) {
-            int yi = a_y[i] + t.dy_u, xi = a_x[i] + t.dx_u;
-            ok = a_ok[i] && (unsigned)yi < (unsigned)Hin && (unsigned)xi < (unsigned)Win;
-            off = a_off[i] + t.tap_off;
-            off += ((yi >> 1) * g.Wi + (xi >> 1)) * g.Cin;
-        } else if (MODE == 1) {
-            const int k0 = t.kb + a_ck[i] * 8;
-            const int kc = k0 < (int)g.K ? k0 : 0;
-            const int tap = kc / g.Cin;
-            const int ci = kc - tap * g.Cin;
-            const int dy = tap / 3, dx = tap - dy * 3;
-            int yi = a_y[i] + dy, xi = a_x[i] + dx;
-            ok = a_ok[i] && k0 < (int)g.K && (unsigned)yi < (unsigned)Hin && (unsigned)xi < (unsigned)Win;
-            if (g.ups) { yi >>= 1; xi >>= 1; }
-            off = a_off[i] + (yi * g.Wi + xi) * g.Cin + ci;
-        } else {
-            ok = a_ok[i] && (t.kb + a_ck[i] * 8) < (int)g.K;
-            off = a_off[i] + t.kb;
-        }
-        const unsigned char *src = ok ? Ab + (size_t)(unsigned)(off * 2) : Zp;
-        glds16(src, dst);
-    };
-    // has_w(i): W group i of this wave exists (the last group only for the waves with wid + 8 (WI-1) < WG: "w3" waves)
-    auto issue_w = [&](const TileSrc &t, int i, bool has) __attribute__((always_inline)) {
-        if (has) {
-            const unsigned dst = t.sbase + (unsigned)(BM * 128 + (wid + 8 * i) * 1024);
-            if (MODE == 3 || CONVF) { glds16_s(Wb + (size_t)t.kb * 2, (unsigned)(w_off[i] * 2), dst); return; }   // K % 64 == 0: rows past N re-read row 0
-            const bool ok = w_ok[i] && (t.kb + w_ck[i] * 8) < (int)g.K;
-            const unsigned char *src = ok ? Wb + (size_t)(unsigned)((w_off[i] + t.kb) * 2) : Zp;
-            glds16(src, dst);
-        }
-    };
-    auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
-        const TileSrc t = issue_begin(kt, stage);
-#pragma unroll
-        for (int i = 0; i < AI; ++i) issue_a(t, i);
-#pragma unroll
-        for (int i = 0; i < WI; ++i) issue_w(t, i, wid + 8 * i < WG);
-    };
-
-    f32x4 acc[NTW][MT];
-#pragma unroll
-    for (int a = 0; a < NTW; ++a)
-#pragma unroll
-        for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int fr = lane & 15, fc = lane >> 4;
-    const int swz = (fr >> 1) & 7;
-    const int fx0 = ((fc ^ swz) << 4), fx1 = (((fc + 4) ^ swz) << 4);
-    const int aw0 = BM * 128 + (wn * (16 * NTW) + fr) * 128, aa0 = (wm * (16 * MT) + fr) * 128;
-    struct Frag { uint4 w[NTW], a[MT]; };
-    auto load_frag = [&](Frag &f, int stage, int ks) __attribute__((always_inline)) {
-        const unsigned char *sb = smem + stage * STAGE;
-        const int fx = ks ? fx1 : fx0;
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) f.w[t] = *reinterpret_cast<const uint4 *>(sb + aw0 + fx + t * 2048);
-#pragma unroll
-        for (int t = 0; t < MT; ++t) f.a[t] = *reinterpret_cast<const uint4 *>(sb + aa0 + fx + t * 2048);
-    };
-    // one MFMA block (NTW x MT MFMAs on the fragments of one k-half).  After the FIRST MFMA the fragment reads of the next
-    // block are issued (the s_waitcnt for this block's operands then never waits behind fresh reads); with DMA = true the LDS-DMA
-    // instructions of a later k-tile (and their address arithmetic) are spread between the remaining MFMAs, where a few VALU /
-    // SALU instructions per MFMA issue for free.
-    constexpr int NMM = NTW * MT, NPC = AI + WI;
-    auto block = [&](const Frag &f, Frag &fn, int st_next, int ks_next, bool load_next, const TileSrc &t, auto dma_tag, auto w3_tag) __attribute__((always_inline)) {
-        constexpr bool DMA = decltype(dma_tag)::value, W3 = decltype(w3_tag)::value;
-        static_for<0, NMM>([&](auto m_) __attribute__((always_inline)) {
-            constexpr int m = decltype(m_)::value, nt = m / MT, mt = m % MT;
-            acc[nt][mt] = T::mfma(f.w[nt], f.a[mt], acc[nt][mt]);
-            if constexpr (m == 0) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (load_next) load_frag(fn, st_next, ks_next);
-                __builtin_amdgcn_sched_barrier(0);
-            } else if constexpr (DMA && m >= 2) {
-                // pieces p = 0 .. NPC-1 after MFMA index 2 + p * (NMM - 3) / NPC
-                static_for<0, NPC>([&](auto p_) __attribute__((always_inline)) {
-                    constexpr int pp = decltype(p_)::value;
-                    if constexpr (m == 2 + (pp * (NMM - 3)) / NPC) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        if constexpr (pp < AI) issue_a(t, pp); else issue_w(t, pp - AI, (pp - AI) < WI - 1 || W3 || WG % 8 == 0);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                });
-            }
-        });
-    };
-
-    // Software pipeline over k-tiles (3 LDS stages, LDS-DMA two tiles ahead; fragment registers double-buffered per k half):
-    //   [ MFMAs on F0 = (kt, half 0) | read F1 <- (kt, half 1) ]  wait(tile kt+1 landed) + barrier
-    //   [ MFMAs on F1 | read F0 <- (kt+1, half 0) | DMA tile kt+3 -> stage of kt ]
-    // ONE barrier per k-tile, sitting between two MFMA blocks whose operands are already in registers; every ds_read has a full
-    // MFMA block (16-20 x 16 clk) to land.  Counted vmcnt: tile kt+2 stays in flight across the barrier.
-    const bool w3 = (wid + 8 * (WI - 1)) < WG;     // this wave owns the last W group (instructions per tile are wave-uniform)
-    Frag f0, f1;
-    const TileSrc tnone = {0, 0, 0, 0, 0, 0u};
-    // The whole k loop is instantiated twice (W3 = this wave issues WI / WI-1 W loads per tile) so that the counted waits and the
-    // DMA pieces carry no run-time branches; the steady state (tiles kt+1 .. kt+3 exist) is a branch-free loop, the last three
-    // k-tiles run through the generic tail.
-    auto run = [&](auto w3_tag) __attribute__((always_inline)) {
-        constexpr bool W3 = decltype(w3_tag)::value;
-        constexpr int GRPW = AI + ((W3 || WG % 8 == 0) ? WI : WI - 1);        // LDS-DMA instructions of this wave per k-tile
-        static_assert(2 * GRPW < 64, "vmcnt range");
-        auto wait_tiles = [&](auto n_) __attribute__((always_inline)) {        // n tiles may stay in flight
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(n_)::value * GRPW) : "memory");
-        };
-        issue(0, 0);
-        if (nk > 1) issue(1, 1);
-        if (nk > 2) issue(2, 2);
-        if (nk > 2) wait_tiles(std::integral_constant<int, 2>{}); else if (nk > 1) wait_tiles(std::integral_constant<int, 1>{}); else wait_tiles(std::integral_constant<int, 0>{});
-        __builtin_amdgcn_s_barrier();
-        load_frag(f0, 0, 0);
-        int st = 0, kt = 0;                   // st = stage of tile kt
-        for (; kt + 3 < nk; ++kt) {
-            const int st1 = st + 1 == NS ? 0 : st + 1;
-            block(f0, f1, st, 1, true, tnone, std::false_type{}, w3_tag);
-            wait_tiles(std::integral_constant<int, 1>{});
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of stage st are complete
-            __builtin_amdgcn_s_barrier();    // tile kt+1 is in LDS for every wave; every wave finished reading stage st
-            const TileSrc t = issue_begin(kt + 3, st);
-            block(f1, f0, st1, 0, true, t, std::true_type{}, w3_tag);
-            st = st1;
-        }
-        for (; kt < nk; ++kt) {
-            const int st1 = st + 1 == NS ? 0 : st + 1;
-            block(f0, f1, st, 1, true, tnone, std::false_type{}, w3_tag);
-            if (kt + 1 < nk) {
-                if (kt + 2 < nk) wait_tiles(std::integral_constant<int, 1>{}); else wait_tiles(std::integral_constant<int, 0>{});
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                block(f1, f0, st1, 0, true, tnone, std::false_type{}, w3_tag);
-            } else {
-                block(f1, f0, st1, 0, false, tnone, std::false_type{}, w3_tag);
-            }
-            st = st1;
-        }
-    };
-    if (w3) run(std::true_type{}); else run(std::false_type{});
-
-    // ---- epilogue (shared with k_gemm): wave tile (16 MT) x (16 NTW)
-    wave_epilogue<T, NTW, MT, 512>(g, acc, m_base, m_base + wm * (16 * MT), n_base + wn * (16 * NTW), lane, smem);
-}
-
-// epilogue of a split-K problem: ws fp32 [splits][M][N] -> out (same epilogue as the fused path; no GEGLU).
-// Workgroup = 64 column quads (256 columns) x 4 row lanes over 16 rows of ONE batch, 4 rows per thread with independent loads:
-// coalesced 16-byte slab reads; row statistics by a wave sum (slot = blockIdx.x), group statistics via LDS.
-template <class T>
-__global__ __launch_bounds__(256) void k_splitk_epilogue(const GemmArgs g)
-{
-    __shared__ float red[GS_MAXG * 2];
-    constexpr int RPB = 16;
-    const int64_t nq = g.N / 4;
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int64_t cq = (int64_t)blockIdx.x * 64 + cl;
-    const int64_t m0 = (int64_t)blockIdx.y * RPB;
-    const bool okc = cq < nq;
-    const int64_t n = (okc ? cq : 0) * 4;
-    if (g.out_group_stats) {
-        if (threadIdx.x < GS_MAXG * 2) red[threadIdx.x] = 0.f;
-        __syncthreads();
-    }
-    float v[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { v[i][0] = 0.f; v[i][1] = 0.f; v[i][2] = 0.f; v[i][3] = 0.f; }
-    if (okc) {
-        for (int z = 0; z < g.splits; ++z) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {           // 4 independent 16-byte loads in flight per slab
-                const int64_t m = m0 + rl + 4 * i;
-                if (m < g.M) {
-                    const float4 a = *reinterpret_cast<const float4 *>(g.ws + ((int64_t)z * g.M + m) * g.N + n);
-                    v[i][0] += a.x; v[i][1] += a.y; v[i][2] += a.z; v[i][3] += a.w;
-                }
-            }
-        }
-    }
-    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t m = m0 + rl + 4 * i;          // rl is wave-uniform: every lane of a wave works on the same rows
-        if (m >= g.M) break;
-        if (okc) {
-            float gate[4] = {0.f, 0.f, 0.f, 0.f};
-            epilogue_store<T>(g, m, n, n, v[i], gate);
-        }
-        if (g.out_row_stats) {
-            const float a = wave_sum_f(okc ? (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]) : 0.f);
-            const float b = wave_sum_f(okc ? (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]) : 0.f);
-            if (cl == 0) *reinterpret_cast<float2 *>(g.out_row_stats + ((int64_t)blockIdx.x * g.M + m) * 2) = make_float2(a, b);
-        }
-        if (okc) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { cs[2 * r] += v[i][r]; cs[2 * r + 1] += v[i][r] * v[i][r]; }
-        }
-    }
-    if (g.out_group_stats) {
-        if (okc) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gi = (int)(n + r) / g.gn_cpg;
-                __hip_atomic_fetch_add(red + 2 * gi, cs[2 * r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(red + 2 * gi + 1, cs[2 * r + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < GS_MAXG * 2) {
-            const float t = red[threadIdx.x];
-            if (t != 0.f) unsafeAtomicAdd(g.out_group_stats + (m0 / g.rows_per_batch) * g.gn_groups * 2 + threadIdx.x, t);
-        }
-    }
-}
 
 int choose_splits(int64_t blocks, int nk)
 {
@@ -878,52 +15,6 @@ int choose_splits(int64_t blocks, int nk)
     if (s > nk / 8) s = nk / 8;
     if (s > 16) s = 16;
     return s < 2 ? 1 : s;
-}
-
-template <class T, int MODE, int NTW>
-void launch(const GemmArgs &g, dim3 grid, hipStream_t s)
-{
-    constexpr size_t lds = 2 * (BM * 128 + 32 * NTW * 128);
-    static gc::AttrOnce once;      // per device, thread-safe (no function-local bool latch)
-    gc::ensure_dynamic_lds(once, (const void *)k_gemm<T, MODE, NTW>, (int)lds);
-    hipLaunchKernelGGL((k_gemm<T, MODE, NTW>), grid, dim3(NT), lds, s, g);
-}
-
-template <class T, int MODE, int NTW, int MT>
-void launch8(const GemmArgs &g, dim3 grid, hipStream_t s)
-{
-    constexpr size_t lds = 3 * (64 * MT * 128 + 32 * NTW * 128);
-    static_assert(lds <= 160 * 1024, "LDS ring");
-    static gc::AttrOnce once;
-    gc::ensure_dynamic_lds(once, (const void *)k_gemm8<T, MODE, NTW, MT>, (int)lds);
-    hipLaunchKernelGGL((k_gemm8<T, MODE, NTW, MT>), grid, dim3(512), lds, s, g);
-}
-
-template <class T, int NTW, int MT>
-void dispatch8m(const GemmArgs &g, int mode, dim3 grid, hipStream_t s)
-{
-    if (mode == 0) { if (g.K % 64 == 0) launch8<T, 3, NTW, MT>(g, grid, s); else launch8<T, 0, NTW, MT>(g, grid, s); }
-    else if (mode == 1) launch8<T, 1, NTW, MT>(g, grid, s);
-    else if (g.ups) launch8<T, 4, NTW, MT>(g, grid, s); else launch8<T, 2, NTW, MT>(g, grid, s);
-}
-template <class T>
-void dispatch8(const GemmArgs &g, int mode, int ntw, int mt, dim3 grid, hipStream_t s)
-{
-    if (ntw == 5) {
-        if (mt == 4) dispatch8m<T, 5, 4>(g, mode, grid, s); else if (mt == 3) dispatch8m<T, 5, 3>(g, mode, grid, s); else dispatch8m<T, 5, 2>(g, mode, grid, s);
-    } else {
-        if (mt == 4) dispatch8m<T, 4, 4>(g, mode, grid, s); else if (mt == 3) dispatch8m<T, 4, 3>(g, mode, grid, s); else dispatch8m<T, 4, 2>(g, mode, grid, s);
-    }
-}
-
-template <class T>
-void dispatch(const GemmArgs &g, int mode, int ntw, dim3 grid, hipStream_t s)
-{
-    if (ntw == 5) {
-        if (mode == 0) launch<T, 0, 5>(g, grid, s); else if (mode == 1) launch<T, 1, 5>(g, grid, s); else launch<T, 2, 5>(g, grid, s);
-    } else {
-        if (mode == 0) launch<T, 0, 4>(g, grid, s); else if (mode == 1) launch<T, 1, 4>(g, grid, s); else launch<T, 2, 4>(g, grid, s);
-    }
 }
 
 // 8-wave kernel: pick the m-tiles per wave (workgroup rows = 64 MT); 0 = use the 4-wave kernel.  One workgroup per CU, so the
@@ -959,7 +50,7 @@ void plan(const gc_gemm_desc *d, int *ntw, int *splits, int *tps)
 
 extern "C" size_t gc_dn_gemm_workspace_bytes(const gc_gemm_desc *d)
 {
-    if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+    if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->fp8) return 0;
     int ntw, splits, tps;
     plan(d, &ntw, &splits, &tps);
     return splits > 1 ? sizeof(float) * (size_t)splits * (size_t)d->M * (size_t)d->N : 0;
@@ -1013,6 +104,7 @@ int select(const gc_gemm_desc *d, Sel *o)
 extern "C" int gc_dn_gemm_row_stat_slots(const gc_gemm_desc *d)
 {
     if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+    if (d->fp8) { const int ntw = (d->N % 160 == 0 && d->N % 128 != 0) ? 5 : 4; return (int)((d->N + 16 * ntw - 1) / (16 * ntw)); }
     Sel sel;
     select(d, &sel);
     return sel.splits > 1 ? (int)((d->N / 4 + 63) / 64) : (int)((d->N + 16 * sel.ntw - 1) / (16 * sel.ntw));
@@ -1036,6 +128,8 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
     g.colsum = d->ln_colsum; g.ln_eps = d->ln_eps; g.ln_inv_k = 1.f / (float)d->K;
     g.out_row_stats = d->out_row_stats; g.out_group_stats = d->out_group_stats; g.gn_groups = d->gn_groups;
     g.gn_cpg = d->gn_groups > 0 ? (int)(d->N / d->gn_groups) : 1;
+    g.w_scale = (const unsigned char *)d->w_scale; g.a_scale = d->a_scale;
+    g.dbg = (d->kernel_variant >> 8) & 0xff;
     GC_REQUIRE((d->ln_row_stats == nullptr) == (d->ln_colsum == nullptr), "ln_row_stats and ln_colsum must be given together");
     GC_REQUIRE(!d->ln_row_stats || d->mode == 0, "LayerNorm folding applies to linear GEMMs");
     GC_REQUIRE(!(d->out_row_stats || d->out_group_stats) || (!d->geglu && !d->out_t && d->out), "output statistics need a plain (non-GEGLU, non-transposed) output");
@@ -1053,24 +147,39 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
     GC_REQUIRE(force_mt == 0 || (force_mt >= 2 && force_mt <= 4), "kernel_variant: MT must be 0, 2, 3 or 4");
     Sel sel;
     select(d, &sel);
+    if (fuse_of(g) && sel.mt8) {     // the 8-wave kernel carries the fused epilogue for conv (generic / fast) and K % 64 == 0 linears only
+        const bool upsampled = d->mode == 1 && d->upsample, ragged = d->mode == 0 && d->K % 64 != 0;
+        GC_REQUIRE(!upsampled && !ragged, "row / group statistics and LayerNorm folding: not with upsample-fused convs or K % 64 != 0 linears");
+    }
     hipStream_t s = gc::S(stream);
-    g.splits = sel.splits; g.tiles_per_split = sel.tps; g.ws = (float *)d->workspace;
     g.zeros = d->zeros;
+    if (d->fp8) {      // OCP e4m3 operands on the block-scaled MFMA (k_gemm8q): A / W are bytes, K counts fp8 elements
+        GC_REQUIRE(d->zeros && d->w_scale, "fp8: zeros page and per-row weight scales are required");
+        GC_REQUIRE(d->K % 128 == 0 && !d->geglu && !d->out_t, "fp8: K % 128 == 0, no GEGLU / transposed output");
+        GC_REQUIRE(d->mode == 0 || (d->Cin % 128 == 0 && !d->upsample), "fp8 conv: Cin (padded) % 128 == 0, no fused upsample");
+        GC_REQUIRE(d->mode == 1 || d->lda % 16 == 0, "fp8 linear: lda % 16 == 0");
+        GC_REQUIRE((int64_t)d->N * d->K < ((int64_t)1 << 31) && (d->mode == 1 ? (int64_t)d->B * d->Hi * d->Wi * d->Cin : d->M * d->lda) < ((int64_t)1 << 31), "fp8: 32-bit offsets");
+        const int ntw = (d->N % 160 == 0 && d->N % 128 != 0) ? 5 : 4;
+        int mt = force_mt ? force_mt : choose_mt(d->M, d->N, ntw, true);
+        if (ntw == 5 && mt == 4) mt = 3;
+        g.splits = 1; g.tiles_per_split = (int)(d->K / 128); g.ws = nullptr;
+        const int64_t nbn_q = (d->N + 32 * ntw - 1) / (32 * ntw), nbm_q = (d->M + 64 * mt - 1) / (64 * mt);
+        const dim3 gq((unsigned)(nbm_q * nbn_q), 1u);
+        dn_gemm_launch_fp8(g, d->dtype, d->mode == 1 ? 2 : 3, ntw, mt, gq, s);
+        return gc::check_launch("gc_dn_gemm(fp8)");
+    }
+    g.splits = sel.splits; g.tiles_per_split = sel.tps; g.ws = (float *)d->workspace;
     const int bn = 32 * sel.ntw;
     const int64_t nbn = (d->N + bn - 1) / bn;
     if (sel.mt8) {
         const int64_t nbm8 = (d->M + 64 * sel.mt8 - 1) / (64 * sel.mt8);
         const dim3 grid8((unsigned)(nbm8 * nbn), (unsigned)sel.splits);
-        if (d->dtype == DT_BF16) dispatch8<BF16>(g, sel.mode, sel.ntw, sel.mt8, grid8, s); else dispatch8<F16>(g, sel.mode, sel.ntw, sel.mt8, grid8, s);
+        if (fuse_of(g)) dn_gemm_launch_fuse(g, d->dtype, sel.mode, sel.ntw, sel.mt8, grid8, s); else dn_gemm_launch_plain(g, d->dtype, sel.mode, sel.ntw, sel.mt8, grid8, s);
     } else {
         const int64_t nbm = (d->M + BM - 1) / BM;
         const dim3 grid((unsigned)(nbm * nbn), (unsigned)sel.splits);
-        if (d->dtype == DT_BF16) dispatch<BF16>(g, sel.mode, sel.ntw, grid, s); else dispatch<F16>(g, sel.mode, sel.ntw, grid, s);
+        if (fuse_of(g)) dn_gemm_launch_fuse(g, d->dtype, sel.mode, sel.ntw, 0, grid, s); else dn_gemm_launch_plain(g, d->dtype, sel.mode, sel.ntw, 0, grid, s);
     }
-    if (sel.splits > 1) {
-        const dim3 eg((unsigned)((d->N / 4 + 63) / 64), (unsigned)((d->M + 15) / 16));
-        if (d->dtype == DT_BF16) hipLaunchKernelGGL((k_splitk_epilogue<BF16>), eg, dim3(256), 0, s, g);
-        else hipLaunchKernelGGL((k_splitk_epilogue<F16>), eg, dim3(256), 0, s, g);
-    }
+    if (sel.splits > 1) dn_gemm_launch_splitk_epilogue(g, d->dtype, s);
     return gc::check_launch("gc_dn_gemm");
 }

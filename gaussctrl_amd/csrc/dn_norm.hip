@@ -210,6 +210,54 @@ __global__ __launch_bounds__(256) void k_gn_apply_stats(const unsigned short *__
     }
 }
 
+// The same GroupNorm(+SiLU) with an OCP fp8 (e4m3) OUTPUT for the fp8 convolution path (k_gemm8q): y8[b][p][Cp] bytes, Cp = C rounded
+// up to a multiple of 128 (one 3x3 tap per 128-byte k-tile), padding channels written as zero; stored value = y * qscale (a power of
+// two: the tensor-wide E8M0 activation scale), saturated to +-448.
+template <class T>
+__global__ __launch_bounds__(256) void k_gn_apply_stats_fp8(const unsigned short *__restrict__ x, unsigned char *__restrict__ y8, unsigned HW,
+                                                            unsigned C, unsigned Cp, int G, const float *__restrict__ stats,
+                                                            const float *__restrict__ gamma, const float *__restrict__ beta, float eps, int act,
+                                                            float qscale)
+{
+    extern __shared__ float coef[];          // [C][2]
+    const unsigned b = blockIdx.y, tid = threadIdx.x, cpg = C / G;
+    const float *sb = stats + (size_t)b * G * 2;
+    const float n = (float)HW * (float)cpg;
+    for (unsigned c = tid; c < C; c += 256) {
+        const unsigned g = c / cpg;
+        const float mu = sb[2 * g] / n;
+        const float rstd = rsqrtf(fmaxf(sb[2 * g + 1] / n - mu * mu, 0.f) + eps);
+        const float a = rstd * gamma[c];
+        coef[2 * c] = a; coef[2 * c + 1] = beta[c] - mu * a;
+    }
+    __syncthreads();
+    const unsigned nch = C / 8, nchp = Cp / 8, per_img = HW * nchp;
+    const unsigned short *xb = x + (size_t)b * HW * C;
+    unsigned char *yb = y8 + (size_t)b * HW * Cp;
+    for (unsigned q = blockIdx.x * 256u + tid; q < per_img; q += gridDim.x * 256u) {
+        const unsigned p = q / nchp, ch = q - p * nchp;
+        uint2 o = make_uint2(0u, 0u);
+        if (ch < nch) {
+            const unsigned c0 = ch * 8;
+            float f[8];
+            unpack8<T>(*reinterpret_cast<const uint4 *>(xb + (size_t)p * C + c0), f);
+            const float4 *cf = reinterpret_cast<const float4 *>(coef + 2 * c0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 ab = cf[j];
+                float v0 = f[2 * j] * ab.x + ab.y, v1 = f[2 * j + 1] * ab.z + ab.w;
+                if (act) { v0 = silu(v0); v1 = silu(v1); }
+                f[2 * j] = fminf(fmaxf(v0 * qscale, -448.f), 448.f); f[2 * j + 1] = fminf(fmaxf(v1 * qscale, -448.f), 448.f);
+            }
+            int w0 = 0, w1 = 0;
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
+            o = make_uint2((unsigned)w0, (unsigned)w1);
+        }
+        *reinterpret_cast<uint2 *>(yb + (size_t)q * 8) = o;
+    }
+}
+
 // out[b][p][C1+C2] = [a | b (+ c)] with the per-(batch, group) sums of the OUTPUT accumulated on the way (the input of the next
 // GroupNorm): slab structure of k_gn_partial -- a thread owns one 16-byte channel chunk and walks the pixels of its slab, partial
 // sums are combined over the block's pixel lanes in LDS, one atomic pair per channel per block.
@@ -248,7 +296,7 @@ __global__ __launch_bounds__(256) void k_concat_add_stats(const unsigned short *
                     unpack8<T>(v, f);        // statistics of the values as stored
                 }
             }
-            *reinterpret_cast<uint4 *>(out + m * C + c0) = v;
+            if (out) *reinterpret_cast<uint4 *>(out + m * C + c0) = v;
 #pragma unroll
             for (int j = 0; j < 8; ++j) { s1[j] += f[j]; s2[j] += f[j] * f[j]; }
         }
@@ -559,6 +607,27 @@ int gc_dn_groupnorm_apply(int dtype, const void *x, void *y, int64_t B, int64_t 
     return gc::check_launch("gc_dn_groupnorm_apply");
 }
 
+int gc_dn_groupnorm_apply_fp8(int dtype, const void *x, void *y8, int64_t B, int64_t HW, int C, int C_padded, int G, const float *gamma,
+                              const float *beta, float eps, int act, const float *group_stats, int a_scale, void *stream)
+{
+    GC_REQUIRE(C % 8 == 0 && C % G == 0 && group_stats && gamma && beta, "groupnorm_apply_fp8: C must be a multiple of 8 and of G; statistics required");
+    GC_REQUIRE(C_padded >= C && C_padded % 128 == 0, "groupnorm_apply_fp8: padded channel count must be a multiple of 128");
+    GC_REQUIRE(HW * (int64_t)(C_padded / 8) < (int64_t)1 << 31 && B <= 65535 && a_scale > 0 && a_scale < 255, "groupnorm_apply_fp8: bad size / scale");
+    const int64_t per_img = HW * (C_padded / 8);
+    int64_t gx = (per_img + 255) / 256;
+    const int64_t cap = std::max<int64_t>(1, (256 * 4 + B - 1) / B);
+    if (gx > cap) gx = cap;
+    const size_t lds = sizeof(float) * 2 * (size_t)C;
+    const float qscale = exp2f((float)(127 - a_scale));          // stored = value * 2^(127 - byte); the MFMA multiplies by 2^(byte - 127)
+    dim3 grid((unsigned)gx, (unsigned)B);
+    DN_DISPATCH(dtype,
+                hipLaunchKernelGGL((k_gn_apply_stats_fp8<BF16>), grid, dim3(256), lds, gc::S(stream), (const unsigned short *)x, (unsigned char *)y8,
+                                   (unsigned)HW, (unsigned)C, (unsigned)C_padded, G, group_stats, gamma, beta, eps, act, qscale),
+                hipLaunchKernelGGL((k_gn_apply_stats_fp8<F16>), grid, dim3(256), lds, gc::S(stream), (const unsigned short *)x, (unsigned char *)y8,
+                                   (unsigned)HW, (unsigned)C, (unsigned)C_padded, G, group_stats, gamma, beta, eps, act, qscale));
+    return gc::check_launch("gc_dn_groupnorm_apply_fp8");
+}
+
 int gc_dn_layernorm(int dtype, const void *x, void *y, int64_t M, int C, const float *gamma, const float *beta,
                     float eps, void *stream)
 {
@@ -597,6 +666,22 @@ int gc_dn_concat_add(int dtype, const void *a, int C1, const void *b, const void
                 hipLaunchKernelGGL((k_concat_add<F16>), dim3(ew_grid(chunks)), dim3(256), 0, gc::S(stream), (const unsigned short *)a, C1,
                                    (const unsigned short *)b, (const unsigned short *)c, C2, (unsigned short *)out, (unsigned)chunks));
     return gc::check_launch("gc_dn_concat_add");
+}
+
+int gc_dn_group_stats(int dtype, const void *x, int64_t B, int64_t HW, int C, int G, float *group_stats, void *stream)
+{
+    GC_REQUIRE(C % 8 == 0 && G >= 1 && G <= 64 && C % G == 0 && group_stats && B <= 65535, "group_stats: C % 8 == 0, G | C, statistics buffer required");
+    int nslab, ppb, ny, nchb;
+    gn_plan(B, HW, C, &nslab, &ppb, &ny, &nchb);
+    const int lanes = 256 / nchb;
+    dim3 grid((unsigned)nslab, ny, (unsigned)B);
+    const size_t lds = sizeof(float) * 16 * (size_t)lanes * nchb;
+    DN_DISPATCH(dtype,
+                hipLaunchKernelGGL((k_concat_add_stats<BF16>), grid, dim3(256), lds, gc::S(stream), (const unsigned short *)x, C, (const unsigned short *)nullptr,
+                                   (const unsigned short *)nullptr, 0, (unsigned short *)nullptr, (int)HW, nchb, ppb, G, group_stats),
+                hipLaunchKernelGGL((k_concat_add_stats<F16>), grid, dim3(256), lds, gc::S(stream), (const unsigned short *)x, C, (const unsigned short *)nullptr,
+                                   (const unsigned short *)nullptr, 0, (unsigned short *)nullptr, (int)HW, nchb, ppb, G, group_stats));
+    return gc::check_launch("gc_dn_group_stats");
 }
 
 int gc_dn_axpby(int dtype, const void *a, float sa, const void *b, float sb, int act, void *out, int64_t n, void *stream)

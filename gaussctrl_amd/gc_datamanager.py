@@ -119,4 +119,14 @@ else:
             return cam, dict(self.train_data[i])
 
 
-SimpleDataManager = GaussCtrlDataManager      # name used by round-1 callers
+class SimpleDataManager(GaussCtrlDataManager if not HAVE_NERFSTUDIO else _NextTrainMixin):
+    """cameras (+ images) in, no I/O: `SimpleDataManager(cameras, images=None, seed=0)` (tests, bench, stand-alone use)."""
+
+    def __init__(self, cameras: Cameras, images=None, seed: int = 0, load_all: bool = True):
+        if HAVE_NERFSTUDIO:      # the nerfstudio-backed class needs a dataparser: keep the plain holder
+            self.cameras = cameras
+            self.train_data = [{"image_idx": i, "image": None if images is None else images[i]} for i in range(len(cameras))]
+            self._init_sampling(len(self.train_data))
+            return
+        cfg = GaussCtrlDataManagerConfig(load_all=load_all)
+        super().__init__(cfg, cameras=cameras, images=images, seed=seed)

@@ -25,6 +25,7 @@ class GemmDesc(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("zeros", C.c_void_p),
                 ("ln_row_stats", C.c_void_p), ("ln_row_stat_slots", C.c_int), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float),
                 ("out_row_stats", C.c_void_p), ("out_group_stats", C.c_void_p), ("gn_groups", C.c_int),
+                ("fp8", C.c_int), ("w_scale", C.c_void_p), ("a_scale", C.c_int),
                 ("kernel_variant", C.c_int)]
 
 
@@ -56,6 +57,7 @@ def _variant_from_env():
         g |= 0x40
     elif cs == "2":
         g |= 0x80
+    g |= (int(os.environ.get("GC_GEMM_DBG", "0")) & 0xff) << 8
     return {"gemm": g, "attn": 1 if os.environ.get("GC_ATTN_SAFE", "0") not in ("", "0") else 0}
 
 
@@ -215,6 +217,83 @@ def groupnorm_apply(x, group_stats, gamma, beta, groups, eps, silu):
     L.check(L.lib().gc_dn_groupnorm_apply(_dt(x), _p(x), _p(y), C.c_int64(B), C.c_int64(HW), Cc, groups, _p(gamma), _p(beta),
                                           C.c_float(eps), int(silu), _p(chan_stats), _stream()), "gc_dn_groupnorm_apply")
     return y
+
+
+def pad128(c):
+    return (c + 127) // 128 * 128
+
+
+def groupnorm_apply_fp8(x, group_stats, gamma, beta, groups, eps, silu, a_scale=127):
+    """GroupNorm(+SiLU) with an e4m3 output [B,H,W,pad128(C)] (uint8) for conv3x3_fp8; a_scale = E8M0 byte of the tensor-wide scale."""
+    _gpu(x, group_stats)
+    B, Cc = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * Cc)
+    Cp = pad128(Cc)
+    y = torch.empty(x.shape[:-1] + (Cp,), dtype=torch.uint8, device=x.device)
+    L.check(L.lib().gc_dn_groupnorm_apply_fp8(_dt(x), _p(x), _p(y), C.c_int64(B), C.c_int64(HW), Cc, Cp, groups, _p(gamma), _p(beta),
+                                              C.c_float(eps), int(silu), _p(group_stats), int(a_scale), _stream()), "gc_dn_groupnorm_apply_fp8")
+    return y
+
+
+def groupnorm_fp8(x, gamma, beta, groups, eps, silu, a_scale=127):
+    """Stand-alone GroupNorm(+SiLU) -> e4m3: one statistics launch (gc_dn_group_stats) + the quantising apply."""
+    _gpu(x)
+    B, Cc = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * Cc)
+    gs = torch.zeros(B, groups, 2, dtype=torch.float32, device=x.device)
+    L.check(L.lib().gc_dn_group_stats(_dt(x), _p(x), C.c_int64(B), C.c_int64(HW), Cc, groups, _p(gs), _stream()), "gc_dn_group_stats")
+    return groupnorm_apply_fp8(x, gs, gamma, beta, groups, eps, silu, a_scale)
+
+
+def conv3x3_fp8(x8, w8, w_scale, out_dtype, bias=None, stride=1, rowvec=None, ld_rowvec=None, residual=None, act=0, scale=1.0, a_scale=127,
+                group_stats=None):
+    """3x3 conv (pad 1) on e4m3 operands with the block-scaled MFMA: x8 [B,H,W,Cp] uint8 (Cp % 128 == 0), w8 [N, 9*Cp] uint8 ((tap, cin)
+    order), w_scale [N] uint8 E8M0 per output channel; output in `out_dtype` (bf16 / f16) with the usual fused epilogue."""
+    _gpu(x8, w8, w_scale)
+    B, H, W_, Cp = x8.shape
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W_ + 2 - 3) // stride + 1
+    N = w8.shape[0]
+    out = torch.empty(B, Ho, Wo, N, dtype=out_dtype, device=x8.device)
+    d = GemmDesc()
+    d.dtype = DT[out_dtype]; d.mode = 1; d.M, d.N, d.K = B * Ho * Wo, N, 9 * Cp
+    d.A = x8.data_ptr(); d.lda = Cp
+    d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.stride, d.upsample = B, H, W_, Cp, Ho, Wo, stride, 0
+    d.pad_lo = 1
+    d.W = w8.data_ptr(); d.bias = None if bias is None else bias.data_ptr()
+    if rowvec is not None:
+        d.rowvec = rowvec.data_ptr(); d.ld_rowvec = rowvec.stride(0) if ld_rowvec is None else ld_rowvec
+    d.rows_per_batch = Ho * Wo
+    if residual is not None:
+        d.residual = residual.data_ptr(); d.ldr = N
+    d.out_scale = scale; d.act = act
+    d.out = out.data_ptr(); d.ldc = N; d.out_f32 = 0
+    d.fp8 = 1; d.w_scale = w_scale.data_ptr(); d.a_scale = int(a_scale)
+    _stats_args(d, None, group_stats)
+    _run_gemm(d, x8.device, "gc_dn_gemm(conv3x3 fp8)")
+    return out
+
+
+def linear_fp8(x8, w8, w_scale, out_dtype, bias=None, residual=None, act=0, scale=1.0, a_scale=127, rows_per_batch=0, row_stats=None,
+               group_stats=None, ln=None):
+    """x8 [..., K] e4m3 bytes @ w8[N, K]^T (K % 128 == 0) on the block-scaled MFMA, output `out_dtype`."""
+    _gpu(x8, w8, w_scale)
+    K = x8.shape[-1]
+    M = x8.numel() // K
+    N = w8.shape[0]
+    out = torch.empty(x8.shape[:-1] + (N,), dtype=out_dtype, device=x8.device)
+    d = GemmDesc()
+    d.dtype = DT[out_dtype]; d.mode = 0; d.M, d.N, d.K = M, N, K
+    d.A = x8.data_ptr(); d.lda = x8.stride(-2) if x8.dim() > 1 else K; d.W = w8.data_ptr()
+    d.bias = None if bias is None else bias.data_ptr()
+    d.rows_per_batch = rows_per_batch
+    if residual is not None:
+        d.residual = residual.data_ptr(); d.ldr = residual.stride(-2)
+    d.out_scale = scale; d.act = act
+    d.out = out.data_ptr(); d.ldc = N
+    d.fp8 = 1; d.w_scale = w_scale.data_ptr(); d.a_scale = int(a_scale)
+    _stats_args(d, ln, group_stats)
+    _run_gemm(d, x8.device, "gc_dn_gemm(linear fp8)", row_stats)
+    return out
 
 
 def layernorm(x, gamma, beta, eps=1e-5):

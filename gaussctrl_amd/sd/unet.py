@@ -103,7 +103,10 @@ class SDNet:
         self._temb_cache = {}
         self.qpre = bool(weights.get("_attn_q_prescaled", False))   # softmax scale folded into the Q weights (weights.prepare(heads=))
         self.ln_folded = bool(weights.get("_ln_folded", False))     # LayerNorms folded into their consumer GEMMs (weights.prepare(fold_ln=))
-        self.fuse_stats = True                                      # GroupNorm statistics from the producing kernel's epilogue
+        self.fuse_stats = False                                     # GroupNorm statistics from the producing kernel's epilogue: opt-in
+                                                                    # (measured slower than the stand-alone statistics pass)
+        self.fp8 = bool(weights.get("_fp8_convs", False))           # resnet 3x3 convs on e4m3 operands (weights.add_fp8_convs)
+        self.fp8_a_scale = 127                                      # E8M0 byte of the conv inputs (GroupNorm + SiLU outputs are O(1): 2^0)
         self._arenas = {}
         self.arena = None
 
@@ -120,6 +123,15 @@ class SDNet:
         """zeroed [B, G, 2] buffer for a producer's GroupNorm-group sums; None (stand-alone GroupNorm) when the map is too small for the
         epilogue's 16-row tiles to stay inside one image (HW % 16 != 0: only the toy test geometries)"""
         return self.arena.alloc(B, self.cfg["groups"], 2) if (self.fuse_stats and HW % 16 == 0) else None
+
+    def gn_fp8(self, x, xs, p, eps):
+        """GroupNorm + SiLU with an e4m3 output (input of an fp8 convolution): from the producer's group sums when it left them,
+        else the stand-alone statistics pass + a quantising apply"""
+        w = self.w
+        g = self.cfg["groups"]
+        if xs is not None:
+            return ops.groupnorm_apply_fp8(x, xs, w[p + ".weight"], w[p + ".bias"], g, eps, True, self.fp8_a_scale)
+        return ops.groupnorm_fp8(x, w[p + ".weight"], w[p + ".bias"], g, eps, True, self.fp8_a_scale)
 
     def gn(self, x, xs, p, eps, silu):
         """GroupNorm(+SiLU): one launch when the producer of x left its channel sums (xs), else the three-kernel stand-alone path"""
@@ -151,16 +163,27 @@ class SDNet:
         """ResnetBlock2D on (x, xs = channel sums of x or None) -> (out, channel sums of out)"""
         w = self.w
         B, HW = x.shape[0], x.shape[1] * x.shape[2]
-        h = self.gn(x, xs, p + ".norm1", eps, True)
         rv = None if temb_act is None else temb_act[p]
         cout = w[p + ".conv1.weight"].shape[0]
         hs = self._cs(B, cout, HW)
-        h = ops.conv3x3(h, w[p + ".conv1.weight"], w[p + ".conv1.bias"], rowvec=rv, ld_rowvec=0, group_stats=hs)
-        h = self.gn(h, hs, p + ".norm2", eps, True)
+        g = self.cfg["groups"]
+        q8 = self.fp8 and (p + ".conv1.w8") in w
+        if q8:        # fp8 path: the GroupNorm writes e4m3, the conv runs on the block-scaled MFMA
+            h8 = self.gn_fp8(x, xs, p + ".norm1", eps)
+            h = ops.conv3x3_fp8(h8, w[p + ".conv1.w8"], w[p + ".conv1.w8_scale"], x.dtype, w[p + ".conv1.bias"], rowvec=rv, ld_rowvec=0,
+                                a_scale=self.fp8_a_scale, group_stats=hs)
+        else:
+            h = self.gn(x, xs, p + ".norm1", eps, True)
+            h = ops.conv3x3(h, w[p + ".conv1.weight"], w[p + ".conv1.bias"], rowvec=rv, ld_rowvec=0, group_stats=hs)
         sc = x
         if (p + ".conv_shortcut.weight") in w:
             sc = ops.linear(x, w[p + ".conv_shortcut.weight"], w[p + ".conv_shortcut.bias"])
         os_ = self._cs(B, cout, HW)
+        if q8:
+            h8 = self.gn_fp8(h, hs, p + ".norm2", eps)
+            return ops.conv3x3_fp8(h8, w[p + ".conv2.w8"], w[p + ".conv2.w8_scale"], x.dtype, w[p + ".conv2.bias"], residual=sc,
+                                   a_scale=self.fp8_a_scale, group_stats=os_), os_
+        h = self.gn(h, hs, p + ".norm2", eps, True)
         return ops.conv3x3(h, w[p + ".conv2.weight"], w[p + ".conv2.bias"], residual=sc, group_stats=os_), os_
 
     def _self_attention(self, p, n, actx: AttnCtx, ln=None):

@@ -44,11 +44,12 @@ def geglu_permute(w, b):
 LOG2E = 1.4426950408889634
 
 
-def prepare(sd: dict, dtype, device, heads=None, fold_ln=True) -> dict:
+def prepare(sd: dict, dtype, device, heads=None, fold_ln=False) -> dict:
     """Generic pass over a diffusers state dict.  `heads` (attention heads of the network) folds the softmax scale
     head_dim**-0.5 * log2(e) into the Q projection weights in fp32, before the single rounding to `dtype`: the attention
     kernel then exponentiates the QK^T MFMA output directly (gc_attn_desc.q_prescaled).  fold_ln folds the three LayerNorms of every
-    transformer block into the GEMMs that consume them (norm1 -> Q|K|V, norm2 -> attn2.to_q, norm3 -> GEGLU projection)."""
+    transformer block into the GEMMs that consume them (norm1 -> Q|K|V, norm2 -> attn2.to_q, norm3 -> GEGLU projection); OFF by default:
+    on MI355X the longer epilogues of the one-workgroup-per-CU GEMMs cost more than the LayerNorm launches they remove."""
     out = {}
     for k, v in sd.items():
         v = v.to(device)
@@ -117,3 +118,33 @@ def _fold_ln(out, name, w32, bias, gamma, beta, dtype):
     out[name + ".colsum"] = wf.float().sum(1).contiguous()
     b2 = w32 @ beta.float()
     out[name + ".bias"] = (b2 if bias is None else bias.float() + b2).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ fp8 (BASELINE configs[3])
+def quantize_rows_e4m3(w32: torch.Tensor):
+    """[N, K] fp32 -> (e4m3 bytes [N, K] uint8, E8M0 scale bytes [N] uint8): per output row a power-of-two scale that puts the row
+    maximum just under the e4m3 maximum (448); real value = stored * 2^(byte - 127), the factor the block-scaled MFMA applies."""
+    amax = w32.abs().amax(dim=1).clamp_min(1e-30)
+    e = torch.floor(torch.log2(448.0 / amax)).clamp(-100, 100)                 # stored = w * 2^e
+    q = (w32 * torch.exp2(e)[:, None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8).contiguous(), (127 - e).to(torch.uint8).contiguous()
+
+
+def conv3x3_weight_fp8(w: torch.Tensor):
+    """[Cout, Cin, 3, 3] -> (bytes [Cout_p8, 9 * pad128(Cin)] in (tap, cin) order with zero channel padding, scale bytes [Cout_p8])"""
+    cout, cin = w.shape[0], w.shape[1]
+    cp, op = (cin + 127) // 128 * 128, _pad8(cout)
+    t = torch.zeros(op, 3, 3, cp, dtype=torch.float32, device=w.device)
+    t[:cout, :, :, :cin] = w.float().permute(0, 2, 3, 1)
+    return quantize_rows_e4m3(t.reshape(op, 9 * cp))
+
+
+def add_fp8_convs(out: dict, sd: dict, device) -> dict:
+    """fp8 copies of the resnet 3x3 convolutions (conv1 / conv2: their inputs are GroupNorm + SiLU outputs, quantised by
+    gc_dn_groupnorm_apply_fp8); everything else of the network stays in the 2-byte type."""
+    for k, v in sd.items():
+        if k.endswith((".conv1.weight", ".conv2.weight")) and ".resnets." in k and v.dim() == 4 and v.shape[-1] == 3:
+            q, sc = conv3x3_weight_fp8(v.to(device))
+            out[k[:-len("weight")] + "w8"], out[k[:-len("weight")] + "w8_scale"] = q, sc
+    out["_fp8_convs"] = True
+    return out

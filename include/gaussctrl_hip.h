@@ -237,6 +237,11 @@ typedef struct gc_gemm_desc {
                                /* plain stores (no atomics, no zero-init needed) -> ln_row_stats of a following GEMM */
     float *out_group_stats;    /* [M / rows_per_batch][gn_groups][2]: per (batch, GroupNorm group of N / gn_groups channels) sums, ADDED with */
     int gn_groups;             /* float atomics (caller zero-fills) -> gc_dn_groupnorm_apply; needs rows_per_batch % 16 == 0, gn_groups <= 32 */
+    /* fp8 path (BASELINE configs[3]): A and W hold OCP e4m3 bytes (K, lda, Cin count fp8 elements; K % 128 == 0, conv: Cin % 128 == 0), */
+    /* multiplied on the block-scaled MFMA; real value = stored * 2^(scale byte - 127) (E8M0): one byte per weight row, one for all of A. */
+    int fp8;
+    const void *w_scale;       /* [N] E8M0 bytes */
+    int a_scale;               /* E8M0 byte of the activation tensor */
     int kernel_variant;        /* 0 = automatic.  Overrides for tests / experiments: bits 0-2 force the 8-wave kernel's m-tiles per wave (2,3,4); */
                                /* 0x10 4-wave kernel only; 0x20 force the 8-wave kernel; 0x40 no k-slices for part-filled conv grids; 0x80 slice 8x8-map convs too */
 } gc_gemm_desc;
@@ -280,6 +285,12 @@ int gc_dn_groupnorm(int dtype, const void *x, void *y, int64_t B, int64_t HW, in
  * One launch instead of three. */
 int gc_dn_groupnorm_apply(int dtype, const void *x, void *y, int64_t B, int64_t HW, int C, int G, const float *gamma,
                           const float *beta, float eps, int act, const float *group_stats, void *stream);
+/* The same with an OCP fp8 (e4m3) output for the fp8 convolution path: y8[B][HW][C_padded] bytes (C_padded % 128 == 0, padding = 0),
+ * stored = y * 2^(127 - a_scale) saturated to +-448 (a_scale = E8M0 byte handed to gc_gemm_desc.a_scale). */
+int gc_dn_groupnorm_apply_fp8(int dtype, const void *x, void *y8, int64_t B, int64_t HW, int C, int C_padded, int G, const float *gamma,
+                              const float *beta, float eps, int act, const float *group_stats, int a_scale, void *stream);
+/* per-(batch, GroupNorm group) (sum, sum of squares) of x[B][HW][C], ADDED into the caller-zeroed group_stats[B][G][2] (one streaming launch). */
+int gc_dn_group_stats(int dtype, const void *x, int64_t B, int64_t HW, int C, int G, float *group_stats, void *stream);
 /* LayerNorm over C on [M][C]. */
 int gc_dn_layernorm(int dtype, const void *x, void *y, int64_t M, int C, const float *gamma, const float *beta,
                     float eps, void *stream);

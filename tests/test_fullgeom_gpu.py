@@ -151,3 +151,30 @@ def test_vae_decode_h64(dt):
         assert float(err.max()) <= 1.0 / 255.0, float(err.max())
     else:
         assert float(err.mean()) <= 1.0 / 255.0 and float(err.max()) <= 8.0 / 255.0, (float(err.mean()), float(err.max()))
+
+
+def test_edit_f7_h64_fp8_convs(nets):
+    """BASELINE configs[3] "fp8 MFMA UNet path": the resnet 3x3 convolutions of UNet and ControlNet on e4m3 operands (block-scaled
+    MFMA, GroupNorm writing e4m3), bf16 elsewhere, all 20 DDIM steps at the benchmarked geometry against the fp32 oracle fixture.
+    e4m3 keeps 3 mantissa bits (2^-4 relative rounding): the bar is its own -- relative L2 of the latents <= 6e-2 at every step."""
+    from oracle import sd15_torch as sd
+    from gaussctrl_amd.sd.pipeline import DenoisePipeline
+    from gaussctrl_amd.sd.weights import add_fp8_convs
+    z = np.load(os.path.join(GOLD, "fullgeom_edit_f7_h64.npz"))
+    ref = z["lat_steps"]
+    f, h, steps, seed = [int(v) for v in z["meta"][:4]]
+    lat, disp, cn, cp = _inputs(f, h, seed)
+    dt = torch.bfloat16
+    uw, cw = nets(dt)
+    uw, cw = dict(uw), dict(cw)
+    r = lambda w: {k: v.to(torch.bfloat16).float() for k, v in w.items() if k.endswith((".conv1.weight", ".conv2.weight"))}
+    add_fp8_convs(uw, r(sd.make_unet_weights(sd.SD15, 100)), DEV)
+    add_fp8_convs(cw, r(sd.make_controlnet_weights(sd.SD15, 200)), DEV)
+    pipe = DenoisePipeline(uw, cw, None, 20, 5.0)
+    assert pipe.unet.fp8 and pipe.controlnet.fp8
+    trace = []
+    pipe.edit_chunk(lat.to(DEV), disp.to(DEV), cn.to(DEV), cp.to(DEV), steps=steps,
+                    on_step=lambda i, l: trace.append(l.permute(0, 3, 1, 2).float().cpu()))
+    cur = _curve(trace, ref)
+    print("\nedit f=7 h=64 fp8 convs: rel L2 per step:\n  " + " ".join(f"{e:.2e}" for e in cur))
+    assert max(cur) <= 6e-2, cur

@@ -61,3 +61,29 @@ def test_vae_decode_shape():
     w = sd.make_vae_decoder_weights(sd.VAE_TINY, 3)
     img = sd.vae_decode(w, torch.randn(1, 4, 4, 4), sd.VAE_TINY)
     assert img.shape == (1, 3, 32, 32)
+
+
+def test_layernorm_fold_algebra():
+    """weights.prepare(fold_ln=True): LN(x) W^T + b == rstd (x W'^T - mean colsum) + b' with W' = W diag(gamma), b' = b + W beta --
+    checked in fp32 on the CPU for the three folded GEMMs of a transformer block (Q|K|V, attn2.to_q, GEGLU projection)."""
+    import torch.nn.functional as F
+    from gaussctrl_amd.sd import weights as W
+    cfg = sd.TINY
+    uw = sd.make_unet_weights(cfg, 1)
+    out = W.prepare(uw, torch.float32, "cpu", heads=cfg["heads"], fold_ln=True)
+    t = "down_blocks.0.attentions.0.transformer_blocks.0."
+    C = cfg["block_out_channels"][0]
+    x = torch.randn(10, C, generator=torch.Generator().manual_seed(0)) * 2 + 0.7
+    mean = x.mean(1, keepdim=True); rstd = ((x * x).mean(1, keepdim=True) - mean ** 2 + 1e-5).rsqrt()
+    fold = lambda name: rstd * (x @ out[name + ".weight"].T - mean * out[name + ".colsum"][None]) + out[name + ".bias"][None]
+    sc = (C // cfg["heads"]) ** -0.5 * W.LOG2E
+    ln1 = F.layer_norm(x, (C,), uw[t + "norm1.weight"], uw[t + "norm1.bias"], 1e-5)
+    ref = ln1 @ torch.cat([uw[t + "attn1.to_q.weight"] * sc, uw[t + "attn1.to_k.weight"], uw[t + "attn1.to_v.weight"]], 0).T
+    assert float((fold(t + "attn1.to_qkv") - ref).abs().max()) < 5e-6
+    ln2 = F.layer_norm(x, (C,), uw[t + "norm2.weight"], uw[t + "norm2.bias"], 1e-5)
+    assert float((fold(t + "attn2.to_q") - ln2 @ (uw[t + "attn2.to_q.weight"] * sc).T).abs().max()) < 5e-6
+    ln3 = F.layer_norm(x, (C,), uw[t + "norm3.weight"], uw[t + "norm3.bias"], 1e-5)
+    pr = ln3 @ uw[t + "ff.net.0.proj.weight"].T + uw[t + "ff.net.0.proj.bias"]
+    n = pr.shape[1] // 2
+    idx = torch.arange(n).reshape(n // 16, 16); perm = torch.cat([idx, idx + n], 1).reshape(-1)
+    assert float((fold(t + "ff.net.0.proj") - pr[:, perm]).abs().max()) < 5e-6

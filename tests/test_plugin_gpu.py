@@ -80,7 +80,11 @@ def test_image2latent_and_pipeline_flow(oracle_c):
     cams = Cameras(syn.make_cameras(V, seed=1), 70.0, 70.0, 32.0, 32.0, W, H)
     model = GaussCtrlModel(GaussCtrlModelConfig(background_color="black"), params=P, device=DEV)
     enc_w = sd.make_vae_encoder_weights(sd.VAE_SD, 400)
-    cfg = GaussCtrlPipelineConfig(edit_prompt="a polar bear", reverse_prompt="a bear", chunk_size=2, num_inference_steps=2, dtype="f16")
+    cfg = GaussCtrlPipelineConfig(edit_prompt="a polar bear", reverse_prompt="a bear", chunk_size=2, num_inference_steps=2, dtype="f16",
+                                  synthetic_weights=True)      # no checkpoints here: seeded random SD1.5-shaped weights, explicitly
+    with pytest.raises((KeyError, ValueError, FileNotFoundError)):         # without the flag nothing falls back to random weights silently
+        GaussCtrlPipeline(GaussCtrlPipelineConfig(edit_prompt="x", reverse_prompt="y"), DEV, datamanager=SimpleDataManager(cams), model=model,
+                          diffusion_weights={"vae_encoder": {}})
     pipe = GaussCtrlPipeline(cfg, DEV, datamanager=SimpleDataManager(cams), model=model,
                              diffusion_weights={"vae_encoder": {k: v.to(DEV) for k, v in enc_w.items()}})
     assert len(pipe.ref_indices) == 4 and max(pipe.ref_indices) < V

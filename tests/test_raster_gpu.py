@@ -29,14 +29,14 @@ def _relerr(a, b):
     return np.abs(a - b).max() / (np.abs(b).max() + 1e-12)
 
 
-def _img_close(got, ref, rel=1e-4):
+def _img_close(got, ref, rel=1e-4, frac_max=1e-5):
     """|diff| <= rel * max|ref| on every pixel, except for knife-edge pixels where a 1-ulp difference in
     exp() flips one of the discrete decisions of SURVEY A.4 (alpha >= 1/255, T' <= 1e-4): at most 1e-5
     of all values may exceed the bound, and then by no more than one dropped splat (1/255 * max colour)."""
     got = np.asarray(got, np.float64); ref = np.asarray(ref, np.float64)
     d = np.abs(got - ref); bound = rel * (np.abs(ref).max() + 1e-12)
     frac = float((d > bound).mean())
-    assert frac <= 1e-5, f"fraction of values beyond {rel} rel: {frac}"
+    assert frac <= frac_max, f"fraction of values beyond {rel} rel: {frac}"
     assert d.max() <= (1.0 / 255.0) * max(1.0, np.abs(ref).max()), d.max()
 
 
@@ -324,7 +324,8 @@ def test_sh_degree0_sigmoid_colour(oracle_c):
     tp = {k: _t(v).requires_grad_(True) for k, v in P.items()}
     rgb, alpha, _ = ops.render_view(tp["means"], tp["scales"], tp["quats"], tp["opacities"], tp["features_dc"], tp["features_rest"],
                                     cam, _t(BG), False, -1, None)
-    _img_close(rgb.detach().cpu().numpy(), o["rgb"])
+    # a 160 x 128 image has 61 k values: one knife-edge pixel (3 values) is already 5e-5 of them
+    _img_close(rgb.detach().cpu().numpy(), o["rgb"], frac_max=2e-4)
     (rgb * _t(v_rgb)).sum().backward()
     scale = max(np.abs(o["grads"][k]).max() for k in ("means", "scales", "quats", "opacities", "features_dc"))
     for k in ("means", "scales", "quats", "opacities", "features_dc"):
