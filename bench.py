@@ -147,8 +147,7 @@ def main():
     bg = torch.zeros(3, device=dev)
     pipe = None
     if args.workload == "edit":
-        fold_ln = os.environ.get("GC_DN_FOLD_LN", "1") != "0"          # A/B switches of the round-2 normalisation fusions
-        fuse_gn = os.environ.get("GC_DN_FUSE_GN", "1") != "0"
+        fold_ln = os.environ.get("GC_DN_FOLD_LN", "0") != "0"          # A/B switches of the round-2 normalisation fusions (default: off)
         usd, csd = arch.random_state_dict(arch.unet_shapes(), 100, dev), arch.random_state_dict(arch.controlnet_shapes(), 200, dev)
         uw = prepare(usd, dt, dev, heads=8, fold_ln=fold_ln)
         cw = prepare(csd, dt, dev, heads=8, fold_ln=fold_ln)
@@ -158,7 +157,8 @@ def main():
         del usd, csd
         vw = prepare_vae_weights(arch.random_state_dict(arch.vae_decoder_shapes(), 300, dev), dt, dev)
         pipe = DenoisePipeline(uw, cw, vw, nsteps, 5.0)
-        pipe.unet.fuse_stats = pipe.controlnet.fuse_stats = fuse_gn
+        pipe.unet.fuse_stats = pipe.controlnet.fuse_stats = os.environ.get("GC_DN_FUSE_GN", "0") != "0"
+        pipe.unet.gn_two_pass = pipe.controlnet.gn_two_pass = os.environ.get("GC_DN_GN2", "0") != "0"
     g = torch.Generator(device=dev).manual_seed(2 + rank)
     ctx_neg = torch.randn(1, 77, 768, device=dev, generator=g)
     ctx_pos = torch.randn(1, 77, 768, device=dev, generator=g)
@@ -348,7 +348,9 @@ class LibTimer:
 
 
 # algorithmic HBM bytes of one training render (forward + backward) per stage: coefficients of (N Gaussians, M tile
-# intersections, HW pixels) from SURVEY.md 8(d); they add up to N*868 + M*124 + HW*44
+# intersections, HW pixels) from SURVEY.md 8(d), which add up to N*868 + M*124 + HW*44 -- except k_project_sh_bwd: since round 2 it takes
+# the forward colours instead of re-reading the 192-byte SH record (reads 108 B, writes 236 B per Gaussian: 344 instead of 552), so the
+# chain total is N*660 + M*124 + HW*44
 RASTER_STAGES = {
     "gc_project_sh_fwd": ("k_project_sh_fwd", 280, 0, 0),
     "gc_raster_depth_order": ("binning: depth keys + 4 radix passes + scan (raster_sort.hip)", 0, 0, 0),      # counted with the next row
@@ -358,7 +360,7 @@ RASTER_STAGES = {
     "gc_raster_finalize": ("k_raster_finalize", 0, 0, 0),
     "gc_l1_ssim_fwd_bwd": ("k_ssim_stats + k_ssim_grad (loss, not in the 8d byte count)", 0, 0, 0),
     "gc_rasterize_bwd": ("k_rasterize_bwd", 36, 40, 24),
-    "gc_project_sh_bwd": ("k_project_sh_bwd", 552, 0, 0),
+    "gc_project_sh_bwd": ("k_project_sh_bwd", 344, 0, 0),
 }
 
 
@@ -407,7 +409,7 @@ def raster_roofline(args, step, g, stats, HW):
             "avg_launch_us": d["avg_us"], "algorithmic_bytes_per_launch": d["algorithmic_MB"] * 1e6,
             "chain": {"algorithmic_MB_per_view": round(tot_b / 1e6, 1), "kernel_us_per_view": round(tot_s * 1e6, 1),
                       "GBps": round(tot_b / tot_s / 1e9, 1), "frac": round(tot_b / tot_s / 8e12, 4), "views_in_sample": nviews,
-                      "N": N, "M_mean": int(M), "formula": "N*868 + M*124 + HW*44 bytes per view (SURVEY.md 8d)"},
+                      "N": N, "M_mean": int(M), "formula": "N*660 + M*124 + HW*44 bytes per view (SURVEY.md 8d with the SH record no longer re-read in the backward)"},
             "stages": stages}
 
 

@@ -160,8 +160,10 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
         GC_REQUIRE(d->mode == 1 || d->lda % 16 == 0, "fp8 linear: lda % 16 == 0");
         GC_REQUIRE((int64_t)d->N * d->K < ((int64_t)1 << 31) && (d->mode == 1 ? (int64_t)d->B * d->Hi * d->Wi * d->Cin : d->M * d->lda) < ((int64_t)1 << 31), "fp8: 32-bit offsets");
         const int ntw = (d->N % 160 == 0 && d->N % 128 != 0) ? 5 : 4;
+        // the e4m3 fragments are 8 registers each (32 k per lane): only the variants that stay under 256 VGPRs without spilling are
+        // instantiated -- (NTW 5, MT 2), (NTW 4, MT 2 | 3); a spill reload is a VM load that stalls behind the LDS-DMA queue
         int mt = force_mt ? force_mt : choose_mt(d->M, d->N, ntw, true);
-        if (ntw == 5 && mt == 4) mt = 3;
+        if (ntw == 5) mt = 2; else if (mt > 3) mt = 3;
         g.splits = 1; g.tiles_per_split = (int)(d->K / 128); g.ws = nullptr;
         const int64_t nbn_q = (d->N + 32 * ntw - 1) / (32 * ntw), nbm_q = (d->M + 64 * mt - 1) / (64 * mt);
         const dim3 gq((unsigned)(nbm_q * nbn_q), 1u);

@@ -20,8 +20,8 @@ template <class T>
 void dispatch8q(const GemmArgs &g, int mode, int ntw, int mt, dim3 grid, hipStream_t s)
 {
 #define GC_Q(NTW_, MT_) do { if (mode == 2) launch8q<T, 2, NTW_, MT_>(g, grid, s); else launch8q<T, 3, NTW_, MT_>(g, grid, s); } while (0)
-    if (ntw == 5) { if (mt == 3) GC_Q(5, 3); else GC_Q(5, 2); }
-    else { if (mt == 4) GC_Q(4, 4); else if (mt == 3) GC_Q(4, 3); else GC_Q(4, 2); }
+    if (ntw == 5) GC_Q(5, 2);
+    else { if (mt == 3) GC_Q(4, 3); else GC_Q(4, 2); }
 #undef GC_Q
 }
 }  // namespace

@@ -1146,38 +1146,40 @@ __global__ __launch_bounds__(512, 1) void k_gemm8q(const GemmArgs g)
     const int swz = (fr >> 1) & 7;
     const int fx0 = (((2 * fc) ^ swz) << 4), fx1 = (((2 * fc + 1) ^ swz) << 4);
     const int aw0 = BM * 128 + (wn * (16 * NTW) + fr) * 128, aa0 = (wm * (16 * MT) + fr) * 128;
-    struct Frag { uint4 w[NTW][2], a[MT][2]; };
+    // Fragment registers: 8-register MFMA operands assembled ONCE at load time from two ds_read_b128, double-buffered per k-tile (the two
+    // buffers alternate by NAME in the 2x unrolled loop: an in-place reload would cost a register copy per fragment at the back edge).
+    typedef __attribute__((ext_vector_type(4))) int i32x4;
+    struct Frag { i32x8 w[NTW], a[MT]; };
+    auto ld32 = [&](const unsigned char *p0, const unsigned char *p1) __attribute__((always_inline)) -> i32x8 {
+        const i32x4 lo = *reinterpret_cast<const i32x4 *>(p0), hi = *reinterpret_cast<const i32x4 *>(p1);
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
     auto load_frag = [&](Frag &f, int stage) __attribute__((always_inline)) {
         const unsigned char *sb = smem + stage * STAGE;
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-            f.w[t][0] = *reinterpret_cast<const uint4 *>(sb + aw0 + fx0 + t * 2048);
-            f.w[t][1] = *reinterpret_cast<const uint4 *>(sb + aw0 + fx1 + t * 2048);
-        }
+        for (int t = 0; t < NTW; ++t) f.w[t] = ld32(sb + aw0 + fx0 + t * 2048, sb + aw0 + fx1 + t * 2048);
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            f.a[t][0] = *reinterpret_cast<const uint4 *>(sb + aa0 + fx0 + t * 2048);
-            f.a[t][1] = *reinterpret_cast<const uint4 *>(sb + aa0 + fx1 + t * 2048);
-        }
+        for (int t = 0; t < MT; ++t) f.a[t] = ld32(sb + aa0 + fx0 + t * 2048, sb + aa0 + fx1 + t * 2048);
     };
-    // block scales: the weight row's exponent (constant over k) and the tensor-wide activation exponent, in byte 0 of the scale VGPRs
+    // block scales: the weight row's exponent (constant over k) and the tensor-wide activation exponent, in byte 0 of the scale VGPRs.
+    // These are the only compiler-visible global loads of the kernel: they are waited for HERE, before the first LDS-DMA is issued --
+    // a compiler-placed vmcnt for them inside the k loop would count (and drain) the inline-asm DMA loads every iteration.
     int sw[NTW];
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
         const int64_t n = n_base + wn * (16 * NTW) + t * 16 + fr;
         sw[t] = g.w_scale[n < g.N ? n : g.N - 1];
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) asm volatile("" : "+v"(sw[t]));
     const int sa = g.a_scale;
-    auto cat = [](uint4 lo, uint4 hi) __attribute__((always_inline)) -> i32x8 {
-        return i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
-    };
     constexpr int NMM = NTW * MT, NPC = AI + WI;
     auto block = [&](const Frag &f, Frag &fn, int st_next, bool load_next, const TileSrc &t, auto dma_tag, auto w3_tag) __attribute__((always_inline)) {
         constexpr bool DMA = decltype(dma_tag)::value, W3 = decltype(w3_tag)::value;
         static_for<0, NMM>([&](auto m_) __attribute__((always_inline)) {
             constexpr int m = decltype(m_)::value, nt = m / MT, mt = m % MT;
-            acc[nt][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(cat(f.w[nt][0], f.w[nt][1]), cat(f.a[mt][0], f.a[mt][1]), acc[nt][mt],
-                                                                           0, 0, 0, sw[nt], 0, sa);
+            acc[nt][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(f.w[nt], f.a[mt], acc[nt][mt], 0, 0, 0, sw[nt], 0, sa);
             if constexpr (m == 0) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (load_next) load_frag(fn, st_next);

@@ -235,6 +235,15 @@ def groupnorm_apply_fp8(x, group_stats, gamma, beta, groups, eps, silu, a_scale=
     return y
 
 
+def group_stats(x, gs):
+    """per-(batch, GroupNorm group) (sum, sum^2) of x [B, ..., C], ADDED into the zeroed fp32 gs [B, G, 2] (one streaming launch)."""
+    _gpu(x, gs)
+    B, Cc = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * Cc)
+    L.check(L.lib().gc_dn_group_stats(_dt(x), _p(x), C.c_int64(B), C.c_int64(HW), Cc, gs.shape[-2], _p(gs), _stream()), "gc_dn_group_stats")
+    return gs
+
+
 def groupnorm_fp8(x, gamma, beta, groups, eps, silu, a_scale=127):
     """Stand-alone GroupNorm(+SiLU) -> e4m3: one statistics launch (gc_dn_group_stats) + the quantising apply."""
     _gpu(x)

@@ -105,6 +105,8 @@ class SDNet:
         self.ln_folded = bool(weights.get("_ln_folded", False))     # LayerNorms folded into their consumer GEMMs (weights.prepare(fold_ln=))
         self.fuse_stats = False                                     # GroupNorm statistics from the producing kernel's epilogue: opt-in
                                                                     # (measured slower than the stand-alone statistics pass)
+        self.gn_two_pass = False                                    # stand-alone GroupNorm as group-sums + apply (2 launches, not 3): opt-in,
+                                                                    # measured neutral (7.02 vs 6.97 views/s) and it gives up the shifted sums
         self.fp8 = bool(weights.get("_fp8_convs", False))           # resnet 3x3 convs on e4m3 operands (weights.add_fp8_convs)
         self.fp8_a_scale = 127                                      # E8M0 byte of the conv inputs (GroupNorm + SiLU outputs are O(1): 2^0)
         self._arenas = {}
@@ -119,9 +121,12 @@ class SDNet:
         a.reset(device)
         self.arena = a
 
-    def _cs(self, B, C, HW):
-        """zeroed [B, G, 2] buffer for a producer's GroupNorm-group sums; None (stand-alone GroupNorm) when the map is too small for the
-        epilogue's 16-row tiles to stay inside one image (HW % 16 != 0: only the toy test geometries)"""
+    def _cs(self, B, C, HW, streaming=False):
+        """zeroed [B, G, 2] buffer for a producer's GroupNorm-group sums, or None (the consumer computes the statistics itself).
+        GEMM-epilogue producers: only with fuse_stats (opt-in) and when the epilogue's 16-row tiles stay inside one image (HW % 16 == 0);
+        streaming producers (the decoder's skip concat, which reads every element anyway): whenever gn_two_pass is on."""
+        if streaming:
+            return self.arena.alloc(B, self.cfg["groups"], 2) if (self.gn_two_pass or self.fuse_stats) else None
         return self.arena.alloc(B, self.cfg["groups"], 2) if (self.fuse_stats and HW % 16 == 0) else None
 
     def gn_fp8(self, x, xs, p, eps):
@@ -139,6 +144,11 @@ class SDNet:
         g = self.cfg["groups"]
         if xs is not None:
             return ops.groupnorm_apply(x, xs, w[p + ".weight"], w[p + ".bias"], g, eps, silu)
+        if self.gn_two_pass and x.numel() > (1 << 20):      # (<= 2 MB: the one-launch small-map kernel inside ops.groupnorm wins)
+            # two launches instead of three: group sums (float atomics into the zeroed arena) + apply with the coefficient prologue
+            gs = self.arena.alloc(x.shape[0], g, 2)
+            ops.group_stats(x, gs)
+            return ops.groupnorm_apply(x, gs, w[p + ".weight"], w[p + ".bias"], g, eps, silu)
         return ops.groupnorm(x, w[p + ".weight"], w[p + ".bias"], g, eps, silu)
 
     # ---------------------------------------------------------------------------------------- blocks
@@ -167,7 +177,7 @@ class SDNet:
         cout = w[p + ".conv1.weight"].shape[0]
         hs = self._cs(B, cout, HW)
         g = self.cfg["groups"]
-        q8 = self.fp8 and (p + ".conv1.w8") in w
+        q8 = self.fp8 and (p + ".conv1.w8") in w and HW >= 1024      # 16x16 / 8x8 maps: few tiles, long K -> the split-K bf16 kernels
         if q8:        # fp8 path: the GroupNorm writes e4m3, the conv runs on the block-scaled MFMA
             h8 = self.gn_fp8(x, xs, p + ".norm1", eps)
             h = ops.conv3x3_fp8(h8, w[p + ".conv1.w8"], w[p + ".conv1.w8_scale"], x.dtype, w[p + ".conv1.bias"], rowvec=rv, ld_rowvec=0,
@@ -336,7 +346,7 @@ class UNet(SDNet):
             for j in range(cfg["layers_per_block"] + 1):
                 s = skips.pop()
                 r = down_res.pop() if down_res is not None else None
-                xs = self._cs(x.shape[0], x.shape[-1] + s.shape[-1], 16)     # the concat kernel has no tile constraint
+                xs = self._cs(x.shape[0], x.shape[-1] + s.shape[-1], 16, streaming=True)     # the concat streams every element anyway
                 x = ops.concat_add(x, s, r, group_stats=xs)   # cat([x, skip + controlnet residual]) + its channel sums
                 x, xs = self.resnet(f"up_blocks.{i}.resnets.{j}", x, xs, temb_act)
                 if rev_attn[i]:

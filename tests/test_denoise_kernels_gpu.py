@@ -372,3 +372,16 @@ def test_groupnorm_apply_fp8(dt, B, HW, C):
         assert float((diff > 0).double().mean()) < 2e-3
         # at most ONE e4m3 step: 2^-3 relative in the normal range, 2^-9 (x the tensor scale) in the subnormal range
         assert bool((diff <= torch.maximum(0.126 * want.abs(), torch.tensor(2.0 ** -9 * 2.0 ** (a_scale - 127)).double()) + 1e-12).all())
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("B,HW,C", [(6, 4096, 320), (2, 1024, 1920), (3, 256, 2560), (2, 100, 960)])
+def test_group_stats_then_apply(dt, B, HW, C):
+    """the two-launch stand-alone GroupNorm: gc_dn_group_stats (atomics into zeroed [B,G,2]) + gc_dn_groupnorm_apply"""
+    from gaussctrl_amd.sd import ops
+    x = (_rand((B, HW, C), dt, 1.0, 1).float() * 1.5 + 0.8).to(dt)
+    gamma = torch.randn(C, device=DEV); beta = torch.randn(C, device=DEV)
+    gs = ops.group_stats(x, torch.zeros(B, 32, 2, device=DEV))
+    _stats_close(gs, _group_sums(x, 32))
+    ref = F.silu(F.group_norm(x.double().transpose(1, 2), 32, gamma.double(), beta.double(), 1e-5).transpose(1, 2))
+    _close(ops.groupnorm_apply(x, gs, gamma, beta, 32, 1e-5, True), ref, dt, extra=2.0)
