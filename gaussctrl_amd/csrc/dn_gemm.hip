@@ -85,6 +85,12 @@ int select(const gc_gemm_desc *d, Sel *o)
         // fill the CUs; variant 0x40 sends such convs back to the 4-wave split-K kernel, 0x80 also takes the 8x8-map convs
         const bool small = tiles8 < 96;
         if (!mt && mode == 0 && !force_mt) mt = 2;       // small linears: the 8-wave kernel's fill + epilogue is the shorter one (12.6 vs 20.9 us at M = 384)
+        // part-filled single-round grids of short-K linears: 64-row tiles, two workgroups per CU (all resident when <= 512 tiles)
+        if (mode == 0 && !force_mt && ntw == 4 && d->K % 64 == 0 && !d->geglu && !d->out_t && !(kv & 0x100) &&
+            !(d->ln_row_stats || d->out_row_stats || d->out_group_stats)) {
+            const int64_t t1 = ((d->M + 63) / 64) * nbn, t2 = ((d->M + 127) / 128) * nbn;
+            if (mt == 2 && t2 <= 256 && t1 <= 512 && t1 > 128 && nk_host <= 24) mt = 1;
+        }
         const bool want_split = !force_mt && use8 != 2 && !d->geglu && d->workspace && tiles8 <= 128 && (mode == 0 ? (!small || nk_host >= 24) : (convsplit >= (small ? 2 : 1)));
         int s8 = 1, tps8 = nk_host;
         if (want_split) {
@@ -144,7 +150,7 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
     }
     if (d->geglu) GC_REQUIRE(d->N % 32 == 0 && !d->out_t, "geglu needs N % 32 == 0");
     const int force_mt = d->kernel_variant & 7;
-    GC_REQUIRE(force_mt == 0 || (force_mt >= 2 && force_mt <= 4), "kernel_variant: MT must be 0, 2, 3 or 4");
+    GC_REQUIRE(force_mt >= 0 && force_mt <= 4, "kernel_variant: MT must be 0 .. 4");
     Sel sel;
     select(d, &sel);
     if (fuse_of(g) && sel.mt8) {     // the 8-wave kernel carries the fused epilogue for conv (generic / fast) and K % 64 == 0 linears only

@@ -700,7 +700,7 @@ __device__ __forceinline__ void glds16_s(const void *sbase, unsigned voff, unsig
 // so a k-tile's DMA is a uniform base + constant per-lane offset: no VALU at all in the issue path.
 // MT: m-tiles (of 16) per wave: workgroup tile (64 MT) x (32 NTW), waves 4 (M) x 2 (N), wave tile (16 MT) x (16 NTW).
 template <class T, int MODE, int NTW, int MT, bool FUSE>
-__global__ __launch_bounds__(512, MT == 2 ? 2 : 1) void k_gemm8(const GemmArgs g)
+__global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g)
 {
     constexpr int BM = 64 * MT;
     constexpr bool CONVF = MODE == 2 || MODE == 4, UPS = MODE == 4;   // MODE 4 = MODE 2 + fused nearest-x2 upsample
@@ -1449,6 +1449,12 @@ void dispatch8m(const GemmArgs &g, int mode, dim3 grid, hipStream_t s)
 template <class T, bool FUSE>
 void dispatch8(const GemmArgs &g, int mode, int ntw, int mt, dim3 grid, hipStream_t s)
 {
+    if constexpr (!FUSE) {
+        // MT = 1 (64 x 128 tile, 72 KiB LDS, <= 128 VGPRs): TWO workgroups per CU -- for the K = N = C linears of the 32x32 / 16x16 levels,
+        // whose few k-tiles leave a one-workgroup-per-CU kernel with its fill and epilogue latency fully exposed
+        if (mt == 1 && ntw == 4 && mode == 0 && g.K % 64 == 0) { launch8<T, 3, 4, 1, false>(g, grid, s); return; }
+    }
+    if (mt < 2) mt = 2;
     if (ntw == 5) {
         if (mt == 4) dispatch8m<T, 5, 4, FUSE>(g, mode, grid, s); else if (mt == 3) dispatch8m<T, 5, 3, FUSE>(g, mode, grid, s); else dispatch8m<T, 5, 2, FUSE>(g, mode, grid, s);
     } else {
