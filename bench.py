@@ -70,7 +70,11 @@ class GemmProfiler:
             lk = k.shape[1] if Lk is None else Lk
             D = q.shape[2] // heads
             fast = D in (40, 80) and len(sets) * ((lk + 63) // 64) >= 4                      # mirrors launch_attn() in dn_attn.hip
-            name = f"k_attn3<{prof.dt},{D},{2 if D == 40 else 1},3>" if fast else f"k_attn<{prof.dt},{D},{1 if D == 160 else 2}>"
+            variant = getattr(ops, "KERNEL_VARIANT", {}).get("attn", 0)
+            if fast and D == 40 and not (variant & 2):
+                name = f"k_attn4<{prof.dt},40,3,{8 if variant & 4 else 4}>"
+            else:
+                name = f"k_attn3<{prof.dt},{D},{2 if D == 40 else 1},3>" if fast else f"k_attn<{prof.dt},{D},{1 if D == 160 else 2}>"
             prof.rec.append((name, 4.0 * q.shape[0] * q.shape[1] * lk * q.shape[2] * len(sets), s, e))
             return out
 

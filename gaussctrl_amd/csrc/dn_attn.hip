@@ -61,9 +61,10 @@ template <int D> struct SafeLds {
 
 // The "safe" form: online softmax with a running row maximum (no assumption on the logits).  It is the whole kernel for the
 // head sizes without spare contraction columns and the in-kernel fallback of k_attn3.
-template <class T, int D, int QT>
+template <class T, int D, int QT, int NW = 4>
 __device__ __forceinline__ void attn_safe_body(const AttnArgs &a, int qblk, int h, int b, unsigned char *sK, unsigned char *sV)
 {
+    constexpr int NT = NW * 64;                 // threads of the workgroup
     constexpr int DP = (D + 31) / 32 * 32;      // contraction length of QK^T, padded to the MFMA k = 32
     constexpr int DV = (D + 15) / 16 * 16;      // output rows of O^T, padded to the MFMA m = 16
     constexpr int KS = DP / 32, DT = DV / 16;
@@ -74,15 +75,15 @@ __device__ __forceinline__ void attn_safe_body(const AttnArgs &a, int qblk, int 
     // denominator sum_k P[q][k] inside the P V MFMAs (same rounding of P as the numerator) -- no VALU adds for l.
     constexpr bool ONES = (DV > D);
     constexpr int NKC = 64 * (D / 8), NVC = D * 8;                     // 16-byte chunks per K / V^T tile
-    constexpr int KIT = (NKC + 255) / 256, VIT = (NVC + 255) / 256;
+    constexpr int KIT = (NKC + NT - 1) / NT, VIT = (NVC + NT - 1) / NT;
     static_assert(KROW == SafeLds<D>::KROW && VROW == SafeLds<D>::VROW && DV == SafeLds<D>::DV, "LDS plan");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, g = lane >> 4;
-    const int q_wave0 = (qblk * 4 + wid) * (QT * 16);
+    const int q_wave0 = (qblk * NW + wid) * (QT * 16);
 
     // zero the LDS once: pad columns / pad rows are never written again
-    for (int i = tid; i < 64 * KROW / 16; i += 256) reinterpret_cast<uint4 *>(sK)[i] = make_uint4(0, 0, 0, 0);
-    for (int i = tid; i < DV * VROW / 16; i += 256) reinterpret_cast<uint4 *>(sV)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < 64 * KROW / 16; i += NT) reinterpret_cast<uint4 *>(sK)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < DV * VROW / 16; i += NT) reinterpret_cast<uint4 *>(sV)[i] = make_uint4(0, 0, 0, 0);
     if (ONES) {
         __syncthreads();
         if (tid < 64) reinterpret_cast<unsigned short *>(sV + D * VROW)[tid] = One<T>::v;
@@ -106,14 +107,14 @@ __device__ __forceinline__ void attn_safe_body(const AttnArgs &a, int qblk, int 
     int k_go[KIT], k_lo[KIT], k_r[KIT], v_go[VIT], v_lo[VIT], v_c[VIT];
 #pragma unroll
     for (int j = 0; j < KIT; ++j) {
-        const int c = tid + 256 * j, r = c / (D / 8), cc = c - r * (D / 8);
+        const int c = tid + NT * j, r = c / (D / 8), cc = c - r * (D / 8);
         k_r[j] = c < NKC ? r : -1;
         k_go[j] = c < NKC ? r * (int)a.ldk + cc * 8 : 0;
         k_lo[j] = SWZ ? r * 128 + ((cc ^ ((r >> 1) & 7)) << 4) : r * KROW + cc * 16;
     }
 #pragma unroll
     for (int j = 0; j < VIT; ++j) {
-        const int c = tid + 256 * j, r = c >> 3, cc = c & 7;
+        const int c = tid + NT * j, r = c >> 3, cc = c & 7;
         v_c[j] = c < NVC ? cc * 8 : -1;
         v_go[j] = c < NVC ? r * (int)a.ldvt + cc * 8 : 0;
         v_lo[j] = r * VROW + cc * 16;
@@ -724,6 +725,325 @@ __global__ __launch_bounds__(256, 2) void k_attn3(const AttnArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// k_attn4: the k_attn3 scheme (offset / mask columns inside the QK^T contraction, denominator from a ones row of V^T, LDS-DMA
+// ring, flattened (set, tile) steps, in-kernel safe fallback) on v_mfma_f32_32x32x16.  Why: scripts/ubench/issue_model.hip (round 2,
+// profiles/r02_issue_model_32x32.txt) -- a 32x32x16 MFMA (33.5 clk) hides ~3 v_exp_f32 / ~4 plain VALU in its shadow, a 16x16x32
+// (18.5 clk, half the flops) hides only one v_exp_f32; per unit of matrix work the big tile carries 1.5x the softmax VALU for free,
+// and D = 40 pads to 48 contraction columns (3 k-steps of 16) instead of 64.
+// One wave owns 32 query rows (lane & 31; the two lane halves hold different key / channel rows).  Per 64-key step:
+//   S'^T[key][q]: 2 key blocks x KS k-steps     A = K rows (LDS), B = Q (registers)                     6 MFMAs  (D = 40)
+//   O^T[d][q]  += V^T P^T: DB row blocks x 4    A = V^T rows (LDS), B = P packed straight from S'^T     8 MFMAs
+// MFMA row i of a key block is key pi(i) = i with bits 2 and 3 swapped, so that the eight S'^T registers a lane feeds to one P V k-step
+// are eight CONSECUTIVE keys (V^T fragment = one ds_read_b128).
+__device__ __forceinline__ int swz4(int row) { return ((row >> 1) ^ (row << 1) ^ (row << 2)) & 7; }   // conflict-free for both tiles (search: scripts/lds_swizzle_search.py)
+
+template <class T, int D, int NST, int NW, bool RAG, bool PRE, int PF = 3>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_attn4(const AttnArgs a)
+{
+    static_assert(D % 8 == 0 && D % 16 != 0, "needs two spare contraction columns inside the 16-column padding");
+    constexpr int DP = (D + 15) / 16 * 16, KS = DP / 16;                   // contraction length of QK^T, k-steps
+    constexpr int DB = (D + 32) / 32;                                      // 32-row blocks of O^T: D channels, the ones row, zero rows
+    static_assert(DP <= 64, "key rows keep a 128-byte LDS pitch");
+    constexpr int KBYTES = 64 * 128, VBYTES = DB * 32 * 128;
+    constexpr int LCS = D / 8, KSS = LCS / 2, HS = LCS & 1;                // the special chunk: columns D (offset) and D+1 (mask)
+    constexpr int NT = NW * 64, KI = 8 / NW;                               // K DMA instructions per wave per tile (8 rows each)
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+    constexpr int VSH = 8 * D / NW, VI = (VSH + 63) / 64;                       // V^T chunks per wave per tile, DMA instructions
+    constexpr int PD = NST - 1;
+    constexpr float BIG = 30000.f;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *sK = smem, *sV = smem + NST * KBYTES;
+    const unsigned ldsK = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem, ldsV = ldsK + NST * KBYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qi = lane & 31, hg = lane >> 5;
+    int qblk, h, b;
+    block_coords(a, 2, qblk, h, b);
+    const int q_wave0 = (qblk * NW + wid) * 32;
+    const int ntiles = (a.Lk + 63) / 64;
+    const int nsteps = a.nsets * ntiles;
+
+    // ---- LDS image, written once: zeros, column D of every key row = 1, the ones row of V^T
+    for (int i = tid; i < NST * (KBYTES + VBYTES) / 16; i += NT) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    for (int i = tid; i < NST * 64; i += NT) {
+        const int st = i >> 6, row = i & 63;
+        *reinterpret_cast<unsigned short *>(sK + st * KBYTES + row * 128 + ((LCS ^ swz4(row)) << 4)) = One<T>::v;
+    }
+    for (int i = tid; i < NST * 64; i += NT) reinterpret_cast<unsigned short *>(sV + (i >> 6) * VBYTES + D * 128)[i & 63] = One<T>::v;
+
+    // ---- Q fragments (B operand): lane holds Q[q = qi][d = 16 ks + 8 hg .. +8]
+    uint4 qf[KS];
+    {
+        const int q = q_wave0 + qi;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d = ks * 16 + hg * 8;
+            qf[ks] = (q < a.Lq && d + 8 <= D)
+                         ? *reinterpret_cast<const uint4 *>(a.Q + (int64_t)b * a.q_bs + (int64_t)q * a.ldq + h * D + d)
+                         : make_uint4(0, 0, 0, 0);
+        }
+    }
+    const float c2 = a.scale_log2e;
+    float moff = 0.f;
+    if (hg == HS) qf[KSS].x = pack2<T>(0.f, -BIG);
+
+    // ---- LDS-DMA plan of this lane (as k_attn3, 8 chunk slots per key row)
+    int k_off[KI], k_row[KI];
+    unsigned long long k_msk[KI], k_smk[KI];
+#pragma unroll
+    for (int j = 0; j < KI; ++j) {
+        const int p = (j * NW + wid) * 64 + lane, row = p >> 3, lc = (p & 7) ^ swz4(row);
+        k_row[j] = row;
+        k_msk[j] = __ballot(lc * 8 < D);
+        k_smk[j] = __ballot(lc == LCS);
+        k_off[j] = (row * (int)a.ldk + lc * 8) * 2;
+    }
+    int v_off[VI], v_tok[VI];
+    unsigned long long v_msk[VI];
+#pragma unroll
+    for (int j = 0; j < VI; ++j) {
+        const int q = j * 64 + lane, p = VSH * wid + q, row = p >> 3, lc = (p & 7) ^ swz4(row);
+        v_msk[j] = __ballot(q < VSH);
+        v_tok[j] = lc * 8;
+        v_off[j] = (row * (int)a.ldvt + lc * 8) * 2;
+    }
+    const int lk8 = (a.Lk + 7) / 8 * 8;
+    constexpr int GRP = KI * (RAG ? 2 : 1) + VI;
+
+    unsigned long long kb_tab = 0, vb_tab = 0;
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        if (s < a.nsets) {
+            const int kind = a.set_kind[s];
+            const unsigned short *Kb, *Vb;
+            if (kind >= 0) {
+                const int kvb = (b / a.f) * a.ref_fph + kind;
+                Kb = a.Kr + (int64_t)kvb * a.kr_bs + h * D;
+                Vb = a.Vtr + (int64_t)kvb * a.vtr_bs + (int64_t)h * D * a.ldvt;
+            } else {
+                const int kvb = kind == -1 ? b : b / a.f;
+                Kb = a.K + (int64_t)kvb * a.k_bs + h * D;
+                Vb = a.Vt + (int64_t)kvb * a.vt_bs + (int64_t)h * D * a.ldvt;
+            }
+            if (lane == s) { kb_tab = (unsigned long long)Kb; vb_tab = (unsigned long long)Vb; }
+        }
+    }
+    auto tab = [&](unsigned long long t, int s) __attribute__((always_inline)) -> const unsigned char * {
+        const unsigned lo = __builtin_amdgcn_readlane((unsigned)t, s), hi = __builtin_amdgcn_readlane((unsigned)(t >> 32), s);
+        return (const unsigned char *)(((unsigned long long)hi << 32) | lo);
+    };
+    struct Cur { const unsigned char *p; int tile, s; unsigned dst; };
+    Cur ck, cv;
+    ck.p = tab(kb_tab, 0); ck.tile = 0; ck.s = 0; ck.dst = ldsK + wid * 1024;
+    cv.p = tab(vb_tab, 0); cv.tile = 0; cv.s = 0; cv.dst = ldsV + wid * (VSH * 16);
+    const int64_t kstride = (int64_t)128 * a.ldk;
+    auto issue_k = [&]() __attribute__((always_inline)) {
+        if (!RAG) {
+#pragma unroll
+            for (int j = 0; j < KI; ++j) glds16_s(ck.p, (unsigned)k_off[j], ck.dst + j * (NW * 1024), k_msk[j]);
+        } else {
+            const int lim = a.Lk - ck.tile * 64;
+#pragma unroll
+            for (int j = 0; j < KI; ++j) {
+                const bool ok = k_row[j] < lim;
+                glds16_s(ck.p, (unsigned)(ok ? k_off[j] : k_off[j] - k_row[j] * (int)a.ldk * 2), ck.dst + j * (NW * 1024), k_msk[j]);
+                glds16_v(ok ? Pages<T>::e0() : Pages<T>::e1(), ck.dst + j * (NW * 1024), k_smk[j]);
+            }
+        }
+        ck.dst = ck.dst + KBYTES == ldsK + wid * 1024 + NST * KBYTES ? ldsK + wid * 1024 : ck.dst + KBYTES;
+        ck.p += kstride;
+        if (++ck.tile == ntiles) { ck.tile = 0; ck.s = ck.s + 1 < a.nsets ? ck.s + 1 : ck.s; ck.p = tab(kb_tab, ck.s); }
+    };
+    auto issue_v = [&]() __attribute__((always_inline)) {
+        const int lim = lk8 - cv.tile * 64;
+#pragma unroll
+        for (int j = 0; j < VI; ++j)
+            glds16_s(cv.p, (unsigned)(!RAG || v_tok[j] < lim ? v_off[j] : v_off[j] - v_tok[j] * 2), cv.dst + j * 1024, v_msk[j]);
+        cv.dst = cv.dst + VBYTES == ldsV + wid * (VSH * 16) + NST * VBYTES ? ldsV + wid * (VSH * 16) : cv.dst + VBYTES;
+        cv.p += 128;
+        if (++cv.tile == ntiles) { cv.tile = 0; cv.s = cv.s + 1 < a.nsets ? cv.s + 1 : cv.s; cv.p = tab(vb_tab, cv.s); }
+    };
+
+    // fragment read offsets.  K: MFMA row qi of key block kb is key 32 kb + pi(qi); chunk 2 ks + hg.  V^T: row 32 db + qi, chunk 2 t + hg
+    int kfo[KS], vfo[4];
+    {
+        const int row = (qi & ~12) | (((qi >> 2) & 1) << 3) | (((qi >> 3) & 1) << 2);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kfo[ks] = row * 128 + (((2 * ks + hg) ^ swz4(row)) << 4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) vfo[t] = qi * 128 + (((2 * t + hg) ^ swz4(qi)) << 4);
+    }
+
+    f32x16 otot[DB], os[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { otot[db][r] = 0.f; os[db][r] = 0.f; }
+    int bad = 0;
+
+    constexpr int NQ = 2 * KS, NPV = 4 * DB, NM = NQ + NPV, NU = 16;       // QK MFMAs, PV MFMAs, exp units (2 v_exp + 1 cvt_pk) per step
+    constexpr int NG = NM - DB;                                           // MFMA gaps that carry exp units (the last k-step's P V needs all of them)
+
+    const unsigned char *rk = sK + (NST > 1 ? KBYTES : 0), *rv = sV;
+    auto body = [&](f32x16(&cur)[2], f32x16(&nxt)[2], auto first_tag) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        wait_vmcnt<(PD - 1) * GRP>();          // K(i+1), V(i) (and everything older) have landed for this wave
+        __builtin_amdgcn_s_barrier();          // ... for every wave; every wave is done with step i-1's buffers
+        issue_k();
+        issue_v();
+        const unsigned char *kb_ = rk, *vb_ = rv;
+        rk = rk + KBYTES == sK + NST * KBYTES ? sK : rk + KBYTES;
+        rv = rv + VBYTES == sV + NST * VBYTES ? sV : rv + VBYTES;
+        if (FIRST) {      // first tile of a K/V set: its row maximum becomes the set's offset (cur still carries the previous one)
+            float t = fmaxf(fmaxf(cur[0][0], cur[0][1]), cur[0][2]);
+#pragma unroll
+            for (int r = 3; r + 1 < 16; r += 2) t = fmaxf(fmaxf(t, cur[0][r]), cur[0][r + 1]);
+            t = fmaxf(fmaxf(t, cur[0][15]), cur[1][0]);
+#pragma unroll
+            for (int r = 1; r + 1 < 16; r += 2) t = fmaxf(fmaxf(t, cur[1][r]), cur[1][r + 1]);
+            t = fmaxf(t, cur[1][15]);
+            const unsigned x = __float_as_uint(t);
+            const auto r1 = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+            t = fmaxf(__uint_as_float(r1[0]), __uint_as_float(r1[1]));
+            const float mq = T::to_f(T::from_f(moff + t));
+            const float dlt = mq - moff;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cur[kb][r] -= dlt;
+            moff = mq;
+            if (hg == HS) qf[KSS].x = pack2<T>(-mq, -BIG);
+        }
+        uint4 pf[4], kf[NQ], vf[NPV];
+        auto rd_k = [&](int n) __attribute__((always_inline)) {       // n = ks * 2 + kb
+            const int ks = n >> 1, kb = n & 1;
+            kf[n] = *reinterpret_cast<const uint4 *>(kb_ + kfo[ks] + kb * 4096);
+        };
+        auto rd_v = [&](int n) __attribute__((always_inline)) {       // n = t * DB + db
+            const int t = n / DB, db = n - t * DB;
+            vf[n] = *reinterpret_cast<const uint4 *>(vb_ + vfo[t] + db * 4096);
+        };
+        auto mma_qk = [&](int n) __attribute__((always_inline)) {
+            const int ks = n >> 1, kb = n & 1;
+            if (ks == 0) {
+                f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                nxt[kb] = T::mfma32(kf[n], qf[ks], z);
+            } else nxt[kb] = T::mfma32(kf[n], qf[ks], nxt[kb]);
+        };
+        auto mma_pv = [&](int n) __attribute__((always_inline)) {
+            const int t = n / DB, db = n - t * DB;
+            os[db] = T::mfma32(vf[n], pf[t], os[db]);
+        };
+        // exp unit x: k-step t = x / 4 (keys 32 (t/2) + 16 (t&1) + 8 hg ..+8), word w = x % 4 = registers 8 (t&1) + 2 w, +1 of cur[t/2]
+        auto unit = [&](auto x_) __attribute__((always_inline)) {
+            constexpr int x = decltype(x_)::value, t = x >> 2, w = x & 3, kb = t >> 1, r0 = 8 * (t & 1) + 2 * w;
+            const float x0 = PRE ? cur[kb][r0] : cur[kb][r0] * c2, x1 = PRE ? cur[kb][r0 + 1] : cur[kb][r0 + 1] * c2;
+            const unsigned v = pack2<T>(__builtin_amdgcn_exp2f(x0), __builtin_amdgcn_exp2f(x1));
+            if constexpr (w == 0) pf[t].x = v;
+            else if constexpr (w == 1) pf[t].y = v;
+            else if constexpr (w == 2) pf[t].z = v;
+            else pf[t].w = v;
+        };
+        static_for<0, PF>([&](auto n_) __attribute__((always_inline)) { rd_k(decltype(n_)::value); });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, NM>([&](auto m_) __attribute__((always_inline)) {
+            constexpr int m = decltype(m_)::value;
+            if constexpr (m + PF < NQ) rd_k(m + PF);
+            if constexpr (m + PF >= NQ && m + PF - NQ < NPV) rd_v(m + PF - NQ);    // fragments PF MFMAs ahead of their use
+            if constexpr (m < NQ) mma_qk(m);
+            else mma_pv(m - NQ);
+            if constexpr (m < NG) {
+                static_for<(NU * m) / NG, (NU * (m + 1)) / NG>([&](auto x_) __attribute__((always_inline)) { unit(x_); });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+    // end of a K/V set: O_total += w / l * O_set; the denominator l is row D of O^T (the ones row of V^T)
+    auto fold = [&](int s) __attribute__((always_inline)) {
+        constexpr int db_l = D / 32, dl = D % 32, r_l = (dl >> 3) * 4 + (dl & 3), hg_l = (dl >> 2) & 1;
+        const float l = __shfl(os[db_l][r_l], qi + 32 * hg_l, 64);
+        bad |= !(l > 0.f && l < 1e37f);
+        const float inv = a.set_w[s] / l;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { otot[db][r] += os[db][r] * inv; os[db][r] = 0.f; }
+    };
+
+    // ---- prologue: K(0) alone, then PD groups {K(j+1), V(j)}
+    __syncthreads();
+    issue_k();
+#pragma unroll
+    for (int j = 0; j < PD; ++j) { issue_k(); issue_v(); }
+    wait_vmcnt<PD * GRP>();
+    __builtin_amdgcn_s_barrier();
+    f32x16 sa[2], sb[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sa[kb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            sa[kb] = T::mfma32(*reinterpret_cast<const uint4 *>(sK + kfo[ks] + kb * 4096), qf[ks], sa[kb]);
+    }
+
+    int tile = 0, s = 0;
+    auto step = [&](f32x16(&cur)[2], f32x16(&nxt)[2]) __attribute__((always_inline)) {
+        if (tile == 0) body(cur, nxt, std::true_type{});
+        else body(cur, nxt, std::false_type{});
+        if (++tile == ntiles) { fold(s); tile = 0; ++s; }
+    };
+    int i = 0;
+    for (; i + 1 < nsteps; i += 2) { step(sa, sb); step(sb, sa); }
+    if (i < nsteps) step(sa, sb);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    if (__syncthreads_or(bad)) {      // some row left the exponent range of its first-tile offset: safe recomputation
+        attn_safe_body<T, D, 2, NW>(a, qblk, h, b, smem, smem + SafeLds<D>::KBYTES);
+        return;
+    }
+    // ---- store: lane owns O[q = qi][d = 32 db + 8 (r / 4) + 4 hg .. +4]
+    const int q = q_wave0 + qi;
+    if (q < a.Lq) {
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int d = 32 * db + 8 * rq + 4 * hg;
+                if (32 * db + 8 * rq + 8 > D) continue;      // D % 8 == 0: both halves of the 8-channel group are data, or neither
+                *reinterpret_cast<uint2 *>(a.O + (int64_t)b * a.o_bs + (int64_t)q * a.ldo + h * D + d) =
+                    make_uint2(pack2<T>(otot[db][4 * rq], otot[db][4 * rq + 1]), pack2<T>(otot[db][4 * rq + 2], otot[db][4 * rq + 3]));
+            }
+    }
+}
+
+template <class T, int D, int NST, int NW, bool RAG, bool PRE, int PF = 3>
+void launch_attn4_(const AttnArgs &a, int B, hipStream_t s)
+{
+    constexpr int DB = (D + 32) / 32;
+    constexpr size_t ring = (size_t)NST * (64 * 128 + DB * 32 * 128), safe = SafeLds<D>::KBYTES + SafeLds<D>::VBYTES;
+    constexpr size_t lds = ring > safe ? ring : safe;
+    static gc::AttrOnce once;
+    gc::ensure_dynamic_lds(once, (const void *)k_attn4<T, D, NST, NW, RAG, PRE, PF>, (int)lds);
+    AttnArgs aa = a;
+    aa.nqb = (a.Lq + 32 * NW - 1) / (32 * NW);
+    dim3 grid((unsigned)(aa.nqb * a.H * B));
+    hipLaunchKernelGGL((k_attn4<T, D, NST, NW, RAG, PRE, PF>), grid, dim3(NW * 64), lds, s, aa);
+}
+template <class T, int D, int NST, int NW>
+void launch_attn4(const AttnArgs &a, int B, hipStream_t s)
+{
+    const bool pre = a.scale_log2e == 1.f;
+    if (a.Lk & 63) { if (pre) launch_attn4_<T, D, NST, NW, true, true>(a, B, s); else launch_attn4_<T, D, NST, NW, true, false>(a, B, s); }
+    else { if (pre) launch_attn4_<T, D, NST, NW, false, true>(a, B, s); else launch_attn4_<T, D, NST, NW, false, false>(a, B, s); }
+}
+
 template <class T, int D, int QT, int NST, bool RAG, bool PRE>
 void launch_attn3_(const AttnArgs &a, int B, hipStream_t s)
 {
@@ -749,11 +1069,15 @@ void launch_attn3(const AttnArgs &a, int B, hipStream_t s)
 #define ATT80_QT 1
 #endif
 template <class T>
-int launch_attn(const AttnArgs &a, int D, int B, bool fast, hipStream_t s)
+int launch_attn(const AttnArgs &a, int D, int B, bool fast, int variant, hipStream_t s)
 {
     if (fast && (int64_t)a.nsets * ((a.Lk + 63) / 64) >= 4) {   // short key streams: the pipeline's fill / LDS set-up does not amortise
         switch (D) {
-        case 40: launch_attn3<T, 40, 2, 3>(a, B, s); return GC_OK;
+        case 40:
+            if (variant & 2) launch_attn3<T, 40, 2, 3>(a, B, s);     // kernel_variant bit 1: the 16x16x32 form (A/B measurements)
+            else if (variant & 4) launch_attn4<T, 40, 3, 8>(a, B, s);      // bit 2: 8 waves, one workgroup per CU
+            else launch_attn4<T, 40, 3, 4>(a, B, s);
+            return GC_OK;
         case 80: launch_attn3<T, 80, ATT80_QT, 3>(a, B, s); return GC_OK;
         default: break;
         }
@@ -803,8 +1127,8 @@ extern "C" int gc_dn_attention(const gc_attn_desc *d, void *stream)
     for (int i = 0; i < d->nsets; ++i) GC_REQUIRE(d->set_kind[i] >= -2 && d->set_kind[i] < a.ref_fph, "bad set_kind");
     a.scale_log2e = d->q_prescaled ? 1.f : d->scale * 1.4426950408889634f;
     const bool fast = !(d->kernel_variant & 1);      // kernel_variant bit 0: online-softmax kernel everywhere (tests)
-    int rc = d->dtype == DT_BF16 ? launch_attn<BF16>(a, d->head_dim, d->batch, fast, gc::S(stream))
-             : d->dtype == DT_F16 ? launch_attn<F16>(a, d->head_dim, d->batch, fast, gc::S(stream)) : GC_EINVAL;
+    int rc = d->dtype == DT_BF16 ? launch_attn<BF16>(a, d->head_dim, d->batch, fast, d->kernel_variant, gc::S(stream))
+             : d->dtype == DT_F16 ? launch_attn<F16>(a, d->head_dim, d->batch, fast, d->kernel_variant, gc::S(stream)) : GC_EINVAL;
     if (rc != GC_OK) return rc;
     return gc::check_launch("gc_dn_attention");
 }

@@ -7,6 +7,7 @@ namespace dn {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 // dtype codes of the C ABI
 enum { DT_BF16 = 0, DT_F16 = 1 };
@@ -17,6 +18,10 @@ struct BF16 {
     static __device__ __forceinline__ f32x4 mfma(uint4 a, uint4 b, f32x4 c)
     {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x16 mfma32(uint4 a, uint4 b, f32x16 c)      // v_mfma_f32_32x32x16_bf16
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
     static __device__ __forceinline__ float to_f(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
     static __device__ __forceinline__ unsigned short from_f(float f)
@@ -32,6 +37,10 @@ struct F16 {
     static __device__ __forceinline__ f32x4 mfma(uint4 a, uint4 b, f32x4 c)
     {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x16 mfma32(uint4 a, uint4 b, f32x16 c)      // v_mfma_f32_32x32x16_f16
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     }
     static __device__ __forceinline__ float to_f(unsigned short u) { return (float)__builtin_bit_cast(_Float16, u); }
     static __device__ __forceinline__ unsigned short from_f(float f)

@@ -58,7 +58,7 @@ def _variant_from_env():
     elif cs == "2":
         g |= 0x80
     g |= (int(os.environ.get("GC_GEMM_DBG", "0")) & 0xff) << 8
-    return {"gemm": g, "attn": 1 if os.environ.get("GC_ATTN_SAFE", "0") not in ("", "0") else 0}
+    return {"gemm": g, "attn": (1 if os.environ.get("GC_ATTN_SAFE", "0") not in ("", "0") else 0) | (2 if os.environ.get("GC_ATTN_16", "0") not in ("", "0") else 0) | (int(os.environ.get("GC_ATTN_V", "0")) << 2)}
 
 
 KERNEL_VARIANT = _variant_from_env()
