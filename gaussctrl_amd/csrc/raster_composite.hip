@@ -26,6 +26,43 @@ struct SplatA { float x, y, opac, cxx; };
 struct SplatB { float cxy, cyy, r, g; };
 struct SplatC { float b, e; };
 
+// ---- strip culling ---------------------------------------------------------------------------------------------------------
+// gsplat bins a Gaussian into every tile of the BOX around a circle of 3 sqrt(lambda_max); most (tile, Gaussian) pairs of an anisotropic
+// or faint Gaussian never reach alpha >= 1/255 anywhere in the tile, and of the rest few touch all four 16x4 strips.  When a batch is
+// staged, the lane that loads a record also evaluates -- exactly, the form is convex -- the minimum of sigma over each strip's
+// rectangle of pixel centres and keeps a 4-bit mask "strip w can reach alpha >= 1/255" (threshold sigma <= ln(255 opacity), with a
+// margin far above the rounding of either side).  A wave then walks only the set bits of its strip's ballot (scalar loop: s_ff1 +
+// s_andn2), so culled pairs cost no vector work at all.  The per-pixel test is unchanged: results are bit-identical to the unculled loop.
+__device__ __forceinline__ float edge_min(float a, float b, float c, float e, float lo, float hi)
+{
+    // min over v in [lo, hi] of 0.5 (a e^2 + c v^2) + b e v   (c > 0): v* = clamp(-b e / c)
+    const float v = fminf(fmaxf(-b * e / c, lo), hi);
+    return 0.5f * (a * e * e + c * v * v) + b * e * v;
+}
+
+__device__ __forceinline__ unsigned strip_mask(const float x, const float y, const float opac, const float cxx, const float cxy,
+                                               const float cyy, const float tile_x0, const float tile_y0)
+{
+    if (!(cxx > 0.f && cyy > 0.f)) return 0xFu;                       // degenerate conic: no culling
+    const float tau = __logf(255.f * opac) * 1.001f + 0.01f;          // alpha >= 1/255  <=>  sigma <= ln(255 opacity)
+    if (!(tau >= 0.f)) return tau < 0.f ? 0u : 0xFu;                  // NaN -> keep
+    const float dx0 = x - (tile_x0 + 15.f), dx1 = x - tile_x0;        // d = splat - pixel over the tile's columns
+    const bool in_x = dx0 <= 0.f && dx1 >= 0.f;
+    unsigned m = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const float dy0 = y - (tile_y0 + 4.f * w + 3.f), dy1 = y - (tile_y0 + 4.f * w);
+        float smin;
+        if (in_x && dy0 <= 0.f && dy1 >= 0.f) smin = 0.f;
+        else {
+            smin = fminf(fminf(edge_min(cxx, cxy, cyy, dx0, dy0, dy1), edge_min(cxx, cxy, cyy, dx1, dy0, dy1)),
+                         fminf(edge_min(cyy, cxy, cxx, dy0, dx0, dx1), edge_min(cyy, cxy, cxx, dy1, dx0, dx1)));
+        }
+        if (!(smin > tau)) m |= 1u << w;
+    }
+    return m;
+}
+
 template <bool HAS_EXTRA>
 __global__ __launch_bounds__(BLOCK) void k_rasterize_fwd(int H, int W, int tiles_x,
                                                          const int32_t *__restrict__ ids_sorted,
@@ -39,12 +76,14 @@ __global__ __launch_bounds__(BLOCK) void k_rasterize_fwd(int H, int W, int tiles
     __shared__ SplatA sA[BLOCK];
     __shared__ SplatB sB[BLOCK];
     __shared__ SplatC sC[BLOCK];
+    __shared__ unsigned char sMask[BLOCK];
     const int tile = blockIdx.y * tiles_x + blockIdx.x;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int j = blockIdx.x * TILE + (tid & 15);
     const int i = blockIdx.y * TILE + (tid >> 4);
     const bool inside = (i < H) && (j < W);
     const float px = (float)j, py = (float)i;
+    const float tx0 = (float)(blockIdx.x * TILE), ty0 = (float)(blockIdx.y * TILE);
     const int start = tile_bins[2 * tile], end = tile_bins[2 * tile + 1];
     bool done = !inside;
     float T = 1.f, r = 0.f, g = 0.f, b = 0.f, e = 0.f;
@@ -52,32 +91,46 @@ __global__ __launch_bounds__(BLOCK) void k_rasterize_fwd(int H, int W, int tiles
     for (int bs = start; bs < end; bs += BLOCK) {
         if (__syncthreads_and(done)) break;
         const int idx = bs + tid;
+        unsigned mk = 0;
         if (idx < end) {
             const int gid = ids_sorted[idx];
             const float2 xy = *reinterpret_cast<const float2 *>(xys + 2 * gid);
             const float c0 = conics[3 * gid], c1 = conics[3 * gid + 1], c2 = conics[3 * gid + 2];
-            sA[tid] = {xy.x, xy.y, opacities[gid], c0};
+            const float op = opacities[gid];
+            sA[tid] = {xy.x, xy.y, op, c0};
             sB[tid] = {c1, c2, colors[3 * gid], colors[3 * gid + 1]};
             sC[tid] = {colors[3 * gid + 2], HAS_EXTRA ? extra[gid] : 0.f};
+            mk = strip_mask(xy.x, xy.y, op, c0, c1, c2, tx0, ty0);
         }
+        sMask[tid] = (unsigned char)mk;
         __syncthreads();
         const int n = min(BLOCK, end - bs);
-        if (!__all(done)) {   // a finished wave only helps staging
-            for (int t = 0; t < n && !done; ++t) {
-                const SplatA a = sA[t];
-                const SplatB bb = sB[t];
-                const float dx = a.x - px, dy = a.y - py;
-                const float sigma = 0.5f * (a.cxx * dx * dx + bb.cyy * dy * dy) + bb.cxy * dx * dy;
-                const float alpha = fminf(ALPHA_CAP, a.opac * __expf(-sigma));
-                if (sigma < 0.f || alpha < ALPHA_MIN) continue;
-                const float next_T = T * (1.f - alpha);
-                if (next_T <= T_STOP) { done = true; break; }
-                const float vis = alpha * T;
-                const SplatC cc = sC[t];
-                r += bb.r * vis; g += bb.g * vis; b += cc.b * vis;
-                if (HAS_EXTRA) e += cc.e * vis;
-                T = next_T;
-                last = bs + t;
+        bool wave_done = __all(done);                                  // a finished wave only helps staging
+        for (int c = 0; c * 64 < n && !wave_done; ++c) {
+            unsigned long long bal = __ballot((sMask[c * 64 + lane] >> wid) & 1);
+            while (bal) {                                              // scalar walk over the splats that can touch this strip
+                const int t = c * 64 + __builtin_ctzll(bal);
+                bal &= bal - 1;
+                if (!done) {
+                    const SplatA a = sA[t];
+                    const SplatB bb = sB[t];
+                    const float dx = a.x - px, dy = a.y - py;
+                    const float sigma = 0.5f * (a.cxx * dx * dx + bb.cyy * dy * dy) + bb.cxy * dx * dy;
+                    const float alpha = fminf(ALPHA_CAP, a.opac * __expf(-sigma));
+                    if (!(sigma < 0.f || alpha < ALPHA_MIN)) {
+                        const float next_T = T * (1.f - alpha);
+                        if (next_T <= T_STOP) done = true;
+                        else {
+                            const float vis = alpha * T;
+                            const SplatC cc = sC[t];
+                            r += bb.r * vis; g += bb.g * vis; b += cc.b * vis;
+                            if (HAS_EXTRA) e += cc.e * vis;
+                            T = next_T;
+                            last = bs + t;
+                        }
+                    }
+                }
+                if (__all(done)) { wave_done = true; break; }
             }
         }
     }
@@ -92,24 +145,39 @@ __global__ __launch_bounds__(BLOCK) void k_rasterize_fwd(int H, int W, int tiles
     }
 }
 
-// ---- wave64 sum via DPP; the total lands in lane 63 and is broadcast with readlane -------------
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_mov0(float v)
+// ---- reduction of the nine per-splat partials ------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v)      // v + v[dpp lane], all rows / banks
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row_sum(float v)      // every lane ends with the sum over its row of 16 lanes
+{
+    v = dpp_add<0xB1>(v);     // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);     // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);    // row_half_mirror
+    v = dpp_add<0x140>(v);    // row_mirror
+    return v;
+}
+__device__ __forceinline__ float xor_rows_sum(float v)  // sum over the four rows, lane-wise (lane l: lanes l%16 + 16 k)
+{
+    {
+        const unsigned x = __float_as_uint(v);
+        const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    {
+        const unsigned x = __float_as_uint(v);
+        const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    return v;
 }
 
-__device__ __forceinline__ float wave_sum(float v)
-{
-    v += dpp_mov0<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
-    v += dpp_mov0<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
-    v += dpp_mov0<0x141, 0xF>(v);   // row_half_mirror
-    v += dpp_mov0<0x140, 0xF>(v);   // row_mirror  -> every lane holds its 16-lane row sum
-    v += dpp_mov0<0x142, 0xA>(v);   // row_bcast:15 into rows 1,3
-    v += dpp_mov0<0x143, 0xC>(v);   // row_bcast:31 into rows 2,3 -> lane 63 = total
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-
+// Backward.  Per (strip, splat) with at least one contributing pixel: nine partials are summed over the rows with DPP (36 adds), lane c
+// of every row picks value c, two lane-swap steps add the four rows, and lanes 0..8 add their value into a per-batch LDS accumulator
+// (ONE ds_add_f32 instruction).  After a batch the staging lane of each splat flushes nine hardware float atomics -- once per
+// (tile, splat) instead of once per (strip, splat), issued by 256 lanes at a time.
 __global__ __launch_bounds__(BLOCK) void k_rasterize_bwd(int H, int W, int tiles_x,
                                                          const int32_t *__restrict__ ids_sorted,
                                                          const int32_t *__restrict__ tile_bins,
@@ -124,7 +192,8 @@ __global__ __launch_bounds__(BLOCK) void k_rasterize_bwd(int H, int W, int tiles
     __shared__ SplatA sA[BLOCK];
     __shared__ SplatB sB[BLOCK];
     __shared__ float sBlue[BLOCK];
-    __shared__ int sId[BLOCK];
+    __shared__ float sG[BLOCK * 9];
+    __shared__ unsigned char sMask[BLOCK];
     __shared__ int sMax[4];
     const int tile = blockIdx.y * tiles_x + blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -132,6 +201,7 @@ __global__ __launch_bounds__(BLOCK) void k_rasterize_bwd(int H, int W, int tiles
     const int i = blockIdx.y * TILE + (tid >> 4);
     const bool inside = (i < H) && (j < W);
     const float px = (float)j, py = (float)i;
+    const float tx0 = (float)(blockIdx.x * TILE), ty0 = (float)(blockIdx.y * TILE);
     const int start = tile_bins[2 * tile], end = tile_bins[2 * tile + 1];
     if (end <= start) return;
     const int pix = inside ? i * W + j : 0;
@@ -150,70 +220,98 @@ __global__ __launch_bounds__(BLOCK) void k_rasterize_bwd(int H, int W, int tiles
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, __shfl_xor(wmax, d, 64));
     if (lane == 0) sMax[wid] = wmax;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) sG[q * BLOCK + tid] = 0.f;
     __syncthreads();
     const int kmax = max(max(sMax[0], sMax[1]), max(sMax[2], sMax[3]));
     if (kmax < start) return;
+    const int col = lane & 15;
     for (int batch_end = kmax; batch_end >= start; batch_end -= BLOCK) {
-        __syncthreads();
         const int idx = batch_end - tid;
+        int gid = -1;
+        unsigned mk = 0;
         if (idx >= start) {
-            const int gid = ids_sorted[idx];
+            gid = ids_sorted[idx];
             const float2 xy = *reinterpret_cast<const float2 *>(xys + 2 * gid);
-            sId[tid] = gid;
-            sA[tid] = {xy.x, xy.y, opacities[gid], conics[3 * gid]};
-            sB[tid] = {conics[3 * gid + 1], conics[3 * gid + 2], colors[3 * gid], colors[3 * gid + 1]};
+            const float op = opacities[gid], c0 = conics[3 * gid], c1 = conics[3 * gid + 1], c2 = conics[3 * gid + 2];
+            sA[tid] = {xy.x, xy.y, op, c0};
+            sB[tid] = {c1, c2, colors[3 * gid], colors[3 * gid + 1]};
             sBlue[tid] = colors[3 * gid + 2];
+            mk = strip_mask(xy.x, xy.y, op, c0, c1, c2, tx0, ty0);
         }
+        sMask[tid] = (unsigned char)mk;
         __syncthreads();
         const int n = min(BLOCK, batch_end - start + 1);
-        for (int t = max(0, batch_end - wmax); t < n; ++t) {   // wave-uniform bounds
-            const int k = batch_end - t;
-            const SplatA a = sA[t];
-            const SplatB bb = sB[t];
-            const float dx = a.x - px, dy = a.y - py;
-            const float sigma = 0.5f * (a.cxx * dx * dx + bb.cyy * dy * dy) + bb.cxy * dx * dy;
-            const float vis = __expf(-sigma);
-            const float araw = a.opac * vis;
-            const float alpha = fminf(ALPHA_CAP, araw);
-            const bool valid = (k <= bin_final) && !(sigma < 0.f || alpha < ALPHA_MIN);
-            if (!__any(valid)) continue;
-            float g_r = 0.f, g_g = 0.f, g_b = 0.f, g_cxx = 0.f, g_cxy = 0.f, g_cyy = 0.f, g_x = 0.f, g_y = 0.f, g_o = 0.f;
-            if (valid) {
-                const float ra = 1.f / (1.f - alpha);
-                T *= ra;
-                const float fac = alpha * T;
-                g_r = fac * vo0; g_g = fac * vo1; g_b = fac * vo2;
-                const float cb = sBlue[t];
-                float v_alpha = (bb.r * T - S0 * ra) * vo0 + (bb.g * T - S1 * ra) * vo1 + (cb * T - S2 * ra) * vo2;
-                v_alpha += T_final * ra * voa;
-                v_alpha += -T_final * ra * bgdot;
-                S0 += bb.r * fac; S1 += bb.g * fac; S2 += cb * fac;
-                if (!(araw > ALPHA_CAP)) {
-                    const float v_sigma = -a.opac * vis * v_alpha;
-                    g_cxx = 0.5f * v_sigma * dx * dx;
-                    g_cxy = v_sigma * dx * dy;
-                    g_cyy = 0.5f * v_sigma * dy * dy;
-                    g_x = v_sigma * (a.cxx * dx + bb.cxy * dy);
-                    g_y = v_sigma * (bb.cxy * dx + bb.cyy * dy);
-                    g_o = vis * v_alpha;
+        const int t0 = max(0, batch_end - wmax);                       // wave-uniform: splats behind every pixel's last one
+        for (int c = t0 >> 6; c * 64 < n; ++c) {
+            unsigned long long bal = __ballot((sMask[c * 64 + lane] >> wid) & 1);
+            if (c * 64 < t0) bal &= ~0ull << (t0 - c * 64);
+            while (bal) {
+                const int t = c * 64 + __builtin_ctzll(bal);
+                bal &= bal - 1;
+                const int k = batch_end - t;
+                const SplatA a = sA[t];
+                const SplatB bb = sB[t];
+                const float dx = a.x - px, dy = a.y - py;
+                const float sigma = 0.5f * (a.cxx * dx * dx + bb.cyy * dy * dy) + bb.cxy * dx * dy;
+                const float vis = __expf(-sigma);
+                const float araw = a.opac * vis;
+                const float alpha = fminf(ALPHA_CAP, araw);
+                const bool valid = (k <= bin_final) && !(sigma < 0.f || alpha < ALPHA_MIN);
+                if (!__any(valid)) continue;
+                float g_r = 0.f, g_g = 0.f, g_b = 0.f, g_cxx = 0.f, g_cxy = 0.f, g_cyy = 0.f, g_x = 0.f, g_y = 0.f, g_o = 0.f;
+                if (valid) {
+                    const float ra = 1.f / (1.f - alpha);
+                    T *= ra;
+                    const float fac = alpha * T;
+                    g_r = fac * vo0; g_g = fac * vo1; g_b = fac * vo2;
+                    const float cb = sBlue[t];
+                    float v_alpha = (bb.r * T - S0 * ra) * vo0 + (bb.g * T - S1 * ra) * vo1 + (cb * T - S2 * ra) * vo2;
+                    v_alpha += T_final * ra * voa;
+                    v_alpha += -T_final * ra * bgdot;
+                    S0 += bb.r * fac; S1 += bb.g * fac; S2 += cb * fac;
+                    if (!(araw > ALPHA_CAP)) {
+                        const float v_sigma = -a.opac * vis * v_alpha;
+                        g_cxx = 0.5f * v_sigma * dx * dx;
+                        g_cxy = v_sigma * dx * dy;
+                        g_cyy = 0.5f * v_sigma * dy * dy;
+                        g_x = v_sigma * (a.cxx * dx + bb.cxy * dy);
+                        g_y = v_sigma * (bb.cxy * dx + bb.cyy * dy);
+                        g_o = vis * v_alpha;
+                    }
                 }
-            }
-            g_r = wave_sum(g_r); g_g = wave_sum(g_g); g_b = wave_sum(g_b);
-            g_cxx = wave_sum(g_cxx); g_cxy = wave_sum(g_cxy); g_cyy = wave_sum(g_cyy);
-            g_x = wave_sum(g_x); g_y = wave_sum(g_y); g_o = wave_sum(g_o);
-            if (lane == 0) {
-                const int gid = sId[t];
-                unsafeAtomicAdd(v_colors + 3 * gid, g_r);
-                unsafeAtomicAdd(v_colors + 3 * gid + 1, g_g);
-                unsafeAtomicAdd(v_colors + 3 * gid + 2, g_b);
-                unsafeAtomicAdd(v_conic + 3 * gid, g_cxx);
-                unsafeAtomicAdd(v_conic + 3 * gid + 1, g_cxy);
-                unsafeAtomicAdd(v_conic + 3 * gid + 2, g_cyy);
-                unsafeAtomicAdd(v_xy + 2 * gid, g_x);
-                unsafeAtomicAdd(v_xy + 2 * gid + 1, g_y);
-                unsafeAtomicAdd(v_opacity + gid, g_o);
+                g_r = row_sum(g_r); g_g = row_sum(g_g); g_b = row_sum(g_b);
+                g_cxx = row_sum(g_cxx); g_cxy = row_sum(g_cxy); g_cyy = row_sum(g_cyy);
+                g_x = row_sum(g_x); g_y = row_sum(g_y); g_o = row_sum(g_o);
+                float x = g_r;                                          // lane column c keeps value c
+                x = col == 1 ? g_g : x; x = col == 2 ? g_b : x; x = col == 3 ? g_cxx : x; x = col == 4 ? g_cxy : x;
+                x = col == 5 ? g_cyy : x; x = col == 6 ? g_x : x; x = col == 7 ? g_y : x; x = col == 8 ? g_o : x;
+                x = xor_rows_sum(x);
+                if (lane < 9) __hip_atomic_fetch_add(&sG[lane * BLOCK + t], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
+        __syncthreads();
+        if (gid >= 0) {                                                 // flush: nine atomics per (tile, splat) that was touched at all
+            float v[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) { v[q] = sG[q * BLOCK + tid]; sG[q * BLOCK + tid] = 0.f; }
+            bool any = false;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) any |= v[q] != 0.f;
+            if (any) {
+                unsafeAtomicAdd(v_colors + 3 * gid, v[0]);
+                unsafeAtomicAdd(v_colors + 3 * gid + 1, v[1]);
+                unsafeAtomicAdd(v_colors + 3 * gid + 2, v[2]);
+                unsafeAtomicAdd(v_conic + 3 * gid, v[3]);
+                unsafeAtomicAdd(v_conic + 3 * gid + 1, v[4]);
+                unsafeAtomicAdd(v_conic + 3 * gid + 2, v[5]);
+                unsafeAtomicAdd(v_xy + 2 * gid, v[6]);
+                unsafeAtomicAdd(v_xy + 2 * gid + 1, v[7]);
+                unsafeAtomicAdd(v_opacity + gid, v[8]);
+            }
+        }
+        // the next staging pass overwrites sA / sB / sMask: every wave has left the loop (barrier above); sG slots are private to
+        // their staging lane until the next barrier
     }
 }
 
