@@ -40,7 +40,7 @@ __device__ __forceinline__ int64_t live_count(int64_t n, const int32_t *n_dev)
 }
 
 __global__ __launch_bounds__(RT) void k_radix_hist(const uint32_t *__restrict__ keys, int64_t n, const int32_t *__restrict__ n_dev,
-                                                   int shift, int nblocks, int32_t *__restrict__ hist /* [256][nblocks] */)
+                                                   int shift, unsigned dmask, int nblocks, int32_t *__restrict__ hist /* [digits][nblocks] */)
 {
     n = live_count(n, n_dev);
     __shared__ int h[256];
@@ -50,10 +50,10 @@ __global__ __launch_bounds__(RT) void k_radix_hist(const uint32_t *__restrict__ 
 #pragma unroll
     for (int j = 0; j < RI; ++j) {
         const int64_t i = base + j * RT + threadIdx.x;
-        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255], 1);
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & dmask], 1);
     }
     __syncthreads();
-    hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+    if (threadIdx.x <= dmask) hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
 // offs = INCLUSIVE scan of hist ([digit][block] flattened); exclusive offset of (d, b) = offs[d*nb + b] - hist[d*nb + b]
@@ -108,6 +108,95 @@ __global__ __launch_bounds__(RT) void k_radix_scatter(const uint32_t *__restrict
             keys_out[pos] = k[j];
             vals_out[pos] = v[j];
         }
+    }
+}
+
+// Scatter of the TILE passes: few digits (2^DB <= 64; the tile-id bits are split evenly over the two passes), so the (round, wave) x digit
+// table is small and the 4096 items of the workgroup are first put in digit order in LDS and then streamed out: consecutive lanes write
+// consecutive addresses inside each digit run (full-line stores).  The direct form above issues one isolated 4-byte store per item and
+// array -- 2 M of them per pass, which is what bounded it (329 us per pass at M = 20 M vs 110 us of bytes at 3 TB/s).
+template <int DB>
+__global__ __launch_bounds__(RT) void k_radix_scatter_staged(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                             uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int64_t n,
+                                                             const int32_t *__restrict__ n_dev, int shift, int nblocks,
+                                                             const int32_t *__restrict__ hist, const int32_t *__restrict__ offs)
+{
+    constexpr int ND = 1 << DB, NS = RI * 4;      // digits, (round, wave) slots
+    constexpr int PARTS = RT / ND, SPP = NS / PARTS;   // prefix step: PARTS lanes per digit, SPP slots each
+    static_assert(ND <= 64 && NS % PARTS == 0, "digit table");
+    __shared__ int tbl[NS * ND];
+    __shared__ int part[PARTS * ND];
+    __shared__ int lbase[ND], gbase[ND];          // start of the digit's run inside the workgroup's 4096 items / in the output
+    __shared__ uint32_t sk[RB], sv[RB];
+    n = live_count(n, n_dev);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int i = tid; i < NS * ND; i += RT) tbl[i] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RB;
+    const int cnt = (int)(n - base < RB ? n - base : RB);
+    uint32_t k[RI], v[RI];
+    unsigned short rk[RI];
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int j = 0; j < RI; ++j) {
+        const int64_t i = base + j * RT + tid;
+        const bool ok = i < n;
+        k[j] = ok ? keys[i] : 0xFFFFFFFFu;
+        v[j] = ok ? vals[i] : 0u;
+        const unsigned d = (k[j] >> shift) & (ND - 1);
+        unsigned long long m = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < DB; ++b) {
+            const unsigned long long bal = __ballot((d >> b) & 1);
+            m &= ((d >> b) & 1) ? bal : ~bal;
+        }
+        rk[j] = (unsigned short)__popcll(m & lt);
+        if (ok && (m & lt) == 0) tbl[(j * 4 + wid) * ND + d] = __popcll(m);
+    }
+    __syncthreads();
+    {   // exclusive prefix over the NS slots of each digit, PARTS lanes per digit
+        const int d = tid % ND, pt = tid / ND;
+        int run = 0;
+#pragma unroll
+        for (int q = 0; q < SPP; ++q) {
+            const int sidx = (pt * SPP + q) * ND + d;
+            const int c = tbl[sidx];
+            tbl[sidx] = run;
+            run += c;
+        }
+        part[pt * ND + d] = run;
+    }
+    __syncthreads();
+    if (tid < 64) {   // one wave: per-digit totals -> run starts (wave scan over the digits)
+        int tot = 0;
+        if (tid < ND)
+            for (int pt = 0; pt < PARTS; ++pt) { const int c = part[pt * ND + tid]; part[pt * ND + tid] = tot; tot += c; }
+        int inc = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(inc, o, 64); if (lane >= o) inc += y; }
+        if (tid < ND) {
+            lbase[tid] = inc - tot;
+            gbase[tid] = offs[(int64_t)tid * nblocks + blockIdx.x] - hist[(int64_t)tid * nblocks + blockIdx.x];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RI; ++j) {
+        if (j * RT + tid < cnt) {
+            const unsigned d = (k[j] >> shift) & (ND - 1);
+            const int sl = j * 4 + wid;
+            const int lp = lbase[d] + part[(sl / SPP) * ND + d] + tbl[sl * ND + d] + rk[j];
+            sk[lp] = k[j];
+            sv[lp] = v[j];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < cnt; i += RT) {
+        const uint32_t kk = sk[i];
+        const unsigned d = (kk >> shift) & (ND - 1);
+        const int pos = gbase[d] + (i - lbase[d]);
+        keys_out[pos] = kk;
+        vals_out[pos] = sv[i];
     }
 }
 
@@ -203,16 +292,22 @@ void set_attr()
     gc::ensure_dynamic_lds(once, (const void *)k_radix_scatter, RI * 4 * 256 * 4);
 }
 
-// one stable 8-bit radix pass
+// one stable radix pass of `dbits` bits (8: the direct scatter; 5 / 6: the LDS-staged scatter of the tile passes)
 int radix_pass(const uint32_t *ki, const uint32_t *vi, uint32_t *ko, uint32_t *vo, int64_t n, const int32_t *n_dev, int shift,
-               const Plan &p, unsigned char *w, hipStream_t s)
+               const Plan &p, unsigned char *w, hipStream_t s, int dbits = 8)
 {
     int32_t *hist = (int32_t *)(w + p.off_hist), *offs = (int32_t *)(w + p.off_offs), *cnt = (int32_t *)(w + p.off_cnt);
-    hipLaunchKernelGGL(k_radix_hist, dim3(p.nb), dim3(RT), 0, s, ki, n, n_dev, shift, p.nb, hist);
-    int rc = gc_raster_scan_tiles(256 * (int64_t)p.nb, hist, offs, cnt, w + p.off_scan, p.scan_bytes, (void *)s);
+    const int nd = 1 << dbits;
+    hipLaunchKernelGGL(k_radix_hist, dim3(p.nb), dim3(RT), 0, s, ki, n, n_dev, shift, (unsigned)(nd - 1), p.nb, hist);
+    int rc = gc_raster_scan_tiles(nd * (int64_t)p.nb, hist, offs, cnt, w + p.off_scan, p.scan_bytes, (void *)s);
     if (rc != GC_OK) return rc;
-    hipLaunchKernelGGL(k_radix_scatter, dim3(p.nb), dim3(RT), (size_t)RI * 4 * 256 * sizeof(int), s, ki, vi, ko, vo, n, n_dev,
-                       shift, p.nb, hist, offs);
+    if (dbits == 5)
+        hipLaunchKernelGGL(k_radix_scatter_staged<5>, dim3(p.nb), dim3(RT), 0, s, ki, vi, ko, vo, n, n_dev, shift, p.nb, hist, offs);
+    else if (dbits == 6)
+        hipLaunchKernelGGL(k_radix_scatter_staged<6>, dim3(p.nb), dim3(RT), 0, s, ki, vi, ko, vo, n, n_dev, shift, p.nb, hist, offs);
+    else
+        hipLaunchKernelGGL(k_radix_scatter, dim3(p.nb), dim3(RT), (size_t)RI * 4 * 256 * sizeof(int), s, ki, vi, ko, vo, n, n_dev,
+                           shift, p.nb, hist, offs);
     return GC_OK;
 }
 
@@ -277,11 +372,16 @@ int bin_tiles_impl(int64_t N, int64_t M, const int32_t *m_dev, int32_t *overflow
     uint32_t *k1 = (uint32_t *)(w + p.off_keys[1]), *v1 = (uint32_t *)(w + p.off_vals[1]);
     hipLaunchKernelGGL(k_emit_sorted, dim3(gc::cdiv(N, 256)), dim3(256), 0, s, N, M, (const uint32_t *)depth_order, xys, radii,
                        cum_sorted, tiles_x, tiles_y, k0, v0);
-    const int passes = num_tiles <= 256 ? 1 : 2;
+    // the tile-id bits are split evenly over two passes (1024 tiles: 5 + 5, 4096: 6 + 6) and scattered through LDS; above 12 bits
+    // (or for a single pass) the 8-bit direct scatter runs
+    int tbits = 1;
+    while ((1 << tbits) < num_tiles) ++tbits;
+    const int passes = tbits <= 6 ? 1 : 2;
+    const int dbits = tbits <= 5 ? 5 : (tbits <= 6 ? 6 : (tbits <= 10 ? 5 : (tbits <= 12 ? 6 : 8)));
     uint32_t *ks = k0, *vs = v0;
     for (int pass = 0; pass < passes; ++pass) {
         uint32_t *ko = ks == k0 ? k1 : k0, *vo = vs == v0 ? v1 : v0;
-        int rc = radix_pass(ks, vs, ko, vo, M, m_dev, 8 * pass, p, w, s);
+        int rc = radix_pass(ks, vs, ko, vo, M, m_dev, dbits * pass, p, w, s, dbits);
         if (rc != GC_OK) return rc;
         ks = ko; vs = vo;
     }
