@@ -217,27 +217,60 @@ __global__ __launch_bounds__(256) void k_gather_tiles(int64_t N, const uint32_t 
     nth_sorted[j] = nth[order[j]];
 }
 
-// emission in depth order: pair (tile id, gaussian id) for every tile of the box of order[j]
+// emission in depth order: pair (tile id, gaussian id) for every tile of the box of order[j].  The 256 Gaussians of a workgroup own ONE
+// contiguous output range [cum[j0-1], cum[j0+255]); their hits are laid out in LDS in output order (windows of EW) and streamed out with
+// consecutive lanes writing consecutive addresses -- a lane walking its own box would issue isolated 4-byte stores (202 us -> see DESIGN).
+constexpr int EW = 4096;
 __global__ __launch_bounds__(256) void k_emit_sorted(int64_t N, int64_t M_cap, const uint32_t *__restrict__ order,
                                                      const float *__restrict__ xys, const int32_t *__restrict__ radii,
                                                      const int32_t *__restrict__ cum_sorted, int tiles_x, int tiles_y,
                                                      uint32_t *__restrict__ tile_keys, uint32_t *__restrict__ gids)
 {
-    int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= N) return;
-    const uint32_t g = order[j];
-    const int r = radii[g];
-    if (r <= 0) return;
-    // same float expressions as the projection kernel / oracle (bit-exact tile box)
-    float tcx = xys[2 * (size_t)g] / (float)TILE, tcy = xys[2 * (size_t)g + 1] / (float)TILE, tr = (float)r / (float)TILE;
-    int minx = clampi((int)(tcx - tr), 0, tiles_x), maxx = clampi((int)(tcx + tr + 1.f), 0, tiles_x);
-    int miny = clampi((int)(tcy - tr), 0, tiles_y), maxy = clampi((int)(tcy + tr + 1.f), 0, tiles_y);
-    int64_t cur = j == 0 ? 0 : cum_sorted[j - 1];
-    for (int ty = miny; ty < maxy; ++ty)
-        for (int tx = minx; tx < maxx; ++tx) {
-            if (cur < M_cap) { tile_keys[cur] = (uint32_t)(ty * tiles_x + tx); gids[cur] = g; }
-            ++cur;
+    __shared__ uint32_t sT[EW], sG[EW];
+    __shared__ int64_t sRange[2];
+    const int tid = threadIdx.x;
+    const int64_t j0 = (int64_t)blockIdx.x * 256, j = j0 + tid;
+    if (tid == 0) {
+        const int64_t jl = j0 + 255 < N ? j0 + 255 : N - 1;
+        sRange[0] = j0 == 0 ? 0 : cum_sorted[j0 - 1];
+        sRange[1] = cum_sorted[jl];
+    }
+    uint32_t g = 0;
+    int minx = 0, w = 0, miny = 0;
+    int64_t lo = 0, hi = 0;                       // this Gaussian's output range
+    if (j < N) {
+        g = order[j];
+        const int r = radii[g];
+        if (r > 0) {
+            // same float expressions as the projection kernel / oracle (bit-exact tile box)
+            const float tcx = xys[2 * (size_t)g] / (float)TILE, tcy = xys[2 * (size_t)g + 1] / (float)TILE, tr = (float)r / (float)TILE;
+            minx = clampi((int)(tcx - tr), 0, tiles_x);
+            const int maxx = clampi((int)(tcx + tr + 1.f), 0, tiles_x);
+            miny = clampi((int)(tcy - tr), 0, tiles_y);
+            const int maxy = clampi((int)(tcy + tr + 1.f), 0, tiles_y);
+            w = maxx - minx;
+            lo = j == 0 ? 0 : cum_sorted[j - 1];
+            hi = lo + (int64_t)w * (maxy - miny);
         }
+    }
+    __syncthreads();
+    const int64_t base = sRange[0], total = sRange[1] - base;
+    const float rw = w > 0 ? 1.f / (float)w : 0.f;
+    for (int64_t win = 0; win < total; win += EW) {
+        const int64_t w0 = base + win, w1 = w0 + EW;
+        const int64_t a = lo > w0 ? lo : w0, b = hi < w1 ? hi : w1;
+        for (int64_t h = a; h < b; ++h) {
+            const int i = (int)(h - lo);
+            const int q = (int)(((float)i + 0.5f) * rw);            // i / w (exact: i < 2^16 tiles)
+            sT[h - w0] = (uint32_t)((miny + q) * tiles_x + minx + (i - q * w));
+            sG[h - w0] = g;
+        }
+        __syncthreads();
+        const int64_t cnt = total - win < EW ? total - win : EW;
+        for (int64_t i = tid; i < cnt; i += 256)
+            if (w0 + i < M_cap) { tile_keys[w0 + i] = sT[i]; gids[w0 + i] = sG[i]; }
+        __syncthreads();
+    }
 }
 
 __global__ __launch_bounds__(256) void k_tile_bins32(int64_t M, const int32_t *__restrict__ m_dev, int32_t *__restrict__ overflow,
@@ -250,9 +283,11 @@ __global__ __launch_bounds__(256) void k_tile_bins32(int64_t M, const int32_t *_
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= M) return;
     const int t = (int)tkeys[i];
-    const uint32_t g = gids[i];
-    if (ids_out) ids_out[i] = (int32_t)g;
-    if (keys64) keys64[i] = ((int64_t)t << 32) | (int64_t)__float_as_uint(depths[g]);
+    if (ids_out || keys64) {            // the last radix pass normally writes the ids straight into gaussian_ids_sorted (ids_out == NULL)
+        const uint32_t g = gids[i];
+        if (ids_out) ids_out[i] = (int32_t)g;
+        if (keys64) keys64[i] = ((int64_t)t << 32) | (int64_t)__float_as_uint(depths[g]);
+    }
     if (i == 0) bins[2 * t] = 0;
     else {
         const int tp = (int)tkeys[i - 1];
@@ -380,13 +415,13 @@ int bin_tiles_impl(int64_t N, int64_t M, const int32_t *m_dev, int32_t *overflow
     const int dbits = tbits <= 5 ? 5 : (tbits <= 6 ? 6 : (tbits <= 10 ? 5 : (tbits <= 12 ? 6 : 8)));
     uint32_t *ks = k0, *vs = v0;
     for (int pass = 0; pass < passes; ++pass) {
-        uint32_t *ko = ks == k0 ? k1 : k0, *vo = vs == v0 ? v1 : v0;
+        uint32_t *ko = ks == k0 ? k1 : k0, *vo = pass == passes - 1 ? (uint32_t *)gaussian_ids_sorted : (vs == v0 ? v1 : v0);
         int rc = radix_pass(ks, vs, ko, vo, M, m_dev, dbits * pass, p, w, s, dbits);
         if (rc != GC_OK) return rc;
         ks = ko; vs = vo;
     }
     hipLaunchKernelGGL(k_tile_bins32, dim3(gc::cdiv(M, 256)), dim3(256), 0, s, M, m_dev, overflow_dev, num_tiles, ks, vs, depths,
-                       tile_bins, isect_ids_sorted, gaussian_ids_sorted);
+                       tile_bins, isect_ids_sorted, (int32_t *)nullptr);
     return gc::check_launch(what);
 }
 }  // namespace
