@@ -39,6 +39,8 @@ __device__ __forceinline__ int64_t live_count(int64_t n, const int32_t *n_dev)
     return m < n ? m : n;
 }
 
+// PAIR: keys points at (key, value) uint2 pairs -- the depth passes keep the pair together so that a scattered item is ONE 8-byte store
+template <bool PAIR>
 __global__ __launch_bounds__(RT) void k_radix_hist(const uint32_t *__restrict__ keys, int64_t n, const int32_t *__restrict__ n_dev,
                                                    int shift, unsigned dmask, int nblocks, int32_t *__restrict__ hist /* [digits][nblocks] */)
 {
@@ -50,13 +52,14 @@ __global__ __launch_bounds__(RT) void k_radix_hist(const uint32_t *__restrict__ 
 #pragma unroll
     for (int j = 0; j < RI; ++j) {
         const int64_t i = base + j * RT + threadIdx.x;
-        if (i < n) atomicAdd(&h[(keys[i] >> shift) & dmask], 1);
+        if (i < n) atomicAdd(&h[((PAIR ? keys[2 * i] : keys[i]) >> shift) & dmask], 1);
     }
     __syncthreads();
     if (threadIdx.x <= dmask) hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
 // offs = INCLUSIVE scan of hist ([digit][block] flattened); exclusive offset of (d, b) = offs[d*nb + b] - hist[d*nb + b]
+template <bool PAIR>
 __global__ __launch_bounds__(RT) void k_radix_scatter(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
                                                       uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int64_t n,
                                                       const int32_t *__restrict__ n_dev, int shift, int nblocks,
@@ -75,8 +78,13 @@ __global__ __launch_bounds__(RT) void k_radix_scatter(const uint32_t *__restrict
     for (int j = 0; j < RI; ++j) {
         const int64_t i = base + j * RT + tid;
         const bool ok = i < n;
-        k[j] = ok ? keys[i] : 0xFFFFFFFFu;
-        v[j] = ok ? vals[i] : 0u;
+        if (PAIR) {
+            const uint2 kv = ok ? reinterpret_cast<const uint2 *>(keys)[i] : make_uint2(0xFFFFFFFFu, 0u);
+            k[j] = kv.x; v[j] = kv.y;
+        } else {
+            k[j] = ok ? keys[i] : 0xFFFFFFFFu;
+            v[j] = ok ? vals[i] : 0u;
+        }
         const unsigned d = (k[j] >> shift) & 255;
         unsigned long long m = __ballot(ok);
 #pragma unroll
@@ -105,8 +113,13 @@ __global__ __launch_bounds__(RT) void k_radix_scatter(const uint32_t *__restrict
         if (i < n) {
             const unsigned d = (k[j] >> shift) & 255;
             const int pos = tbl[(j * 4 + wid) * 256 + d] + rk[j];
-            keys_out[pos] = k[j];
-            vals_out[pos] = v[j];
+            if (PAIR) {       // keys_out == NULL: last pass, only the values are still needed
+                if (keys_out) reinterpret_cast<uint2 *>(keys_out)[pos] = make_uint2(k[j], v[j]);
+                else vals_out[pos] = v[j];
+            } else {
+                keys_out[pos] = k[j];
+                vals_out[pos] = v[j];
+            }
         }
     }
 }
@@ -201,12 +214,11 @@ __global__ __launch_bounds__(RT) void k_radix_scatter_staged(const uint32_t *__r
 }
 
 __global__ __launch_bounds__(256) void k_depth_keys(int64_t N, const float *__restrict__ depths, const int32_t *__restrict__ radii,
-                                                    uint32_t *__restrict__ keys, uint32_t *__restrict__ ids)
+                                                    uint2 *__restrict__ pairs)
 {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
-    keys[i] = radii[i] > 0 ? __float_as_uint(depths[i]) : 0xFFFFFFFFu;
-    ids[i] = (uint32_t)i;
+    pairs[i] = make_uint2(radii[i] > 0 ? __float_as_uint(depths[i]) : 0xFFFFFFFFu, (uint32_t)i);
 }
 
 __global__ __launch_bounds__(256) void k_gather_tiles(int64_t N, const uint32_t *__restrict__ order, const int32_t *__restrict__ nth,
@@ -324,24 +336,30 @@ Plan make_plan(int64_t n)
 void set_attr()
 {
     static gc::AttrOnce once;
-    gc::ensure_dynamic_lds(once, (const void *)k_radix_scatter, RI * 4 * 256 * 4);
+    gc::ensure_dynamic_lds(once, (const void *)k_radix_scatter<false>, RI * 4 * 256 * 4);
+    static gc::AttrOnce once_p;
+    gc::ensure_dynamic_lds(once_p, (const void *)k_radix_scatter<true>, RI * 4 * 256 * 4);
 }
 
 // one stable radix pass of `dbits` bits (8: the direct scatter; 5 / 6: the LDS-staged scatter of the tile passes)
 int radix_pass(const uint32_t *ki, const uint32_t *vi, uint32_t *ko, uint32_t *vo, int64_t n, const int32_t *n_dev, int shift,
-               const Plan &p, unsigned char *w, hipStream_t s, int dbits = 8)
+               const Plan &p, unsigned char *w, hipStream_t s, int dbits = 8, bool pair = false)
 {
     int32_t *hist = (int32_t *)(w + p.off_hist), *offs = (int32_t *)(w + p.off_offs), *cnt = (int32_t *)(w + p.off_cnt);
     const int nd = 1 << dbits;
-    hipLaunchKernelGGL(k_radix_hist, dim3(p.nb), dim3(RT), 0, s, ki, n, n_dev, shift, (unsigned)(nd - 1), p.nb, hist);
+    if (pair) hipLaunchKernelGGL(k_radix_hist<true>, dim3(p.nb), dim3(RT), 0, s, ki, n, n_dev, shift, (unsigned)(nd - 1), p.nb, hist);
+    else hipLaunchKernelGGL(k_radix_hist<false>, dim3(p.nb), dim3(RT), 0, s, ki, n, n_dev, shift, (unsigned)(nd - 1), p.nb, hist);
     int rc = gc_raster_scan_tiles(nd * (int64_t)p.nb, hist, offs, cnt, w + p.off_scan, p.scan_bytes, (void *)s);
     if (rc != GC_OK) return rc;
     if (dbits == 5)
         hipLaunchKernelGGL(k_radix_scatter_staged<5>, dim3(p.nb), dim3(RT), 0, s, ki, vi, ko, vo, n, n_dev, shift, p.nb, hist, offs);
     else if (dbits == 6)
         hipLaunchKernelGGL(k_radix_scatter_staged<6>, dim3(p.nb), dim3(RT), 0, s, ki, vi, ko, vo, n, n_dev, shift, p.nb, hist, offs);
+    else if (pair)
+        hipLaunchKernelGGL(k_radix_scatter<true>, dim3(p.nb), dim3(RT), (size_t)RI * 4 * 256 * sizeof(int), s, ki, vi, ko, vo, n, n_dev,
+                           shift, p.nb, hist, offs);
     else
-        hipLaunchKernelGGL(k_radix_scatter, dim3(p.nb), dim3(RT), (size_t)RI * 4 * 256 * sizeof(int), s, ki, vi, ko, vo, n, n_dev,
+        hipLaunchKernelGGL(k_radix_scatter<false>, dim3(p.nb), dim3(RT), (size_t)RI * 4 * 256 * sizeof(int), s, ki, vi, ko, vo, n, n_dev,
                            shift, p.nb, hist, offs);
     return GC_OK;
 }
@@ -366,15 +384,15 @@ int gc_raster_depth_order(int64_t N, const float *depths, const int32_t *radii, 
     if (workspace_bytes < gc_raster_depth_order_workspace_bytes(N)) { gc::set_error("gc_raster_depth_order: workspace too small"); return GC_ENOSPC; }
     set_attr();
     unsigned char *w = (unsigned char *)workspace;
-    uint32_t *k0 = (uint32_t *)(w + p.off_keys[0]), *v0 = (uint32_t *)(w + p.off_vals[0]);
-    uint32_t *k1 = (uint32_t *)(w + p.off_keys[1]), *v1 = (uint32_t *)(w + p.off_vals[1]);
+    uint32_t *k0 = (uint32_t *)(w + p.off_keys[0]), *k1 = (uint32_t *)(w + p.off_keys[1]);
     int32_t *nth_s = (int32_t *)(w + p.total);
-    hipLaunchKernelGGL(k_depth_keys, dim3(gc::cdiv(N, 256)), dim3(256), 0, s, N, depths, radii, k0, v0);
+    // (key, id) pairs ping-pong between the two halves of the workspace (each half = the keys + vals regions of the plan, >= 8 N bytes)
+    uint32_t *pa = k0, *pb = k1;
+    hipLaunchKernelGGL(k_depth_keys, dim3(gc::cdiv(N, 256)), dim3(256), 0, s, N, depths, radii, (uint2 *)pa);
     for (int pass = 0; pass < 4; ++pass) {   // visible depths are > 0: the float bit pattern is monotone
-        const bool odd = pass & 1;
-        uint32_t *vo = pass == 3 ? (uint32_t *)depth_order : (odd ? v0 : v1);
-        int rc = radix_pass(odd ? k1 : k0, odd ? v1 : v0, odd ? k0 : k1, vo, N, nullptr, 8 * pass, p, w, s);
+        int rc = radix_pass(pa, nullptr, pass == 3 ? nullptr : pb, (uint32_t *)depth_order, N, nullptr, 8 * pass, p, w, s, 8, true);
         if (rc != GC_OK) return rc;
+        uint32_t *t = pa; pa = pb; pb = t;
     }
     hipLaunchKernelGGL(k_gather_tiles, dim3(gc::cdiv(N, 256)), dim3(256), 0, s, N, (const uint32_t *)depth_order, num_tiles_hit, nth_s);
     int rc = gc_raster_scan_tiles(N, nth_s, cum_sorted, count_dev, w + p.off_scan, p.scan_bytes, (void *)s);
