@@ -20,7 +20,8 @@ os.environ["TMPDIR"] = "/tmp"
 STAGE = [  # kernel-name regex -> bench.py stage
     (r"k_project_sh_fwd", "gc_project_sh_fwd"), (r"k_project_sh_bwd", "gc_project_sh_bwd"),
     (r"k_rasterize_fwd", "gc_rasterize_fwd"), (r"k_rasterize_bwd", "gc_rasterize_bwd"),
-    (r"k_depth_keys|k_radix_hist|k_radix_scatter|k_gather_tiles|k_emit_sorted|k_tile_bins|k_scan_|k_count", "binning"),
+    (r"k_depth_keys|k_radix_hist<true>|k_radix_scatter<true>|k_gather_tiles|k_scan_", "gc_raster_depth_order"),
+    (r"k_radix_hist<false>|k_radix_scatter|k_emit_sorted|k_tile_bins", "gc_raster_bin_tiles_dev"),
     (r"k_ssim|k_raster_finalize", "loss+finalize"),
     (r"k_calib_copy<.*4u>", "calib16"), (r"k_calib_copy<.*f3>", "calib12"),
     (r"k_calib_copy<.*2u>", "calib8"), (r"k_calib_copy<float>", "calib4"),
@@ -49,7 +50,21 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
                 break
     raw[counter] = {"calib_bytes": calib_bytes, "sum": {k: v[0] for k, v in acc.items()}, "dispatches": {k: v[1] for k, v in acc.items()},
                     "kernels": {f"{a}: {b}": c for (a, b), c in names.items()}, "stdout_tail": r.stdout[-300:]}
-out = {"_detail": raw, "_note": "counter unit: KB as reported by rocprofv3; corrected = counter * (known bytes / counter) of the calibration "
-                                 "copy with the kernel's dominant access width (see DESIGN.md 4)"}
+# per-view corrected traffic: each counter is scaled by (known bytes / counted bytes) of the 16 B/lane calibration copy of the same pass
+# (gfx950: FETCH_SIZE counts half the bytes of every width tried, WRITE_SIZE is exact; the factors are re-measured here, not assumed)
+per_view = {}
+corr = {}
+for counter, r in raw.items():
+    cal = r["sum"].get("calib16", 0.0) * 1024.0
+    corr[counter] = (2.0 * r["calib_bytes"] / cal) if cal else None          # two calibration dispatches of calib_bytes each
+    for st, v in r["sum"].items():
+        if st.startswith("calib") or corr[counter] is None:
+            continue
+        per_view.setdefault(st, {})[counter] = v * 1024.0 * corr[counter] / views / 1e6
+table = {st: round(sum(c.values()), 1) for st, c in per_view.items() if len(c) == 2}
+out = {str(N): table, "_per_counter_MB_per_view": {st: {k: round(x, 1) for k, x in c.items()} for st, c in per_view.items()},
+       "_correction": corr, "_views": views, "_detail": raw,
+       "_note": "MB per view = FETCH_SIZE + WRITE_SIZE (KB as reported by rocprofv3, separate passes), each scaled by the calibration "
+                "factor measured in the same pass on a 768 MiB copy (see DESIGN.md 4)"}
 json.dump(out, open(outp, "w"), indent=1)
 print(json.dumps(out, indent=1)[:6000])
