@@ -121,6 +121,9 @@ class DenoisePipeline:
                     down, mid = self.controlnet.forward(xin, t, ctx, cemb, a_cn, self.cn_scale)
                 x, skips, temb = self.unet.encode(xin, t, ctx, a_un)
                 main.wait_stream(side)
+                # (the join also publishes everything the side stream cached in this step -- text K / V^T, time-embedding rows --
+                # on `main`: a caller that later switches streams and orders the new one after `main`, the usual torch contract,
+                # is ordered after those writes too; nothing produced on `side` is ever consumed before a join)
                 eps = self.unet.decode(x, skips, temb, ctx, down, mid, a_un)
             else:
                 down, mid = self.controlnet.forward(xin, t, ctx, cemb, a_cn, self.cn_scale)
