@@ -39,6 +39,60 @@ __device__ __forceinline__ int64_t live_count(int64_t n, const int32_t *n_dev)
     return m < n ? m : n;
 }
 
+// Scan of a radix pass's [digit][workgroup] table in ONE launch: every workgroup scans its 2048 entries and publishes its total; the last
+// one to arrive (ticket) turns the totals into exclusive offsets in place.  Consumers add sums[entry / 2048] themselves -- the generic
+// three-kernel scan (local / sums / add, raster_bin.hip) costs three launches of 5-8 us for a 1 MB table, seven times per view.
+constexpr int TS_CHUNK = 2048;
+__device__ __forceinline__ int block_incl_scan256(int v, int *total, int *wsum /* LDS[4] */)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int sc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(sc, d, 64); if (lane >= d) sc += y; }
+    __syncthreads();
+    if (lane == 63) wsum[wid] = sc;
+    __syncthreads();
+    int off = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) if (w < wid) off += wsum[w];
+    *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    return sc + off;
+}
+
+__global__ __launch_bounds__(256) void k_table_scan(int64_t n, const int32_t *__restrict__ in, int32_t *__restrict__ out,
+                                                    int32_t *sums, int32_t *ticket)
+{
+    __shared__ int wsum[4];
+    __shared__ int s_last;
+    const int tid = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * TS_CHUNK + (int64_t)tid * 8;
+    int v[8], run = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const int64_t i = base + k; run += i < n ? in[i] : 0; v[k] = run; }
+    int total;
+    const int excl = block_incl_scan256(run, &total, wsum) - run;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const int64_t i = base + k; if (i < n) out[i] = v[k] + excl; }
+    if (tid == 0) {
+        __hip_atomic_store(&sums[blockIdx.x], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        s_last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    int carry = 0;
+    for (int b0 = 0; b0 < (int)gridDim.x; b0 += 256) {
+        const int i = b0 + tid;
+        const int x = i < (int)gridDim.x ? __hip_atomic_load(&sums[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        int tot;
+        const int incl = block_incl_scan256(x, &tot, wsum);
+        if (i < (int)gridDim.x) sums[i] = carry + incl - x;
+        carry += tot;
+    }
+    if (tid == 0) *ticket = 0;         // ready for the next pass
+}
+
 // PAIR: keys points at (key, value) uint2 pairs -- the depth passes keep the pair together so that a scattered item is ONE 8-byte store
 template <bool PAIR>
 __global__ __launch_bounds__(RT) void k_radix_hist(const uint32_t *__restrict__ keys, int64_t n, const int32_t *__restrict__ n_dev,
@@ -63,7 +117,8 @@ template <bool PAIR>
 __global__ __launch_bounds__(RT) void k_radix_scatter(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
                                                       uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int64_t n,
                                                       const int32_t *__restrict__ n_dev, int shift, int nblocks,
-                                                      const int32_t *__restrict__ hist, const int32_t *__restrict__ offs)
+                                                      const int32_t *__restrict__ hist, const int32_t *__restrict__ offs,
+                                                      const int32_t *__restrict__ sums)
 {
     n = live_count(n, n_dev);
     extern __shared__ int tbl[];   // [RI*4][256]
@@ -98,7 +153,8 @@ __global__ __launch_bounds__(RT) void k_radix_scatter(const uint32_t *__restrict
     __syncthreads();
     {   // lane d: exclusive prefix over the 64 (round, wave) slots of digit d, seeded with the global offset
         const int d = tid;
-        int run = offs[(int64_t)d * nblocks + blockIdx.x] - hist[(int64_t)d * nblocks + blockIdx.x];
+        const int64_t e = (int64_t)d * nblocks + blockIdx.x;
+        int run = offs[e] + sums[e / TS_CHUNK] - hist[e];
 #pragma unroll 8
         for (int s = 0; s < RI * 4; ++s) {
             const int c = tbl[s * 256 + d];
@@ -132,7 +188,8 @@ template <int DB>
 __global__ __launch_bounds__(RT) void k_radix_scatter_staged(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
                                                              uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int64_t n,
                                                              const int32_t *__restrict__ n_dev, int shift, int nblocks,
-                                                             const int32_t *__restrict__ hist, const int32_t *__restrict__ offs)
+                                                             const int32_t *__restrict__ hist, const int32_t *__restrict__ offs,
+                                                             const int32_t *__restrict__ sums)
 {
     constexpr int ND = 1 << DB, NS = RI * 4;      // digits, (round, wave) slots
     constexpr int PARTS = RT / ND, SPP = NS / PARTS;   // prefix step: PARTS lanes per digit, SPP slots each
@@ -189,7 +246,8 @@ __global__ __launch_bounds__(RT) void k_radix_scatter_staged(const uint32_t *__r
         for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(inc, o, 64); if (lane >= o) inc += y; }
         if (tid < ND) {
             lbase[tid] = inc - tot;
-            gbase[tid] = offs[(int64_t)tid * nblocks + blockIdx.x] - hist[(int64_t)tid * nblocks + blockIdx.x];
+            const int64_t e = (int64_t)tid * nblocks + blockIdx.x;
+            gbase[tid] = offs[e] + sums[e / TS_CHUNK] - hist[e];
         }
     }
     __syncthreads();
@@ -349,18 +407,20 @@ int radix_pass(const uint32_t *ki, const uint32_t *vi, uint32_t *ko, uint32_t *v
     const int nd = 1 << dbits;
     if (pair) hipLaunchKernelGGL(k_radix_hist<true>, dim3(p.nb), dim3(RT), 0, s, ki, n, n_dev, shift, (unsigned)(nd - 1), p.nb, hist);
     else hipLaunchKernelGGL(k_radix_hist<false>, dim3(p.nb), dim3(RT), 0, s, ki, n, n_dev, shift, (unsigned)(nd - 1), p.nb, hist);
-    int rc = gc_raster_scan_tiles(nd * (int64_t)p.nb, hist, offs, cnt, w + p.off_scan, p.scan_bytes, (void *)s);
-    if (rc != GC_OK) return rc;
+    // cnt[0] is the scan's ticket (zeroed once per phase, self-resetting); the scan scratch holds the per-2048-entry offsets
+    int32_t *sums = (int32_t *)(w + p.off_scan);
+    const int64_t ne = nd * (int64_t)p.nb;
+    hipLaunchKernelGGL(k_table_scan, dim3((unsigned)((ne + TS_CHUNK - 1) / TS_CHUNK)), dim3(256), 0, s, ne, hist, offs, sums, cnt);
     if (dbits == 5)
-        hipLaunchKernelGGL(k_radix_scatter_staged<5>, dim3(p.nb), dim3(RT), 0, s, ki, vi, ko, vo, n, n_dev, shift, p.nb, hist, offs);
+        hipLaunchKernelGGL(k_radix_scatter_staged<5>, dim3(p.nb), dim3(RT), 0, s, ki, vi, ko, vo, n, n_dev, shift, p.nb, hist, offs, sums);
     else if (dbits == 6)
-        hipLaunchKernelGGL(k_radix_scatter_staged<6>, dim3(p.nb), dim3(RT), 0, s, ki, vi, ko, vo, n, n_dev, shift, p.nb, hist, offs);
+        hipLaunchKernelGGL(k_radix_scatter_staged<6>, dim3(p.nb), dim3(RT), 0, s, ki, vi, ko, vo, n, n_dev, shift, p.nb, hist, offs, sums);
     else if (pair)
         hipLaunchKernelGGL(k_radix_scatter<true>, dim3(p.nb), dim3(RT), (size_t)RI * 4 * 256 * sizeof(int), s, ki, vi, ko, vo, n, n_dev,
-                           shift, p.nb, hist, offs);
+                           shift, p.nb, hist, offs, sums);
     else
         hipLaunchKernelGGL(k_radix_scatter<false>, dim3(p.nb), dim3(RT), (size_t)RI * 4 * 256 * sizeof(int), s, ki, vi, ko, vo, n, n_dev,
-                           shift, p.nb, hist, offs);
+                           shift, p.nb, hist, offs, sums);
     return GC_OK;
 }
 
@@ -388,6 +448,7 @@ int gc_raster_depth_order(int64_t N, const float *depths, const int32_t *radii, 
     int32_t *nth_s = (int32_t *)(w + p.total);
     // (key, id) pairs ping-pong between the two halves of the workspace (each half = the keys + vals regions of the plan, >= 8 N bytes)
     uint32_t *pa = k0, *pb = k1;
+    if (hipMemsetAsync(w + p.off_cnt, 0, 4, s) != hipSuccess) return GC_ELAUNCH;          // ticket of k_table_scan
     hipLaunchKernelGGL(k_depth_keys, dim3(gc::cdiv(N, 256)), dim3(256), 0, s, N, depths, radii, (uint2 *)pa);
     for (int pass = 0; pass < 4; ++pass) {   // visible depths are > 0: the float bit pattern is monotone
         int rc = radix_pass(pa, nullptr, pass == 3 ? nullptr : pb, (uint32_t *)depth_order, N, nullptr, 8 * pass, p, w, s, 8, true);
@@ -423,6 +484,7 @@ int bin_tiles_impl(int64_t N, int64_t M, const int32_t *m_dev, int32_t *overflow
     unsigned char *w = (unsigned char *)workspace;
     uint32_t *k0 = (uint32_t *)(w + p.off_keys[0]), *v0 = (uint32_t *)(w + p.off_vals[0]);
     uint32_t *k1 = (uint32_t *)(w + p.off_keys[1]), *v1 = (uint32_t *)(w + p.off_vals[1]);
+    if (hipMemsetAsync(w + p.off_cnt, 0, 4, s) != hipSuccess) return GC_ELAUNCH;          // ticket of k_table_scan
     hipLaunchKernelGGL(k_emit_sorted, dim3(gc::cdiv(N, 256)), dim3(256), 0, s, N, M, (const uint32_t *)depth_order, xys, radii,
                        cum_sorted, tiles_x, tiles_y, k0, v0);
     // the tile-id bits are split evenly over two passes (1024 tiles: 5 + 5, 4096: 6 + 6) and scattered through LDS; above 12 bits
