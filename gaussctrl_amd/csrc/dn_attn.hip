@@ -738,8 +738,10 @@ __global__ __launch_bounds__(256, 2) void k_attn3(const AttnArgs a)
 // are eight CONSECUTIVE keys (V^T fragment = one ds_read_b128).
 __device__ __forceinline__ int swz4(int row) { return ((row >> 1) ^ (row << 1) ^ (row << 2)) & 7; }   // conflict-free for both tiles (search: scripts/lds_swizzle_search.py)
 
-template <class T, int D, int NST, int NW, bool RAG, bool PRE, int PF = 3>
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_attn4(const AttnArgs a)
+// QB: 32-query blocks per wave.  QB = 2 is the one-wave-per-SIMD form (512 registers): every K / V^T fragment read from LDS feeds two
+// MFMAs and the workgroup streams K / V^T once for 256 queries -- half the LDS fragment traffic, LDS-DMA and barriers per unit of work.
+template <class T, int D, int NST, int NW, bool RAG, bool PRE, int PF = 3, int QB = 1>
+__global__ __launch_bounds__(NW * 64, NW == 4 && QB == 1 ? 2 : 1) void k_attn4(const AttnArgs a)
 {
     static_assert(D % 8 == 0 && D % 16 != 0, "needs two spare contraction columns inside the 16-column padding");
     constexpr int DP = (D + 15) / 16 * 16, KS = DP / 16;                   // contraction length of QK^T, k-steps
@@ -761,7 +763,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_attn4(const AttnAr
     const int qi = lane & 31, hg = lane >> 5;
     int qblk, h, b;
     block_coords(a, 2, qblk, h, b);
-    const int q_wave0 = (qblk * NW + wid) * 32;
+    const int q_wave0 = (qblk * NW + wid) * (32 * QB);
     const int ntiles = (a.Lk + 63) / 64;
     const int nsteps = a.nsets * ntiles;
 
@@ -775,20 +777,22 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_attn4(const AttnAr
     for (int i = tid; i < NST * 64; i += NT) reinterpret_cast<unsigned short *>(sV + (i >> 6) * VBYTES + D * 128)[i & 63] = One<T>::v;
 
     // ---- Q fragments (B operand): lane holds Q[q = qi][d = 16 ks + 8 hg .. +8]
-    uint4 qf[KS];
-    {
-        const int q = q_wave0 + qi;
+    uint4 qf[QB][KS];
+    float moff[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int q = q_wave0 + 32 * qb + qi;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int d = ks * 16 + hg * 8;
-            qf[ks] = (q < a.Lq && d + 8 <= D)
-                         ? *reinterpret_cast<const uint4 *>(a.Q + (int64_t)b * a.q_bs + (int64_t)q * a.ldq + h * D + d)
-                         : make_uint4(0, 0, 0, 0);
+            qf[qb][ks] = (q < a.Lq && d + 8 <= D)
+                             ? *reinterpret_cast<const uint4 *>(a.Q + (int64_t)b * a.q_bs + (int64_t)q * a.ldq + h * D + d)
+                             : make_uint4(0, 0, 0, 0);
         }
+        moff[qb] = 0.f;
+        if (hg == HS) qf[qb][KSS].x = pack2<T>(0.f, -BIG);
     }
     const float c2 = a.scale_log2e;
-    float moff = 0.f;
-    if (hg == HS) qf[KSS].x = pack2<T>(0.f, -BIG);
 
     // ---- LDS-DMA plan of this lane (as k_attn3, 8 chunk slots per key row)
     int k_off[KI], k_row[KI];
@@ -877,18 +881,21 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_attn4(const AttnAr
         for (int t = 0; t < 4; ++t) vfo[t] = qi * 128 + (((2 * t + hg) ^ swz4(qi)) << 4);
     }
 
-    f32x16 otot[DB], os[DB];
+    f32x16 otot[QB][DB], os[QB][DB];
 #pragma unroll
-    for (int db = 0; db < DB; ++db)
+    for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { otot[db][r] = 0.f; os[db][r] = 0.f; }
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { otot[qb][db][r] = 0.f; os[qb][db][r] = 0.f; }
     int bad = 0;
 
-    constexpr int NQ = 2 * KS, NPV = 4 * DB, NM = NQ + NPV, NU = 16;       // QK MFMAs, PV MFMAs, exp units (2 v_exp + 1 cvt_pk) per step
-    constexpr int NG = NM - DB;                                           // MFMA gaps that carry exp units (the last k-step's P V needs all of them)
+    constexpr int NKF = 2 * KS, NVF = 4 * DB;                              // K / V^T fragments per step (each feeds QB MFMAs)
+    constexpr int NQ = NKF * QB, NPV = NVF * QB, NM = NQ + NPV, NU = 16 * QB;   // QK MFMAs, PV MFMAs, exp units (2 v_exp + 1 cvt_pk)
+    constexpr int NG = NM - DB * QB;                                      // MFMA gaps that carry exp units (the last k-step's P V needs all of them)
 
     const unsigned char *rk = sK + (NST > 1 ? KBYTES : 0), *rv = sV;
-    auto body = [&](f32x16(&cur)[2], f32x16(&nxt)[2], auto first_tag) __attribute__((always_inline)) {
+    auto body = [&](f32x16(&cur)[QB][2], f32x16(&nxt)[QB][2], auto first_tag) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_tag)::value;
         wait_vmcnt<(PD - 1) * GRP>();          // K(i+1), V(i) (and everything older) have landed for this wave
         __builtin_amdgcn_s_barrier();          // ... for every wave; every wave is done with step i-1's buffers
@@ -898,26 +905,29 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_attn4(const AttnAr
         rk = rk + KBYTES == sK + NST * KBYTES ? sK : rk + KBYTES;
         rv = rv + VBYTES == sV + NST * VBYTES ? sV : rv + VBYTES;
         if (FIRST) {      // first tile of a K/V set: its row maximum becomes the set's offset (cur still carries the previous one)
-            float t = fmaxf(fmaxf(cur[0][0], cur[0][1]), cur[0][2]);
 #pragma unroll
-            for (int r = 3; r + 1 < 16; r += 2) t = fmaxf(fmaxf(t, cur[0][r]), cur[0][r + 1]);
-            t = fmaxf(fmaxf(t, cur[0][15]), cur[1][0]);
+            for (int qb = 0; qb < QB; ++qb) {
+                float t = fmaxf(fmaxf(cur[qb][0][0], cur[qb][0][1]), cur[qb][0][2]);
 #pragma unroll
-            for (int r = 1; r + 1 < 16; r += 2) t = fmaxf(fmaxf(t, cur[1][r]), cur[1][r + 1]);
-            t = fmaxf(t, cur[1][15]);
-            const unsigned x = __float_as_uint(t);
-            const auto r1 = __builtin_amdgcn_permlane32_swap(x, x, false, false);
-            t = fmaxf(__uint_as_float(r1[0]), __uint_as_float(r1[1]));
-            const float mq = T::to_f(T::from_f(moff + t));
-            const float dlt = mq - moff;
+                for (int r = 3; r + 1 < 16; r += 2) t = fmaxf(fmaxf(t, cur[qb][0][r]), cur[qb][0][r + 1]);
+                t = fmaxf(fmaxf(t, cur[qb][0][15]), cur[qb][1][0]);
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+                for (int r = 1; r + 1 < 16; r += 2) t = fmaxf(fmaxf(t, cur[qb][1][r]), cur[qb][1][r + 1]);
+                t = fmaxf(t, cur[qb][1][15]);
+                const unsigned x = __float_as_uint(t);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+                t = fmaxf(__uint_as_float(r1[0]), __uint_as_float(r1[1]));
+                const float mq = T::to_f(T::from_f(moff[qb] + t));
+                const float dlt = mq - moff[qb];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) cur[kb][r] -= dlt;
-            moff = mq;
-            if (hg == HS) qf[KSS].x = pack2<T>(-mq, -BIG);
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cur[qb][kb][r] -= dlt;
+                moff[qb] = mq;
+                if (hg == HS) qf[qb][KSS].x = pack2<T>(-mq, -BIG);
+            }
         }
-        uint4 pf[4], kf[NQ], vf[NPV];
+        uint4 pf[QB][4], kf[NKF], vf[NVF];
         auto rd_k = [&](int n) __attribute__((always_inline)) {       // n = ks * 2 + kb
             const int ks = n >> 1, kb = n & 1;
             kf[n] = *reinterpret_cast<const uint4 *>(kb_ + kfo[ks] + kb * 4096);
@@ -926,35 +936,35 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_attn4(const AttnAr
             const int t = n / DB, db = n - t * DB;
             vf[n] = *reinterpret_cast<const uint4 *>(vb_ + vfo[t] + db * 4096);
         };
-        auto mma_qk = [&](int n) __attribute__((always_inline)) {
-            const int ks = n >> 1, kb = n & 1;
+        auto mma_qk = [&](int m) __attribute__((always_inline)) {     // m = fragment * QB + query block
+            const int n = m / QB, qb = m - n * QB, ks = n >> 1, kb = n & 1;
             if (ks == 0) {
                 f32x16 z;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) z[r] = 0.f;
-                nxt[kb] = T::mfma32(kf[n], qf[ks], z);
-            } else nxt[kb] = T::mfma32(kf[n], qf[ks], nxt[kb]);
+                nxt[qb][kb] = T::mfma32(kf[n], qf[qb][ks], z);
+            } else nxt[qb][kb] = T::mfma32(kf[n], qf[qb][ks], nxt[qb][kb]);
         };
-        auto mma_pv = [&](int n) __attribute__((always_inline)) {
-            const int t = n / DB, db = n - t * DB;
-            os[db] = T::mfma32(vf[n], pf[t], os[db]);
+        auto mma_pv = [&](int m) __attribute__((always_inline)) {
+            const int n = m / QB, qb = m - n * QB, t = n / DB, db = n - t * DB;
+            os[qb][db] = T::mfma32(vf[n], pf[qb][t], os[qb][db]);
         };
         // exp unit x: k-step t = x / 4 (keys 32 (t/2) + 16 (t&1) + 8 hg ..+8), word w = x % 4 = registers 8 (t&1) + 2 w, +1 of cur[t/2]
-        auto unit = [&](auto x_) __attribute__((always_inline)) {
-            constexpr int x = decltype(x_)::value, t = x >> 2, w = x & 3, kb = t >> 1, r0 = 8 * (t & 1) + 2 * w;
-            const float x0 = PRE ? cur[kb][r0] : cur[kb][r0] * c2, x1 = PRE ? cur[kb][r0 + 1] : cur[kb][r0 + 1] * c2;
+        auto unit = [&](auto x_) __attribute__((always_inline)) {     // units ordered by (k-step, word, query block)
+            constexpr int x = decltype(x_)::value, qb = x % QB, y = x / QB, t = y >> 2, w = y & 3, kb = t >> 1, r0 = 8 * (t & 1) + 2 * w;
+            const float x0 = PRE ? cur[qb][kb][r0] : cur[qb][kb][r0] * c2, x1 = PRE ? cur[qb][kb][r0 + 1] : cur[qb][kb][r0 + 1] * c2;
             const unsigned v = pack2<T>(__builtin_amdgcn_exp2f(x0), __builtin_amdgcn_exp2f(x1));
-            if constexpr (w == 0) pf[t].x = v;
-            else if constexpr (w == 1) pf[t].y = v;
-            else if constexpr (w == 2) pf[t].z = v;
-            else pf[t].w = v;
+            if constexpr (w == 0) pf[qb][t].x = v;
+            else if constexpr (w == 1) pf[qb][t].y = v;
+            else if constexpr (w == 2) pf[qb][t].z = v;
+            else pf[qb][t].w = v;
         };
         static_for<0, PF>([&](auto n_) __attribute__((always_inline)) { rd_k(decltype(n_)::value); });
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, NM>([&](auto m_) __attribute__((always_inline)) {
-            constexpr int m = decltype(m_)::value;
-            if constexpr (m + PF < NQ) rd_k(m + PF);
-            if constexpr (m + PF >= NQ && m + PF - NQ < NPV) rd_v(m + PF - NQ);    // fragments PF MFMAs ahead of their use
+            constexpr int m = decltype(m_)::value, fr = m / QB + PF;               // fragments PF fragment-uses ahead
+            if constexpr (m % QB == 0 && fr < NKF) rd_k(fr);
+            if constexpr (m % QB == 0 && fr >= NKF && fr - NKF < NVF) rd_v(fr - NKF);
             if constexpr (m < NQ) mma_qk(m);
             else mma_pv(m - NQ);
             if constexpr (m < NG) {
@@ -967,13 +977,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_attn4(const AttnAr
     // end of a K/V set: O_total += w / l * O_set; the denominator l is row D of O^T (the ones row of V^T)
     auto fold = [&](int s) __attribute__((always_inline)) {
         constexpr int db_l = D / 32, dl = D % 32, r_l = (dl >> 3) * 4 + (dl & 3), hg_l = (dl >> 2) & 1;
-        const float l = __shfl(os[db_l][r_l], qi + 32 * hg_l, 64);
-        bad |= !(l > 0.f && l < 1e37f);
-        const float inv = a.set_w[s] / l;
 #pragma unroll
-        for (int db = 0; db < DB; ++db)
+        for (int qb = 0; qb < QB; ++qb) {
+            const float l = __shfl(os[qb][db_l][r_l], qi + 32 * hg_l, 64);
+            bad |= !(l > 0.f && l < 1e37f);
+            const float inv = a.set_w[s] / l;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { otot[db][r] += os[db][r] * inv; os[db][r] = 0.f; }
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { otot[qb][db][r] += os[qb][db][r] * inv; os[qb][db][r] = 0.f; }
+        }
     };
 
     // ---- prologue: K(0) alone, then PD groups {K(j+1), V(j)}
@@ -983,18 +996,23 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_attn4(const AttnAr
     for (int j = 0; j < PD; ++j) { issue_k(); issue_v(); }
     wait_vmcnt<PD * GRP>();
     __builtin_amdgcn_s_barrier();
-    f32x16 sa[2], sb[2];
+    f32x16 sa[QB][2], sb[QB][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sa[kb][r] = 0.f;
+        for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            sa[kb] = T::mfma32(*reinterpret_cast<const uint4 *>(sK + kfo[ks] + kb * 4096), qf[ks], sa[kb]);
+            for (int r = 0; r < 16; ++r) sa[qb][kb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const uint4 kfr = *reinterpret_cast<const uint4 *>(sK + kfo[ks] + kb * 4096);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) sa[qb][kb] = T::mfma32(kfr, qf[qb][ks], sa[qb][kb]);
+        }
     }
 
     int tile = 0, s = 0;
-    auto step = [&](f32x16(&cur)[2], f32x16(&nxt)[2]) __attribute__((always_inline)) {
+    auto step = [&](f32x16(&cur)[QB][2], f32x16(&nxt)[QB][2]) __attribute__((always_inline)) {
         if (tile == 0) body(cur, nxt, std::true_type{});
         else body(cur, nxt, std::false_type{});
         if (++tile == ntiles) { fold(s); tile = 0; ++s; }
@@ -1005,12 +1023,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_attn4(const AttnAr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     if (__syncthreads_or(bad)) {      // some row left the exponent range of its first-tile offset: safe recomputation
-        attn_safe_body<T, D, 2, NW>(a, qblk, h, b, smem, smem + SafeLds<D>::KBYTES);
+        attn_safe_body<T, D, 2 * QB, NW>(a, qblk, h, b, smem, smem + SafeLds<D>::KBYTES);
         return;
     }
     // ---- store: lane owns O[q = qi][d = 32 db + 8 (r / 4) + 4 hg .. +4]
-    const int q = q_wave0 + qi;
-    if (q < a.Lq) {
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int q = q_wave0 + 32 * qb + qi;
+        if (q >= a.Lq) continue;
 #pragma unroll
         for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -1018,30 +1038,30 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_attn4(const AttnAr
                 const int d = 32 * db + 8 * rq + 4 * hg;
                 if (32 * db + 8 * rq + 8 > D) continue;      // D % 8 == 0: both halves of the 8-channel group are data, or neither
                 *reinterpret_cast<uint2 *>(a.O + (int64_t)b * a.o_bs + (int64_t)q * a.ldo + h * D + d) =
-                    make_uint2(pack2<T>(otot[db][4 * rq], otot[db][4 * rq + 1]), pack2<T>(otot[db][4 * rq + 2], otot[db][4 * rq + 3]));
+                    make_uint2(pack2<T>(otot[qb][db][4 * rq], otot[qb][db][4 * rq + 1]), pack2<T>(otot[qb][db][4 * rq + 2], otot[qb][db][4 * rq + 3]));
             }
     }
 }
 
-template <class T, int D, int NST, int NW, bool RAG, bool PRE, int PF = 3>
+template <class T, int D, int NST, int NW, bool RAG, bool PRE, int PF = 3, int QB = 1>
 void launch_attn4_(const AttnArgs &a, int B, hipStream_t s)
 {
     constexpr int DB = (D + 32) / 32;
     constexpr size_t ring = (size_t)NST * (64 * 128 + DB * 32 * 128), safe = SafeLds<D>::KBYTES + SafeLds<D>::VBYTES;
     constexpr size_t lds = ring > safe ? ring : safe;
     static gc::AttrOnce once;
-    gc::ensure_dynamic_lds(once, (const void *)k_attn4<T, D, NST, NW, RAG, PRE, PF>, (int)lds);
+    gc::ensure_dynamic_lds(once, (const void *)k_attn4<T, D, NST, NW, RAG, PRE, PF, QB>, (int)lds);
     AttnArgs aa = a;
-    aa.nqb = (a.Lq + 32 * NW - 1) / (32 * NW);
+    aa.nqb = (a.Lq + 32 * QB * NW - 1) / (32 * QB * NW);
     dim3 grid((unsigned)(aa.nqb * a.H * B));
-    hipLaunchKernelGGL((k_attn4<T, D, NST, NW, RAG, PRE, PF>), grid, dim3(NW * 64), lds, s, aa);
+    hipLaunchKernelGGL((k_attn4<T, D, NST, NW, RAG, PRE, PF, QB>), grid, dim3(NW * 64), lds, s, aa);
 }
-template <class T, int D, int NST, int NW>
+template <class T, int D, int NST, int NW, int PF = 3, int QB = 1>
 void launch_attn4(const AttnArgs &a, int B, hipStream_t s)
 {
     const bool pre = a.scale_log2e == 1.f;
-    if (a.Lk & 63) { if (pre) launch_attn4_<T, D, NST, NW, true, true>(a, B, s); else launch_attn4_<T, D, NST, NW, true, false>(a, B, s); }
-    else { if (pre) launch_attn4_<T, D, NST, NW, false, true>(a, B, s); else launch_attn4_<T, D, NST, NW, false, false>(a, B, s); }
+    if (a.Lk & 63) { if (pre) launch_attn4_<T, D, NST, NW, true, true, PF, QB>(a, B, s); else launch_attn4_<T, D, NST, NW, true, false, PF, QB>(a, B, s); }
+    else { if (pre) launch_attn4_<T, D, NST, NW, false, true, PF, QB>(a, B, s); else launch_attn4_<T, D, NST, NW, false, false, PF, QB>(a, B, s); }
 }
 
 template <class T, int D, int QT, int NST, bool RAG, bool PRE>
@@ -1076,6 +1096,7 @@ int launch_attn(const AttnArgs &a, int D, int B, bool fast, int variant, hipStre
         case 40:
             if (variant & 2) launch_attn3<T, 40, 2, 3>(a, B, s);     // kernel_variant bit 1: the 16x16x32 form (A/B measurements)
             else if (variant & 4) launch_attn4<T, 40, 3, 8>(a, B, s);      // bit 2: 8 waves, one workgroup per CU
+            else if (variant & 8) launch_attn4<T, 40, 4, 4, 3, 2>(a, B, s); // bit 3: 64 queries per wave (one wave per SIMD)
             else launch_attn4<T, 40, 3, 4>(a, B, s);
             return GC_OK;
         case 80: launch_attn3<T, 80, ATT80_QT, 3>(a, B, s); return GC_OK;

@@ -273,7 +273,8 @@ typedef struct gc_attn_desc {
     int ref_frames_per_half;
     int q_prescaled;                 /* Q is already multiplied by scale*log2(e) (folded into the Q projection weights): `scale` is ignored */
     int kernel_variant;              /* 0 = automatic; bit 0: online-softmax kernel for every shape (tests); bit 1: head_dim 40 on the
-                                        16x16x32 kernel (k_attn3) instead of the 32x32x16 one (k_attn4); bit 2: k_attn4 with 8 waves */
+                                        16x16x32 kernel (k_attn3) instead of the 32x32x16 one (k_attn4); bit 2: k_attn4 with 8 waves; bit 3: k_attn4 with 64 queries
+                                        per wave, one wave per SIMD (measured 25 % slower: DESIGN.md 7.1) */
 } gc_attn_desc;
 int gc_dn_attention(const gc_attn_desc *desc, void *stream);
 
