@@ -120,12 +120,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # GC_BENCH_ONE_GPU=1 + GC_BENCH_BACKEND=gloo: every rank on cuda:0 over gloo -- exercises the N > 1 code path on a 1-GPU box
+    # (a functional check only; its number means nothing).  The driver's multi-GPU runs use neither.
+    if os.environ.get("GC_BENCH_ONE_GPU", "0") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("GC_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         dist = None
 
