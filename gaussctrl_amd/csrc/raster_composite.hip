@@ -44,6 +44,9 @@ __device__ __forceinline__ float edge_min(float a, float b, float c, float e, fl
 __device__ __forceinline__ unsigned block_mask(const float x, const float y, const float opac, const float cxx, const float cxy,
                                                const float cyy, const float tile_x0, const float tile_y0)
 {
+#ifdef GC_NO_BLOCK_CULL                                                  // A/B builds only (tests compare culled vs unculled)
+    return 0xFu;
+#endif
     if (!(cxx > 0.f && cyy > 0.f)) return 0xFu;                       // degenerate conic: no culling
     const float tau = __logf(255.f * opac) * 1.001f + 0.01f;          // alpha >= 1/255  <=>  sigma <= ln(255 opacity)
     if (!(tau >= 0.f)) return tau < 0.f ? 0u : 0xFu;                  // NaN -> keep
