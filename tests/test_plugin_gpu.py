@@ -68,6 +68,24 @@ def test_model_get_outputs_contract(oracle_c):
     assert set(model.get_param_groups()) == {"xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation"}
 
 
+def test_render_entrypoint_writes_rgb_and_depth(oracle_c, tmp_path):
+    """ns-gaussctrl-render (gc_render.py:875-892): stand-alone mode renders a camera file to rgb + depth_npy frames (1-based)."""
+    import json
+    from gaussctrl_amd import gc_render, synthetic as syn
+    P = syn.make_gaussians(20000, seed=0, scale_mean=0.02)
+    c2w = syn.make_cameras(2, seed=1)
+    np.savez(tmp_path / "scene.npz", **P)
+    frames = [dict(camera_to_world=np.asarray(c)[:3, :4].tolist(), fx=130.0, fy=131.0, cx=64.5, cy=47.0, w=128, h=96) for c in c2w]
+    (tmp_path / "cams.json").write_text(json.dumps({"frames": frames}))
+    assert gc_render.entrypoint(["dataset", "--load-gaussians", str(tmp_path / "scene.npz"), "--cameras", str(tmp_path / "cams.json"),
+                                 "--output-path", str(tmp_path / "out")]) == 0
+    rgb = np.load(tmp_path / "out" / "rgb" / "frame_00001.npy"); depth = np.load(tmp_path / "out" / "depth_npy" / "frame_00002.npy")
+    assert rgb.shape == (96, 128, 3) and depth.shape == (96, 128, 1)
+    o = oracle_c.render(P, c2w[0], 130.0, 131.0, 64.5, 47.0, 128, 96, np.zeros(3, np.float32), training=False)
+    assert np.abs(rgb - o["rgb"]).max() < 1e-4
+    assert (tmp_path / "out" / "rgb" / "frame_00002.ppm").stat().st_size == 128 * 96 * 3 + len(b"P6\n128 96\n255\n")
+
+
 def test_image2latent_and_pipeline_flow(oracle_c):
     """render_reverse -> edit_images -> get_train_loss_dict on a tiny scene (2 DDIM steps); image2latent vs the oracle."""
     from oracle import sd15_torch as sd
