@@ -294,10 +294,12 @@ constexpr int EW = 4096;
 __global__ __launch_bounds__(256) void k_emit_sorted(int64_t N, int64_t M_cap, const uint32_t *__restrict__ order,
                                                      const float *__restrict__ xys, const int32_t *__restrict__ radii,
                                                      const int32_t *__restrict__ cum_sorted, int tiles_x, int tiles_y,
-                                                     uint32_t *__restrict__ tile_keys, uint32_t *__restrict__ gids)
+                                                     uint32_t *__restrict__ tile_keys, uint32_t *__restrict__ gids,
+                                                     unsigned dmask, int nblocks, int32_t *__restrict__ hist /* [digits][nblocks], zeroed */)
 {
     __shared__ uint32_t sT[EW], sG[EW];
     __shared__ int64_t sRange[2];
+    __shared__ int sH[2 * 64];                    // first tile pass's digit counts of the (at most two) 4096-blocks a window touches
     const int tid = threadIdx.x;
     const int64_t j0 = (int64_t)blockIdx.x * 256, j = j0 + tid;
     if (tid == 0) {
@@ -335,10 +337,19 @@ __global__ __launch_bounds__(256) void k_emit_sorted(int64_t N, int64_t M_cap, c
             sT[h - w0] = (uint32_t)((miny + q) * tiles_x + minx + (i - q * w));
             sG[h - w0] = g;
         }
+        if (tid < 128) sH[tid] = 0;
         __syncthreads();
         const int64_t cnt = total - win < EW ? total - win : EW;
+        const int64_t b0 = w0 / RB;
         for (int64_t i = tid; i < cnt; i += 256)
-            if (w0 + i < M_cap) { tile_keys[w0 + i] = sT[i]; gids[w0 + i] = sG[i]; }
+            if (w0 + i < M_cap) {
+                const uint32_t t = sT[i];
+                tile_keys[w0 + i] = t; gids[w0 + i] = sG[i];
+                atomicAdd(&sH[(int)((w0 + i) / RB - b0) * 64 + (int)(t & dmask)], 1);     // saves the pass's k_radix_hist (a read of all M keys)
+            }
+        __syncthreads();
+        if (tid < 128 && sH[tid] != 0 && b0 + (tid >> 6) < nblocks)
+            atomicAdd(&hist[(int64_t)(tid & 63) * nblocks + b0 + (tid >> 6)], sH[tid]);
         __syncthreads();
     }
 }
@@ -401,11 +412,12 @@ void set_attr()
 
 // one stable radix pass of `dbits` bits (8: the direct scatter; 5 / 6: the LDS-staged scatter of the tile passes)
 int radix_pass(const uint32_t *ki, const uint32_t *vi, uint32_t *ko, uint32_t *vo, int64_t n, const int32_t *n_dev, int shift,
-               const Plan &p, unsigned char *w, hipStream_t s, int dbits = 8, bool pair = false)
+               const Plan &p, unsigned char *w, hipStream_t s, int dbits = 8, bool pair = false, bool have_hist = false)
 {
     int32_t *hist = (int32_t *)(w + p.off_hist), *offs = (int32_t *)(w + p.off_offs), *cnt = (int32_t *)(w + p.off_cnt);
     const int nd = 1 << dbits;
-    if (pair) hipLaunchKernelGGL(k_radix_hist<true>, dim3(p.nb), dim3(RT), 0, s, ki, n, n_dev, shift, (unsigned)(nd - 1), p.nb, hist);
+    if (have_hist) {}                     // the producer of `ki` already accumulated this pass's histogram (k_emit_sorted)
+    else if (pair) hipLaunchKernelGGL(k_radix_hist<true>, dim3(p.nb), dim3(RT), 0, s, ki, n, n_dev, shift, (unsigned)(nd - 1), p.nb, hist);
     else hipLaunchKernelGGL(k_radix_hist<false>, dim3(p.nb), dim3(RT), 0, s, ki, n, n_dev, shift, (unsigned)(nd - 1), p.nb, hist);
     // cnt[0] is the scan's ticket (zeroed once per phase, self-resetting); the scan scratch holds the per-2048-entry offsets
     int32_t *sums = (int32_t *)(w + p.off_scan);
@@ -485,18 +497,21 @@ int bin_tiles_impl(int64_t N, int64_t M, const int32_t *m_dev, int32_t *overflow
     uint32_t *k0 = (uint32_t *)(w + p.off_keys[0]), *v0 = (uint32_t *)(w + p.off_vals[0]);
     uint32_t *k1 = (uint32_t *)(w + p.off_keys[1]), *v1 = (uint32_t *)(w + p.off_vals[1]);
     if (hipMemsetAsync(w + p.off_cnt, 0, 4, s) != hipSuccess) return GC_ELAUNCH;          // ticket of k_table_scan
-    hipLaunchKernelGGL(k_emit_sorted, dim3(gc::cdiv(N, 256)), dim3(256), 0, s, N, M, (const uint32_t *)depth_order, xys, radii,
-                       cum_sorted, tiles_x, tiles_y, k0, v0);
     // the tile-id bits are split evenly over two passes (1024 tiles: 5 + 5, 4096: 6 + 6) and scattered through LDS; above 12 bits
     // (or for a single pass) the 8-bit direct scatter runs
     int tbits = 1;
     while ((1 << tbits) < num_tiles) ++tbits;
     const int passes = tbits <= 6 ? 1 : 2;
     const int dbits = tbits <= 5 ? 5 : (tbits <= 6 ? 6 : (tbits <= 10 ? 5 : (tbits <= 12 ? 6 : 8)));
+    const bool fused_hist = dbits <= 6;          // the emission also counts the first pass's digits (64 LDS counters per 4096-block)
+    if (fused_hist && hipMemsetAsync(w + p.off_hist, 0, sizeof(int32_t) * ((size_t)1 << dbits) * p.nb, s) != hipSuccess) return GC_ELAUNCH;
+    hipLaunchKernelGGL(k_emit_sorted, dim3(gc::cdiv(N, 256)), dim3(256), 0, s, N, M, (const uint32_t *)depth_order, xys, radii,
+                       cum_sorted, tiles_x, tiles_y, k0, v0, fused_hist ? (1u << dbits) - 1u : 0u, fused_hist ? p.nb : 0,
+                       (int32_t *)(w + p.off_hist));
     uint32_t *ks = k0, *vs = v0;
     for (int pass = 0; pass < passes; ++pass) {
         uint32_t *ko = ks == k0 ? k1 : k0, *vo = pass == passes - 1 ? (uint32_t *)gaussian_ids_sorted : (vs == v0 ? v1 : v0);
-        int rc = radix_pass(ks, vs, ko, vo, M, m_dev, dbits * pass, p, w, s, dbits);
+        int rc = radix_pass(ks, vs, ko, vo, M, m_dev, dbits * pass, p, w, s, dbits, false, fused_hist && pass == 0);
         if (rc != GC_OK) return rc;
         ks = ko; vs = vo;
     }
