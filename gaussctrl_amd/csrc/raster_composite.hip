@@ -111,29 +111,37 @@ __global__ __launch_bounds__(BLOCK) void k_rasterize_fwd(int H, int W, int tiles
         bool wave_done = __all(done);                                  // a finished wave only helps staging
         for (int c = 0; c * 64 < n && !wave_done; ++c) {
             unsigned long long bal = __ballot((sMask[c * 64 + lane] >> wid) & 1);
-            while (bal) {                                              // scalar walk over the splats that can touch this block
-                const int t = c * 64 + __builtin_ctzll(bal);
+            if (!bal) continue;
+            // scalar walk over the splats that can touch this block; branch-free body (selects), the next record is read from LDS
+            // while the current one is evaluated
+            int t = c * 64 + __builtin_ctzll(bal);
+            bal &= bal - 1;
+            SplatA a = sA[t];
+            SplatB bb = sB[t];
+            SplatC cc = sC[t];
+            for (;;) {
+                const int tn = c * 64 + (bal ? __builtin_ctzll(bal) : 0);
+                const bool more = bal != 0;
                 bal &= bal - 1;
-                if (!done) {
-                    const SplatA a = sA[t];
-                    const SplatB bb = sB[t];
-                    const float dx = a.x - px, dy = a.y - py;
-                    const float sigma = 0.5f * (a.cxx * dx * dx + bb.cyy * dy * dy) + bb.cxy * dx * dy;
-                    const float alpha = fminf(ALPHA_CAP, a.opac * __expf(-sigma));
-                    if (!(sigma < 0.f || alpha < ALPHA_MIN)) {
-                        const float next_T = T * (1.f - alpha);
-                        if (next_T <= T_STOP) done = true;
-                        else {
-                            const float vis = alpha * T;
-                            const SplatC cc = sC[t];
-                            r += bb.r * vis; g += bb.g * vis; b += cc.b * vis;
-                            if (HAS_EXTRA) e += cc.e * vis;
-                            T = next_T;
-                            last = bs + t;
-                        }
-                    }
-                }
+                const SplatA an = sA[tn];
+                const SplatB bn = sB[tn];
+                const SplatC cn = sC[tn];
+                const float dx = a.x - px, dy = a.y - py;
+                const float sigma = 0.5f * (a.cxx * dx * dx + bb.cyy * dy * dy) + bb.cxy * dx * dy;
+                const float alpha = fminf(ALPHA_CAP, a.opac * __expf(-sigma));
+                const bool hit = !done && !(sigma < 0.f || alpha < ALPHA_MIN);
+                const float next_T = T * (1.f - alpha);
+                const bool stop = hit && next_T <= T_STOP;
+                const bool add = hit && !stop;
+                const float vis = add ? alpha * T : 0.f;
+                r += bb.r * vis; g += bb.g * vis; b += cc.b * vis;
+                if (HAS_EXTRA) e += cc.e * vis;
+                T = add ? next_T : T;
+                last = add ? bs + t : last;
+                done |= stop;
+                if (!more) break;
                 if (__all(done)) { wave_done = true; break; }
+                t = tn; a = an; bb = bn; cc = cn;
             }
         }
     }
