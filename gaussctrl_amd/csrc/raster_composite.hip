@@ -34,10 +34,11 @@ struct SplatC { float b, e; };
 // rectangle of pixel centres and keeps a 4-bit mask "block w can reach alpha >= 1/255" (threshold sigma <= ln(255 opacity), with a
 // margin far above the rounding of either side).  A wave then walks only the set bits of its block's ballot (scalar loop: s_ff1 +
 // s_andn2), so culled pairs cost no vector work at all.  The per-pixel test is unchanged: results are bit-identical to the unculled loop.
-__device__ __forceinline__ float edge_min(float a, float b, float c, float e, float lo, float hi)
+__device__ __forceinline__ float edge_min(float a, float b, float c, float rc, float e, float lo, float hi)
 {
-    // min over v in [lo, hi] of 0.5 (a e^2 + c v^2) + b e v   (c > 0): v* = clamp(-b e / c)
-    const float v = fminf(fmaxf(-b * e / c, lo), hi);
+    // min over v in [lo, hi] of 0.5 (a e^2 + c v^2) + b e v   (c > 0, rc = 1-ulp reciprocal of c): v* = clamp(-b e / c).  Evaluating at a
+    // v that is off by delta overestimates the minimum by c delta^2 / 2 ~ 1e-14 sigma -- twelve orders below the margin kept on tau
+    const float v = fminf(fmaxf(-b * e * rc, lo), hi);
     return 0.5f * (a * e * e + c * v * v) + b * e * v;
 }
 
@@ -50,6 +51,7 @@ __device__ __forceinline__ unsigned block_mask(const float x, const float y, con
     if (!(cxx > 0.f && cyy > 0.f)) return 0xFu;                       // degenerate conic: no culling
     const float tau = __logf(255.f * opac) * 1.001f + 0.01f;          // alpha >= 1/255  <=>  sigma <= ln(255 opacity)
     if (!(tau >= 0.f)) return tau < 0.f ? 0u : 0xFu;                  // NaN -> keep
+    const float rxx = __builtin_amdgcn_rcpf(cxx), ryy = __builtin_amdgcn_rcpf(cyy);
     unsigned m = 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {                                     // wave w owns the 8x8 block (w & 1, w >> 1) of the tile
@@ -58,8 +60,8 @@ __device__ __forceinline__ unsigned block_mask(const float x, const float y, con
         float smin;
         if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) smin = 0.f;
         else {
-            smin = fminf(fminf(edge_min(cxx, cxy, cyy, dx0, dy0, dy1), edge_min(cxx, cxy, cyy, dx1, dy0, dy1)),
-                         fminf(edge_min(cyy, cxy, cxx, dy0, dx0, dx1), edge_min(cyy, cxy, cxx, dy1, dx0, dx1)));
+            smin = fminf(fminf(edge_min(cxx, cxy, cyy, ryy, dx0, dy0, dy1), edge_min(cxx, cxy, cyy, ryy, dx1, dy0, dy1)),
+                         fminf(edge_min(cyy, cxy, cxx, rxx, dy0, dx0, dx1), edge_min(cyy, cxy, cxx, rxx, dy1, dx0, dx1)));
         }
         if (!(smin > tau)) m |= 1u << w;
     }
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(BLOCK) void k_rasterize_bwd(int H, int W, int tiles
                 if (!__any(valid)) continue;
                 float g_r = 0.f, g_g = 0.f, g_b = 0.f, g_cxx = 0.f, g_cxy = 0.f, g_cyy = 0.f, g_x = 0.f, g_y = 0.f, g_o = 0.f;
                 if (valid) {
-                    const float ra = 1.f / (1.f - alpha);
+                    const float ra = __builtin_amdgcn_rcpf(1.f - alpha);      // 1-ulp reciprocal: alpha <= 0.999, the IEEE division sequence is 10 instructions
                     T *= ra;
                     const float fac = alpha * T;
                     g_r = fac * vo0; g_g = fac * vo1; g_b = fac * vo2;
