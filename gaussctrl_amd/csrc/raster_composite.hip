@@ -232,11 +232,12 @@ __global__ __launch_bounds__(BLOCK) void k_rasterize_bwd(int H, int W, int tiles
     int wmax = bin_final;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, __shfl_xor(wmax, d, 64));
+    wmax = __builtin_amdgcn_readfirstlane(wmax);                       // wave-uniform: keeps the splat walk below in scalar registers
     if (lane == 0) sMax[wid] = wmax;
 #pragma unroll
     for (int q = 0; q < 9; ++q) sG[q * BLOCK + tid] = 0.f;
     __syncthreads();
-    const int kmax = max(max(sMax[0], sMax[1]), max(sMax[2], sMax[3]));
+    const int kmax = __builtin_amdgcn_readfirstlane(max(max(sMax[0], sMax[1]), max(sMax[2], sMax[3])));
     if (kmax < start) return;
     const int col = lane & 15;
     for (int batch_end = kmax; batch_end >= start; batch_end -= BLOCK) {
