@@ -284,15 +284,15 @@ __global__ __launch_bounds__(BLOCK) void k_rasterize_bwd(int H, int W, int tiles
                     v_alpha += T_final * ra * voa;
                     v_alpha += -T_final * ra * bgdot;
                     S0 += bb.r * fac; S1 += bb.g * fac; S2 += cb * fac;
-                    if (!(araw > ALPHA_CAP)) {
-                        const float v_sigma = -a.opac * vis * v_alpha;
-                        g_cxx = 0.5f * v_sigma * dx * dx;
-                        g_cxy = v_sigma * dx * dy;
-                        g_cyy = 0.5f * v_sigma * dy * dy;
-                        g_x = v_sigma * (a.cxx * dx + bb.cxy * dy);
-                        g_y = v_sigma * (bb.cxy * dx + bb.cyy * dy);
-                        g_o = vis * v_alpha;
-                    }
+                    // alpha clamped at the cap passes no gradient to sigma / opacity (select instead of a nested exec-mask branch)
+                    const float va = araw > ALPHA_CAP ? 0.f : vis * v_alpha;
+                    const float v_sigma = -a.opac * va;
+                    g_cxx = 0.5f * v_sigma * dx * dx;
+                    g_cxy = v_sigma * dx * dy;
+                    g_cyy = 0.5f * v_sigma * dy * dy;
+                    g_x = v_sigma * (a.cxx * dx + bb.cxy * dy);
+                    g_y = v_sigma * (bb.cxy * dx + bb.cyy * dy);
+                    g_o = va;
                 }
                 g_r = row_sum(g_r); g_g = row_sum(g_g); g_b = row_sum(g_b);
                 g_cxx = row_sum(g_cxx); g_cxy = row_sum(g_cxy); g_cyy = row_sum(g_cyy);
