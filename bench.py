@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "fp8"])     # fp8: e4m3 resnet convs on the block-scaled MFMA, bf16 elsewhere
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="edit", choices=["edit", "raster"])
+    ap.add_argument("--mask", action="store_true")   # BASELINE configs[3]: edits composited through a (synthetic elliptical) mask, gc_pipeline.py:226-234
     return ap.parse_args()
 
 
@@ -184,6 +185,7 @@ def main():
     syncfree = os.environ.get("GC_BENCH_SYNCFREE", "1") != "0"
     from gaussctrl_amd.train_ops import l1_ssim_loss
     raster_target = torch.rand(H, W, 3, device=dev, generator=g)      # raster-only workload: a fixed synthetic target image
+    edit_mask = torch.tensor(syn.elliptical_mask(H, W, soft=True), device=dev, dtype=torch.float32) if args.mask else None
 
     def new_aux():
         aux = gops.RenderAux()
@@ -225,7 +227,8 @@ def main():
                 state["bank"] = pipe.advance_ref_bank(start_ref_trajectory())
             if state["next"] is None:                # the following scene's references start with this scene
                 state["next"] = start_ref_trajectory()
-            disp = torch.stack([disparity_of(render_eval(i)[1]) for i in views])                           # (a)
+            evals = [render_eval(i) for i in views]                                                         # (a)
+            disp = torch.stack([disparity_of(e[1]) for e in evals])
             lat = pipe.edit_chunk_cached(z0[views], disp, ctx_neg, ctx_pos, state["bank"])                 # (b)
             edited = pipe.decode(lat)                                                                       # (c)
             quota = (nsteps * (j + 1)) // chunks_per_scene - (nsteps * j) // chunks_per_scene
@@ -243,6 +246,8 @@ def main():
                                              params["features_dc"], params["features_rest"], my_cams[i],
                                              torch.rand(3, device=dev), False, 3, aux)
             target = edited[j].permute(1, 2, 0).contiguous() if edited[j] is not None else raster_target
+            if args.mask and edited[j] is not None:          # edited inside the mask, the un-edited render outside (one HIP kernel)
+                target = sdops.mask_composite(target, evals[j][0].contiguous(), edit_mask)
             loss = l1_ssim_loss(rgb, target, 0.2)             # the product path's loss (fused L1 + SSIM value and gradient kernels)
             loss.backward()
             note_m(aux)
@@ -321,7 +326,7 @@ def main():
                "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * dt_s / args.steps, 2), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype if args.workload == "edit" else "f32", "data": "synthetic",
-               "config": {"workload": f"bear-like scene, {V} views/GPU, ref_view_num=4, chunk_size={c}, "
+               "config": {"workload": f"{'masked-edit' if args.mask else 'bear-like'} scene, {V} views/GPU, ref_view_num=4, chunk_size={c}, "
                                       f"{nsteps} DDIM steps, SD1.5+ControlNet-depth shapes (random weights), "
                                       f"{args.gaussians} Gaussians, 512x512" if args.workload == "edit" else
                                       f"raster-only fwd+bwd (+ fused L1+SSIM loss), {args.gaussians} Gaussians, {V} random cameras/GPU, 512x512, fx=fy=540",
