@@ -302,10 +302,18 @@ def main():
         dom = max(sm.items(), key=lambda kv: kv[1]["ms"])
         kind, d = dom
         ach = d["flop"] / (d["ms"] * 1e-3) / 1e12
+        # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r02_attn_traffic.json, scripts/
+        # pmc_kernel_traffic.py: FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes on the UNet's 5-set launch at chunk_size 3)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r02_attn_traffic.json")
+        if kind.startswith("k_attn4") and c == 3 and os.path.exists(tpath):
+            for kn, v in json.load(open(tpath))["kernels"].items():
+                if "k_attn4" in kn and "traffic_MB_per_dispatch" in v:
+                    traffic = v["traffic_MB_per_dispatch"] * 1e6
         roof = {"bound": "mfma", "kernel": kind + (" (multi-K/V-set flash attention, dn_attn.hip)" if kind.startswith("k_attn") else
                                                     " (k_gemm / k_gemm8 MFMA GEMM and implicit 3x3 conv, variant picked per grid, dn_gemm.hip)"),
                 "achieved": round(ach, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": traffic,
                 "launches": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
                 "algorithmic_gflop_per_launch": round(d["flop"] / d["launches"] / 1e9, 3),
                 "other": {k: {"launches": v["launches"], "ms": round(v["ms"], 2),
