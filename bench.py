@@ -309,7 +309,7 @@ def main():
         if kind.startswith("k_attn4") and c == 3 and os.path.exists(tpath):
             for kn, v in json.load(open(tpath))["kernels"].items():
                 if "k_attn4" in kn and "traffic_MB_per_dispatch" in v:
-                    traffic = v["traffic_MB_per_dispatch"] * 1e6
+                    traffic = int(round(v["traffic_MB_per_dispatch"] * 1e6))
         roof = {"bound": "mfma", "kernel": kind + (" (multi-K/V-set flash attention, dn_attn.hip)" if kind.startswith("k_attn") else
                                                     " (k_gemm / k_gemm8 MFMA GEMM and implicit 3x3 conv, variant picked per grid, dn_gemm.hip)"),
                 "achieved": round(ach, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
