@@ -179,6 +179,13 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
     g.splits = sel.splits; g.tiles_per_split = sel.tps; g.ws = (float *)d->workspace;
     const int bn = 32 * sel.ntw;
     const int64_t nbn = (d->N + bn - 1) / bn;
+    g.persist = 0;
+    if (sel.mt8 == 4 && sel.ntw == 4 && sel.mode == 0 && sel.splits == 1 && d->K % 64 == 0 && d->K <= 64 * 24 && !fuse_of(g) &&
+        !g.rowvec && !g.out_t && !g.out_f32 && g.out && g.act != 2 && !(d->kernel_variant & 0x200)) {
+        // multi-round short-K linear (the GEGLU FF-up projections): persistent workgroups, next tile's fill under this tile's epilogue
+        const int64_t tiles = ((d->M + 255) / 256) * nbn;
+        if (tiles > 256) g.persist = 256;
+    }
     if (sel.mt8) {
         const int64_t nbm8 = (d->M + 64 * sel.mt8 - 1) / (64 * sel.mt8);
         const dim3 grid8((unsigned)(nbm8 * nbn), (unsigned)sel.splits);

@@ -38,6 +38,7 @@ struct GemmArgs {
     void *out; int64_t ldc; int out_f32;
     void *out_t; int64_t ldt; int64_t t_batch_stride; int64_t t_col0;
     int splits; int tiles_per_split;    // split-K: k-tiles [z*tps, min(nk, (z+1)*tps))
+    int persist;                        // > 0: k_gemm8p with this many workgroups (multi-round short-K linears)
     float *ws;                          // fp32 [splits][M][N] partial slabs when splits > 1
     const void *zeros;                  // >= 16 bytes of zeros (k_gemm8: source of out-of-range / padding lanes)
     // LayerNorm folded into this GEMM (consumer side): Act rows are the UN-normalised x, W carries gamma, and
@@ -1038,6 +1039,214 @@ __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g
 
 
 // =====================================================================================================================
+// k_gemm8p -- PERSISTENT form of k_gemm8 for multi-round short-K linears (MODE 3: K % 64 == 0; the GEGLU FF-up projections:
+// M = 24576, K = 320, N = 2560 is 1920 tiles of 5 k-tiles each).  In k_gemm8 such a tile spends ~2 us in MFMAs and ~10 us in its
+// launch slot, pipeline fill and epilogue.  Here one workgroup per CU walks tiles bid, bid + G, ...; when the k loop of a tile ends
+// it issues the first three k-tiles of the NEXT tile (the LDS ring is free, the accumulators are not touched by the DMA) and only
+// then runs the epilogue, so fill latency and epilogue overlap and there is no per-tile dispatch.
+template <class T, int NTW, int MT>
+__global__ __launch_bounds__(512, 1) void k_gemm8p(const GemmArgs g)
+{
+    constexpr int BM = 64 * MT, BN = 32 * NTW, STAGE = BM * 128 + BN * 128, NS = 3;
+    constexpr int AG = BM / 8, WG = BN / 8, AI = AG / 8, WI = (WG + 7) / 8;
+    static_assert(WG % 8 == 0, "every wave issues the same number of W loads");
+    constexpr int GRPW = AI + WI;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int nbn = (int)((g.N + BN - 1) / BN);
+    const int64_t ntiles = ((g.M + BM - 1) / BM) * nbn;
+    const int nk = (int)(g.K / BK);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    const int lr = lane >> 3, ls = lane & 7;
+    const unsigned char *Ab = (const unsigned char *)g.A, *Wb = (const unsigned char *)g.W;
+    // dispatch-order tile d -> XCD d % 8 (gridDim.x is a multiple of 8); remapped so that consecutive tiles share an XCD's L2
+    auto tile_of = [&](int64_t d, int64_t &m_base, int64_t &n_base) __attribute__((always_inline)) {
+        const int64_t xcd = d & 7, qq = ntiles >> 3, rr = ntiles & 7;
+        const int64_t bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (d >> 3);
+        m_base = (bid / nbn) * BM; n_base = (bid % nbn) * BN;
+    };
+    int a_off[AI], w_off[WI];
+    auto set_offsets = [&](int64_t m_base, int64_t n_base) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int row = (wid + 8 * i) * 8 + lr;
+            const int64_t m = m_base + row;
+            a_off[i] = (int)(m < g.M ? m : g.M - 1) * (int)g.lda + (ls ^ ((row >> 1) & 7)) * 8;
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const int row = (wid + 8 * i) * 8 + lr;
+            const int64_t n = n_base + row;
+            w_off[i] = (int)(n < g.N ? n : g.N - 1) * (int)g.K + (ls ^ ((row >> 1) & 7)) * 8;
+        }
+    };
+    auto issue_a = [&](int kt, int stage, int i) __attribute__((always_inline)) {
+        glds16_s(Ab + (size_t)kt * (BK * 2), (unsigned)(a_off[i] * 2), lds0 + stage * STAGE + (unsigned)((wid + 8 * i) * 1024));
+    };
+    auto issue_w = [&](int kt, int stage, int i) __attribute__((always_inline)) {
+        glds16_s(Wb + (size_t)kt * (BK * 2), (unsigned)(w_off[i] * 2), lds0 + stage * STAGE + (unsigned)(BM * 128 + (wid + 8 * i) * 1024));
+    };
+    auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) issue_a(kt, stage, i);
+#pragma unroll
+        for (int i = 0; i < WI; ++i) issue_w(kt, stage, i);
+    };
+    const int fr = lane & 15, fc = lane >> 4;
+    const int swz = (fr >> 1) & 7;
+    const int fx0 = ((fc ^ swz) << 4), fx1 = (((fc + 4) ^ swz) << 4);
+    const int aw0 = BM * 128 + (wn * (16 * NTW) + fr) * 128, aa0 = (wm * (16 * MT) + fr) * 128;
+    struct Frag { uint4 w[NTW], a[MT]; };
+    auto load_frag = [&](Frag &f, int stage, int ks) __attribute__((always_inline)) {
+        const unsigned char *sb = smem + stage * STAGE;
+        const int fx = ks ? fx1 : fx0;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) f.w[t] = *reinterpret_cast<const uint4 *>(sb + aw0 + fx + t * 2048);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) f.a[t] = *reinterpret_cast<const uint4 *>(sb + aa0 + fx + t * 2048);
+    };
+    f32x4 acc[NTW][MT];
+    constexpr int NMM = NTW * MT, NPC = AI + WI;
+    auto block = [&](const Frag &f, Frag &fn, int st_next, int ks_next, bool load_next, int dma_kt, int dma_stage, auto dma_tag) __attribute__((always_inline)) {
+        constexpr bool DMA = decltype(dma_tag)::value;
+        static_for<0, NMM>([&](auto m_) __attribute__((always_inline)) {
+            constexpr int m = decltype(m_)::value, nt = m / MT, mt = m % MT;
+            acc[nt][mt] = T::mfma(f.w[nt], f.a[mt], acc[nt][mt]);
+            if constexpr (m == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (load_next) load_frag(fn, st_next, ks_next);
+                __builtin_amdgcn_sched_barrier(0);
+            } else if constexpr (DMA && m >= 2) {
+                static_for<0, NPC>([&](auto p_) __attribute__((always_inline)) {
+                    constexpr int pp = decltype(p_)::value;
+                    if constexpr (m == 2 + (pp * (NMM - 3)) / NPC) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (pp < AI) issue_a(dma_kt, dma_stage, pp); else issue_w(dma_kt, dma_stage, pp - AI);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
+            }
+        });
+    };
+    auto wait_tiles = [&](auto n_) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(n_)::value * GRPW) : "memory");
+    };
+
+    int64_t d = blockIdx.x, m_base, n_base;
+    if (d >= ntiles) return;
+    tile_of(d, m_base, n_base);
+    set_offsets(m_base, n_base);
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    if (nk > 2) issue(2, 2);
+    bool first = true;
+    for (;;) {
+#pragma unroll
+        for (int a = 0; a < NTW; ++a)
+#pragma unroll
+            for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // ---- k loop (the first min(nk, 3) k-tiles of this tile are already in flight)
+        if (first) { if (nk > 2) wait_tiles(std::integral_constant<int, 2>{}); else if (nk > 1) wait_tiles(std::integral_constant<int, 1>{}); else wait_tiles(std::integral_constant<int, 0>{}); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // prefetched under the previous epilogue (its stores are counted too)
+        first = false;
+        __builtin_amdgcn_s_barrier();
+        Frag f0, f1;
+        load_frag(f0, 0, 0);
+        int st = 0, kt = 0;
+        for (; kt + 3 < nk; ++kt) {
+            const int st1 = st + 1 == NS ? 0 : st + 1;
+            block(f0, f1, st, 1, true, 0, 0, std::false_type{});
+            wait_tiles(std::integral_constant<int, 1>{});
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            block(f1, f0, st1, 0, true, kt + 3, st, std::true_type{});
+            st = st1;
+        }
+        for (; kt < nk; ++kt) {
+            const int st1 = st + 1 == NS ? 0 : st + 1;
+            block(f0, f1, st, 1, true, 0, 0, std::false_type{});
+            if (kt + 1 < nk) {
+                if (kt + 2 < nk) wait_tiles(std::integral_constant<int, 1>{}); else wait_tiles(std::integral_constant<int, 0>{});
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                block(f1, f0, st1, 0, true, 0, 0, std::false_type{});
+            } else {
+                block(f1, f0, st1, 0, false, 0, 0, std::false_type{});
+            }
+            st = st1;
+        }
+        // ---- next tile: its first k-tiles go into the (now idle) ring before this tile's epilogue
+        const int64_t cm = m_base, cn = n_base;
+        d += gridDim.x;
+        const bool more = d < ntiles;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                 // every wave has read its last fragments
+        if (more) {
+            tile_of(d, m_base, n_base);
+            set_offsets(m_base, n_base);
+            issue(0, 0);
+            if (nk > 1) issue(1, 1);
+            if (nk > 2) issue(2, 2);
+        }
+        // ---- epilogue of tile (cm, cn): bias, GEGLU / activation, scale, residual; 8-byte stores
+        {
+            const int64_t n_lane = cn + wn * (16 * NTW) + fc * 4;
+            float4 bia[NTW];
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int64_t n = n_lane + nt * 16;
+                bia[nt] = (g.bias && n < g.N) ? *reinterpret_cast<const float4 *>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int64_t m = cm + wm * (16 * MT) + mt * 16 + fr;
+                if (m >= g.M) continue;
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    const int64_t n = n_lane + nt * 16;
+                    if (n >= g.N) continue;
+                    if (g.geglu && (nt & 1)) continue;
+                    float v[4] = {acc[nt][mt][0] + bia[nt].x, acc[nt][mt][1] + bia[nt].y, acc[nt][mt][2] + bia[nt].z, acc[nt][mt][3] + bia[nt].w};
+                    int64_t on = n;
+                    if (g.geglu) {
+                        constexpr int NP = NTW - 1;
+                        const int np = nt + 1 < NTW ? nt + 1 : NP;
+                        v[0] *= gelu_erf(acc[np][mt][0] + bia[np].x); v[1] *= gelu_erf(acc[np][mt][1] + bia[np].y);
+                        v[2] *= gelu_erf(acc[np][mt][2] + bia[np].z); v[3] *= gelu_erf(acc[np][mt][3] + bia[np].w);
+                        on = (cn + wn * (16 * NTW) + nt * 16) / 2 + fc * 4;
+                    }
+                    if (g.act == 1) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = silu(v[r]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= g.out_scale;
+                    if (g.residual) {
+                        const uint2 rs = *reinterpret_cast<const uint2 *>((const unsigned char *)g.residual + (m * g.ldr + on) * 2);
+                        v[0] += T::to_f((unsigned short)(rs.x & 0xffff)); v[1] += T::to_f((unsigned short)(rs.x >> 16));
+                        v[2] += T::to_f((unsigned short)(rs.y & 0xffff)); v[3] += T::to_f((unsigned short)(rs.y >> 16));
+                    }
+                    *reinterpret_cast<uint2 *>((unsigned char *)g.out + (m * g.ldc + on) * 2) = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
+                }
+            }
+        }
+        if (!more) break;
+    }
+}
+
+template <class T, int NTW, int MT>
+void launch8p(const GemmArgs &g, int nwg, hipStream_t s)
+{
+    constexpr size_t lds = 3 * (64 * MT * 128 + 32 * NTW * 128);
+    static_assert(lds <= 160 * 1024, "LDS ring");
+    static gc::AttrOnce once;
+    gc::ensure_dynamic_lds(once, (const void *)k_gemm8p<T, NTW, MT>, (int)lds);
+    hipLaunchKernelGGL((k_gemm8p<T, NTW, MT>), dim3(nwg), dim3(512), lds, s, g);
+}
+
+// =====================================================================================================================
 // k_gemm8q -- the 8-wave LDS-DMA GEMM on OCP fp8 (e4m3) operands with the block-scaled MFMA v_mfma_scale_f32_16x16x128_f8f6f4
 // (K = 128 per instruction, 2x the bf16 MFMA rate; MI355X_MICROARCH.md "Matrix cores").  BASELINE configs[3] "fp8 MFMA UNet path".
 // Operands: Act e4m3 bytes [..][Cin_p] (NHWC, Cin_p % 128 == 0: one 3x3 tap per 128-byte k-tile) or [M][K] (linear, K % 128 == 0);
@@ -1453,6 +1662,7 @@ void dispatch8(const GemmArgs &g, int mode, int ntw, int mt, dim3 grid, hipStrea
         // MT = 1 (64 x 128 tile, 72 KiB LDS, <= 128 VGPRs): TWO workgroups per CU -- for the K = N = C linears of the 32x32 / 16x16 levels,
         // whose few k-tiles leave a one-workgroup-per-CU kernel with its fill and epilogue latency fully exposed
         if (mt == 1 && ntw == 4 && mode == 0 && g.K % 64 == 0) { launch8<T, 3, 4, 1, false>(g, grid, s); return; }
+        if (g.persist > 0 && ntw == 4 && mt == 4 && mode == 0) { launch8p<T, 4, 4>(g, g.persist, s); return; }
     }
     if (mt < 2) mt = 2;
     if (ntw == 5) {

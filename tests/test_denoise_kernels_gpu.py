@@ -63,6 +63,27 @@ def test_linear_geglu_rowvec_transposed(dt):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("M,K,N,geglu", [(24576, 320, 2560, True), (6144, 640, 5120, True), (24576 + 77, 320, 2560 + 128, False),
+                                         (70000, 64, 640, False)])
+def test_linear_persistent_multi_round(dt, M, K, N, geglu):
+    """Multi-round short-K linears take the persistent kernel (k_gemm8p: > 256 tiles of 256 x 128, next tile's fill under the
+    epilogue): GEGLU FF-up shapes of the 64x64 / 32x32 levels, a ragged M / N case and a one-k-tile case; bias, SiLU + scale, residual."""
+    from gaussctrl_amd.sd import ops
+    from gaussctrl_amd.sd.weights import geglu_permute
+    x = _rand((M, K), dt, 1.0, 1); w = _rand((N, K), dt, K ** -0.5, 2); b = torch.randn(N, device=DEV)
+    pr = x.double() @ w.double().T + b.double()
+    if geglu:
+        hid, gate = pr.chunk(2, dim=-1)
+        wp, bp = geglu_permute(w, b)
+        _close(ops.linear(x, wp, bp, geglu=True), hid * F.gelu(gate), dt, extra=2.0)
+    else:
+        r = _rand((M, N), dt, 1.0, 3)
+        _close(ops.linear(x, w, b), pr, dt)
+        _close(ops.linear(x, w, b, residual=r), pr + r.double(), dt)
+        _close(ops.linear(x, w, b, act=1, scale=0.5), F.silu(pr) * 0.5, dt)
+
+
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride,ups", [(2, 16, 16, 64, 128, 1, False), (3, 16, 12, 320, 320, 1, False),
                                                        (2, 16, 16, 128, 64, 2, False), (2, 8, 8, 64, 64, 1, True),
                                                        (2, 32, 32, 8, 320, 1, False), (1, 64, 64, 16, 32, 2, False),
