@@ -251,7 +251,7 @@ def main():
             loss = l1_ssim_loss(rgb, target, 0.2)             # the product path's loss (fused L1 + SSIM value and gradient kernels)
             loss.backward()
             note_m(aux)
-        if dist is not None:
+        if dist is not None and not state.get("rank0_only"):      # (the instrumented roofline steps run on rank 0 alone: no collective)
             flat = torch.cat([p.grad.reshape(-1) for p in params.values()])
             dist.all_reduce(flat)
 
@@ -320,6 +320,7 @@ def main():
                               "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in sm.items() if k != kind}}
 
     if args.workload == "raster" and rank == 0:
+        state["rank0_only"] = True
         roof = raster_roofline(args, step, g, stats, H * W)
 
     # ---------------------------------------------------------------- CPU baseline (oracle, rank 0, bounded sample)
