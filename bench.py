@@ -344,8 +344,9 @@ def main():
                           "ref_trajectory_in_timed_region": bool(args.workload == "edit"),
                           "ref_trajectory_share_per_step": f"{nsteps}/{chunks_per_scene} DDIM steps of the next scene's 4 reference views" if args.workload == "edit" else None},
                "roofline": roof, "cpu_baseline": cpu}
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()                      # ranks leave together (rank 0 ran one more instrumented step)
         dist.destroy_process_group()
 
 
