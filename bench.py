@@ -187,6 +187,8 @@ def main():
     raster_target = torch.rand(H, W, 3, device=dev, generator=g)      # raster-only workload: a fixed synthetic target image
     edit_mask = torch.tensor(syn.elliptical_mask(H, W, soft=True), device=dev, dtype=torch.float32) if args.mask else None
 
+    grad_buf = {k: torch.zeros_like(v) for k, v in params.items()}        # the chunk's summed leaf gradients (what an optimizer step reads)
+
     def new_aux():
         aux = gops.RenderAux()
         if syncfree and state.get("cap"):
@@ -238,10 +240,9 @@ def main():
                 state["bank"], state["next"] = done, None
         else:
             edited = [None] * len(views)
-        for p in params.values():
-            p.grad = None
         for j, i in enumerate(views):                                                                       # (d)
             aux = new_aux()
+            aux.grad_into, aux.grad_accumulate = grad_buf, j > 0      # the batch's gradient sum is formed inside the backward kernel
             rgb, alpha, _ = gops.render_view(params["means"], params["scales"], params["quats"], params["opacities"],
                                              params["features_dc"], params["features_rest"], my_cams[i],
                                              torch.rand(3, device=dev), False, 3, aux)
@@ -252,7 +253,7 @@ def main():
             loss.backward()
             note_m(aux)
         if dist is not None and not state.get("rank0_only"):      # (the instrumented roofline steps run on rank 0 alone: no collective)
-            flat = torch.cat([p.grad.reshape(-1) for p in params.values()])
+            flat = torch.cat([t.reshape(-1) for t in grad_buf.values()])
             dist.all_reduce(flat)
 
     def barrier():

@@ -405,7 +405,9 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(int64_t N, Cam cam, int 
 // Backward of the above.  The colour path needs only the FORWARD colours (rgbs): the clamp(min = 0) mask is rgbs > 0 and the
 // sigmoid mode's derivative is s (1 - s), so the 192-byte SH record is not re-read; the 180-byte features_rest gradient is staged in
 // LDS and written with 16-byte-per-lane stores (a lane-strided 45-float store has the same 64-lines-per-instruction problem).
-template <int K>
+// ACC: the six outputs are accumulated into (+=) instead of written -- gradient accumulation over the views of a batch without a
+// separate read-add-write pass per tensor (the caller owns zeroing / the first view runs with ACC = false).
+template <int K, bool ACC>
 __global__ __launch_bounds__(256) void k_project_sh_bwd(int64_t N, Cam cam, int n_use,
                                                         const float *__restrict__ means, const float *__restrict__ log_scales,
                                                         const float *__restrict__ quats, const float *__restrict__ op_logit,
@@ -423,12 +425,15 @@ __global__ __launch_bounds__(256) void k_project_sh_bwd(int64_t N, Cam cam, int 
     const int64_t i0 = (int64_t)blockIdx.x * 256;
     const int64_t i = i0 + tid;
     float *vr = svr + tid * R;
+    auto put = [](float *p, float v) __attribute__((always_inline)) { *p = ACC ? *p + v : v; };
     if (i < N) {
         if (radii[i] <= 0) {
+            if (!ACC) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { v_means[3 * i + k] = 0.f; v_ls[3 * i + k] = 0.f; v_dc[3 * i + k] = 0.f; }
-            *reinterpret_cast<float4 *>(v_quats + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
-            v_oplogit[i] = 0.f;
+                for (int k = 0; k < 3; ++k) { v_means[3 * i + k] = 0.f; v_ls[3 * i + k] = 0.f; v_dc[3 * i + k] = 0.f; }
+                *reinterpret_cast<float4 *>(v_quats + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+                v_oplogit[i] = 0.f;
+            }
 #pragma unroll
             for (int k = 0; k < R; ++k) vr[k] = 0.f;
         } else {
@@ -440,18 +445,19 @@ __global__ __launch_bounds__(256) void k_project_sh_bwd(int64_t N, Cam cam, int 
             ProjGrad g;
             project_one_bwd(cam, p0, p1, p2, s0, s1, s2, q0, q1, q2, q3, conics[3 * i], conics[3 * i + 1], conics[3 * i + 2],
                             v_xy[2 * i], v_xy[2 * i + 1], 0.f, v_conic[3 * i], v_conic[3 * i + 1], v_conic[3 * i + 2], g);
-            v_means[3 * i] = g.vm[0]; v_means[3 * i + 1] = g.vm[1]; v_means[3 * i + 2] = g.vm[2];
-            v_ls[3 * i] = g.vs[0] * s0; v_ls[3 * i + 1] = g.vs[1] * s1; v_ls[3 * i + 2] = g.vs[2] * s2;
+            put(v_means + 3 * i, g.vm[0]); put(v_means + 3 * i + 1, g.vm[1]); put(v_means + 3 * i + 2, g.vm[2]);
+            put(v_ls + 3 * i, g.vs[0] * s0); put(v_ls + 3 * i + 1, g.vs[1] * s1); put(v_ls + 3 * i + 2, g.vs[2] * s2);
             // outer normalisation q/|q| (gc_model.py:144)
             float dq = q0 * g.vq[0] + q1 * g.vq[1] + q2 * g.vq[2] + q3 * g.vq[3];
-            *reinterpret_cast<float4 *>(v_quats + 4 * i) =
-                make_float4((g.vq[0] - q0 * dq) / qn, (g.vq[1] - q1 * dq) / qn, (g.vq[2] - q2 * dq) / qn, (g.vq[3] - q3 * dq) / qn);
+            float4 vq4 = make_float4((g.vq[0] - q0 * dq) / qn, (g.vq[1] - q1 * dq) / qn, (g.vq[2] - q2 * dq) / qn, (g.vq[3] - q3 * dq) / qn);
+            if (ACC) { const float4 o = *reinterpret_cast<const float4 *>(v_quats + 4 * i); vq4.x += o.x; vq4.y += o.y; vq4.z += o.z; vq4.w += o.w; }
+            *reinterpret_cast<float4 *>(v_quats + 4 * i) = vq4;
             float op = sigmoidf(op_logit[i]);
-            v_oplogit[i] = v_opac[i] * op * (1.f - op);
+            put(v_oplogit + i, v_opac[i] * op * (1.f - op));
             const float r0 = rgbs[3 * i], r1 = rgbs[3 * i + 1], r2 = rgbs[3 * i + 2];
             if (n_use < 0) {        // d sigmoid(features_dc)
-                v_dc[3 * i] = v_rgbs[3 * i] * r0 * (1.f - r0); v_dc[3 * i + 1] = v_rgbs[3 * i + 1] * r1 * (1.f - r1);
-                v_dc[3 * i + 2] = v_rgbs[3 * i + 2] * r2 * (1.f - r2);
+                put(v_dc + 3 * i, v_rgbs[3 * i] * r0 * (1.f - r0)); put(v_dc + 3 * i + 1, v_rgbs[3 * i + 1] * r1 * (1.f - r1));
+                put(v_dc + 3 * i + 2, v_rgbs[3 * i + 2] * r2 * (1.f - r2));
 #pragma unroll
                 for (int k = 0; k < R; ++k) vr[k] = 0.f;
             } else {
@@ -465,7 +471,7 @@ __global__ __launch_bounds__(256) void k_project_sh_bwd(int64_t N, Cam cam, int 
                 float v0 = r0 > 0.f ? v_rgbs[3 * i] : 0.f;
                 float v1 = r1 > 0.f ? v_rgbs[3 * i + 1] : 0.f;
                 float v2 = r2 > 0.f ? v_rgbs[3 * i + 2] : 0.f;
-                v_dc[3 * i] = B[0] * v0; v_dc[3 * i + 1] = B[0] * v1; v_dc[3 * i + 2] = B[0] * v2;
+                put(v_dc + 3 * i, B[0] * v0); put(v_dc + 3 * i + 1, B[0] * v1); put(v_dc + 3 * i + 2, B[0] * v2);
 #pragma unroll
                 for (int k = 1; k < K; ++k) {
                     float b = k < Ku ? B[k] : 0.f;
@@ -478,8 +484,12 @@ __global__ __launch_bounds__(256) void k_project_sh_bwd(int64_t N, Cam cam, int 
         __syncthreads();
         const int64_t cnt = ((N - i0 < 256 ? N - i0 : 256)) * R;
         float *dst = v_rest + i0 * R;
-        for (int64_t j = tid; j < cnt / 4; j += 256) reinterpret_cast<float4 *>(dst)[j] = reinterpret_cast<const float4 *>(svr)[j];
-        for (int64_t j = (cnt / 4) * 4 + tid; j < cnt; j += 256) dst[j] = svr[j];
+        for (int64_t j = tid; j < cnt / 4; j += 256) {
+            float4 v = reinterpret_cast<const float4 *>(svr)[j];
+            if (ACC) { const float4 o = reinterpret_cast<const float4 *>(dst)[j]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            reinterpret_cast<float4 *>(dst)[j] = v;
+        }
+        for (int64_t j = (cnt / 4) * 4 + tid; j < cnt; j += 256) dst[j] = ACC ? dst[j] + svr[j] : svr[j];
     }
 }
 
@@ -584,7 +594,7 @@ int gc_project_sh_fwd(int64_t N, const float *means, const float *log_scales, co
     return gc::check_launch("gc_project_sh_fwd");
 }
 
-int gc_project_sh_bwd(int64_t N, const float *means, const float *log_scales, const float *quats,
+static int project_sh_bwd_impl(bool accumulate, int64_t N, const float *means, const float *log_scales, const float *quats,
                       const float *opacity_logits, const float *rgbs,
                       int sh_degree, int degrees_to_use, const float *viewmat, const float *projmat,
                       const float *cam_origin, float fx, float fy, float cx, float cy, int img_h, int img_w,
@@ -596,9 +606,37 @@ int gc_project_sh_bwd(int64_t N, const float *means, const float *log_scales, co
     GC_REQUIRE(viewmat && projmat && cam_origin, "camera pointers are host pointers and must not be NULL");
     if (N == 0) return GC_OK;
     Cam cam = make_cam(viewmat, projmat, fx, fy, cx, cy, img_h, img_w, 0, 0, 0.f, 1.f, cam_origin);
-    GC_SH_DISPATCH(k_project_sh_bwd, N, cam, degrees_to_use, means, log_scales, quats, opacity_logits, rgbs, radii, conics, v_xy, v_conic, v_rgbs, v_opac, v_means, v_log_scales, v_quats,
-                   v_opacity_logits, v_features_dc, v_features_rest)
+#define GC_BWD_K(KK) \
+    do { if (accumulate) hipLaunchKernelGGL((k_project_sh_bwd<KK, true>), dim3(gc::cdiv(N, 256)), dim3(256), 0, gc::S(stream), GC_BWD_ARGS); \
+         else hipLaunchKernelGGL((k_project_sh_bwd<KK, false>), dim3(gc::cdiv(N, 256)), dim3(256), 0, gc::S(stream), GC_BWD_ARGS); } while (0)
+#define GC_BWD_ARGS N, cam, degrees_to_use, means, log_scales, quats, opacity_logits, rgbs, radii, conics, v_xy, v_conic, v_rgbs, v_opac, v_means, v_log_scales, v_quats, v_opacity_logits, v_features_dc, v_features_rest
+    switch (sh_degree) { case 0: GC_BWD_K(1); break; case 1: GC_BWD_K(4); break; case 2: GC_BWD_K(9); break; default: GC_BWD_K(16); break; }
+#undef GC_BWD_K
+#undef GC_BWD_ARGS
     return gc::check_launch("gc_project_sh_bwd");
+}
+
+int gc_project_sh_bwd(int64_t N, const float *means, const float *log_scales, const float *quats,
+                      const float *opacity_logits, const float *rgbs,
+                      int sh_degree, int degrees_to_use, const float *viewmat, const float *projmat,
+                      const float *cam_origin, float fx, float fy, float cx, float cy, int img_h, int img_w,
+                      const int32_t *radii, const float *conics, const float *v_xy, const float *v_conic,
+                      const float *v_rgbs, const float *v_opac, float *v_means, float *v_log_scales, float *v_quats,
+                      float *v_opacity_logits, float *v_features_dc, float *v_features_rest, void *stream)
+{
+    return project_sh_bwd_impl(false, N, means, log_scales, quats, opacity_logits, rgbs, sh_degree, degrees_to_use, viewmat, projmat, cam_origin, fx, fy, cx, cy, img_h, img_w, radii, conics, v_xy, v_conic, v_rgbs, v_opac, v_means, v_log_scales, v_quats, v_opacity_logits, v_features_dc, v_features_rest, stream);
+}
+
+/* Same, but the six outputs are ACCUMULATED into (+=): gradient accumulation over the views of a batch inside the kernel. */
+int gc_project_sh_bwd_accumulate(int64_t N, const float *means, const float *log_scales, const float *quats,
+                      const float *opacity_logits, const float *rgbs,
+                      int sh_degree, int degrees_to_use, const float *viewmat, const float *projmat,
+                      const float *cam_origin, float fx, float fy, float cx, float cy, int img_h, int img_w,
+                      const int32_t *radii, const float *conics, const float *v_xy, const float *v_conic,
+                      const float *v_rgbs, const float *v_opac, float *v_means, float *v_log_scales, float *v_quats,
+                      float *v_opacity_logits, float *v_features_dc, float *v_features_rest, void *stream)
+{
+    return project_sh_bwd_impl(true, N, means, log_scales, quats, opacity_logits, rgbs, sh_degree, degrees_to_use, viewmat, projmat, cam_origin, fx, fy, cx, cy, img_h, img_w, radii, conics, v_xy, v_conic, v_rgbs, v_opac, v_means, v_log_scales, v_quats, v_opacity_logits, v_features_dc, v_features_rest, stream);
 }
 
 int gc_raster_finalize(int64_t num_pixels, float *out_img, float *out_extra, const float *final_Ts, float *alpha,

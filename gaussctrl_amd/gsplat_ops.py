@@ -283,6 +283,11 @@ class RenderAux:
     final_index = None
     isect_ids_sorted = None
     m_cap = None          # set to an intersection capacity for the sync-free path: M then is (count, overflow) device tensors
+    # Gradient accumulation inside the backward kernel: grad_into = {"means", "scales", "quats", "opacities", "features_dc",
+    # "features_rest"} -> fp32 tensors shaped like the parameters.  The backward then writes (grad_accumulate = False) or adds
+    # (True) the six leaf gradients there and hands autograd None for them -- no separate read-add-write pass per tensor and view.
+    grad_into = None
+    grad_accumulate = False
 
 
 class _RenderView(torch.autograd.Function):
@@ -342,14 +347,25 @@ class _RenderView(torch.autograd.Function):
         v_xy, v_conic, v_col, v_op = _rasterize_bwd(H, W, tb, N, ids_s, bins, xys, conics, rgbs, opac, bg, fT, fi, vo, va)
         if ctx.aux is not None:
             ctx.aux.xys_grad = v_xy
-        vm = torch.empty(N, 3, device=dev); vls = torch.empty(N, 3, device=dev); vq = torch.empty(N, 4, device=dev)
-        vop = torch.empty(N, device=dev); vdc = torch.empty(N, 3, device=dev)
-        vrest = torch.empty(rest.shape, device=dev)
-        L.check(L.lib().gc_project_sh_bwd(
+        into = ctx.aux.grad_into if ctx.aux is not None else None
+        if into is not None:
+            vm, vls, vq, vop, vdc, vrest = (into[k] for k in ("means", "scales", "quats", "opacities", "features_dc", "features_rest"))
+            for t, ref in ((vm, m), (vls, ls), (vq, q), (vdc, dc), (vrest, rest)):
+                assert t.is_contiguous() and t.dtype == torch.float32 and t.shape == ref.shape and t.device == dev
+            assert vop.is_contiguous() and vop.dtype == torch.float32 and vop.numel() == N and vop.device == dev
+            fn = L.lib().gc_project_sh_bwd_accumulate if ctx.aux.grad_accumulate else L.lib().gc_project_sh_bwd
+        else:
+            vm = torch.empty(N, 3, device=dev); vls = torch.empty(N, 3, device=dev); vq = torch.empty(N, 4, device=dev)
+            vop = torch.empty(N, device=dev); vdc = torch.empty(N, 3, device=dev)
+            vrest = torch.empty(rest.shape, device=dev)
+            fn = L.lib().gc_project_sh_bwd
+        L.check(fn(
             L.i64(N), L.ptr(m), L.ptr(ls), L.ptr(q), L.ptr(op), L.ptr(rgbs), L.i32(sh_degree), L.i32(n_use),
             V, P, O, L.f32(cam["fx"]), L.f32(cam["fy"]), L.f32(cam["cx"]), L.f32(cam["cy"]), L.i32(H), L.i32(W),
             L.ptr(radii), L.ptr(conics), L.ptr(v_xy), L.ptr(v_conic), L.ptr(v_col), L.ptr(v_op), L.ptr(vm), L.ptr(vls),
             L.ptr(vq), L.ptr(vop), L.ptr(vdc), L.ptr(vrest), L.stream_ptr()), "gc_project_sh_bwd")
+        if into is not None:
+            return (None,) * 11
         return vm, vls, vq, vop[:, None], vdc, vrest, None, None, None, None, None
 
 

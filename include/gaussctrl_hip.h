@@ -168,6 +168,16 @@ int gc_project_sh_bwd(int64_t N, const float *means, const float *log_scales, co
                       const float *v_xy, const float *v_conic, const float *v_rgbs, const float *v_opac,
                       float *v_means, float *v_log_scales, float *v_quats, float *v_opacity_logits,
                       float *v_features_dc, float *v_features_rest, void *stream);
+/* The same with the six outputs ACCUMULATED into (+=): gradient accumulation over the views of a batch inside the kernel (what
+ * autograd otherwise does with one read-add-write pass per tensor and view). */
+int gc_project_sh_bwd_accumulate(int64_t N, const float *means, const float *log_scales, const float *quats,
+                      const float *opacity_logits, const float *rgbs,
+                      int sh_degree, int degrees_to_use, const float *viewmat, const float *projmat,
+                      const float *cam_origin, float fx, float fy, float cx, float cy, int img_h, int img_w,
+                      const int32_t *radii, const float *conics,
+                      const float *v_xy, const float *v_conic, const float *v_rgbs, const float *v_opac,
+                      float *v_means, float *v_log_scales, float *v_quats, float *v_opacity_logits,
+                      float *v_features_dc, float *v_features_rest, void *stream);
 
 /* Epilogue of get_outputs (gc_model.py:188,197-204): rgb=min(rgb,1); alpha=1-final_T;
  * depth = alpha>0 ? depth/alpha : 1000.  In place on out_img / out_extra; writes alpha[H,W]. */

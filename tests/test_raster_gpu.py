@@ -386,3 +386,39 @@ def test_sh_degree0_sigmoid_colour(oracle_c):
     scale = max(np.abs(o["grads"][k]).max() for k in ("means", "scales", "quats", "opacities", "features_dc"))
     for k in ("means", "scales", "quats", "opacities", "features_dc"):
         _grad_close(tp[k].grad.cpu().numpy(), o["grads"][k], scale)
+
+
+def test_backward_accumulates_into_buffers(oracle_c):
+    """RenderAux.grad_into: the fused backward writes (first view) / adds (further views) the six leaf gradients into caller buffers and
+    autograd gets None for them -- equal to the sum of the per-view autograd gradients."""
+    from gaussctrl_amd import gsplat_ops as ops
+    from gaussctrl_amd.camera import camera_to_gsplat
+    N, W, H = 30000, 160, 112
+    P = syn.make_gaussians(N, seed=2, scale_mean=0.03)
+    cams = syn.make_cameras(3, seed=4)
+    tp = {k: _t(v).requires_grad_(True) for k, v in P.items()}
+    g = torch.Generator(device="cpu").manual_seed(0)
+    vs = [torch.randn(H, W, 3, generator=g).to(DEV) for _ in cams]
+
+    def render(c2w, aux):
+        cam = camera_to_gsplat(c2w, 150.0, 150.0, W / 2, H / 2, W, H)
+        return ops.render_view(tp["means"], tp["scales"], tp["quats"], tp["opacities"], tp["features_dc"], tp["features_rest"], cam, _t(BG),
+                               False, 3, aux)[0]
+    ref = {k: torch.zeros_like(v) for k, v in tp.items()}
+    for c2w, v in zip(cams, vs):
+        for p in tp.values():
+            p.grad = None
+        (render(c2w, ops.RenderAux()) * v).sum().backward()
+        for k in tp:
+            ref[k] += tp[k].grad
+    buf = {k: torch.full_like(v, float("nan")) for k, v in tp.items()}     # the first view must overwrite, not add
+    for p in tp.values():
+        p.grad = None
+    for j, (c2w, v) in enumerate(zip(cams, vs)):
+        aux = ops.RenderAux(); aux.grad_into, aux.grad_accumulate = buf, j > 0
+        (render(c2w, aux) * v).sum().backward()
+    assert all(p.grad is None for p in tp.values())
+    scale = max(float(r.abs().max()) for r in ref.values())
+    for k in tp:
+        assert torch.isfinite(buf[k]).all(), k
+        _grad_close(buf[k].cpu().numpy(), ref[k].cpu().numpy(), scale)
