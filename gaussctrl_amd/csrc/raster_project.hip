@@ -355,6 +355,14 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(int64_t N, Cam cam, int 
     const int tid = threadIdx.x;
     const int64_t i0 = (int64_t)blockIdx.x * 256;
     const int64_t i = i0 + tid;
+    // the lane's own record is requested BEFORE the cooperative staging of the SH block, so that the two HBM round trips overlap
+    // (3 workgroups per CU -- the 46 KB of LDS -- leave little else to hide them behind)
+    const int64_t ic = i < N ? i : N - 1;
+    float p0 = means[3 * ic], p1 = means[3 * ic + 1], p2 = means[3 * ic + 2];
+    const float l0 = log_scales[3 * ic], l1 = log_scales[3 * ic + 1], l2 = log_scales[3 * ic + 2];
+    float4 q = *reinterpret_cast<const float4 *>(quats + 4 * ic);
+    const float opl = op_logit[ic];
+    const float d0 = f_dc[3 * ic], d1 = f_dc[3 * ic + 1], d2 = f_dc[3 * ic + 2];
     if (R > 0 && n_use > 0) {
         const int64_t cnt = ((N - i0 < 256 ? N - i0 : 256)) * R;        // floats of this workgroup's block
         const float *src = f_rest + i0 * R;                              // 256 * R * 4 bytes per block: 16-byte aligned
@@ -363,32 +371,29 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(int64_t N, Cam cam, int 
     }
     Proj o;
     bool ok = false;
-    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
     if (i < N) {
-        p0 = means[3 * i]; p1 = means[3 * i + 1]; p2 = means[3 * i + 2];
-        float s0 = expf(log_scales[3 * i]), s1 = expf(log_scales[3 * i + 1]), s2 = expf(log_scales[3 * i + 2]);
-        float4 q = *reinterpret_cast<const float4 *>(quats + 4 * i);
+        float s0 = expf(l0), s1 = expf(l1), s2 = expf(l2);
         float qn = sqrtf(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w);
         q.x = q.x / qn; q.y = q.y / qn; q.z = q.z / qn; q.w = q.w / qn;
         ok = project_one(cam, p0, p1, p2, s0, s1, s2, q.x, q.y, q.z, q.w, o);
         xys[2 * i] = o.xy[0]; xys[2 * i + 1] = o.xy[1];
         depths[i] = o.depth; radii[i] = o.radius; tiles_hit[i] = o.tiles_hit;
         conics[3 * i] = o.conic[0]; conics[3 * i + 1] = o.conic[1]; conics[3 * i + 2] = o.conic[2];
-        opac[i] = sigmoidf(op_logit[i]);
+        opac[i] = sigmoidf(opl);
     }
     if (R > 0 && n_use > 0) __syncthreads();
     if (i >= N) return;
     float c0 = 0.f, c1 = 0.f, c2 = 0.f;
     if (ok) {
         if (n_use < 0) {          // config.sh_degree == 0: rgbs = sigmoid(features_dc)   (gc_model.py:169)
-            c0 = sigmoidf(f_dc[3 * i]); c1 = sigmoidf(f_dc[3 * i + 1]); c2 = sigmoidf(f_dc[3 * i + 2]);
+            c0 = sigmoidf(d0); c1 = sigmoidf(d1); c2 = sigmoidf(d2);
         } else {
             float dx = p0 - cam.ox, dy = p1 - cam.oy, dz = p2 - cam.oz;
             float dn = sqrtf((dx * dx + dy * dy) + dz * dz);
             dx = dx / dn; dy = dy / dn; dz = dz / dn;
             float B[16];
             sh_basis(n_use, dx, dy, dz, B);
-            c0 = B[0] * f_dc[3 * i]; c1 = B[0] * f_dc[3 * i + 1]; c2 = B[0] * f_dc[3 * i + 2];
+            c0 = B[0] * d0; c1 = B[0] * d1; c2 = B[0] * d2;
             const float *r = srest + tid * R;
             int Ku = (n_use + 1) * (n_use + 1);
 #pragma unroll
