@@ -114,6 +114,9 @@ def broadcast_ref_bank(bank, src: int, world_size: int, rank: int, device=None, 
     return bank
 
 
+MAX_INFLIGHT = 3        # async reference-bank broadcasts in flight (owner: packed copies kept; others: receive buffers posted)
+
+
 def broadcast_ref_bank_pipelined(pipe, ref_z0, ref_disp, ctx_neg, ctx_pos, src: int, world_size: int, rank: int, device, n_steps: int):
     """SURVEY.md 8e collective 1 as a pipeline: the owner advances the 4-view reference trajectory ONE DDIM step at a time and
     posts step i's K / V^T (one flat message, ~0.5 GB at SD1.5 / 512x512) as an ASYNC broadcast while it computes step i+1; the other
@@ -137,6 +140,8 @@ def broadcast_ref_bank_pipelined(pipe, ref_z0, ref_disp, ctx_neg, ctx_pos, src: 
             if flat.is_cuda:
                 torch.cuda.current_stream().synchronize()      # the packed buffer is complete before RCCL's stream reads it
             pending.append((dist.broadcast(flat, src=src, async_op=True), flat))
+            while len(pending) > MAX_INFLIGHT:          # bound the packed copies held beside the bank (~0.5 GB each at SD1.5 / 512^2)
+                pending.pop(0)[0].wait()
         for h, _ in pending:
             h.wait()
         assert done is not None
@@ -146,11 +151,15 @@ def broadcast_ref_bank_pipelined(pipe, ref_z0, ref_disp, ctx_neg, ctx_pos, src: 
     dist.broadcast_object_list(box, src=src)
     layers = box[0]
     dtype = getattr(torch, layers[0][4].split(".")[-1])
-    for i in range(n_steps):
-        flat = torch.empty(_step_numel(layers), dtype=dtype, device=device)
-        pending.append((dist.broadcast(flat, src=src, async_op=True), flat))
-    for i, (h, flat) in enumerate(pending):
+    posted = 0
+    for i in range(n_steps):                            # at most MAX_INFLIGHT receive buffers exist beside the unpacked bank
+        while posted < n_steps and posted - i < MAX_INFLIGHT:
+            flat = torch.empty(_step_numel(layers), dtype=dtype, device=device)
+            pending.append((dist.broadcast(flat, src=src, async_op=True), flat))
+            posted += 1
+        h, flat = pending.pop(0)
         h.wait()
         _unpack_step(bank, i, layers, flat)
+        del flat
     bank.mode = "use"
     return bank

@@ -130,3 +130,18 @@ class SimpleDataManager(GaussCtrlDataManager if not HAVE_NERFSTUDIO else _NextTr
             return
         cfg = GaussCtrlDataManagerConfig(load_all=load_all)
         super().__init__(cfg, cameras=cameras, images=images, seed=seed)
+
+    if HAVE_NERFSTUDIO:      # plain holder: what GaussCtrlPipeline / VanillaPipeline ask of a data manager
+        def next_train(self, step: int):
+            i = self._pop_view()
+            cam = self.cameras[i]
+            if getattr(cam, "metadata", None) is None:
+                cam.metadata = {}
+            cam.metadata["cam_idx"] = i
+            return cam, dict(self.train_data[i])
+
+        def get_training_callbacks(self, training_callback_attributes):
+            return []
+
+        def get_param_groups(self):
+            return {}

@@ -63,6 +63,8 @@ class GaussCtrlPipelineConfig(_PipelineConfigBase):
     cache_reference_kv: bool = True
     ref_bank_owner: int = -1           # world_size > 1: rank that computes the reference trajectory and broadcasts its K / V^T step
                                        # by step (-1: every rank computes it itself -- no data-path collective)
+    round_like_reference: bool = False  # True: round the rendered rgb / depth to fp16 before inversion, disparity and the mask composite,
+                                       # exactly where the reference does (gc_pipeline.py:132-133,155); False keeps the fp32 renders
     synthetic_weights: bool = False    # True: seeded random SD1.5-shaped weights + hashed prompt embeddings (bench / tests; there
                                        # are no checkpoints on the build machines).  False: checkpoints are REQUIRED -- no silent fallback.
 
@@ -80,7 +82,8 @@ class GaussCtrlPipeline(_PipelineBase):
             self.config = config
             self.datamanager = datamanager
             self._model = model
-        self.device = torch.device(device)
+        # nerfstudio's Pipeline.device is a read-only property (= model.device): keep our own handle under another name
+        self._dev = torch.device(device)
         self.test_mode = test_mode
         self.world_size, self.local_rank = world_size, local_rank
         self.edit_prompt, self.reverse_prompt = config.edit_prompt, config.reverse_prompt
@@ -100,7 +103,7 @@ class GaussCtrlPipeline(_PipelineBase):
         self.num_inference_steps, self.guidance_scale = config.num_inference_steps, config.guidance_scale
         self.controlnet_conditioning_scale, self.eta, self.chunk_size = 1.0, 0.0, config.chunk_size
         self.dtype = torch.float16 if config.dtype == "f16" else torch.bfloat16
-        dev = self.device
+        dev = self._dev
         self.weights_source = {}
         w = diffusion_weights
         if w is None and not config.synthetic_weights:                 # the reference's from_pretrained calls (:97-102)
@@ -137,6 +140,12 @@ class GaussCtrlPipeline(_PipelineBase):
         self.mask_fn = mask_fn                                     # LangSAM stand-in: image[H,W,3] -> mask[H,W] (out of scope)
         print("[gaussctrl_amd] diffusion weights: " + ", ".join(f"{k} <- {v}" for k, v in sorted(self.weights_source.items())))
 
+    if not HAVE_NERFSTUDIO:
+        @property
+        def device(self):
+            """nerfstudio's Pipeline exposes this as a read-only property (the model's device); same here without it"""
+            return self._dev
+
     @property
     def model(self):
         return self._model.module if hasattr(self._model, "module") and not isinstance(self._model, GaussCtrlModel) else self._model
@@ -148,7 +157,7 @@ class GaussCtrlPipeline(_PipelineBase):
         return list(self.model.get_training_callbacks(training_callback_attributes))
 
     def _encode(self, prompt):
-        return self.text_encoder(prompt).to(self.device)
+        return self.text_encoder(prompt).to(self._dev)
 
     def _my_views(self):
         from .dist import shard_views
@@ -162,10 +171,13 @@ class GaussCtrlPipeline(_PipelineBase):
         td = self.datamanager.train_data
         for cam_idx in views:
             out = self._model.get_outputs_for_camera(self.datamanager.cameras[cam_idx])
-            td[cam_idx]["unedited_image"] = out["rgb"]                        # [H,W,3] fp32, stays on the GPU
-            td[cam_idx]["depth_image"] = out["depth"][..., 0]                 # [H,W]
+            rgb, depth = out["rgb"], out["depth"][..., 0]
+            if self.config.round_like_reference:                              # :132-133 `.to(torch.float16)` (values kept in fp32 storage)
+                rgb, depth = rgb.to(torch.float16).float(), depth.to(torch.float16).float()
+            td[cam_idx]["unedited_image"] = rgb                               # [H,W,3] fp32, stays on the GPU
+            td[cam_idx]["depth_image"] = depth                                # [H,W]
             if self.config.langsam_obj != "" and self.mask_fn is not None:
-                td[cam_idx]["mask_image"] = self.mask_fn(out["rgb"], self.config.langsam_obj)
+                td[cam_idx]["mask_image"] = self.mask_fn(rgb, self.config.langsam_obj)
         ctx = self._encode(self.positive_reverse_prompt)
         for s in range(0, len(views), max(self.chunk_size, 1)):
             chunk = views[s:s + max(self.chunk_size, 1)]
@@ -196,7 +208,7 @@ class GaussCtrlPipeline(_PipelineBase):
                 # per step) while the owner already computes the next step (SURVEY.md 8e collective 1)
                 from .dist import broadcast_ref_bank_pipelined
                 bank = broadcast_ref_bank_pipelined(self.pipe, ref_z0, ref_disp, cn, cp, owner, self.world_size, self.local_rank,
-                                                    self.device, self.num_inference_steps)
+                                                    self._dev, self.num_inference_steps)
             else:
                 bank = self.pipe.build_ref_bank(ref_z0, ref_disp, cn, cp)
         views = self._my_views()
@@ -228,7 +240,7 @@ class GaussCtrlPipeline(_PipelineBase):
         mine = self._my_views()
         cam = self.datamanager.cameras[0]          # a rank may own no view (V < world_size): the image shape comes from the camera
         shape = (int(cam.height.reshape(-1)[0]), int(cam.width.reshape(-1)[0]), 3)
-        allv = allgather_view_images({i: td[i]["image"] for i in mine}, len(td), self.world_size, self.local_rank, shape, self.device)
+        allv = allgather_view_images({i: td[i]["image"] for i in mine}, len(td), self.world_size, self.local_rank, shape, self._dev)
         for i, img in allv.items():
             td[i]["image"] = img
 
@@ -243,6 +255,12 @@ class GaussCtrlPipeline(_PipelineBase):
     def depth2disparity_torch(self, depth):
         """depth [H,W] (or [1,H,W]) -> disparity [3,H,W] fp32 = 1/(d+1e-5)/max (:258-266)"""
         d = depth.reshape(depth.shape[-2], depth.shape[-1]).float()
+        if self.config.round_like_reference:
+            # the reference evaluates :263-264 on the fp16 depth, i.e. with one fp16 rounding after each of the three operations
+            # (glue, three tiny elementwise launches; only under this flag -- the product path is the fused kernel below)
+            h = 1 / (d.to(torch.float16) + 1e-5)
+            h = h / torch.max(h)
+            return h[None].expand(3, -1, -1).float()
         disp = sdops.depth_to_disparity(d, self.dtype)[..., :3]
         return disp.permute(2, 0, 1).float()
 
@@ -271,7 +289,7 @@ class GaussCtrlPipeline(_PipelineBase):
         found = []
         for i in (self._my_views() if views is None else views):
             if midcache.has_view(root, i):
-                d = midcache.load_view(root, i, self.device)
+                d = midcache.load_view(root, i, self._dev)
                 d["depth_image"] = d["depth_image"][0]                                   # [H,W] as render_reverse stores it
                 td[i].update(d)
                 found.append(i)

@@ -18,14 +18,25 @@ _VAE_ATTN_OLD = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "
 
 
 def resolve(ckpt: str) -> str:
+    """local directory, else the local Hugging Face cache, else (unless HF_HUB_OFFLINE is set) a normal hub download -- what the
+    reference's `from_pretrained` does on a machine with network access and an empty cache"""
     if os.path.isdir(ckpt):
         return ckpt
     try:
         from huggingface_hub import snapshot_download
-        return snapshot_download(ckpt, local_files_only=True)
     except Exception as e:  # noqa: BLE001
-        raise FileNotFoundError(f"diffusion checkpoint '{ckpt}' is neither a local directory nor in the local Hugging Face cache "
-                                f"(no network here): {e}") from e
+        raise FileNotFoundError(f"diffusion checkpoint '{ckpt}' is not a local directory and huggingface_hub is unavailable: {e}") from e
+    try:
+        return snapshot_download(ckpt, local_files_only=True)
+    except Exception as e_local:  # noqa: BLE001
+        if os.environ.get("HF_HUB_OFFLINE", "0") not in ("", "0"):
+            raise FileNotFoundError(f"diffusion checkpoint '{ckpt}' is neither a local directory nor in the local Hugging Face cache "
+                                    f"(HF_HUB_OFFLINE is set): {e_local}") from e_local
+        try:
+            return snapshot_download(ckpt)
+        except Exception as e:  # noqa: BLE001
+            raise FileNotFoundError(f"diffusion checkpoint '{ckpt}' is neither a local directory nor in the local Hugging Face cache, "
+                                    f"and downloading it failed (no network?): {e}") from e
 
 
 def _load_file(folder: str) -> dict:

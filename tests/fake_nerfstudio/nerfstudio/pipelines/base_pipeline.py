@@ -24,5 +24,10 @@ class VanillaPipeline(nn.Module):
     def model(self):
         return self._model
 
+    @property
+    def device(self):
+        """read-only, like nerfstudio's Pipeline.device: assigning to it raises AttributeError"""
+        return getattr(self._model, "device", None)
+
     def get_training_callbacks(self, attrs):
         return self.datamanager.get_training_callbacks(attrs) + self.model.get_training_callbacks(attrs)

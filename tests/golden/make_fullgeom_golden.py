@@ -14,7 +14,12 @@ Attention uses oracle.sd15_torch.ATTN_IMPL = "sdpa" (torch's fused CPU kernel of
 form would materialise 5 x [14*8, 4096, 4096] fp32 tensors per layer); tests/test_oracle_sd.py pins both forms
 against the reference-generated goldens.
 
-usage: python tests/golden/make_fullgeom_golden.py [edit7|vae|invert|edit12 ...]
+`config4` is BASELINE configs[3] end to end on the oracle: f = 4 references + chunk_size 8 = 12 frames (CFG batch 24), ALL 20 DDIM
+steps, the 8 chunk frames decoded by the VAE and composited through the synthetic elliptical object mask
+(gc_pipeline.py:209-234).  Stored: latents after steps 1, 2, 5, 10, 20 and the composited images on a stride-4 pixel lattice
+(full-resolution decode parity has its own fixture, fullgeom_vae_h64.npz).
+
+usage: python tests/golden/make_fullgeom_golden.py [edit7|vae|invert|edit12|config4|vaeenc ...]
 """
 import os
 import sys
@@ -92,6 +97,47 @@ def vae(h, seed, name):
     print(f"{name}: {time.time() - t0:.0f}s", flush=True)
 
 
+def vaeenc(H, seed, name):
+    """image2latent (gc_pipeline.py:239-246) at the full 512 x 512 image: vae.encode(2x-1).mean * 0.18215"""
+    vw = {k: bf16r(v) for k, v in sd.make_vae_encoder_weights(sd.VAE_SD, SEED_VAE + 100).items()}
+    img = torch.rand(H, H, 3, generator=torch.Generator().manual_seed(seed))
+    t0 = time.time()
+    with torch.no_grad():
+        lat = sd.vae_encode_mean(vw, bf16r(img * 2 - 1).permute(2, 0, 1)[None], sd.VAE_SD) * 0.18215
+    np.savez_compressed(os.path.join(HERE, name), latent=lat.numpy(), meta=np.array([H, seed, SEED_VAE + 100], np.int64))
+    print(f"{name}: {time.time() - t0:.0f}s", flush=True)
+
+
+CONFIG4_STEPS = (1, 2, 5, 10, 20)
+CONFIG4_STRIDE = 4
+
+
+def config4(h, seed, name):
+    """BASELINE configs[3]: chunk_size 8 -> f = 12, all 20 steps, VAE decode of the chunk frames, mask composite."""
+    from gaussctrl_amd import synthetic as syn          # numpy-only helper (the mask recipe bench.py --mask uses)
+    f, steps = 12, 20
+    uw, cw = weights()
+    vw = {k: bf16r(v) for k, v in sd.make_vae_decoder_weights(sd.VAE_SD, SEED_VAE).items()}
+    lat, disp, cn, cp = inputs(f, h, seed)
+    trace = []
+    t0 = time.time()
+    with torch.no_grad():
+        out = sd.denoise_chunk(uw, cw, lat, bf16r(disp), bf16r(cn), bf16r(cp), 5.0, steps, sd.SD15, 20, trace=trace)
+        print(f"config4 denoise: {time.time() - t0:.0f}s", flush=True)
+        H = 8 * h
+        mask = torch.tensor(syn.elliptical_mask(H, H, soft=True))
+        g = torch.Generator().manual_seed(seed + 1000)
+        comps = []
+        for j in range(4, f):                      # the references are dropped (gc_pipeline.py:219)
+            img = sd.postprocess_image(sd.vae_decode(vw, bf16r(out[j:j + 1] / 0.18215), sd.VAE_SD))[0]      # [3,H,W]
+            unedited = torch.rand(H, H, 3, generator=g)
+            comps.append(sd.mask_composite(img, unedited, mask)[::CONFIG4_STRIDE, ::CONFIG4_STRIDE].clone())
+    np.savez_compressed(os.path.join(HERE, name), lat_steps=torch.stack([trace[s - 1] for s in CONFIG4_STEPS]).numpy(),
+                        which_steps=np.array(CONFIG4_STEPS, np.int64), composite=torch.stack(comps).numpy(),
+                        meta=np.array([f, h, steps, seed, SEED_UNET, SEED_CN, SEED_VAE, CONFIG4_STRIDE], np.int64))
+    print(f"{name}: {time.time() - t0:.0f}s", flush=True)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(int(os.environ.get("GC_GOLDEN_THREADS", "7")))
     sd.ATTN_IMPL = "sdpa"
@@ -105,3 +151,7 @@ if __name__ == "__main__":
             invert(3, 64, 20, 5, "fullgeom_invert_f3_h64.npz")
         elif w == "edit12":      # BASELINE configs[3]: chunk_size 8 -> f = 12, CFG batch 24 (2 of 20 steps)
             edit(12, 64, 2, 7, "fullgeom_edit_f12_h64.npz")
+        elif w == "vaeenc":      # image2latent at 512 x 512 (render_reverse's encoder call)
+            vaeenc(512, 9, "fullgeom_vaeenc_h512.npz")
+        elif w == "config4":     # BASELINE configs[3] end to end (same inputs as edit12: its 2 steps are this trajectory's first 2)
+            config4(64, 7, "fullgeom_config4_f12_h64.npz")

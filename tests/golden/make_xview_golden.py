@@ -10,7 +10,12 @@ stand-in for diffusers 0.26.0's `Attention` module exposing exactly the attribut
   head_to_batch_dim [B,L,C]->[B*H,L,C/H]; get_attention_scores = softmax(scale * q k^T, dim=-1);
   to_q/to_k/to_v without bias, to_out = [Linear with bias, Dropout(0)].
 
-usage: python tests/golden/make_xview_golden.py
+`big` adds the PRODUCTION geometry of the dominant kernel (SD1.5 level 0: L = 4096 tokens, 8 heads x D = 40, f = 5 frames,
+CFG batch 10 -> the k_attn4 launch; and level 1: L = 1024, D = 80 -> k_attn3), run through the same imported reference
+processor (five [80, L, L] fp32 probability tensors, ~16 GB peak).  Inputs and weights come from seeded CPU generators
+(`big_inputs`, re-created by the GPU test), the .npz keeps the reference's output on a strided subset of token rows.
+
+usage: python tests/golden/make_xview_golden.py [small] [big]
 """
 import importlib.util
 import os
@@ -74,8 +79,54 @@ class FakeAttention(torch.nn.Module):
         return scores.softmax(dim=-1)
 
 
+BIG_CASES = [  # (name, frames f, tokens L, heads, dim_head, text_len, cross_dim, self_attn_coeff, row stride)
+    ("big_l4096_d40", 5, 4096, 8, 40, 77, 768, 0.6, 41),
+    ("big_l1024_d80", 5, 1024, 8, 80, 77, 768, 0.6, 23),
+]
+
+
+def big_inputs(seed, f, L, H, D, Lt, Ct):
+    """Seeded inputs / weights of a production-geometry case (the GPU test re-creates them with the same calls).  to_q / to_k
+    are drawn twice as wide as 1/sqrt(C) so the logits have a spread of ~4 and the softmax is peaked, not uniform."""
+    g = torch.Generator().manual_seed(seed)
+    C, B = H * D, 2 * f
+    r = lambda *s: torch.randn(*s, generator=g)
+    out = {}
+    for kind, cin in (("self", C), ("text", Ct)):
+        out[kind] = dict(x=r(B, L, C), ctx=None if kind == "self" else r(B, Lt, Ct),
+                         wq=r(C, C) * (2.0 * C ** -0.5), wk=r(C, cin) * (2.0 * cin ** -0.5), wv=r(C, cin) * cin ** -0.5,
+                         wo=r(C, C) * C ** -0.5, bo=r(C) * 0.1)
+    return out
+
+
+def big(ref):
+    for case_idx, (name, f, L, H, D, Lt, Ct, coeff, stride) in enumerate(BIG_CASES):
+        seed = 2000 + case_idx
+        C = H * D
+        inp = big_inputs(seed, f, L, H, D, Lt, Ct)
+        proc = ref.CrossViewAttnProcessor(self_attn_coeff=coeff, unet_chunk_size=2)
+        out = {}
+        for kind, cross in (("self", None), ("text", Ct)):
+            d = inp[kind]
+            attn = FakeAttention(C, cross, H, D)
+            with torch.no_grad():
+                attn.to_q.weight.copy_(d["wq"]); attn.to_k.weight.copy_(d["wk"]); attn.to_v.weight.copy_(d["wv"])
+                attn.to_out[0].weight.copy_(d["wo"]); attn.to_out[0].bias.copy_(d["bo"])
+                y = proc(attn, d["x"], encoder_hidden_states=d["ctx"])
+            out[f"{kind}_y_rows"] = y[:, ::stride].contiguous().numpy().astype(np.float32)
+            out[f"{kind}_y_norm"] = np.array(float(y.double().norm()))
+        out["meta"] = np.array([f, L, H, D, Lt, Ct, seed, stride], np.int64); out["coeff"] = np.array(coeff, np.float64)
+        np.savez_compressed(os.path.join(HERE, f"xview_{name}.npz"), **out)
+        print("wrote", name, {k: v.shape for k, v in out.items() if hasattr(v, "shape")}, flush=True)
+
+
 def main():
     ref = load_reference_utils()
+    what = sys.argv[1:] or ["small"]
+    if "big" in what:
+        big(ref)
+    if "small" not in what:
+        return
     cases = [  # (name, frames f, tokens L, heads, dim_head, text_len, cross_dim, self_attn_coeff)
         ("unet_f5", 5, 32, 8, 8, 11, 48, 0.6),
         ("unet_f7", 7, 48, 8, 8, 11, 48, 0.6),

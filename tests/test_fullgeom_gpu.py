@@ -153,6 +153,86 @@ def test_vae_decode_h64(dt):
         assert float(err.mean()) <= 1.0 / 255.0 and float(err.max()) <= 8.0 / 255.0, (float(err.mean()), float(err.max()))
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_vae_encode_h512(dt):
+    """image2latent (gc_pipeline.py:239-246) at the full 512 x 512 render: vae.encode(2x - 1).mean * 0.18215 -> [1,4,64,64]
+    (the encoder's mid-block attention runs at L = 4096, D = 512), against the oracle's fp32 encode of the same bf16-rounded weights
+    and input.  Same relative-L2 bars as the latents of the denoise loop."""
+    from oracle import sd15_torch as sd
+    from gaussctrl_amd.sd.pipeline import to_nhwc8
+    from gaussctrl_amd.sd.vae import VAEEncoder, prepare_vae_encoder_weights
+    z = np.load(os.path.join(GOLD, "fullgeom_vaeenc_h512.npz"))
+    ref = torch.tensor(z["latent"])
+    H, seed, wseed = [int(v) for v in z["meta"]]
+    vw = {k: v.to(torch.bfloat16).float() for k, v in sd.make_vae_encoder_weights(sd.VAE_SD, wseed).items()}
+    img = torch.rand(H, H, 3, generator=torch.Generator().manual_seed(seed))
+    x = (img * 2 - 1).to(torch.bfloat16).float().permute(2, 0, 1)[None]
+    enc = VAEEncoder(prepare_vae_encoder_weights({k: v.to(DEV) for k, v in vw.items()}, dt, DEV))
+    got = (enc.encode_mean(to_nhwc8(x.to(DEV), dt))[..., :4] * 0.18215).permute(0, 3, 1, 2).float().cpu()
+    rel = _rel(got, ref)
+    print(f"\nvae encode 512x512 {dt}: rel L2 {rel:.3e}  max abs {float((got - ref).abs().max()):.3e}")
+    assert got.shape == (1, 4, H // 8, H // 8) and rel <= BAR[dt], rel
+
+
+def _config4_run(nets, dt, fp8):
+    """BASELINE configs[3] end to end against the oracle fixture: f = 4 references + chunk_size 8 (CFG batch 24), ALL 20 DDIM steps,
+    VAE decode of the 8 chunk frames, composite through the synthetic elliptical object mask (gc_pipeline.py:209-234)."""
+    from oracle import sd15_torch as sd
+    from gaussctrl_amd import synthetic as syn
+    from gaussctrl_amd.sd import ops as sdops
+    from gaussctrl_amd.sd.pipeline import DenoisePipeline, to_nhwc8
+    from gaussctrl_amd.sd.vae import prepare_vae_weights
+    from gaussctrl_amd.sd.weights import add_fp8_convs
+    path = os.path.join(GOLD, "fullgeom_config4_f12_h64.npz")
+    z = np.load(path)
+    f, h, steps, seed, _, _, vseed, stride = [int(v) for v in z["meta"]]
+    which = [int(v) for v in z["which_steps"]]
+    lat, disp, cn, cp = _inputs(f, h, seed)
+    uw, cw = nets(dt)
+    if fp8:
+        uw, cw = dict(uw), dict(cw)
+        r = lambda w: {k: v.to(torch.bfloat16).float() for k, v in w.items() if k.endswith((".conv1.weight", ".conv2.weight"))}
+        add_fp8_convs(uw, r(sd.make_unet_weights(sd.SD15, 100)), DEV)
+        add_fp8_convs(cw, r(sd.make_controlnet_weights(sd.SD15, 200)), DEV)
+    vw = {k: v.to(torch.bfloat16).float().to(DEV) for k, v in sd.make_vae_decoder_weights(sd.VAE_SD, vseed).items()}
+    pipe = DenoisePipeline(uw, cw, prepare_vae_weights(vw, dt, DEV), 20, 5.0)
+    assert pipe.unet.fp8 == fp8 and pipe.controlnet.fp8 == fp8
+    trace = []
+    out = pipe.edit_chunk(lat.to(DEV), disp.to(DEV), cn.to(DEV), cp.to(DEV), steps=steps,
+                          on_step=lambda i, l: trace.append(l.permute(0, 3, 1, 2).float().cpu()))
+    assert len(trace) == 20
+    cur = [_rel(trace[s - 1], torch.tensor(z["lat_steps"][k])) for k, s in enumerate(which)]
+    imgs = pipe.vae.decode(to_nhwc8(out[4:] / 0.18215, dt), postprocess=True)          # [8,H,W,8] fp32
+    H = 8 * h
+    mask = torch.tensor(syn.elliptical_mask(H, H, soft=True)).to(DEV)
+    g = torch.Generator().manual_seed(seed + 1000)
+    errs = []
+    for j in range(f - 4):
+        unedited = torch.rand(H, H, 3, generator=g).to(DEV)
+        comp = sdops.mask_composite(imgs[j].contiguous(), unedited, mask)[::stride, ::stride].cpu()
+        errs.append((comp - torch.tensor(z["composite"][j])).abs())
+    e = torch.stack(errs)
+    print(f"\nconfig 4 ({dt}{' + e4m3 convs' if fp8 else ''}): latent rel L2 at steps {which}: " + " ".join(f"{c:.2e}" for c in cur) +
+          f"; composited images: mean abs {float(e.mean()):.3e} max abs {float(e.max()):.3e}")
+    return cur, float(e.mean()), float(e.max())
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_config4_f12_all_steps_decode_mask(nets, dt):
+    cur, mean_e, max_e = _config4_run(nets, dt, False)
+    assert max(cur) <= BAR[dt], cur
+    assert mean_e <= 1.0 / 255.0 and max_e <= (2.0 if dt == torch.float16 else 16.0) / 255.0, (mean_e, max_e)
+
+
+def test_config4_f12_fp8_convs(nets):
+    """configs[3] as named: "fp8 MFMA UNet path" -- e4m3 convolutions ON at f = 12 (B = 24 picks other k_gemm8q tiles than f = 7),
+    all 20 steps, decode, mask.  Own bars of the e4m3 path (3 mantissa bits): latents <= 6e-2 relative L2 at every step, composited
+    image within 2 eight-bit levels on average."""
+    cur, mean_e, max_e = _config4_run(nets, torch.bfloat16, True)
+    assert max(cur) <= 6e-2, cur
+    assert mean_e <= 2.0 / 255.0, (mean_e, max_e)
+
+
 def test_edit_f7_h64_fp8_convs(nets):
     """BASELINE configs[3] "fp8 MFMA UNet path": the resnet 3x3 convolutions of UNet and ControlNet on e4m3 operands (block-scaled
     MFMA, GroupNorm writing e4m3), bf16 elsewhere, all 20 DDIM steps at the benchmarked geometry against the fp32 oracle fixture.

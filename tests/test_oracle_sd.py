@@ -27,8 +27,38 @@ def test_xview_attention_matches_reference_golden(path):
         np.testing.assert_allclose(y.numpy(), z[f"{kind}_y"], rtol=0, atol=2e-6)
 
 
+BIG = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "xview_big_*.npz")))
+
+
+@pytest.mark.parametrize("path", BIG, ids=[os.path.basename(p) for p in BIG])
+def test_xview_attention_matches_reference_golden_production_geometry(path):
+    """The oracle's cross-view attention (sdpa form: what the full-geometry fixtures are generated with) against the REFERENCE's
+    output at SD1.5's own level-0 / level-1 geometry (L = 4096, D = 40 and L = 1024, D = 80; f = 5, CFG batch 10), on the
+    strided token rows the fixture keeps."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from xview_big_inputs import big_inputs
+    z = np.load(path)
+    f, L, H, D, Lt, Ct, seed, stride = [int(v) for v in z["meta"]]
+    inp = big_inputs(seed, f, L, H, D, Lt, Ct)
+    keep, sd.ATTN_IMPL = sd.ATTN_IMPL, "sdpa"
+    try:
+        for kind in ("self", "text"):
+            d = inp[kind]
+            w = {"a.to_q.weight": d["wq"], "a.to_k.weight": d["wk"], "a.to_v.weight": d["wv"], "a.to_out.0.weight": d["wo"],
+                 "a.to_out.0.bias": d["bo"]}
+            with torch.no_grad():
+                y = sd.attention_layer(w, "a", d["x"], d["ctx"], H, "xview", float(z["coeff"]))
+            ref = z[f"{kind}_y_rows"]
+            got = y[:, ::stride].numpy()
+            assert abs(float(y.double().norm()) / float(z[f"{kind}_y_norm"]) - 1) < 1e-5
+            np.testing.assert_allclose(got, ref, rtol=0, atol=1e-5 * max(1.0, float(np.abs(ref).max())))
+    finally:
+        sd.ATTN_IMPL = keep
+
+
 def test_golden_present():
-    assert len(GOLD) >= 4
+    assert len(GOLD) >= 4 and len(BIG) == 2
 
 
 def test_tiny_unet_controlnet_shapes_and_ref_independence():

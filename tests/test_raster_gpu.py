@@ -324,6 +324,17 @@ def test_config3_garden_2m(oracle_c, training):
     print(f"config 3: M = {M}")
 
 
+@pytest.mark.parametrize("training", [False, True])
+def test_config2_bear_1m(oracle_c, training):
+    """BASELINE configs[1] exactly as bench.py renders it: 1 M Gaussians, the bear intrinsics of
+    /root/reference/data/bear/transforms.json (fx 539.05, fy 538.17, cx 258.74, cy 239.35: non-square focal, off-centre
+    principal point), eval (rgb + depth) and training render with backward, against the C oracle."""
+    P = syn.make_gaussians(1_000_000, seed=0)
+    c2w = syn.make_cameras(40, seed=1)[7]
+    M = _full_parity(oracle_c, P, c2w, syn.BEAR_INTRINSICS, training)
+    print(f"config 2 (bear intrinsics, 1 M): M = {M}")
+
+
 def test_config5_raster_4m(oracle_c):
     """BASELINE configs[4]: 4 M random Gaussians, random 512x512 cameras (fx=fy=540, cx=cy=256): one camera against the C
     oracle (image, depth, leaf gradients), further cameras through size-independent properties of the binning and the
