@@ -4,17 +4,22 @@
 One "step" = one chunk of `chunk_size` views pushed through the whole hot path:
   (a) eval render of each view (rgb + depth + alpha, one fused compositing sweep)            [rasterizer fwd]
   (b) 20-step CFG ControlNet+UNet cross-view denoise of the chunk against the 4 reference views' K/V.
-      The reference trajectory (4 views) is computed INSIDE the timed region once per ceil(V/chunk) steps,
-      i.e. each chunk pays its share of the reference work (V=40, c=3 -> every 14 steps).
+      The reference trajectory (4 views) is computed INSIDE the timed region once per scene,
+      i.e. each chunk pays its share of the reference work (V=40, c=3 -> 20/14 DDIM steps per chunk).
   (c) VAE decode of the chunk's edited latents
-  (d) one training render of each view, forward + backward to the six Gaussian parameter tensors with an
-      L1 loss gradient against the edited image, gradients all-reduced over ranks (RCCL) when N > 1.
+  (d) one training render of each view, forward + backward to the six Gaussian parameter tensors with the fused
+      L1+SSIM loss against the edited image, the chunk's gradient sum all-reduced over ranks (RCCL) when N > 1.
 Workload (BASELINE.json configs[1]): "bear"-like scene, V=40 views, 4 reference views, chunk_size=3, ~1M synthetic
 Gaussians, SD1.5 + ControlNet-depth shapes with seeded random weights (no checkpoints / network), bf16.
 
-Prints ONE JSON line on rank 0.  N > 1: launched by torch.distributed.run, one rank per GPU, views sharded over
-ranks (weak scaling: every rank edits its own `chunk_size` views per step; no data-path collective in the denoise
-half -- reference K/V are replicated -- and one gradient all-reduce per step in the render half).
+Prints ONE JSON line on rank 0.  N > 1 (launched by torch.distributed.run, one rank per GPU): the views of ONE scene are
+sharded over the ranks (view v -> rank v % N: 40 views = 5 per GPU at N = 8; `--views 80 --gaussians 2000000` is BASELINE
+configs[2]); a step is one chunk on every rank.  Collectives on the measured path:
+  1. the reference K / V^T bank of the NEXT scene: its owner rank (rotating, scene % N) runs the 4-view trajectory and
+     broadcasts each DDIM step's K / V^T as one flat async RCCL message while everybody edits the current scene
+     (`--ref-mode owner0` pins the owner, `--ref-mode replicate` is the A/B without the collective);
+  2. one flat all-reduce of the chunk's N x 59 fp32 gradient sum, posted asynchronously from the buffer the backward
+     kernel wrote into (two buffers alternate; it completes under the next chunk's denoise).
 """
 from __future__ import annotations
 
@@ -48,6 +53,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "fp8"])     # fp8: e4m3 resnet convs on the block-scaled MFMA, bf16 elsewhere
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="edit", choices=["edit", "raster"])
+    ap.add_argument("--ref-mode", default="rotate", choices=["rotate", "owner0", "replicate"])    # N > 1: who computes the reference bank
+    ap.add_argument("--no-secondary", action="store_true")     # skip the short f16 secondary measurement (default workload, N = 1)
     ap.add_argument("--mask", action="store_true")   # BASELINE configs[3]: edits composited through a (synthetic elliptical) mask, gc_pipeline.py:226-234
     return ap.parse_args()
 
@@ -115,6 +122,232 @@ class GemmProfiler:
         return out
 
 
+VAE_DECODE_GFLOP = 1240.0      # AutoencoderKL decoder, 64x64 latents -> 512x512 (~1.2 TFLOP / frame)
+
+
+class Bench:
+    """State of one benchmark stream on this rank: scene, cameras, networks, reference banks, gradient buffers."""
+
+    def __init__(self, args, dtype_name, rank, world, dev, dist, bank_group):
+        from gaussctrl_amd import gsplat_ops as gops, synthetic as syn
+        from gaussctrl_amd.camera import camera_to_gsplat
+        from gaussctrl_amd.dist import FlatGrads, shard_views
+        from gaussctrl_amd.sd import arch, ops as sdops
+        from gaussctrl_amd.sd.pipeline import DenoisePipeline
+        from gaussctrl_amd.sd.vae import prepare_vae_weights
+        from gaussctrl_amd.sd.weights import prepare
+        from gaussctrl_amd.train_ops import l1_ssim_loss
+        self.args, self.rank, self.world, self.dev, self.dist, self.bank_group = args, rank, world, dev, dist, bank_group
+        self.gops, self.sdops, self.l1_ssim_loss = gops, sdops, l1_ssim_loss
+        self.dtype_name = dtype_name
+        self.dt = dt = torch.float16 if dtype_name == "f16" else torch.bfloat16
+        self.edit = args.workload == "edit"
+        self.c, self.V, self.nsteps = args.chunk_size, args.views, args.denoise_steps
+        self.H = self.W = H = W = 512
+        K = syn.BEAR_INTRINSICS if self.edit else syn.ROUND_INTRINSICS      # SURVEY.md 8d: config 5 uses fx=fy=540, cx=cy=256
+        V, c = self.V, self.c
+        # ------------------------------------------------------------ scene, cameras, networks (untimed setup)
+        P = syn.make_gaussians(args.gaussians, seed=0)
+        self.params = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in P.items()}
+        if self.edit:
+            # ONE scene of V views; rank r edits the views v % world == r (gaussctrl_amd.dist.shard_views)
+            cams = syn.make_cameras(V, seed=1)
+            self.mine = shard_views(V, world, rank)
+            self.cps = math.ceil(math.ceil(V / world) / c)                   # chunks per scene on every rank (ranks stay in lock step)
+        else:
+            # raster-only (configs[4]): every rank renders its own V random cameras of the same 4 M-Gaussian scene
+            cams = syn.make_cameras(V * world, seed=1)[rank * V:(rank + 1) * V]
+            self.mine = list(range(V))
+            self.cps = math.ceil(V / c)
+        self.ref_idx = [min(i, V - 1) for i in (4, 11, 29, 31)]                    # gc_pipeline.py:109-113 for V=40
+        self.cams = {v: camera_to_gsplat(cams[v], K["fx"], K["fy"], K["cx"], K["cy"], W, H)
+                     for v in sorted(set(self.mine) | (set(self.ref_idx) if self.edit else set()))}
+        self.bg = torch.zeros(3, device=dev)
+        self.pipe = None
+        if self.edit:
+            fold_ln = os.environ.get("GC_DN_FOLD_LN", "0") != "0"          # A/B switches of the round-2 normalisation fusions (default: off)
+            usd, csd = arch.random_state_dict(arch.unet_shapes(), 100, dev), arch.random_state_dict(arch.controlnet_shapes(), 200, dev)
+            uw = prepare(usd, dt, dev, heads=8, fold_ln=fold_ln)
+            cw = prepare(csd, dt, dev, heads=8, fold_ln=fold_ln)
+            if dtype_name == "fp8":
+                from gaussctrl_amd.sd.weights import add_fp8_convs
+                add_fp8_convs(uw, usd, dev); add_fp8_convs(cw, csd, dev)
+            del usd, csd
+            vw = prepare_vae_weights(arch.random_state_dict(arch.vae_decoder_shapes(), 300, dev), dt, dev)
+            self.pipe = DenoisePipeline(uw, cw, vw, self.nsteps, 5.0)
+            self.pipe.unet.fuse_stats = self.pipe.controlnet.fuse_stats = os.environ.get("GC_DN_FUSE_GN", "0") != "0"
+            self.pipe.unet.gn_two_pass = self.pipe.controlnet.gn_two_pass = os.environ.get("GC_DN_GN2", "0") != "0"
+        g = torch.Generator(device=dev).manual_seed(2)                             # the same scene inputs on every rank
+        self.ctx_neg = torch.randn(1, 77, 768, device=dev, generator=g)
+        self.ctx_pos = torch.randn(1, 77, 768, device=dev, generator=g)
+        self.z0 = torch.randn(V, 4, 64, 64, device=dev, generator=g)              # stand-in for the DDIM-inverted latents
+        self.stats = {"M": [], "dev": []}
+        self.state = {"bank": None, "next": None, "cap": None, "views_done": 0, "renders_done": 0}
+        self.syncfree = os.environ.get("GC_BENCH_SYNCFREE", "1") != "0"
+        self.raster_target = torch.rand(H, W, 3, device=dev, generator=g)     # raster-only workload: a fixed synthetic target image
+        self.edit_mask = torch.tensor(syn.elliptical_mask(H, W, soft=True), device=dev, dtype=torch.float32) if args.mask else None
+        # the chunk's summed leaf gradients: six views of ONE flat buffer that the backward kernel writes into and RCCL reduces in
+        # place; two buffers alternate so the all-reduce of chunk k completes under the denoise of chunk k + 1
+        self.grads = [FlatGrads(self.params), FlatGrads(self.params)] if world > 1 else [FlatGrads(self.params)]
+        self.ref_mode = args.ref_mode if (world > 1 and self.edit) else "local"
+        self.bank_layers = None
+        self.half_events = []           # (start, end of denoise half, end of step) HIP events of the timed steps
+        self.record_halves = False
+        self.rank0_only = False
+
+    # ------------------------------------------------------------------------------------------------ pieces of a step
+    def new_aux(self):
+        aux = self.gops.RenderAux()
+        if self.syncfree and self.state["cap"]:
+            aux.m_cap = self.state["cap"]          # device-side intersection count + capacity: no host round trip in the frame
+        return aux
+
+    def note_m(self, aux):
+        if isinstance(aux.M, tuple):
+            self.stats["dev"].append(aux.M)        # (count, overflow) device tensors: read after the timed region
+        else:
+            self.stats["M"].append(aux.M)
+            self.state["cap"] = max(self.state["cap"] or 0, int(aux.M * 1.3) + 1024)
+
+    def render_eval(self, i):
+        p, aux = self.params, self.new_aux()
+        with torch.no_grad():
+            rgb, alpha, depth = self.gops.render_view(p["means"], p["scales"], p["quats"], p["opacities"], p["features_dc"], p["features_rest"],
+                                                      self.cams[i], self.bg, True, 3, aux)
+        self.note_m(aux)
+        return rgb, depth, aux
+
+    def disparity_of(self, depth):            # gc_pipeline.py:258-266 as one HIP kernel pair -> [H,W,8] control image (3 channels used)
+        return self.sdops.depth_to_disparity(depth, self.dt)
+
+    def ref_inputs(self):
+        rd = torch.stack([self.disparity_of(self.render_eval(i)[1]) for i in self.ref_idx])
+        return self.z0[self.ref_idx], rd, self.ctx_neg, self.ctx_pos
+
+    def owner_of(self, scene):
+        return scene % self.world if self.ref_mode == "rotate" else 0
+
+    def begin_bank(self, scene):
+        """the reference bank of `scene` as a trajectory that advance_bank() moves: local (N = 1 / replicate) or a RefBankStream"""
+        if self.ref_mode in ("local", "replicate"):
+            return self.pipe.begin_ref_bank(*self.ref_inputs())
+        from gaussctrl_amd.dist import RefBankStream
+        st = RefBankStream(self.pipe, self.owner_of(scene), self.world, self.rank, self.dev, self.nsteps, group=self.bank_group,
+                           layers=self.bank_layers)
+        return st.begin(*self.ref_inputs()) if st.owner else st
+
+    def advance_bank(self, tr, n):
+        """n more DDIM steps (None: all); returns the finished RefBank or None"""
+        if isinstance(tr, dict):
+            return self.pipe.advance_ref_bank(tr, n)
+        tr.drain(0)                       # what the previous chunk posted has had a whole chunk to arrive: unpack it now
+        done = tr.advance(n)
+        self.bank_layers = tr.layers
+        return tr.finish() if done else None
+
+    def step(self, s):
+        """Chunk s of an endless stream of scenes (cps chunks per scene on every rank).  A scene's reference trajectory (4 views x 20
+        DDIM steps, shared by its chunks) is computed while the PREVIOUS scene is edited, 20 / cps DDIM steps per chunk, so every
+        step carries exactly its share of the reference work whatever K is."""
+        st, c, cps, nsteps, p = self.state, self.c, self.cps, self.nsteps, self.params
+        scene, j = divmod(s, cps)
+        views = self.mine[j * c:(j + 1) * c]      # the last chunk of a scene is short (40 = 13 x 3 + 1), gc_pipeline.py:190
+        st["views_done"] += len(views)
+        ev = None
+        if self.record_halves:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            ev[0].record()
+        if self.edit:
+            if st["bank"] is None:                # the very first scene (setup): its whole reference trajectory at once
+                st["bank"] = self.advance_bank(self.begin_bank(scene), None)
+            if st["next"] is None:                # the following scene's references start with this scene
+                st["next"] = self.begin_bank(scene + 1)
+            quota = (nsteps * (j + 1)) // cps - (nsteps * j) // cps
+            done = self.advance_bank(st["next"], quota)          # owner: compute + post sends; others: post receives (they arrive under (b))
+            evals = [self.render_eval(i) for i in views]                                                    # (a)
+            if views:
+                disp = torch.stack([self.disparity_of(e[1]) for e in evals])
+                lat = self.pipe.edit_chunk_cached(self.z0[views], disp, self.ctx_neg, self.ctx_pos, st["bank"])   # (b)
+                edited = self.pipe.decode(lat)                                                              # (c)
+            if j == cps - 1:
+                assert done is not None
+                st["bank"], st["next"] = done, None
+        else:
+            edited = [None] * len(views)
+        if ev:
+            ev[1].record()
+        fg = self.grads[s % len(self.grads)]
+        fg.wait()                                 # the all-reduce posted two chunks ago (N > 1) has finished before its buffer is rewritten
+        for jj, i in enumerate(views):                                                                      # (d)
+            aux = self.new_aux()
+            aux.grad_into, aux.grad_accumulate = fg.views, jj > 0      # the batch's gradient sum is formed inside the backward kernel
+            rgb, alpha, _ = self.gops.render_view(p["means"], p["scales"], p["quats"], p["opacities"], p["features_dc"], p["features_rest"],
+                                                  self.cams[i], torch.rand(3, device=self.dev), False, 3, aux)
+            target = edited[jj].permute(1, 2, 0).contiguous() if edited[jj] is not None else self.raster_target
+            if self.args.mask and edited[jj] is not None:          # edited inside the mask, the un-edited render outside (one HIP kernel)
+                target = self.sdops.mask_composite(target, evals[jj][0].contiguous(), self.edit_mask)
+            loss = self.l1_ssim_loss(rgb, target, 0.2)             # the product path's loss (fused L1 + SSIM value and gradient kernels)
+            loss.backward()
+            self.note_m(aux)
+            st["renders_done"] += 1
+        if not views:
+            fg.flat.zero_()                       # a rank without a view in this chunk contributes zeros to the reduction
+        if self.dist is not None and not self.rank0_only:      # (the instrumented roofline steps run on rank 0 alone: no collective)
+            fg.reduce_async(self.world)
+        if ev:
+            ev[2].record()
+            self.half_events.append(ev)
+
+    def finish(self):
+        for fg in self.grads:
+            fg.wait()
+
+    def barrier(self):
+        torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(self, warmup, steps):
+        """two untimed priming chunks (caching allocator, kernel attribute calls, per-prompt / per-timestep caches reach their steady
+        state), `warmup` untimed steps, then EXACTLY `steps` timed steps between barriers; returns (seconds = max over ranks,
+        views edited by this rank in the timed region, training renders in it)"""
+        g = 0
+        for _ in range(2 + warmup):
+            self.step(g); g += 1
+        self.finish()
+        self.barrier()
+        v0, r0 = self.state["views_done"], self.state["renders_done"]
+        self.record_halves = True
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step(g); g += 1
+        self.finish()
+        self.barrier()
+        dt_s = time.perf_counter() - t0
+        self.record_halves = False
+        self.next_step = g
+        if self.dist is not None:
+            tt = torch.tensor([dt_s], device=self.dev, dtype=torch.float64)
+            self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+            dt_s = float(tt.item())
+        if self.stats["dev"]:                      # sync-free frames: counts / overflow flags are read only now
+            cnts = torch.stack([a for a, _ in self.stats["dev"]]).flatten().cpu()
+            ovfs = torch.stack([b for _, b in self.stats["dev"]]).flatten().cpu()
+            assert int(ovfs.max()) == 0, "intersection capacity exceeded in a sync-free frame: raise the capacity margin"
+            self.stats["M"] += [int(v) for v in cnts]
+            self.stats["dev"] = []
+        return dt_s, self.state["views_done"] - v0, self.state["renders_done"] - r0
+
+    def halves(self):
+        """GPU seconds of the timed steps spent in the denoise half ((a) eval renders + disparity, (b), (c), reference share) and in
+        the raster training half ((d): render fwd + fused loss + bwd [+ posting the all-reduce]), from HIP events on the launch stream"""
+        torch.cuda.synchronize()
+        dn = sum(e[0].elapsed_time(e[1]) for e in self.half_events) * 1e-3
+        rs = sum(e[1].elapsed_time(e[2]) for e in self.half_events) * 1e-3
+        return dn, rs
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -127,165 +360,44 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    bank_group = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("GC_BENCH_BACKEND", "nccl")
+        tmo = datetime.timedelta(minutes=10)       # a rank that never arrives aborts the job instead of hanging the node
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
+        if args.workload == "edit" and args.ref_mode != "replicate":
+            # the reference-bank broadcasts get their own communicator (own RCCL stream): a 0.5 GB message never queues in front of
+            # the gradient all-reduce and the two kinds of collective need no common order
+            bank_group = dist.new_group(list(range(world)), backend=backend, timeout=tmo)
     else:
         dist = None
 
-    from gaussctrl_amd import gsplat_ops as gops, synthetic as syn
-    from gaussctrl_amd.camera import camera_to_gsplat
-    from gaussctrl_amd.sd import arch, ops as sdops
-    from gaussctrl_amd.sd.pipeline import DenoisePipeline
-    from gaussctrl_amd.sd.vae import prepare_vae_weights
-    from gaussctrl_amd.sd.weights import prepare
-
-    dt = torch.float16 if args.dtype == "f16" else torch.bfloat16
+    from gaussctrl_amd.sd import ops as sdops
     if args.views is None:
         args.views = 40 if args.workload == "edit" else 256
     c, V, nsteps = args.chunk_size, args.views, args.denoise_steps
     H = W = 512
-    K = syn.BEAR_INTRINSICS if args.workload == "edit" else syn.ROUND_INTRINSICS      # config 5 uses fx=fy=540, cx=cy=256
-
-    # ---------------------------------------------------------------- scene, cameras, networks (untimed setup)
-    P = syn.make_gaussians(args.gaussians, seed=0)
-    params = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in P.items()}
-    cams = syn.make_cameras(V * world, seed=1)
-    my_cams = [camera_to_gsplat(cams[rank * V + i], K["fx"], K["fy"], K["cx"], K["cy"], W, H) for i in range(V)]
-    bg = torch.zeros(3, device=dev)
-    pipe = None
-    if args.workload == "edit":
-        fold_ln = os.environ.get("GC_DN_FOLD_LN", "0") != "0"          # A/B switches of the round-2 normalisation fusions (default: off)
-        usd, csd = arch.random_state_dict(arch.unet_shapes(), 100, dev), arch.random_state_dict(arch.controlnet_shapes(), 200, dev)
-        uw = prepare(usd, dt, dev, heads=8, fold_ln=fold_ln)
-        cw = prepare(csd, dt, dev, heads=8, fold_ln=fold_ln)
-        if args.dtype == "fp8":
-            from gaussctrl_amd.sd.weights import add_fp8_convs
-            add_fp8_convs(uw, usd, dev); add_fp8_convs(cw, csd, dev)
-        del usd, csd
-        vw = prepare_vae_weights(arch.random_state_dict(arch.vae_decoder_shapes(), 300, dev), dt, dev)
-        pipe = DenoisePipeline(uw, cw, vw, nsteps, 5.0)
-        pipe.unet.fuse_stats = pipe.controlnet.fuse_stats = os.environ.get("GC_DN_FUSE_GN", "0") != "0"
-        pipe.unet.gn_two_pass = pipe.controlnet.gn_two_pass = os.environ.get("GC_DN_GN2", "0") != "0"
-    g = torch.Generator(device=dev).manual_seed(2 + rank)
-    ctx_neg = torch.randn(1, 77, 768, device=dev, generator=g)
-    ctx_pos = torch.randn(1, 77, 768, device=dev, generator=g)
-    z0 = torch.randn(V, 4, 64, 64, device=dev, generator=g)                   # stand-in for the DDIM-inverted latents
-    ref_idx = [4, 11, 29, 31]                                                  # gc_pipeline.py:109-113 for V=40
-    ref_idx = [min(i, V - 1) for i in ref_idx]
-    chunks_per_scene = math.ceil(V / c)
-    stats = {"M": [], "n_visible": [], "dev": []}
-    state = {"bank": None, "next": None}
-
-    syncfree = os.environ.get("GC_BENCH_SYNCFREE", "1") != "0"
-    from gaussctrl_amd.train_ops import l1_ssim_loss
-    raster_target = torch.rand(H, W, 3, device=dev, generator=g)      # raster-only workload: a fixed synthetic target image
-    edit_mask = torch.tensor(syn.elliptical_mask(H, W, soft=True), device=dev, dtype=torch.float32) if args.mask else None
-
-    grad_buf = {k: torch.zeros_like(v) for k, v in params.items()}        # the chunk's summed leaf gradients (what an optimizer step reads)
-
-    def new_aux():
-        aux = gops.RenderAux()
-        if syncfree and state.get("cap"):
-            aux.m_cap = state["cap"]          # device-side intersection count + capacity: no host round trip in the frame
-        return aux
-
-    def note_m(aux):
-        if isinstance(aux.M, tuple):
-            stats["dev"].append(aux.M)        # (count, overflow) device tensors: read after the timed region
-        else:
-            stats["M"].append(aux.M)
-            state["cap"] = max(state.get("cap") or 0, int(aux.M * 1.3) + 1024)
-
-    def render_eval(i):
-        aux = new_aux()
-        with torch.no_grad():
-            rgb, alpha, depth = gops.render_view(params["means"], params["scales"], params["quats"], params["opacities"],
-                                                 params["features_dc"], params["features_rest"], my_cams[i], bg, True, 3, aux)
-        note_m(aux)
-        return rgb, depth, aux
-
-    def disparity_of(depth):            # gc_pipeline.py:258-266 as one HIP kernel pair -> [H,W,8] control image (3 channels used)
-        return sdops.depth_to_disparity(depth, dt)
-
-    def start_ref_trajectory():
-        rd = torch.stack([disparity_of(render_eval(i)[1]) for i in ref_idx])
-        return pipe.begin_ref_bank(z0[ref_idx], rd, ctx_neg, ctx_pos)
-
-    def step(s):
-        """Chunk s of an endless stream of scenes (V views = chunks_per_scene chunks each).  A scene's reference trajectory (4 views
-        x 20 DDIM steps, shared by its chunks) is computed while the PREVIOUS scene is edited, 20 / chunks_per_scene DDIM steps
-        per chunk, so every step carries exactly its share of the reference work whatever K is."""
-        j = s % chunks_per_scene
-        views = list(range(j * c, min(V, (j + 1) * c)))          # the last chunk of a scene is short (40 = 13 x 3 + 1), gc_pipeline.py:190
-        state["views_done"] = state.get("views_done", 0) + len(views)
-        if args.workload == "edit":
-            if state["bank"] is None:                # the very first scene (setup): its whole reference trajectory at once
-                state["bank"] = pipe.advance_ref_bank(start_ref_trajectory())
-            if state["next"] is None:                # the following scene's references start with this scene
-                state["next"] = start_ref_trajectory()
-            evals = [render_eval(i) for i in views]                                                         # (a)
-            disp = torch.stack([disparity_of(e[1]) for e in evals])
-            lat = pipe.edit_chunk_cached(z0[views], disp, ctx_neg, ctx_pos, state["bank"])                 # (b)
-            edited = pipe.decode(lat)                                                                       # (c)
-            quota = (nsteps * (j + 1)) // chunks_per_scene - (nsteps * j) // chunks_per_scene
-            done = pipe.advance_ref_bank(state["next"], quota)
-            if j == chunks_per_scene - 1:
-                assert done is not None
-                state["bank"], state["next"] = done, None
-        else:
-            edited = [None] * len(views)
-        for j, i in enumerate(views):                                                                       # (d)
-            aux = new_aux()
-            aux.grad_into, aux.grad_accumulate = grad_buf, j > 0      # the batch's gradient sum is formed inside the backward kernel
-            rgb, alpha, _ = gops.render_view(params["means"], params["scales"], params["quats"], params["opacities"],
-                                             params["features_dc"], params["features_rest"], my_cams[i],
-                                             torch.rand(3, device=dev), False, 3, aux)
-            target = edited[j].permute(1, 2, 0).contiguous() if edited[j] is not None else raster_target
-            if args.mask and edited[j] is not None:          # edited inside the mask, the un-edited render outside (one HIP kernel)
-                target = sdops.mask_composite(target, evals[j][0].contiguous(), edit_mask)
-            loss = l1_ssim_loss(rgb, target, 0.2)             # the product path's loss (fused L1 + SSIM value and gradient kernels)
-            loss.backward()
-            note_m(aux)
-        if dist is not None and not state.get("rank0_only"):      # (the instrumented roofline steps run on rank 0 alone: no collective)
-            flat = torch.cat([t.reshape(-1) for t in grad_buf.values()])
-            dist.all_reduce(flat)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # setup (untimed, like weight init): two priming chunks so that the caching allocator, the kernel attribute calls and the
-    # per-prompt / per-timestep caches are in their steady state before the W warm-up and K timed steps
-    g = 0
-    for _ in range(2 + args.warmup):
-        step(g); g += 1
-    barrier()
-    v0 = state.get("views_done", 0)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(g); g += 1
-    barrier()
-    state["views_timed"] = state.get("views_done", 0) - v0
-    dt_s = time.perf_counter() - t0
+    B = Bench(args, args.dtype, rank, world, dev, dist, bank_group)
+    pipe, stats, state = B.pipe, B.stats, B.state
+    z0, ctx_neg, ctx_pos = B.z0, B.ctx_neg, B.ctx_pos
+    chunks_per_scene = B.cps
+    dt_s, my_views, my_renders = B.run(args.warmup, args.steps)
+    g = B.next_step
     if dist is not None:
-        tt = torch.tensor([dt_s], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt_s = float(tt.item())
-    if stats["dev"]:                      # sync-free frames: counts / overflow flags are read only now
-        cnts = torch.stack([a for a, _ in stats["dev"]]).flatten().cpu()
-        ovfs = torch.stack([b for _, b in stats["dev"]]).flatten().cpu()
-        assert int(ovfs.max()) == 0, "intersection capacity exceeded in a sync-free frame: raise the capacity margin"
-        stats["M"] += [int(v) for v in cnts]
-    views_done = state["views_timed"] * world
+        tv = torch.tensor([my_views, my_renders], device=dev, dtype=torch.float64)
+        dist.all_reduce(tv)
+        views_done, renders_done = int(tv[0].item()), int(tv[1].item())
+    else:
+        views_done, renders_done = my_views, my_renders
     value = views_done / dt_s
+    dn_s, rs_s = B.halves()          # this rank's GPU time in the two halves (rank 0 reports; ranks run in lock step)
+    step = B.step
 
     # ---------------------------------------------------------------- roofline of the dominant kernel (instrumented extra step)
     roof = None
@@ -306,11 +418,12 @@ def main():
         # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r02_attn_traffic.json, scripts/
         # pmc_kernel_traffic.py: FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes on the UNet's 5-set launch at chunk_size 3)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_attn_traffic.json")
-        if kind.startswith("k_attn4") and c == 3 and os.path.exists(tpath):
-            for kn, v in json.load(open(tpath))["kernels"].items():
-                if "k_attn4" in kn and "traffic_MB_per_dispatch" in v:
-                    traffic = int(round(v["traffic_MB_per_dispatch"] * 1e6))
+        for tname in ("r03_attn_traffic.json", "r02_attn_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if kind.startswith("k_attn4") and c == 3 and os.path.exists(tpath) and traffic is None:
+                for kn, v in json.load(open(tpath))["kernels"].items():
+                    if "k_attn4" in kn and "traffic_MB_per_dispatch" in v:
+                        traffic = int(round(v["traffic_MB_per_dispatch"] * 1e6))
         roof = {"bound": "mfma", "kernel": kind + (" (multi-K/V-set flash attention, dn_attn.hip)" if kind.startswith("k_attn") else
                                                     " (k_gemm / k_gemm8 MFMA GEMM and implicit 3x3 conv, variant picked per grid, dn_gemm.hip)"),
                 "achieved": round(ach, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
@@ -320,9 +433,30 @@ def main():
                 "other": {k: {"launches": v["launches"], "ms": round(v["ms"], 2),
                               "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in sm.items() if k != kind}}
 
-    if args.workload == "raster" and rank == 0:
-        state["rank0_only"] = True
-        roof = raster_roofline(args, step, g, stats, H * W)
+    roof_raster = None
+    if rank == 0:
+        B.rank0_only = True
+        if args.workload == "raster":
+            roof = raster_roofline(args, B, g, stats, H * W)
+        else:
+            rr = raster_roofline(args, B, g, stats, H * W)          # the rasterizer half of the same run: chain roofline at this N
+            roof_raster = {"bound": "hbm", "unit": "GB/s", "peak": 8000.0, "achieved": rr["chain"]["GBps"], "frac": rr["chain"]["frac"],
+                           "kernel_us_per_view": rr["chain"]["kernel_us_per_view"], "algorithmic_MB_per_view": rr["chain"]["algorithmic_MB_per_view"],
+                           "traffic_ratio": rr["chain"].get("traffic_ratio"), "N": rr["chain"]["N"], "M_mean": rr["chain"]["M_mean"],
+                           "formula": rr["chain"]["formula"], "dominant_stage": rr["kernel"], "dominant_stage_frac": rr["frac"]}
+
+    # ---------------------------------------------------------------- secondary: the f16 activation path (the dtype that meets north_star's 1e-3)
+    secondary = None
+    if rank == 0 and world == 1 and args.workload == "edit" and args.dtype == "bf16" and not args.no_secondary:
+        del B, pipe, state, z0, step
+        torch.cuda.empty_cache()
+        B2 = Bench(args, "f16", rank, world, dev, None, None)
+        n2 = min(args.steps, 7)
+        t2, v2, _ = B2.run(1, n2)
+        secondary = {"dtype": "f16", "value": round(v2 / t2, 4), "unit": "views/s", "steps": n2, "warmup": 1,
+                     "note": "same workload with f16 activations (latents within 1e-3 rel of the fp32 oracle, tests/test_fullgeom_gpu.py); short sample"}
+        del B2
+        torch.cuda.empty_cache()
 
     # ---------------------------------------------------------------- CPU baseline (oracle, rank 0, bounded sample)
     cpu = None
@@ -332,22 +466,45 @@ def main():
     if rank == 0:
         metric = ("edited views/sec @512x512 (ControlNet denoise + splat render+bwd)" if args.workload == "edit" else
                   "raster-only train-render fwd+bwd views/sec @512x512 (BASELINE configs[4])")
+        if args.workload == "edit":
+            # algorithmic FLOP of the timed region, as executed (reference K/V cached): CFG doubles every chunk frame; the reference
+            # trajectory (4 views x 2) is computed once per scene by ONE rank (or by every rank with --ref-mode replicate)
+            per_sample = (UNET_GFLOP_XVIEW + CN_GFLOP_XVIEW) * 1e9
+            scenes = args.steps / chunks_per_scene
+            ref_copies = world if args.ref_mode == "replicate" and world > 1 else 1
+            flop = views_done * (nsteps * 2 * per_sample + VAE_DECODE_GFLOP * 1e9) + scenes * ref_copies * nsteps * 8 * per_sample
+            mfma_util = flop / dt_s / (world * PEAK_TFLOPS[args.dtype] * 1e12)
+            par = (f"views of one scene sharded x{world} (v % N); reference bank: " +
+                   ({"rotate": "owner rotates per scene, per-DDIM-step async RCCL broadcast", "owner0": "rank 0 owns, per-DDIM-step async RCCL broadcast",
+                     "replicate": "replicated on every rank (no collective)"}[args.ref_mode] if world > 1 else "local") +
+                   "; flat async gradient all-reduce; ControlNet || UNet encoder on 2 HIP streams")
+        else:
+            flop, mfma_util = None, None
+            par = f"every rank renders its own {V} cameras (x{world}); flat async gradient all-reduce"
         out = {"metric": metric, "value": round(value, 4),
                "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * dt_s / args.steps, 2), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype if args.workload == "edit" else "f32", "data": "synthetic",
-               "config": {"workload": f"{'masked-edit' if args.mask else 'bear-like'} scene, {V} views/GPU, ref_view_num=4, chunk_size={c}, "
+               "config": {"workload": f"{'masked-edit' if args.mask else 'bear-like'} scene, {V} views, ref_view_num=4, chunk_size={c}, "
                                       f"{nsteps} DDIM steps, SD1.5+ControlNet-depth shapes (random weights), "
                                       f"{args.gaussians} Gaussians, 512x512" if args.workload == "edit" else
                                       f"raster-only fwd+bwd (+ fused L1+SSIM loss), {args.gaussians} Gaussians, {V} random cameras/GPU, 512x512, fx=fy=540",
-                          "views_per_step": c * world, "parallelism": f"views sharded x{world}, reference K/V replicated, grad all-reduce; ControlNet || UNet encoder on 2 HIP streams",
+                          "views_per_step": round(views_done / args.steps, 3), "chunks_per_scene_per_rank": chunks_per_scene, "parallelism": par,
                           "mean_intersections_M": int(np.mean(stats["M"])) if stats["M"] else 0,
                           "ref_trajectory_in_timed_region": bool(args.workload == "edit"),
                           "ref_trajectory_share_per_step": f"{nsteps}/{chunks_per_scene} DDIM steps of the next scene's 4 reference views" if args.workload == "edit" else None},
-               "roofline": roof, "cpu_baseline": cpu}
+               # the two halves separately (GPU time of rank 0's launch stream between HIP events in the timed steps)
+               "denoise_views_per_s": round(my_views / dn_s, 4) if (args.workload == "edit" and dn_s > 0) else None,
+               "raster_fwd_bwd_iters_per_s": round(my_renders / rs_s, 2) if rs_s > 0 else None,
+               "halves": {"denoise_s": round(dn_s, 4), "raster_train_s": round(rs_s, 4), "views_rank0": my_views, "train_renders_rank0": my_renders,
+                          "note": "denoise half = eval renders + disparity + 20-step denoise + VAE decode + reference share; raster half = training render fwd + L1/SSIM + bwd"},
+               "mfma_util_step": None if mfma_util is None else round(mfma_util, 4),
+               "algorithmic_tflop_timed_region": None if flop is None else round(flop / 1e12, 1),
+               "secondary": secondary,
+               "roofline": roof, "roofline_raster": roof_raster, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if dist is not None:
-        dist.barrier()                      # ranks leave together (rank 0 ran one more instrumented step)
+        dist.barrier()                      # ranks leave together (rank 0 ran more instrumented steps)
         dist.destroy_process_group()
 
 
@@ -392,7 +549,7 @@ RASTER_STAGES = {
 }
 
 
-def raster_roofline(args, step, g, stats, HW):
+def raster_roofline(args, B, g, stats, HW):
     """One instrumented step of the raster-only workload: per-stage HIP-event durations -> achieved algorithmic GB/s per stage
     and for the whole forward + backward chain; `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes
     (profiles/r02_raster_traffic.json, FETCH_SIZE / WRITE_SIZE collected in separate passes by scripts/pmc_traffic.py) when the
@@ -403,7 +560,14 @@ def raster_roofline(args, step, g, stats, HW):
     n_dev = len(stats["dev"])
     L._lib = timer
     try:
-        step(g)
+        if args.workload == "raster":
+            B.step(g)
+        else:                      # default workload: only the training renders of one chunk (fwd + loss + bwd), no denoise
+            keep, B.edit = B.edit, False
+            try:
+                B.step(0)
+            finally:
+                B.edit = keep
         torch.cuda.synchronize()
     finally:
         L._lib = real
@@ -415,10 +579,10 @@ def raster_roofline(args, step, g, stats, HW):
     for name, s, e in timer.rec:
         per.setdefault(name, []).append(s.elapsed_time(e) * 1e-3)
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r02_raster_traffic.json")
-    if os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        traffic = tj.get(str(N))
+    for tname in ("r03_raster_traffic.json", "r02_raster_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", tname)
+        if traffic is None and os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(str(N))
     stages, tot_b, tot_s = {}, 0.0, 0.0
     for name, (label, cn, cm, chw) in RASTER_STAGES.items():
         if name not in per:
@@ -429,6 +593,10 @@ def raster_roofline(args, step, g, stats, HW):
         stages[name] = {"kernel": label, "avg_us": round(secs * 1e6, 1), "algorithmic_MB": round(b / 1e6, 1),
                         "GBps": round(b / secs / 1e9, 1) if b else None,
                         "traffic_MB": None if not traffic or name not in traffic else traffic[name]}
+    traffic_ratio = None
+    if traffic:                   # counters of the committed PMC passes at this N over the algorithmic bytes of the same stages
+        tb = sum(v for k, v in traffic.items() if k in stages or k == "loss+finalize")
+        traffic_ratio = round(tb * 1e6 / tot_b, 3)
     dom = max((k for k in stages if stages[k]["GBps"]), key=lambda k: stages[k]["avg_us"])
     d = stages[dom]
     ach = d["algorithmic_MB"] * 1e6 / (d["avg_us"] * 1e-6) / 1e9
@@ -437,58 +605,61 @@ def raster_roofline(args, step, g, stats, HW):
             "avg_launch_us": d["avg_us"], "algorithmic_bytes_per_launch": d["algorithmic_MB"] * 1e6,
             "chain": {"algorithmic_MB_per_view": round(tot_b / 1e6, 1), "kernel_us_per_view": round(tot_s * 1e6, 1),
                       "GBps": round(tot_b / tot_s / 1e9, 1), "frac": round(tot_b / tot_s / 8e12, 4), "views_in_sample": nviews,
-                      "N": N, "M_mean": int(M), "formula": "N*660 + M*124 + HW*44 bytes per view (SURVEY.md 8d with the SH record no longer re-read in the backward)"},
+                      "N": N, "M_mean": int(M), "traffic_ratio": traffic_ratio, "formula": "N*660 + M*124 + HW*44 bytes per view (SURVEY.md 8d with the SH record no longer re-read in the backward)"},
             "stages": stages}
 
 
 def cpu_baseline(args):
-    """Oracle ("port") timed on the host cores on a BOUNDED sample: ONE CFG ControlNet+UNet cross-view step at the
-    reference's CPU-runnable shape (configs[0]: chunk_size=1 -> f = 4 refs + 1 = 5 frames, batch 10) on 32x32 latents,
-    scaled to 64x64 latents by the analytic FLOP ratio (conv / linear terms x4, attention core x16
-    -> x6.28), + one C-oracle raster eval + train fwd+bwd at N=200k scaled linearly to N.  An edited view at chunk_size 1
-    costs the whole f=5 batch for 20 steps."""
+    """Oracle ("port") timed on the host cores on a BOUNDED sample of the same workload.
+    Denoise: ONE real CFG ControlNet+UNet cross-view step at the reference's CPU-runnable shape (configs[0]: chunk_size 1 ->
+    f = 4 references + 1 = 5 frames, CFG batch 10) on the full 64 x 64 latents, fp32 torch on every core; an edited view at
+    chunk_size 1 costs the whole f = 5 batch for 20 such steps.  Rasterizer: the C oracle (OpenMP build of oracle/raster_ref.c,
+    every core; the sort is serial) at the run's full N: one eval render + one training render fwd + bwd.  VAE decode: one frame."""
     from oracle import raster_c, sd15_torch as sd
     from gaussctrl_amd import synthetic as syn
     cores = os.cpu_count() or 1
     threads = min(cores, 64)
     torch.set_num_threads(threads)
-    if args.workload == "raster":
-        N = 200_000
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    raster_c.use_threads(True)
+    try:
+        N = args.gaussians
         P = syn.make_gaussians(N, seed=0)
         c2w = syn.make_cameras(1, seed=1)[0]
-        K = syn.ROUND_INTRINSICS
+        K = syn.ROUND_INTRINSICS if args.workload == "raster" else syn.BEAR_INTRINSICS
+        bgc = np.zeros(3, np.float32)
+        v_rgb = np.ones((512, 512, 3), np.float32)
         t0 = time.perf_counter()
-        raster_c.render(P, c2w, K["fx"], K["fy"], K["cx"], K["cy"], 512, 512, np.zeros(3, np.float32), training=True,
-                        v_rgb=np.ones((512, 512, 3), np.float32))
-        t = (time.perf_counter() - t0) * (args.gaussians / N)
-        return {"value": round(1.0 / t, 4), "unit": "views/s", "cores": 1, "kind": "port",
-                "sample": f"C oracle (oracle/raster_ref.c, 1 thread) train render fwd+bwd at N={N} scaled linearly to N={args.gaussians}: {t:.2f}s per view"}
+        if args.workload != "raster":
+            raster_c.render(P, c2w, K["fx"], K["fy"], K["cx"], K["cy"], 512, 512, bgc, training=False)
+        raster_c.render(P, c2w, K["fx"], K["fy"], K["cx"], K["cy"], 512, 512, bgc, training=True, v_rgb=v_rgb)
+        t_raster = time.perf_counter() - t0
+    finally:
+        raster_c.use_threads(False)
+    if args.workload == "raster":
+        return {"value": round(1.0 / t_raster, 4), "unit": "views/s", "cores": cores, "kind": "port",
+                "sample": f"C oracle (oracle/raster_ref.c, OpenMP build, {cores} threads; serial sort) one training render fwd+bwd at the full "
+                          f"N={N}: {t_raster:.2f}s per view"}
+    sd.ATTN_IMPL = "sdpa"                    # the fused CPU attention (the explicit form needs 5 x [80,4096,4096] fp32 tensors per layer)
     with torch.no_grad():
         uw = sd.make_unet_weights(sd.SD15, 100); cw = sd.make_controlnet_weights(sd.SD15, 200)
         f = 5
-        lat = torch.randn(f, 4, 32, 32); disp = torch.rand(f, 3, 256, 256)
+        lat = torch.randn(f, 4, 64, 64); disp = torch.rand(f, 3, 512, 512)
         cn, cp = torch.randn(1, 77, 768), torch.randn(1, 77, 768)
         t0 = time.perf_counter()
         sd.denoise_chunk(uw, cw, lat, disp, cn, cp, 5.0, 1, sd.SD15, 20)
-        t32 = time.perf_counter() - t0
-    del uw, cw
-    scale = (1293.3 + 479.3) / ((1293.3 - 612.5) / 4 + 612.5 / 16 + (479.3 - 245.1) / 4 + 245.1 / 16)
-    t_step = t32 * scale
-    N = 200_000
-    P = syn.make_gaussians(N, seed=0)
-    c2w = syn.make_cameras(1, seed=1)[0]
-    K = syn.BEAR_INTRINSICS
-    bgc = np.zeros(3, np.float32)
-    v_rgb = np.ones((512, 512, 3), np.float32)
-    t0 = time.perf_counter()
-    raster_c.render(P, c2w, K["fx"], K["fy"], K["cx"], K["cy"], 512, 512, bgc, training=False)
-    raster_c.render(P, c2w, K["fx"], K["fy"], K["cx"], K["cy"], 512, 512, bgc, training=True, v_rgb=v_rgb)
-    t_raster = (time.perf_counter() - t0) * (args.gaussians / N)
-    per_view = 20 * t_step + t_raster
+        t_step = time.perf_counter() - t0
+        del uw, cw
+        vw = sd.make_vae_decoder_weights(sd.VAE_SD, 300)
+        t0 = time.perf_counter()
+        sd.vae_decode(vw, torch.randn(1, 4, 64, 64), sd.VAE_SD)
+        t_vae = time.perf_counter() - t0
+        del vw
+    per_view = 20 * t_step + t_vae + t_raster
     return {"value": round(1.0 / per_view, 6), "unit": "views/s", "cores": threads, "kind": "port",
-            "sample": f"1 of 20 CFG ControlNet+UNet cross-view steps, f=5 (batch 10) on 32x32 latents = {t32:.2f}s, x{scale:.2f} "
-                      f"(analytic FLOP ratio) -> {t_step:.1f}s per 64x64 step, x20 steps; C raster eval + train fwd+bwd at "
-                      f"N={N} (1 thread) scaled to N={args.gaussians} = {t_raster:.2f}s; VAE decode not included"}
+            "sample": f"1 of 20 CFG ControlNet+UNet cross-view steps, f=5 (CFG batch 10) on the full 64x64 latents = {t_step:.1f}s (x20 per "
+                      f"edited view at chunk_size 1); VAE decode of one frame = {t_vae:.1f}s; C rasterizer (OpenMP, {cores} threads) eval + "
+                      f"train fwd+bwd at N={N} = {t_raster:.2f}s"}
 
 
 if __name__ == "__main__":

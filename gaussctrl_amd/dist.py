@@ -117,49 +117,113 @@ def broadcast_ref_bank(bank, src: int, world_size: int, rank: int, device=None, 
 MAX_INFLIGHT = 3        # async reference-bank broadcasts in flight (owner: packed copies kept; others: receive buffers posted)
 
 
-def broadcast_ref_bank_pipelined(pipe, ref_z0, ref_disp, ctx_neg, ctx_pos, src: int, world_size: int, rank: int, device, n_steps: int):
-    """SURVEY.md 8e collective 1 as a pipeline: the owner advances the 4-view reference trajectory ONE DDIM step at a time and
-    posts step i's K / V^T (one flat message, ~0.5 GB at SD1.5 / 512x512) as an ASYNC broadcast while it computes step i+1; the other
-    ranks post the matching receives up front and unpack as they complete, so the transfer of step i rides under the compute of step
-    i+1 (RCCL runs on its own stream) instead of 20 serial broadcasts after the whole bank exists.  The per-step layout is the same
-    for every step: it travels once, after step 0."""
-    import torch.distributed as dist
-    from .sd.unet import RefBank
-    pending = []
-    if rank == src:
-        tr = pipe.begin_ref_bank(ref_z0, ref_disp, ctx_neg, ctx_pos)
-        bank = tr["bank"]
-        layers = None
-        for i in range(n_steps):
-            done = pipe.advance_ref_bank(tr, 1)
-            if layers is None:
-                layers = _step_meta(bank, 0)
-                dist.broadcast_object_list([layers], src=src)
-            lay_i = [(l, ks, kst, vs, dt) for (l, ks, kst, vs, dt) in layers]
-            flat = _pack_step(bank, i, lay_i)
-            if flat.is_cuda:
-                torch.cuda.current_stream().synchronize()      # the packed buffer is complete before RCCL's stream reads it
-            pending.append((dist.broadcast(flat, src=src, async_op=True), flat))
-            while len(pending) > MAX_INFLIGHT:          # bound the packed copies held beside the bank (~0.5 GB each at SD1.5 / 512^2)
-                pending.pop(0)[0].wait()
-        for h, _ in pending:
+class RefBankStream:
+    """SURVEY.md 8e collective 1 as a stream.  The owner rank advances the 4-view reference trajectory and posts each finished DDIM
+    step's K / V^T (one flat message, ~0.5 GB at SD1.5 / 512x512) as an ASYNC broadcast; every other rank posts the matching
+    receive.  `advance(n)` moves the stream n DDIM steps (owner: compute + send, others: receive), so a caller that streams scenes
+    spreads the NEXT scene's bank over the chunks of the current one and the transfers ride under the denoise kernels (RCCL runs on
+    its own stream); `drain()` completes what is in flight except the newest `keep` messages; `finish()` returns the RefBank.
+    All ranks must call advance() with the same step counts in the same order relative to the other collectives of `group`.
+    `layers` (the per-step layout, identical for every step and scene) travels once: pass the previous stream's `.layers`."""
+
+    def __init__(self, pipe, src: int, world_size: int, rank: int, device, n_steps: int, group=None, layers=None):
+        from .sd.unet import RefBank
+        self.pipe, self.src, self.world, self.rank, self.device, self.n = pipe, src, world_size, rank, device, n_steps
+        self.group, self.layers = group, layers
+        self.owner = rank == src
+        self.i = 0                    # DDIM steps posted so far
+        self.pending = []             # (step, work handle, flat buffer)
+        self.tr = None
+        self.bank = None if self.owner else RefBank()
+        self._host_sync = None
+
+    def begin(self, ref_z0, ref_disp, ctx_neg, ctx_pos):
+        """owner only: start the reference trajectory (no-op elsewhere)"""
+        if self.owner:
+            self.tr = self.pipe.begin_ref_bank(ref_z0, ref_disp, ctx_neg, ctx_pos)
+            self.bank = self.tr["bank"]
+        return self
+
+    def _needs_host_sync(self):
+        if self._host_sync is None:
+            import torch.distributed as dist
+            self._host_sync = dist.get_backend(self.group) != "nccl"     # c10d's NCCL work orders itself after the current stream
+        return self._host_sync
+
+    def advance(self, nsteps: int | None = None):
+        import torch.distributed as dist
+        end = self.n if nsteps is None else min(self.n, self.i + nsteps)
+        while self.i < end:
+            i = self.i
+            if self.owner:
+                self.pipe.advance_ref_bank(self.tr, 1)
+                if self.layers is None:
+                    self.layers = _step_meta(self.bank, 0)
+                    dist.broadcast_object_list([self.layers], src=self.src, group=self.group)
+                flat = _pack_step(self.bank, i, self.layers)
+                if flat.is_cuda and self._needs_host_sync():
+                    torch.cuda.current_stream().synchronize()      # gloo reads the buffer from the host side
+            else:
+                if self.layers is None:
+                    box = [None]
+                    dist.broadcast_object_list(box, src=self.src, group=self.group)
+                    self.layers = box[0]
+                dtype = getattr(torch, self.layers[0][4].split(".")[-1])
+                flat = torch.empty(_step_numel(self.layers), dtype=dtype, device=self.device)
+            self.pending.append((i, dist.broadcast(flat, src=self.src, group=self.group, async_op=True), flat))
+            self.i = i + 1
+            self.drain(keep=MAX_INFLIGHT if nsteps is None else None)
+        return self.i >= self.n
+
+    def drain(self, keep: int | None = 0):
+        """complete (and on the receivers unpack) everything in flight except the newest `keep` messages (None: nothing)"""
+        if keep is None:
+            return
+        while len(self.pending) > keep:
+            i, h, flat = self.pending.pop(0)
             h.wait()
-        assert done is not None
-        return done
-    bank = RefBank()
-    box = [None]
-    dist.broadcast_object_list(box, src=src)
-    layers = box[0]
-    dtype = getattr(torch, layers[0][4].split(".")[-1])
-    posted = 0
-    for i in range(n_steps):                            # at most MAX_INFLIGHT receive buffers exist beside the unpacked bank
-        while posted < n_steps and posted - i < MAX_INFLIGHT:
-            flat = torch.empty(_step_numel(layers), dtype=dtype, device=device)
-            pending.append((dist.broadcast(flat, src=src, async_op=True), flat))
-            posted += 1
-        h, flat = pending.pop(0)
-        h.wait()
-        _unpack_step(bank, i, layers, flat)
-        del flat
-    bank.mode = "use"
-    return bank
+            if not self.owner:
+                _unpack_step(self.bank, i, self.layers, flat)
+
+    def finish(self):
+        assert self.i >= self.n, "advance() the stream to its last DDIM step first"
+        self.drain(0)
+        self.bank.mode = "use"
+        return self.bank
+
+
+def broadcast_ref_bank_pipelined(pipe, ref_z0, ref_disp, ctx_neg, ctx_pos, src: int, world_size: int, rank: int, device, n_steps: int,
+                                 group=None):
+    """The whole bank of one scene through a RefBankStream: the owner's step i+1 computes while step i travels; at most MAX_INFLIGHT
+    packed / receive buffers exist beside the bank."""
+    st = RefBankStream(pipe, src, world_size, rank, device, n_steps, group=group).begin(ref_z0, ref_disp, ctx_neg, ctx_pos)
+    st.advance(None)
+    return st.finish()
+
+
+class FlatGrads:
+    """The six leaf-gradient tensors as views of ONE flat fp32 allocation (what the fused backward's `grad_into` writes), so the
+    gradient reduction of a training batch is a single RCCL all-reduce of that buffer with no gather copy (SURVEY.md 8e collective 2).
+    `reduce_async()` posts it (c10d orders it after the work queued on the current stream); `wait()` makes the current stream wait for
+    it -- call it before the buffer is read (optimizer) or overwritten (the next-but-one batch when two FlatGrads alternate)."""
+
+    def __init__(self, params: dict, group=None):
+        n = sum(int(v.numel()) for v in params.values())
+        any_p = next(iter(params.values()))
+        self.flat = torch.zeros(n, dtype=torch.float32, device=any_p.device)
+        self.views, o = {}, 0
+        for k, v in params.items():
+            self.views[k] = self.flat[o:o + v.numel()].view(v.shape)
+            o += v.numel()
+        self.group = group
+        self.work = None
+
+    def reduce_async(self, world_size: int):
+        if world_size > 1:
+            import torch.distributed as dist
+            self.work = dist.all_reduce(self.flat, group=self.group, async_op=True)
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None

@@ -37,6 +37,20 @@ def lib():
     return _lib
 
 
+def use_threads(on: bool) -> None:
+    """bench.py's cpu_baseline leg only: switch to the OpenMP build of the same source (liboracle_raster_mt.so; thread count from
+    OMP_NUM_THREADS / all cores).  Its gradient sums use atomics, so the parity tests never load it."""
+    global _lib
+    if not on:
+        _lib = None
+        return
+    so = os.path.join(_HERE, "liboracle_raster_mt.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle_raster_mt.so"], stdout=subprocess.DEVNULL)
+    _lib = C.CDLL(so)
+    _lib.orc_cumsum_tiles.restype = C.c_int64
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 

@@ -33,6 +33,19 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* Optional threaded build (liboracle_raster_mt.so: -fopenmp -DORC_MT), used ONLY by bench.py's cpu_baseline leg so that the CPU
+ * figure uses every host core.  The default build (what the parity tests load) stays single-threaded and deterministic: without
+ * ORC_MT the macros below expand to the plain serial statements. */
+#ifdef ORC_MT
+#define ORC_PAR _Pragma("omp parallel for schedule(dynamic, 256)")
+#define ORC_PAR_ROWS _Pragma("omp parallel for schedule(dynamic, 1)")
+#define ORC_ADD(dst, v) do { _Pragma("omp atomic") dst += (v); } while (0)
+#else
+#define ORC_PAR
+#define ORC_PAR_ROWS
+#define ORC_ADD(dst, v) dst += (v)
+#endif
+
 #define TILE 16
 #define ALPHA_CAP 0.999f
 #define ALPHA_MIN (1.f / 255.f)
@@ -160,6 +173,7 @@ void orc_project_gaussians_fwd(int64_t N, const float *means3d, const float *sca
                                float *cov3d, float *xys, float *depths, int32_t *radii,
                                float *conics, int32_t *num_tiles_hit)
 {
+    ORC_PAR
     for (int64_t i = 0; i < N; ++i) {
         float c3[6] = {0}, xy[2] = {0}, dep = 0.f, con[3] = {0};
         int32_t rad, nth;
@@ -183,6 +197,7 @@ void orc_project_gaussians_bwd(int64_t N, const float *means3d, const float *sca
 {
     (void)cx; (void)cy;
     const float *V = viewmat, *P = projmat;
+    ORC_PAR
     for (int64_t i = 0; i < N; ++i) {
         float *vm = v_mean3d + 3 * i, *vs = v_scale + 3 * i, *vq = v_quat + 4 * i;
         vm[0] = vm[1] = vm[2] = 0.f; vs[0] = vs[1] = vs[2] = 0.f; vq[0] = vq[1] = vq[2] = vq[3] = 0.f;
@@ -304,6 +319,7 @@ static void sh_basis(int n, const float *d, float *B /* 16 */)
 void orc_sh_fwd(int64_t N, int degree, int degrees_to_use, const float *viewdirs, const float *coeffs, float *colors)
 {
     int K = sh_bases(degree), Ku = sh_bases(degrees_to_use);
+    ORC_PAR
     for (int64_t i = 0; i < N; ++i) {
         float B[16];
         sh_basis(degrees_to_use, viewdirs + 3 * i, B);
@@ -318,6 +334,7 @@ void orc_sh_fwd(int64_t N, int degree, int degrees_to_use, const float *viewdirs
 void orc_sh_bwd(int64_t N, int degree, int degrees_to_use, const float *viewdirs, const float *v_colors, float *v_coeffs)
 {
     int K = sh_bases(degree), Ku = sh_bases(degrees_to_use);
+    ORC_PAR
     for (int64_t i = 0; i < N; ++i) {
         float B[16];
         sh_basis(degrees_to_use, viewdirs + 3 * i, B);
@@ -399,6 +416,7 @@ void orc_rasterize_fwd(int H, int W, int tiles_x, int tiles_y,
                        const float *extra, const float *background,
                        float *out_img, float *out_extra, float *final_Ts, int32_t *final_index)
 {
+    ORC_PAR_ROWS
     for (int i = 0; i < H; ++i)
         for (int j = 0; j < W; ++j) {
             int tile = (i / TILE) * tiles_x + (j / TILE);
@@ -442,6 +460,7 @@ void orc_rasterize_bwd(int H, int W, int tiles_x, int64_t N,
 {
     memset(v_xy, 0, N * 2 * sizeof(float)); memset(v_conic, 0, N * 3 * sizeof(float));
     memset(v_colors, 0, N * 3 * sizeof(float)); memset(v_opacity, 0, N * sizeof(float));
+    ORC_PAR_ROWS
     for (int i = 0; i < H; ++i)
         for (int j = 0; j < W; ++j) {
             int tile = (i / TILE) * tiles_x + (j / TILE);
@@ -468,7 +487,7 @@ void orc_rasterize_bwd(int H, int W, int tiles_x, int64_t N,
                 float ra = 1.f / (1.f - alpha);
                 T *= ra;                               /* T before this splat */
                 float fac = alpha * T;
-                v_colors[3 * gid] += fac * vo0; v_colors[3 * gid + 1] += fac * vo1; v_colors[3 * gid + 2] += fac * vo2;
+                ORC_ADD(v_colors[3 * gid], fac * vo0); ORC_ADD(v_colors[3 * gid + 1], fac * vo1); ORC_ADD(v_colors[3 * gid + 2], fac * vo2);
                 const float *c = colors + 3 * gid;
                 float v_alpha = (c[0] * T - S0 * ra) * vo0 + (c[1] * T - S1 * ra) * vo1 + (c[2] * T - S2 * ra) * vo2;
                 v_alpha += T_final * ra * voa;         /* alpha = 1 - T_final */
@@ -476,12 +495,12 @@ void orc_rasterize_bwd(int H, int W, int tiles_x, int64_t N,
                 S0 += c[0] * fac; S1 += c[1] * fac; S2 += c[2] * fac;
                 if (araw > ALPHA_CAP) continue;        /* capped: d alpha / d(opac,sigma) = 0 */
                 float v_sigma = -opac * vis * v_alpha;
-                v_conic[3 * gid] += 0.5f * v_sigma * dx * dx;
-                v_conic[3 * gid + 1] += v_sigma * dx * dy;
-                v_conic[3 * gid + 2] += 0.5f * v_sigma * dy * dy;
-                v_xy[2 * gid] += v_sigma * (cn[0] * dx + cn[1] * dy);
-                v_xy[2 * gid + 1] += v_sigma * (cn[1] * dx + cn[2] * dy);
-                v_opacity[gid] += vis * v_alpha;
+                ORC_ADD(v_conic[3 * gid], 0.5f * v_sigma * dx * dx);
+                ORC_ADD(v_conic[3 * gid + 1], v_sigma * dx * dy);
+                ORC_ADD(v_conic[3 * gid + 2], 0.5f * v_sigma * dy * dy);
+                ORC_ADD(v_xy[2 * gid], v_sigma * (cn[0] * dx + cn[1] * dy));
+                ORC_ADD(v_xy[2 * gid + 1], v_sigma * (cn[1] * dx + cn[2] * dy));
+                ORC_ADD(v_opacity[gid], vis * v_alpha);
             }
         }
 }

@@ -73,7 +73,28 @@ def _worker(rank, world, port, ret):
         for key, (k, vt) in bank2.store.items():
             C_ = vt.shape[1]
             ok_pipe = ok_pipe and torch.equal(k, want2[key][0][..., C_:]) and torch.equal(vt, want2[key][1]) and k.stride(1) == 2 * C_
-        ret[rank] = (mine, ok_grad, ok_img and ok_bank and ok_pipe)
+        # the stream form bench.py / a scene-streaming caller uses: steps posted in uneven groups between other collectives (a flat
+        # gradient all-reduce on the default group), rotating owner (rank 1), layout passed on from the previous stream
+        from gaussctrl_amd.dist import FlatGrads, RefBankStream
+        first = RefBankStream(FakePipe(), 0, world, rank, "cpu", 3).begin(None, None, None, None)
+        first.advance(None); first.finish()
+        st = RefBankStream(FakePipe(), 1, world, rank, "cpu", 3, layers=first.layers).begin(None, None, None, None)
+        fg = FlatGrads({"a": torch.zeros(5, 3), "b": torch.zeros(4, 15, 3), "c": torch.zeros(7)})
+        assert fg.views["b"].data_ptr() == fg.flat[15:].data_ptr() and fg.flat.numel() == 15 + 180 + 7
+        done = st.advance(1)
+        fg.views["b"].fill_(float(rank + 1)); fg.views["c"].fill_(2.0)
+        fg.reduce_async(world)
+        assert not done
+        st.drain(1)
+        done = st.advance(2)
+        fg.wait()
+        ok_fg = bool((fg.views["b"] == 3.0).all()) and bool((fg.views["c"] == 4.0).all()) and bool((fg.views["a"] == 0).all())
+        bank3 = st.finish()
+        ok_stream = done and ok_fg and bank3.mode == "use" and set(bank3.store) == set(want2)
+        for key, (k, vt) in bank3.store.items():
+            C_ = vt.shape[1]
+            ok_stream = ok_stream and torch.equal(k, want2[key][0][..., C_:]) and torch.equal(vt, want2[key][1])
+        ret[rank] = (mine, ok_grad, ok_img and ok_bank and ok_pipe and ok_stream)
     finally:
         dist.destroy_process_group()
 

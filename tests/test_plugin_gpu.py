@@ -181,6 +181,16 @@ def test_image2latent_and_pipeline_flow(oracle_c):
     assert all(np.isfinite(losses)) and not torch.equal(before, model.means.detach())
     with pytest.raises(NotImplementedError):
         pipe.forward()
+    # round_like_reference: rgb / depth rounded to fp16 where the reference does it (gc_pipeline.py:132-133), disparity evaluated in fp16
+    assert pipe.device == torch.device(DEV)
+    pipe.config.round_like_reference = True
+    pipe.render_reverse([1])
+    rgb, dep = td[1]["unedited_image"], td[1]["depth_image"]
+    assert rgb.dtype == torch.float32 and torch.equal(rgb, rgb.half().float()) and torch.equal(dep, dep.half().float())
+    d16 = dep.half()
+    want16 = 1 / (d16 + 1e-5); want16 = want16 / want16.max()
+    assert torch.equal(pipe.depth2disparity_torch(dep)[1], want16.float())
+    pipe.config.round_like_reference = False
 
 
 def test_l1_ssim_loss_and_fused_adam():
