@@ -1,0 +1,348 @@
+// dn_attn5.hip -- k_attn5, the key-split 8-wave form of the D = 40 cross-view attention (its own translation unit: the kernel is
+// register-tight and is iterated on separately; shared pieces in dn_attn_common.h).  Reference semantics: dn_attn.hip header
+// (/root/reference/gaussctrl/utils.py:25-37,86-117).
+#include "dn_attn_common.h"
+
+namespace {
+// ------------------------------------------------------------------------------------------------------------------------
+// k_attn5 (round 3; D = 40, Lk % 64 == 0, Lq % 256 == 0): the k_attn4 arithmetic with the work of a 64-key tile split so that every
+// LDS fragment feeds TWO MFMAs.  Why: per 64-key tile k_attn4's eight co-resident waves (two workgroups of four) issue 8 x 14
+// ds_read_b128 (448 LDS cycles) and DMA two 14 KB tiles (224-448 cycles) for 938 MFMA cycles per SIMD -- the LDS array, not the matrix
+// pipe, is what saturates (profiles/r02_attn4_ablation.txt: no ds_read -26 %, no DMA -17 %).  Here ONE workgroup of eight waves per CU
+// shares one K / V^T stream for 256 queries, and wave w = (query group w >> 1: 64 queries = two 32-query blocks, key half w & 1: 32 of
+// the tile's 64 keys).  Per tile and wave: S'^T = 3 k-steps x 2 query blocks (6 MFMAs, 3 K fragments), O^T += 2 row blocks x 2
+// k-steps x 2 query blocks (8 MFMAs, 4 V^T fragments): the same 14 MFMAs per (32 queries x 64 keys) with 7 fragment reads instead of
+// 14 and one DMA'd tile instead of two -- 36-48 % LDS occupancy instead of 72-96 %.
+// The two key-half waves of a pair use the SAME offset (both evaluate the first key block of a set's first tile), so their partial
+// numerators and denominators simply add: the denominators are exchanged through LDS at the end of each set (w_s / (l_a + l_b)
+// scales both partial O^T), the partial weighted sums once at the end of the kernel.
+template <class T, bool PRE, int NST = 3>
+__global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
+{
+    constexpr int D = 40, NW = 8, KS = 3, DB = 2, QB = 2;
+    constexpr int KBYTES = 64 * 128, VBYTES = DB * 32 * 128;
+    constexpr int LCS = D / 8, KSS = LCS / 2, HS = LCS & 1;
+    constexpr int NT = NW * 64;
+    constexpr int VSH = 8 * D / NW;                                        // V^T chunks per wave per tile (40): one DMA instruction
+    constexpr int PD = NST - 1, GRP = 2;                                   // DMA instructions per wave per tile: one K, one V^T
+    constexpr float BIG = 30000.f;
+    constexpr int XL = NST * (KBYTES + VBYTES);                            // byte offset of the denominator exchange area (2 KB)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *sK = smem, *sV = smem + NST * KBYTES;
+    float *xl = reinterpret_cast<float *>(smem + XL);
+    const unsigned ldsK = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem, ldsV = ldsK + NST * KBYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kh = wid & 1;                                                // key block of every tile this wave owns
+    const int qi = lane & 31, hg = lane >> 5;
+    int qblk, h, b;
+    block_coords(a, 2, qblk, h, b);
+    const int q_wave0 = qblk * 256 + (wid >> 1) * 64;
+    const int ntiles = a.Lk >> 6;
+    const int nsteps = a.nsets * ntiles;
+
+    // ---- LDS image, written once: zeros, column D of every key row = 1, the ones row of V^T
+    for (int i = tid; i < (XL + 2048) / 16; i += NT) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    for (int i = tid; i < NST * 64; i += NT) {
+        const int st = i >> 6, row = i & 63;
+        *reinterpret_cast<unsigned short *>(sK + st * KBYTES + row * 128 + ((LCS ^ swz4(row)) << 4)) = One<T>::v;
+    }
+    for (int i = tid; i < NST * 64; i += NT) reinterpret_cast<unsigned short *>(sV + (i >> 6) * VBYTES + D * 128)[i & 63] = One<T>::v;
+
+    // ---- Q fragments (B operand): lane holds Q[q = qi][d = 16 ks + 8 hg .. +8] of both query blocks
+    uint4 qf[QB][KS];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int q = q_wave0 + 32 * qb + qi;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d = ks * 16 + hg * 8;
+            qf[qb][ks] = (d + 8 <= D) ? *reinterpret_cast<const uint4 *>(a.Q + (int64_t)b * a.q_bs + (int64_t)q * a.ldq + h * D + d)
+                                      : make_uint4(0, 0, 0, 0);
+        }
+        if (hg == HS) qf[qb][KSS].x = pack2<T>(0.f, -BIG);
+    }
+    const float c2 = a.scale_log2e;
+
+    // ---- LDS-DMA plan of this lane (k_attn4's, 8 waves: one K and one V^T instruction per wave and tile)
+    int k_off, v_off;
+    unsigned long long k_msk, v_msk;
+    {
+        const int p = wid * 64 + lane, row = p >> 3, lc = (p & 7) ^ swz4(row);
+        k_msk = __ballot(lc * 8 < D);
+        k_off = (row * (int)a.ldk + lc * 8) * 2;
+    }
+    {
+        const int p = VSH * wid + lane, row = p >> 3, lc = (p & 7) ^ swz4(row);
+        v_msk = __ballot(lane < VSH);
+        v_off = (row * (int)a.ldvt + lc * 8) * 2;
+    }
+    unsigned long long kb_tab = 0, vb_tab = 0;
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        if (s < a.nsets) {
+            const int kind = a.set_kind[s];
+            const unsigned short *Kb, *Vb;
+            if (kind >= 0) {
+                const int kvb = (b / a.f) * a.ref_fph + kind;
+                Kb = a.Kr + (int64_t)kvb * a.kr_bs + h * D;
+                Vb = a.Vtr + (int64_t)kvb * a.vtr_bs + (int64_t)h * D * a.ldvt;
+            } else {
+                const int kvb = kind == -1 ? b : b / a.f;
+                Kb = a.K + (int64_t)kvb * a.k_bs + h * D;
+                Vb = a.Vt + (int64_t)kvb * a.vt_bs + (int64_t)h * D * a.ldvt;
+            }
+            if (lane == s) { kb_tab = (unsigned long long)Kb; vb_tab = (unsigned long long)Vb; }
+        }
+    }
+    auto tab = [&](unsigned long long t, int s) __attribute__((always_inline)) -> const unsigned char * {
+        const unsigned lo = __builtin_amdgcn_readlane((unsigned)t, s), hi = __builtin_amdgcn_readlane((unsigned)(t >> 32), s);
+        return (const unsigned char *)(((unsigned long long)hi << 32) | lo);
+    };
+    struct Cur { const unsigned char *p; int tile, s; unsigned dst; };
+    Cur ck, cv;
+    ck.p = tab(kb_tab, 0); ck.tile = 0; ck.s = 0; ck.dst = ldsK + wid * 1024;
+    cv.p = tab(vb_tab, 0); cv.tile = 0; cv.s = 0; cv.dst = ldsV + wid * (VSH * 16);
+    const int64_t kstride = (int64_t)128 * a.ldk;
+    auto issue_kv = [&]() __attribute__((always_inline)) {
+        glds16_s(ck.p, (unsigned)k_off, ck.dst, k_msk);
+        ck.dst = ck.dst + KBYTES == ldsK + wid * 1024 + NST * KBYTES ? ldsK + wid * 1024 : ck.dst + KBYTES;
+        ck.p += kstride;
+        if (++ck.tile == ntiles) { ck.tile = 0; ck.s = ck.s + 1 < a.nsets ? ck.s + 1 : ck.s; ck.p = tab(kb_tab, ck.s); }
+        glds16_s(cv.p, (unsigned)v_off, cv.dst, v_msk);
+        cv.dst = cv.dst + VBYTES == ldsV + wid * (VSH * 16) + NST * VBYTES ? ldsV + wid * (VSH * 16) : cv.dst + VBYTES;
+        cv.p += 128;
+        if (++cv.tile == ntiles) { cv.tile = 0; cv.s = cv.s + 1 < a.nsets ? cv.s + 1 : cv.s; cv.p = tab(vb_tab, cv.s); }
+    };
+
+    // fragment read offsets.  K: MFMA row qi is key pi(qi) of the wave's key block; chunk 2 ks + hg.  V^T: row 32 db + qi, chunk 2 t + hg
+    // with t = 2 kh + t' the two 16-key k-steps of the wave's key block
+    int kfo[KS], k0o[KS], vfo[2];
+    {
+        const int row = (qi & ~12) | (((qi >> 2) & 1) << 3) | (((qi >> 3) & 1) << 2);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            k0o[ks] = row * 128 + (((2 * ks + hg) ^ swz4(row)) << 4);
+            kfo[ks] = k0o[ks] + kh * 4096;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) vfo[t] = qi * 128 + (((2 * (2 * kh + t) + hg) ^ swz4(qi)) << 4);
+    }
+
+    // O^T rows 40..63 are never stored: of row block 1 only rows 32..39 (registers 0..3) are carried across K/V sets
+    f32x16 os[QB][DB], otot0[QB];
+    f32x4 otot1[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { otot0[qb][r] = 0.f; os[qb][0][r] = 0.f; os[qb][1][r] = 0.f; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) otot1[qb][r] = 0.f;
+    }
+    int bad = 0;
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+
+    const unsigned char *rk = sK, *rv = sV;
+    f32x16 S0, S1;                       // S'^T of the wave's key block for query block 0 / 1 (single-buffered: see the schedule below)
+    uint4 pf[QB][2], kf[KS], vf[2][DB];
+    // exp unit w of k-step t: registers 8 t + 2 w, + 1 of S -> one packed word of the P fragment (2 v_exp_f32 + 1 v_cvt_pk)
+    auto unit = [&](const f32x16 &S, uint4 &p, int w, int t) __attribute__((always_inline)) {
+        const int r0 = 8 * t + 2 * w;
+        const float x0 = PRE ? S[r0] : S[r0] * c2, x1 = PRE ? S[r0 + 1] : S[r0 + 1] * c2;
+        const unsigned v = pack2<T>(__builtin_amdgcn_exp2f(x0), __builtin_amdgcn_exp2f(x1));
+        if (w == 0) p.x = v;
+        else if (w == 1) p.y = v;
+        else if (w == 2) p.z = v;
+        else p.w = v;
+    };
+    // Software pipeline of one tile, in issue order (MFMA groups and the exp units that run in their shadow):
+    //   A  wait + barrier (tile i landed, tile i-1's slot free), DMA of tile i+PD, read the K fragments
+    //   B  units 4..7 of S1(i-1)                                   -- covers the LDS latency of A
+    //   C  S0(i)   = K Q0^T            3 MFMAs
+    //   D  O1 += V^T(i-1) P1(i-1)^T    4 MFMAs   + units 0..3 of S0(i)
+    //   E  read the V^T fragments of tile i (after D: they replace tile i-1's)
+    //   F  S1(i)   = K Q1^T            3 MFMAs   + units 4..7 of S0(i)
+    //   G  O0 += V^T(i) P0(i)^T        4 MFMAs   + units 0..3 of S1(i)
+    // Every exp batch has a 7-MFMA window and every MFMA carries ~1.2 units (2.4 v_exp + 1.2 v_cvt_pk: inside what a 32x32x16 MFMA
+    // hides, profiles/r02_issue_model_32x32.txt); S0 / S1 / P0 / P1 need no second copy.
+    // (one loop body for every tile -- a peeled first-tile variant makes the register allocator shuttle all four accumulators
+    // between two homes, 96 v_mov per tile; at the start of a set the pipeline is primed with P1 = 0 instead, so B and D add nothing)
+    auto tile_step = [&](bool first) __attribute__((always_inline)) {
+        wait_vmcnt<(PD - 1) * GRP>();
+        __builtin_amdgcn_s_barrier();
+        issue_kv();
+        const unsigned char *kb_ = rk, *vb_ = rv;
+        rk = rk + KBYTES == sK + NST * KBYTES ? sK : rk + KBYTES;
+        rv = rv + VBYTES == sV + NST * VBYTES ? sV : rv + VBYTES;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kf[ks] = *reinterpret_cast<const uint4 *>(kb_ + kfo[ks]);
+        if (first) {
+            // first tile of a K/V set: the row maximum over its FIRST key block becomes the set's offset -- evaluated by both waves of
+            // a pair on the same data, so they agree bit for bit without an exchange
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                if (hg == HS) qf[qb][KSS].x = pack2<T>(0.f, -BIG);
+                f32x16 m0 = zero16;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) m0 = T::mfma32(*reinterpret_cast<const uint4 *>(kb_ + k0o[ks]), qf[qb][ks], m0);
+                float t = fmaxf(fmaxf(m0[0], m0[1]), m0[2]);
+#pragma unroll
+                for (int r = 3; r + 1 < 16; r += 2) t = fmaxf(fmaxf(t, m0[r]), m0[r + 1]);
+                t = fmaxf(t, m0[15]);
+                const unsigned x = __float_as_uint(t);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+                t = fmaxf(__uint_as_float(r1[0]), __uint_as_float(r1[1]));
+                const float mq = T::to_f(T::from_f(t));
+                if (hg == HS) qf[qb][KSS].x = pack2<T>(-mq, -BIG);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        unit(S1, pf[1][1], 0, 1); unit(S1, pf[1][1], 1, 1); unit(S1, pf[1][1], 2, 1); unit(S1, pf[1][1], 3, 1);      // B
+        __builtin_amdgcn_sched_barrier(0);
+        S0 = T::mfma32(kf[0], qf[0][0], zero16);        // C
+        S0 = T::mfma32(kf[1], qf[0][1], S0);
+        S0 = T::mfma32(kf[2], qf[0][2], S0);
+        __builtin_amdgcn_sched_barrier(0);
+        os[1][0] = T::mfma32(vf[0][0], pf[1][0], os[1][0]);      // D
+        unit(S0, pf[0][0], 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        os[1][1] = T::mfma32(vf[0][1], pf[1][0], os[1][1]);
+        unit(S0, pf[0][0], 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        os[1][0] = T::mfma32(vf[1][0], pf[1][1], os[1][0]);
+        unit(S0, pf[0][0], 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        os[1][1] = T::mfma32(vf[1][1], pf[1][1], os[1][1]);
+        unit(S0, pf[0][0], 3, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)     // E
+#pragma unroll
+            for (int db = 0; db < DB; ++db) vf[t][db] = *reinterpret_cast<const uint4 *>(vb_ + vfo[t] + db * 4096);
+        S1 = T::mfma32(kf[0], qf[1][0], zero16);        // F
+        unit(S0, pf[0][1], 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        S1 = T::mfma32(kf[1], qf[1][1], S1);
+        unit(S0, pf[0][1], 1, 1); unit(S0, pf[0][1], 2, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        S1 = T::mfma32(kf[2], qf[1][2], S1);
+        unit(S0, pf[0][1], 3, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        os[0][0] = T::mfma32(vf[0][0], pf[0][0], os[0][0]);      // G
+        unit(S1, pf[1][0], 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        os[0][1] = T::mfma32(vf[0][1], pf[0][0], os[0][1]);
+        unit(S1, pf[1][0], 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        os[0][0] = T::mfma32(vf[1][0], pf[0][1], os[0][0]);
+        unit(S1, pf[1][0], 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        os[0][1] = T::mfma32(vf[1][1], pf[0][1], os[0][1]);
+        unit(S1, pf[1][0], 3, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // end of a K/V set: finish the pipeline (B and D of the last tile), then O_total += w / (l_a + l_b) * O_set; a wave's partial
+    // denominator is row D of its O^T (the ones row of V^T)
+    auto fold = [&](int s) __attribute__((always_inline)) {
+        unit(S1, pf[1][1], 0, 1); unit(S1, pf[1][1], 1, 1); unit(S1, pf[1][1], 2, 1); unit(S1, pf[1][1], 3, 1);
+        os[1][0] = T::mfma32(vf[0][0], pf[1][0], os[1][0]);
+        os[1][1] = T::mfma32(vf[0][1], pf[1][0], os[1][1]);
+        os[1][0] = T::mfma32(vf[1][0], pf[1][1], os[1][0]);
+        os[1][1] = T::mfma32(vf[1][1], pf[1][1], os[1][1]);
+        constexpr int db_l = D / 32, dl = D % 32, r_l = (dl >> 3) * 4 + (dl & 3), hg_l = (dl >> 2) & 1;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+            if (hg == hg_l) xl[(wid * QB + qb) * 32 + qi] = os[qb][db_l][r_l];
+        __syncthreads();
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            const float l = xl[(wid * QB + qb) * 32 + qi] + xl[((wid ^ 1) * QB + qb) * 32 + qi];
+            bad |= !(l > 0.f && l < 1e37f);
+            const float inv = a.set_w[s] / l;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { otot0[qb][r] += os[qb][0][r] * inv; os[qb][0][r] = 0.f; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) otot1[qb][r] += os[qb][1][r] * inv;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) os[qb][1][r] = 0.f;
+        }
+    };
+
+    // ---- prologue: PD tiles in flight
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PD; ++j) issue_kv();
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int db = 0; db < DB; ++db) vf[t][db] = make_uint4(0, 0, 0, 0);
+    for (int s = 0; s < a.nsets; ++s) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S1[r] = -BIG;                  // exp2 -> 0: the pipeline starts with P1 = 0
+        pf[1][0] = make_uint4(0, 0, 0, 0);
+        for (int t = 0; t < ntiles; ++t) tile_step(t == 0);
+        fold(s);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    if (__syncthreads_or(bad)) {      // some row left the exponent range of its first-block offset: safe recomputation
+        attn_safe_body<T, D, 2, NW>(a, qblk, h, b, smem, smem + SafeLds<D>::KBYTES);
+        return;
+    }
+    // ---- combine the two key halves: wave kh hands its partial of query block 1 - kh to its partner and stores block kh
+    float *xo = reinterpret_cast<float *>(smem) + (size_t)wid * (20 * 64);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xo[r * 64 + lane] = kh ? otot0[0][r] : otot0[1][r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xo[(16 + r) * 64 + lane] = kh ? otot1[0][r] : otot1[1][r];
+    __syncthreads();
+    const float *xp = reinterpret_cast<const float *>(smem) + (size_t)(wid ^ 1) * (20 * 64);
+    const int q = q_wave0 + 32 * kh + qi;
+    unsigned short *orow = a.O + (int64_t)b * a.o_bs + (int64_t)q * a.ldo + h * D;
+    {
+        float o[20];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = (kh ? otot0[1][r] : otot0[0][r]) + xp[r * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[16 + r] = (kh ? otot1[1][r] : otot1[0][r]) + xp[(16 + r) * 64 + lane];
+#pragma unroll
+        for (int rq = 0; rq < 5; ++rq)      // channels 8 rq + 4 hg .. + 4 (rq = 4: rows 32..39 of row block 1)
+            *reinterpret_cast<uint2 *>(orow + 8 * rq + 4 * hg) =
+                make_uint2(pack2<T>(o[4 * rq], o[4 * rq + 1]), pack2<T>(o[4 * rq + 2], o[4 * rq + 3]));
+    }
+}
+
+template <class T, bool PRE>
+void launch_attn5_(const AttnArgs &a, int B, hipStream_t s)
+{
+    constexpr int NST = 3;
+    constexpr size_t ring = (size_t)NST * (64 * 128 + 2 * 32 * 128) + 2048, xchg = (size_t)8 * 20 * 64 * 4;
+    constexpr size_t safe = SafeLds<40>::KBYTES + SafeLds<40>::VBYTES;
+    constexpr size_t lds = ring > xchg ? (ring > safe ? ring : safe) : (xchg > safe ? xchg : safe);
+    static gc::AttrOnce once;
+    gc::ensure_dynamic_lds(once, (const void *)k_attn5<T, PRE, NST>, (int)lds);
+    AttnArgs aa = a;
+    aa.nqb = a.Lq / 256;
+    dim3 grid((unsigned)(aa.nqb * a.H * B));
+    hipLaunchKernelGGL((k_attn5<T, PRE, NST>), grid, dim3(512), lds, s, aa);
+}
+template <class T>
+void launch_attn5(const AttnArgs &a, int B, hipStream_t s)
+{
+    if (a.scale_log2e == 1.f) launch_attn5_<T, true>(a, B, s);
+    else launch_attn5_<T, false>(a, B, s);
+}
+
+}  // namespace
+
+// AttnArgs has internal linkage per translation unit (same definition in both): the entry point takes it through a void pointer
+void gc_dn_launch_attn5(const void *args, int dtype, int B, hipStream_t s)
+{
+    const AttnArgs &a = *static_cast<const AttnArgs *>(args);
+    if (dtype == DT_BF16) launch_attn5<BF16>(a, B, s);
+    else launch_attn5<F16>(a, B, s);
+}

@@ -1,0 +1,91 @@
+"""k_attn5 (kernel_variant bit 4) vs k_attn4 and a torch fp32 reference: parity at small sizes, timing at the production launch
+(L = 4096, 8 heads x D = 40, B = 6 frames, 5 K/V sets incl. a cached reference bank).   python scripts/attn5_check.py"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from gaussctrl_amd.sd import ops
+
+DEV = "cuda:0"
+
+
+def ref_attn(q, k, v, heads, scale):
+    B, L, C = q.shape
+    D = C // heads
+    qh = q.float().view(B, L, heads, D).transpose(1, 2); kh = k.float().view(B, -1, heads, D).transpose(1, 2)
+    vh = v.float().view(B, -1, heads, D).transpose(1, 2)
+    p = (qh @ kh.transpose(-1, -2) * scale).softmax(-1)
+    return (p @ vh).transpose(1, 2).reshape(B, L, C)
+
+
+def run(variant, *a, **kw):
+    ops.KERNEL_VARIANT["attn"] = variant
+    try:
+        return ops.attention(*a, **kw)
+    finally:
+        ops.KERNEL_VARIANT["attn"] = 0
+
+
+def parity(dt, f, L, heads, coeff, spike=False, pre=False):
+    D = 40
+    B, C = 2 * f, heads * D
+    g = torch.Generator(device=DEV).manual_seed(L + f)
+    q = torch.randn(B, L, C, device=DEV, generator=g).to(dt); k = torch.randn(B, L, C, device=DEV, generator=g).to(dt)
+    v = torch.randn(B, L, C, device=DEV, generator=g).to(dt)
+    if spike:
+        k[:, 200, :] = q[:, 17, :] * 40.0
+    vt = v.transpose(1, 2).contiguous()
+    scale = D ** -0.5
+    sets = ([(-1, coeff)] if coeff != 0 else []) + [(r, (1 - coeff) / 4) for r in range(4)]
+    qq = (q.float() * (scale * 1.4426950408889634)).to(dt) if pre else q
+    sc = float(np.log(2.0)) if pre else scale
+    ref = coeff * ref_attn(qq, k, v, heads, sc)
+    for r in range(4):
+        idx = torch.arange(B, device=DEV) // f * f + r
+        ref = ref + (1 - coeff) / 4 * ref_attn(qq, k[idx], v[idx], heads, sc)
+    a4 = run(0, qq, k, vt, heads, sets, f, Lk=L, q_prescaled=pre).float()
+    a5 = run(16, qq, k, vt, heads, sets, f, Lk=L, q_prescaled=pre).float()
+    e4 = float((a4 - ref).norm() / ref.norm()); e5 = float((a5 - ref).norm() / ref.norm())
+    d45 = float((a5 - a4).abs().max())
+    print(f"{str(dt):16s} f={f} L={L} heads={heads} coeff={coeff} spike={spike} pre={pre}: rel L2 k_attn4 {e4:.3e}  k_attn5 {e5:.3e}  max|a5-a4| {d45:.3e}"
+          f"  finite={bool(torch.isfinite(a5).all())}")
+    return e4, e5
+
+
+def timing(dt, variant, iters=20):
+    f, L, heads, D = 3, 4096, 8, 40
+    B, C = 2 * f, heads * D
+    g = torch.Generator(device=DEV).manual_seed(0)
+    qk = torch.randn(B, L, 2 * C, device=DEV, generator=g).to(dt)
+    q, k = qk[..., :C], qk[..., C:]
+    vt = torch.randn(B, C, L, device=DEV, generator=g).to(dt)
+    kr = torch.randn(8, L, 2 * C, device=DEV, generator=g).to(dt)[..., C:]
+    vtr = torch.randn(8, C, L, device=DEV, generator=g).to(dt)
+    sets = [(-1, 0.6)] + [(r, 0.1) for r in range(4)]
+    for _ in range(3):
+        run(variant, q, k, vt, heads, sets, f, Lk=L, kref=kr, vtref=vtr, ref_fph=4, q_prescaled=True)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ops.KERNEL_VARIANT["attn"] = variant
+    s.record()
+    for _ in range(iters):
+        ops.attention(q, k, vt, heads, sets, f, Lk=L, kref=kr, vtref=vtr, ref_fph=4, q_prescaled=True)
+    e.record(); torch.cuda.synchronize()
+    ops.KERNEL_VARIANT["attn"] = 0
+    us = s.elapsed_time(e) * 1e3 / iters
+    fl = 4.0 * B * L * L * C * 5
+    print(f"timing {str(dt):16s} variant {variant:2d}: {us:8.1f} us   {fl / us / 1e6:7.1f} TF/s   frac of 2.5 PF {fl / us / 1e6 / 2500:.3f}")
+    return us
+
+
+if __name__ == "__main__":
+    ok = True
+    for dt in (torch.bfloat16, torch.float16):
+        for (f, L, heads, coeff, spike, pre) in [(4, 256, 2, 0.6, False, False), (5, 512, 2, 0.6, False, True), (5, 256, 1, 0.0, False, True),
+                                                 (4, 256, 2, 0.6, True, False), (4, 1024, 8, 0.6, False, True)]:
+            e4, e5 = parity(dt, f, L, heads, coeff, spike, pre)
+            ok = ok and e5 <= max(1.5 * e4, 2e-3 if dt == torch.float16 else 1.2e-2)
+    print("PARITY", "OK" if ok else "FAIL")
+    for dt in (torch.bfloat16, torch.float16):
+        for v in (0, 16, 0, 16):
+            timing(dt, v)
