@@ -79,7 +79,9 @@ class GemmProfiler:
             D = q.shape[2] // heads
             fast = D in (40, 80) and len(sets) * ((lk + 63) // 64) >= 4                      # mirrors launch_attn() in dn_attn.hip
             variant = getattr(ops, "KERNEL_VARIANT", {}).get("attn", 0)
-            if fast and D == 40 and not (variant & 2):
+            if fast and D == 40 and not (variant & 30) and lk % 64 == 0 and q.shape[1] % 256 == 0:
+                name = f"k_attn5<{prof.dt},40> (8 waves, key-split)"
+            elif fast and D == 40 and not (variant & 2):
                 name = f"k_attn4<{prof.dt},40,3,{8 if variant & 4 else 4}>"
             else:
                 name = f"k_attn3<{prof.dt},{D},{2 if D == 40 else 1},3>" if fast else f"k_attn<{prof.dt},{D},{1 if D == 160 else 2}>"
@@ -420,9 +422,9 @@ def main():
         traffic = None
         for tname in ("r03_attn_traffic.json", "r02_attn_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
-            if kind.startswith("k_attn4") and c == 3 and os.path.exists(tpath) and traffic is None:
+            if kind.startswith(("k_attn4", "k_attn5")) and c == 3 and os.path.exists(tpath) and traffic is None:
                 for kn, v in json.load(open(tpath))["kernels"].items():
-                    if "k_attn4" in kn and "traffic_MB_per_dispatch" in v:
+                    if kind[:7] in kn and "traffic_MB_per_dispatch" in v:
                         traffic = int(round(v["traffic_MB_per_dispatch"] * 1e6))
         roof = {"bound": "mfma", "kernel": kind + (" (multi-K/V-set flash attention, dn_attn.hip)" if kind.startswith("k_attn") else
                                                     " (k_gemm / k_gemm8 MFMA GEMM and implicit 3x3 conv, variant picked per grid, dn_gemm.hip)"),

@@ -18,7 +18,7 @@
 // ([B][C][L], written by the projection GEMM's epilogue) so no transpose happens here.
 #include "dn_attn_common.h"
 
-void gc_dn_launch_attn5(const void *args, int dtype, int B, hipStream_t s);      // dn_attn5.hip
+void gc_dn_launch_attn5(const void *args, int dtype, int B, int depth, hipStream_t s);      // dn_attn5.hip
 
 namespace {
 using namespace dn;
@@ -772,7 +772,9 @@ int launch_attn(const AttnArgs &a, int D, int B, bool fast, int variant, hipStre
     if (fast && (int64_t)a.nsets * ((a.Lk + 63) / 64) >= 4) {   // short key streams: the pipeline's fill / LDS set-up does not amortise
         switch (D) {
         case 40:
-            if ((variant & 16) && (a.Lk & 63) == 0 && (a.Lq & 255) == 0) gc_dn_launch_attn5(&a, std::is_same<T, BF16>::value ? DT_BF16 : DT_F16, B, s);   // bit 4: k_attn5 (dn_attn5.hip)
+            // default: k_attn5 (key-split 8-wave form, dn_attn5.hip) when the tile shapes fit; kernel_variant bit 4 keeps k_attn4 (A/B)
+            if (!(variant & 30) && (a.Lk & 63) == 0 && (a.Lq & 255) == 0)
+                gc_dn_launch_attn5(&a, std::is_same<T, BF16>::value ? DT_BF16 : DT_F16, B, (variant & 32) ? 4 : (variant & 64) ? 8 : 6, s);
             else if (variant & 2) launch_attn3<T, 40, 2, 3>(a, B, s);     // kernel_variant bit 1: the 16x16x32 form (A/B measurements)
             else if (variant & 4) launch_attn4<T, 40, 3, 8>(a, B, s);      // bit 2: 8 waves, one workgroup per CU
             else if (variant & 8) launch_attn4<T, 40, 4, 4, 3, 2>(a, B, s); // bit 3: 64 queries per wave (one wave per SIMD)
@@ -826,6 +828,7 @@ extern "C" int gc_dn_attention(const gc_attn_desc *d, void *stream)
     GC_REQUIRE((d->Kref == nullptr) == (d->Vtref == nullptr), "Kref and Vtref must be given together");
     for (int i = 0; i < d->nsets; ++i) GC_REQUIRE(d->set_kind[i] >= -2 && d->set_kind[i] < a.ref_fph, "bad set_kind");
     a.scale_log2e = d->q_prescaled ? 1.f : d->scale * 1.4426950408889634f;
+    a.abl = d->kernel_variant >> 8;
     const bool fast = !(d->kernel_variant & 1);      // kernel_variant bit 0: online-softmax kernel everywhere (tests)
     int rc = d->dtype == DT_BF16 ? launch_attn<BF16>(a, d->head_dim, d->batch, fast, d->kernel_variant, gc::S(stream))
              : d->dtype == DT_F16 ? launch_attn<F16>(a, d->head_dim, d->batch, fast, d->kernel_variant, gc::S(stream)) : GC_EINVAL;

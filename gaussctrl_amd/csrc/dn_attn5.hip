@@ -16,7 +16,9 @@ namespace {
 // The two key-half waves of a pair use the SAME offset (both evaluate the first key block of a set's first tile), so their partial
 // numerators and denominators simply add: the denominators are exchanged through LDS at the end of each set (w_s / (l_a + l_b)
 // scales both partial O^T), the partial weighted sums once at the end of the kernel.
-template <class T, bool PRE, int NST = 3>
+// ABL: instrumented instantiation for timing ablations (results wrong by construction): a.abl bit 0 no v_exp, 1 no exp units at
+// all, 2 no s_barrier, 3 no LDS-DMA, 4 no LDS fragment reads
+template <class T, bool PRE, int NST = 4, bool ABL = false>
 __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
 {
     constexpr int D = 40, NW = 8, KS = 3, DB = 2, QB = 2;
@@ -65,6 +67,9 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
         if (hg == HS) qf[qb][KSS].x = pack2<T>(0.f, -BIG);
     }
     const float c2 = a.scale_log2e;
+    const int abl = ABL ? __builtin_amdgcn_readfirstlane(a.abl) : 0;
+    float abl_x = -(float)(lane & 7);
+    unsigned abl_sink = 0;
 
     // ---- LDS-DMA plan of this lane (k_attn4's, 8 waves: one K and one V^T instruction per wave and tile)
     int k_off, v_off;
@@ -152,34 +157,39 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
     // exp unit w of k-step t: registers 8 t + 2 w, + 1 of S -> one packed word of the P fragment (2 v_exp_f32 + 1 v_cvt_pk)
     auto unit = [&](const f32x16 &S, uint4 &p, int w, int t) __attribute__((always_inline)) {
         const int r0 = 8 * t + 2 * w;
-        const float x0 = PRE ? S[r0] : S[r0] * c2, x1 = PRE ? S[r0 + 1] : S[r0 + 1] * c2;
-        const unsigned v = pack2<T>(__builtin_amdgcn_exp2f(x0), __builtin_amdgcn_exp2f(x1));
+        float x0 = PRE ? S[r0] : S[r0] * c2, x1 = PRE ? S[r0 + 1] : S[r0 + 1] * c2;
+        if (ABL && (abl & 2)) return;
+        if (ABL && (abl & 32)) { x0 = abl_x; x1 = abl_x; }          // inputs that do not come from an MFMA
+        const unsigned v = (ABL && (abl & 1)) ? pack2<T>(x0, x1) : pack2<T>(__builtin_amdgcn_exp2f(x0), __builtin_amdgcn_exp2f(x1));
+        if (ABL && (abl & 64)) { abl_sink ^= v; return; }           // outputs that no MFMA reads
         if (w == 0) p.x = v;
         else if (w == 1) p.y = v;
         else if (w == 2) p.z = v;
         else p.w = v;
     };
     // Software pipeline of one tile, in issue order (MFMA groups and the exp units that run in their shadow):
-    //   A  wait + barrier (tile i landed, tile i-1's slot free), DMA of tile i+PD, read the K fragments
-    //   B  units 4..7 of S1(i-1)                                   -- covers the LDS latency of A
-    //   C  S0(i)   = K Q0^T            3 MFMAs
-    //   D  O1 += V^T(i-1) P1(i-1)^T    4 MFMAs   + units 0..3 of S0(i)
+    //   A  wait + barrier (tiles i and i+1 landed, tile i-1's slot free), DMA of tile i+PD
+    //   C  S0(i)   = K Q0^T            3 MFMAs   + units 4..7 of S1(i-1)        (K fragments were read one tile ahead)
+    //   D  O1 += V^T(i-1) P1(i-1)^T    4 MFMAs   + units 0..2 of S0(i)          (the first MFMA bare: S0 is still in the pipe)
     //   E  read the V^T fragments of tile i (after D: they replace tile i-1's)
-    //   F  S1(i)   = K Q1^T            3 MFMAs   + units 4..7 of S0(i)
-    //   G  O0 += V^T(i) P0(i)^T        4 MFMAs   + units 0..3 of S1(i)
+    //   F  S1(i)   = K Q1^T            3 MFMAs   + units 3..7 of S0(i);  then read the K fragments of tile i+1
+    //   G  O0 += V^T(i) P0(i)^T        4 MFMAs   + units 0..3 of S1(i)          (the first MFMA bare)
     // Every exp batch has a 7-MFMA window and every MFMA carries ~1.2 units (2.4 v_exp + 1.2 v_cvt_pk: inside what a 32x32x16 MFMA
-    // hides, profiles/r02_issue_model_32x32.txt); S0 / S1 / P0 / P1 need no second copy.
+    // hides, profiles/r02_issue_model_32x32.txt); S0 / S1 / P0 / P1 / the fragments need no second copy.
     // (one loop body for every tile -- a peeled first-tile variant makes the register allocator shuttle all four accumulators
-    // between two homes, 96 v_mov per tile; at the start of a set the pipeline is primed with P1 = 0 instead, so B and D add nothing)
+    // between two homes, 96 v_mov per tile; at the start of a set the pipeline is primed with P1 = 0 instead, so C and D add nothing)
+    auto rd_kf = [&](const unsigned char *kb_) __attribute__((always_inline)) {
+        if (ABL && (abl & 16)) return;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kf[ks] = *reinterpret_cast<const uint4 *>(kb_ + kfo[ks]);
+    };
     auto tile_step = [&](bool first) __attribute__((always_inline)) {
-        wait_vmcnt<(PD - 1) * GRP>();
-        __builtin_amdgcn_s_barrier();
-        issue_kv();
+        wait_vmcnt<(PD - 2) * GRP>();
+        if (!(ABL && (abl & 4))) __builtin_amdgcn_s_barrier();
+        if (!(ABL && (abl & 8))) issue_kv();
         const unsigned char *kb_ = rk, *vb_ = rv;
         rk = rk + KBYTES == sK + NST * KBYTES ? sK : rk + KBYTES;
         rv = rv + VBYTES == sV + NST * VBYTES ? sV : rv + VBYTES;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) kf[ks] = *reinterpret_cast<const uint4 *>(kb_ + kfo[ks]);
         if (first) {
             // first tile of a K/V set: the row maximum over its FIRST key block becomes the set's offset -- evaluated by both waves of
             // a pair on the same data, so they agree bit for bit without an exchange
@@ -201,30 +211,34 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        unit(S1, pf[1][1], 0, 1); unit(S1, pf[1][1], 1, 1); unit(S1, pf[1][1], 2, 1); unit(S1, pf[1][1], 3, 1);      // B
-        __builtin_amdgcn_sched_barrier(0);
         S0 = T::mfma32(kf[0], qf[0][0], zero16);        // C
+        unit(S1, pf[1][1], 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
         S0 = T::mfma32(kf[1], qf[0][1], S0);
+        unit(S1, pf[1][1], 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
         S0 = T::mfma32(kf[2], qf[0][2], S0);
+        unit(S1, pf[1][1], 2, 1); unit(S1, pf[1][1], 3, 1);
         __builtin_amdgcn_sched_barrier(0);
         os[1][0] = T::mfma32(vf[0][0], pf[1][0], os[1][0]);      // D
-        unit(S0, pf[0][0], 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         os[1][1] = T::mfma32(vf[0][1], pf[1][0], os[1][1]);
-        unit(S0, pf[0][0], 1, 0);
+        unit(S0, pf[0][0], 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         os[1][0] = T::mfma32(vf[1][0], pf[1][1], os[1][0]);
-        unit(S0, pf[0][0], 2, 0);
+        unit(S0, pf[0][0], 1, 0);
         __builtin_amdgcn_sched_barrier(0);
         os[1][1] = T::mfma32(vf[1][1], pf[1][1], os[1][1]);
-        unit(S0, pf[0][0], 3, 0);
+        unit(S0, pf[0][0], 2, 0);
         __builtin_amdgcn_sched_barrier(0);
+        if (!(ABL && (abl & 16))) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)     // E
+            for (int t = 0; t < 2; ++t)     // E
 #pragma unroll
-            for (int db = 0; db < DB; ++db) vf[t][db] = *reinterpret_cast<const uint4 *>(vb_ + vfo[t] + db * 4096);
+                for (int db = 0; db < DB; ++db) vf[t][db] = *reinterpret_cast<const uint4 *>(vb_ + vfo[t] + db * 4096);
+        }
         S1 = T::mfma32(kf[0], qf[1][0], zero16);        // F
-        unit(S0, pf[0][1], 0, 1);
+        unit(S0, pf[0][0], 3, 0); unit(S0, pf[0][1], 0, 1);
         __builtin_amdgcn_sched_barrier(0);
         S1 = T::mfma32(kf[1], qf[1][1], S1);
         unit(S0, pf[0][1], 1, 1); unit(S0, pf[0][1], 2, 1);
@@ -232,11 +246,11 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
         S1 = T::mfma32(kf[2], qf[1][2], S1);
         unit(S0, pf[0][1], 3, 1);
         __builtin_amdgcn_sched_barrier(0);
+        rd_kf(rk);                                      // tile i+1 (landed: the barrier above waited for it)
         os[0][0] = T::mfma32(vf[0][0], pf[0][0], os[0][0]);      // G
-        unit(S1, pf[1][0], 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         os[0][1] = T::mfma32(vf[0][1], pf[0][0], os[0][1]);
-        unit(S1, pf[1][0], 1, 0);
+        unit(S1, pf[1][0], 0, 0); unit(S1, pf[1][0], 1, 0);
         __builtin_amdgcn_sched_barrier(0);
         os[0][0] = T::mfma32(vf[1][0], pf[0][1], os[0][0]);
         unit(S1, pf[1][0], 2, 0);
@@ -276,6 +290,9 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < PD; ++j) issue_kv();
+    wait_vmcnt<(PD - 1) * GRP>();
+    __builtin_amdgcn_s_barrier();
+    rd_kf(rk);                          // K fragments run one tile ahead of the loop
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -289,7 +306,8 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    if (__syncthreads_or(bad)) {      // some row left the exponent range of its first-block offset: safe recomputation
+    if (ABL && abl_sink == 0x12345u) bad = 1;
+    if (__syncthreads_or(ABL ? (bad & 2) : bad)) {      // some row left the exponent range of its first-block offset: safe recomputation
         attn_safe_body<T, D, 2, NW>(a, qblk, h, b, smem, smem + SafeLds<D>::KBYTES);
         return;
     }
@@ -316,33 +334,40 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
     }
 }
 
-template <class T, bool PRE>
+template <class T, bool PRE, int NST, bool ABL = false>
 void launch_attn5_(const AttnArgs &a, int B, hipStream_t s)
 {
-    constexpr int NST = 3;
     constexpr size_t ring = (size_t)NST * (64 * 128 + 2 * 32 * 128) + 2048, xchg = (size_t)8 * 20 * 64 * 4;
     constexpr size_t safe = SafeLds<40>::KBYTES + SafeLds<40>::VBYTES;
     constexpr size_t lds = ring > xchg ? (ring > safe ? ring : safe) : (xchg > safe ? xchg : safe);
     static gc::AttrOnce once;
-    gc::ensure_dynamic_lds(once, (const void *)k_attn5<T, PRE, NST>, (int)lds);
+    gc::ensure_dynamic_lds(once, (const void *)k_attn5<T, PRE, NST, ABL>, (int)lds);
     AttnArgs aa = a;
     aa.nqb = a.Lq / 256;
     dim3 grid((unsigned)(aa.nqb * a.H * B));
-    hipLaunchKernelGGL((k_attn5<T, PRE, NST>), grid, dim3(512), lds, s, aa);
+    hipLaunchKernelGGL((k_attn5<T, PRE, NST, ABL>), grid, dim3(512), lds, s, aa);
 }
-template <class T>
+template <class T, int NST>
 void launch_attn5(const AttnArgs &a, int B, hipStream_t s)
 {
-    if (a.scale_log2e == 1.f) launch_attn5_<T, true>(a, B, s);
-    else launch_attn5_<T, false>(a, B, s);
+    if (a.scale_log2e == 1.f) launch_attn5_<T, true, NST>(a, B, s);
+    else launch_attn5_<T, false, NST>(a, B, s);
 }
-
 }  // namespace
 
-// AttnArgs has internal linkage per translation unit (same definition in both): the entry point takes it through a void pointer
-void gc_dn_launch_attn5(const void *args, int dtype, int B, hipStream_t s)
+// AttnArgs has internal linkage per translation unit (same definition in both): the entry point takes it through a void pointer.
+// depth: stages of the K / V^T LDS ring (4, 6 or 8: the DMA of a tile is issued depth - 1 tiles before its barrier)
+void gc_dn_launch_attn5(const void *args, int dtype, int B, int depth, hipStream_t s)
 {
     const AttnArgs &a = *static_cast<const AttnArgs *>(args);
-    if (dtype == DT_BF16) launch_attn5<BF16>(a, B, s);
-    else launch_attn5<F16>(a, B, s);
+    if (a.abl) { launch_attn5_<BF16, true, 6, true>(a, B, s); return; }
+    if (dtype == DT_BF16) {
+        if (depth == 4) launch_attn5<BF16, 4>(a, B, s);
+        else if (depth == 8) launch_attn5<BF16, 8>(a, B, s);
+        else launch_attn5<BF16, 6>(a, B, s);
+    } else {
+        if (depth == 4) launch_attn5<F16, 4>(a, B, s);
+        else if (depth == 8) launch_attn5<F16, 8>(a, B, s);
+        else launch_attn5<F16, 6>(a, B, s);
+    }
 }

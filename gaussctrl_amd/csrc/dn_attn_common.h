@@ -21,6 +21,7 @@ struct AttnArgs {
     int nsets; int set_kind[5]; float set_w[5];      // kind -1: own frame; -2: frame b / f (shared text K/V); r >= 0: reference r of the half
     float scale_log2e;
     int nqb;                                         // query blocks per (batch, head)
+    int abl;                                         // timing ablations of k_attn5's instrumented instantiation (kernel_variant >> 8; 0 in production)
 };
 
 // 1-D grid, XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the id is remapped

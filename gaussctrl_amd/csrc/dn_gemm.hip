@@ -39,7 +39,8 @@ void plan(const gc_gemm_desc *d, int *ntw, int *splits, int *tps)
     // GEGLU pairs tiles (nt, nt+1) inside a wave: needs an even number of n-tiles per wave
     *ntw = (d->N % 160 == 0 && d->N % 128 != 0 && !d->geglu) ? 5 : 4;
     const int bn = 32 * *ntw;
-    const int64_t blocks = ((d->M + BM - 1) / BM) * ((d->N + bn - 1) / bn);
+    const int64_t Msel = d->plan_rows > 0 ? d->plan_rows : d->M;         // batch-invariant planning: the rows of one frame
+    const int64_t blocks = ((Msel + BM - 1) / BM) * ((d->N + bn - 1) / bn);
     const int nk = (int)((d->K + BK - 1) / BK);
     *splits = d->geglu ? 1 : choose_splits(blocks, nk);
     *tps = (nk + *splits - 1) / *splits;
@@ -79,8 +80,12 @@ int select(const gc_gemm_desc *d, Sel *o)
     o->mode = mode; o->ntw = ntw; o->splits = splits; o->tps = tps; o->mt8 = 0;
     // 8-wave LDS-DMA kernel (one workgroup per CU, software-pipelined): workgroup tile (64 MT) x (32 NTW).
     if (use8 && d->zeros) {
-        int mt = force_mt ? force_mt : choose_mt(d->M, d->N, ntw, use8 == 2);
-        const int64_t tiles8 = ((d->M + 127) / 128) * nbn;
+        // (plan_rows: the kernel family and the k-slices follow the per-frame problem; the m-tiles per wave, which do not change any
+        // accumulation order, follow the real grid)
+        const int64_t Msel = d->plan_rows > 0 ? d->plan_rows : d->M;
+        int mt = force_mt ? force_mt : choose_mt(Msel, d->N, ntw, use8 == 2);
+        if (mt && !force_mt && Msel != d->M) mt = choose_mt(d->M, d->N, ntw, true);
+        const int64_t tiles8 = ((Msel + 127) / 128) * nbn;
         // long-K problems with a part-filled grid (16x16-map convs, the 5120 -> 1280 FF projection): k-slices of >= 12 k-tiles
         // fill the CUs; variant 0x40 sends such convs back to the 4-wave split-K kernel, 0x80 also takes the 8x8-map convs
         const bool small = tiles8 < 96;
@@ -89,7 +94,7 @@ int select(const gc_gemm_desc *d, Sel *o)
         if (mode == 0 && !force_mt && ntw == 4 && d->K % 64 == 0 && !d->geglu && !d->out_t && !(kv & 0x100) &&
             !(d->ln_row_stats || d->out_row_stats || d->out_group_stats)) {
             const int64_t t1 = ((d->M + 63) / 64) * nbn, t2 = ((d->M + 127) / 128) * nbn;
-            if (mt == 2 && t2 <= 256 && t1 <= 512 && t1 > 128 && nk_host <= 24) mt = 1;
+            if (mt == 2 && t2 <= 256 && t1 <= 512 && t1 > 128 && nk_host <= 24) mt = 1;      // (same accumulation order as MT 2)
         }
         const bool want_split = !force_mt && use8 != 2 && !d->geglu && d->workspace && tiles8 <= 128 && (mode == 0 ? (!small || nk_host >= 24) : (convsplit >= (small ? 2 : 1)));
         int s8 = 1, tps8 = nk_host;

@@ -557,7 +557,10 @@ int gc_dn_groupnorm(int dtype, const void *x, void *y, int64_t B, int64_t HW, in
     GC_REQUIRE(C % 8 == 0 && C % G == 0 && stats_ws, "groupnorm: C must be a multiple of 8 and of G; workspace required");
     GC_REQUIRE(C / G <= 256 && B * HW * (C / 8) < (int64_t)1 << 31, "groupnorm: group too wide / tensor too large");
     hipStream_t s = gc::S(stream);
-    if ((C / G) % 2 == 0 && B * HW * (int64_t)C <= ((int64_t)1 << 20) && B * G >= 64) {      // <= 2 MB (the 8x8 maps): one launch, 5 vs 12 us
+    // act bit 8: batch-invariant planning -- the one-launch form (other summation order) is chosen from the per-frame size only
+    const int64_t Bsel = (act & 0x100) ? 1 : B;
+    act &= 0xff;
+    if ((C / G) % 2 == 0 && Bsel * HW * (int64_t)C <= ((int64_t)1 << 20) && Bsel * G >= 64) {      // <= 2 MB (the 8x8 maps): one launch, 5 vs 12 us
         DN_DISPATCH(dtype,
                     hipLaunchKernelGGL((k_gn_small<BF16>), dim3((unsigned)(B * G)), dim3(256), 0, s, (const unsigned short *)x,
                                        (unsigned short *)y, (int)HW, C, G, gamma, beta, eps, act),

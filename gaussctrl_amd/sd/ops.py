@@ -7,6 +7,7 @@ kernel behind the C ABI.  No CPU / eager fallback exists.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -26,7 +27,7 @@ class GemmDesc(C.Structure):
                 ("ln_row_stats", C.c_void_p), ("ln_row_stat_slots", C.c_int), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float),
                 ("out_row_stats", C.c_void_p), ("out_group_stats", C.c_void_p), ("gn_groups", C.c_int),
                 ("fp8", C.c_int), ("w_scale", C.c_void_p), ("a_scale", C.c_int),
-                ("kernel_variant", C.c_int)]
+                ("kernel_variant", C.c_int), ("plan_rows", C.c_int64)]
 
 
 class AttnDesc(C.Structure):
@@ -62,6 +63,10 @@ def _variant_from_env():
 
 
 KERNEL_VARIANT = _variant_from_env()
+# Batch-invariant kernel planning (gc_gemm_desc.plan_rows, GroupNorm act bit 8): every output row is accumulated in an order that
+# depends on the layer's shape only, so a view's latents are bit-identical whatever shares its chunk or however many ranks shard
+# the scene (SURVEY.md 8e "bit-compatible with the single-GPU result").  Costs throughput (k-slices sized for one frame); off by default.
+BATCH_INVARIANT = os.environ.get("GC_BATCH_INVARIANT", "0") not in ("", "0")
 
 
 DT = {torch.bfloat16: 0, torch.float16: 1}
@@ -145,6 +150,8 @@ def linear(x, w, bias=None, residual=None, act=0, geglu=False, out_f32=False, sc
     if rowvec is not None:
         d.rowvec = rowvec.data_ptr(); d.ld_rowvec = rowvec.stride(0) if ld_rowvec is None else ld_rowvec
     d.rows_per_batch = rows_per_batch
+    if BATCH_INVARIANT and x.dim() >= 3:
+        d.plan_rows = M // x.shape[0]                 # the rows one frame contributes
     No = N // 2 if geglu else (N if out_cols is None else out_cols)
     if residual is not None:
         d.residual = residual.data_ptr(); d.ldr = residual.stride(-2)
@@ -179,6 +186,8 @@ def conv3x3(x, w, bias=None, stride=1, upsample=False, rowvec=None, ld_rowvec=No
     if rowvec is not None:
         d.rowvec = rowvec.data_ptr(); d.ld_rowvec = rowvec.stride(0) if ld_rowvec is None else ld_rowvec
     d.rows_per_batch = Ho * Wo
+    if BATCH_INVARIANT:
+        d.plan_rows = Ho * Wo
     if residual is not None:
         d.residual = residual.data_ptr(); d.ldr = N
     d.out_scale = scale; d.act = act
@@ -203,7 +212,7 @@ def groupnorm(x, gamma, beta, groups, eps, silu):
         ws = _gn_ws[key] = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
     y = torch.empty_like(x)
     L.check(L.lib().gc_dn_groupnorm(_dt(x), _p(x), _p(y), C.c_int64(B), C.c_int64(HW), Cc, groups, _p(gamma), _p(beta),
-                                    C.c_float(eps), int(silu), _p(ws), _stream()), "gc_dn_groupnorm")
+                                    C.c_float(eps), int(silu) | (0x100 if BATCH_INVARIANT else 0), _p(ws), _stream()), "gc_dn_groupnorm")
     return y
 
 

@@ -254,6 +254,9 @@ typedef struct gc_gemm_desc {
     int a_scale;               /* E8M0 byte of the activation tensor */
     int kernel_variant;        /* 0 = automatic.  Overrides for tests / experiments: bits 0-2 force the 8-wave kernel's m-tiles per wave (2,3,4); */
                                /* 0x10 4-wave kernel only; 0x20 force the 8-wave kernel; 0x40 no k-slices for part-filled conv grids; 0x80 slice 8x8-map convs too */
+    int64_t plan_rows;         /* 0 = plan for M.  > 0 (the rows ONE frame contributes: tokens, or Ho * Wo): kernel family and split-K are planned as if */
+                               /* M were plan_rows, so every output row is accumulated in the same order whatever else shares the batch */
+                               /* (batch-invariant results: a view's latents do not depend on its chunk-mates or on the rank count) */
 } gc_gemm_desc;
 size_t gc_dn_gemm_workspace_bytes(const gc_gemm_desc *desc);
 int gc_dn_gemm_row_stat_slots(const gc_gemm_desc *desc);   /* column slabs per row this problem writes to out_row_stats (with desc->workspace set) */

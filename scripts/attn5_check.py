@@ -1,4 +1,4 @@
-"""k_attn5 (kernel_variant bit 4) vs k_attn4 and a torch fp32 reference: parity at small sizes, timing at the production launch
+"""k_attn5 (the default D = 40 kernel; kernel_variant bit 4 = 16 selects k_attn4) vs k_attn4 and a torch fp32 reference: parity at small sizes, timing at the production launch
 (L = 4096, 8 heads x D = 40, B = 6 frames, 5 K/V sets incl. a cached reference bank).   python scripts/attn5_check.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -43,8 +43,8 @@ def parity(dt, f, L, heads, coeff, spike=False, pre=False):
     for r in range(4):
         idx = torch.arange(B, device=DEV) // f * f + r
         ref = ref + (1 - coeff) / 4 * ref_attn(qq, k[idx], v[idx], heads, sc)
-    a4 = run(0, qq, k, vt, heads, sets, f, Lk=L, q_prescaled=pre).float()
-    a5 = run(16, qq, k, vt, heads, sets, f, Lk=L, q_prescaled=pre).float()
+    a4 = run(16, qq, k, vt, heads, sets, f, Lk=L, q_prescaled=pre).float()
+    a5 = run(0, qq, k, vt, heads, sets, f, Lk=L, q_prescaled=pre).float()
     e4 = float((a4 - ref).norm() / ref.norm()); e5 = float((a5 - ref).norm() / ref.norm())
     d45 = float((a5 - a4).abs().max())
     print(f"{str(dt):16s} f={f} L={L} heads={heads} coeff={coeff} spike={spike} pre={pre}: rel L2 k_attn4 {e4:.3e}  k_attn5 {e5:.3e}  max|a5-a4| {d45:.3e}"
@@ -52,11 +52,11 @@ def parity(dt, f, L, heads, coeff, spike=False, pre=False):
     return e4, e5
 
 
-def timing(dt, variant, iters=20):
+def timing(dt, variant, iters=20, qscale=0.5):
     f, L, heads, D = 3, 4096, 8, 40
     B, C = 2 * f, heads * D
     g = torch.Generator(device=DEV).manual_seed(0)
-    qk = torch.randn(B, L, 2 * C, device=DEV, generator=g).to(dt)
+    qk = (torch.randn(B, L, 2 * C, device=DEV, generator=g) * qscale).to(dt)      # logits of a few units: inside f16's P range
     q, k = qk[..., :C], qk[..., C:]
     vt = torch.randn(B, C, L, device=DEV, generator=g).to(dt)
     kr = torch.randn(8, L, 2 * C, device=DEV, generator=g).to(dt)[..., C:]
@@ -74,11 +74,23 @@ def timing(dt, variant, iters=20):
     ops.KERNEL_VARIANT["attn"] = 0
     us = s.elapsed_time(e) * 1e3 / iters
     fl = 4.0 * B * L * L * C * 5
-    print(f"timing {str(dt):16s} variant {variant:2d}: {us:8.1f} us   {fl / us / 1e6:7.1f} TF/s   frac of 2.5 PF {fl / us / 1e6 / 2500:.3f}")
+    print(f"timing {str(dt):16s} qscale {qscale} variant {variant:2d}: {us:8.1f} us   {fl / us / 1e6:7.1f} TF/s   frac of 2.5 PF {fl / us / 1e6 / 2500:.3f}")
     return us
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "abl":           # timing ablations of k_attn5 (results wrong by construction)
+        names = {0: "everything (instrumented build)", 1: "no v_exp", 2: "no exp units (no v_exp, no v_cvt_pk)", 4: "no s_barrier", 8: "no LDS-DMA",
+                 16: "no LDS fragment reads", 24: "no DMA, no fragment reads", 26: "MFMA only (+ barrier)", 30: "MFMA only",
+                 32: "units read a constant, not S", 64: "units write a sink, not P", 96: "units detached from both MFMAs", 120: "detached units, no LDS traffic"}
+        timing(torch.bfloat16, 16)
+        for bits, nm in names.items():
+            print(f"ablation {bits:2d} {nm:40s}", end=" ")
+            timing(torch.bfloat16, 16 | ((bits or 32) << 8))
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "time":          # timing only (PMC passes: python scripts/pmc.py 'k_attn' -- python scripts/attn5_check.py time 16)
+        timing(torch.bfloat16, int(sys.argv[2]), iters=3)
+        sys.exit(0)
     ok = True
     for dt in (torch.bfloat16, torch.float16):
         for (f, L, heads, coeff, spike, pre) in [(4, 256, 2, 0.6, False, False), (5, 512, 2, 0.6, False, True), (5, 256, 1, 0.0, False, True),
@@ -89,3 +101,8 @@ if __name__ == "__main__":
     for dt in (torch.bfloat16, torch.float16):
         for v in (0, 16, 0, 16):
             timing(dt, v)
+    for qs in (0.25, 0.35):
+        for v in (0, 16):
+            timing(torch.float16, v, qscale=qs)
+    for v in (16, 16 + 32, 16 + 64, 0, 16, 16 + 32, 16 + 64):       # ring depth 6 (default) / 4 / 8
+        timing(torch.bfloat16, v)

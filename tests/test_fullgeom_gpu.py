@@ -237,6 +237,35 @@ def test_config4_f12_fp8_convs(nets):
     assert mean_e <= 2.0 / 255.0, (mean_e, max_e)
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_batch_invariant_mode_bit_identical(nets, dt):
+    """sd.ops.BATCH_INVARIANT (gc_gemm_desc.plan_rows, GroupNorm planning bit): a view's latents are BIT-identical whatever shares its
+    chunk -- the property that makes an N-rank edit (other chunk compositions) equal to the single-GPU one.
+    Full SD1.5 widths at 64 x 64 latents, cached reference bank, 3 DDIM steps: chunk {0,1,2} vs chunks {0} and {1,2}."""
+    from gaussctrl_amd.sd import ops
+    from gaussctrl_amd.sd.pipeline import DenoisePipeline
+    lat, disp, cn, cp = _inputs(7, 64, 2)
+    uw, cw = nets(dt)
+    keep = ops.BATCH_INVARIANT
+    ops.BATCH_INVARIANT = True
+    try:
+        pipe = DenoisePipeline(uw, cw, None, 20, 5.0)
+        to = lambda t: t.to(DEV)
+        bank = pipe.build_ref_bank(to(lat[:4]), to(disp[:4]), to(cn), to(cp), steps=3)
+        full = pipe.edit_chunk_cached(to(lat[4:7]), to(disp[4:7]), to(cn), to(cp), bank, steps=3)
+        one = pipe.edit_chunk_cached(to(lat[4:5]), to(disp[4:5]), to(cn), to(cp), bank, steps=3)
+        two = pipe.edit_chunk_cached(to(lat[5:7]), to(disp[5:7]), to(cn), to(cp), bank, steps=3)
+        assert torch.isfinite(full).all()
+        assert torch.equal(full[0:1], one), float((full[0:1] - one).abs().max())
+        assert torch.equal(full[1:3], two), float((full[1:3] - two).abs().max())
+        # and it is still the same computation: within the dtype's bar of the default planning
+        ops.BATCH_INVARIANT = False
+        ref = pipe.edit_chunk_cached(to(lat[4:7]), to(disp[4:7]), to(cn), to(cp), bank, steps=3)
+        assert _rel(full, ref) <= BAR[dt]
+    finally:
+        ops.BATCH_INVARIANT = keep
+
+
 def test_edit_f7_h64_fp8_convs(nets):
     """BASELINE configs[3] "fp8 MFMA UNet path": the resnet 3x3 convolutions of UNet and ControlNet on e4m3 operands (block-scaled
     MFMA, GroupNorm writing e4m3), bf16 elsewhere, all 20 DDIM steps at the benchmarked geometry against the fp32 oracle fixture.
