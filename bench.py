@@ -151,16 +151,36 @@ class Bench:
         # ------------------------------------------------------------ scene, cameras, networks (untimed setup)
         P = syn.make_gaussians(args.gaussians, seed=0)
         self.params = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in P.items()}
+        self.ref_mode = args.ref_mode if (world > 1 and self.edit) else "local"
         if self.edit:
-            # ONE scene of V views; rank r edits the views v % world == r (gaussctrl_amd.dist.shard_views)
+            # ONE scene of V views sharded over the ranks.  With a bank owner (rotate / owner0) the sharding is load balanced
+            # (gaussctrl_amd.dist.shard_views_balanced): the rank that computes the NEXT scene's reference trajectory during this scene
+            # edits ~4 views fewer, everybody else correspondingly more, and every rank's views are spread evenly over the scene's cps
+            # lock-step chunks.  Replicated bank / N = 1: plain v % N sharding in chunks of chunk_size.
+            from gaussctrl_amd.dist import shard_views_balanced, split_chunks
             cams = syn.make_cameras(V, seed=1)
-            self.mine = shard_views(V, world, rank)
-            self.cps = math.ceil(math.ceil(V / world) / c)                   # chunks per scene on every rank (ranks stay in lock step)
+            if self.ref_mode in ("rotate", "owner0"):
+                most = max(len(shard_views_balanced(V, world, r, 0)) for r in range(world))
+                self.cps = math.ceil(most / c)
+
+                def chunks_of(scene, _cache={}):
+                    o = self.owner_of(scene + 1)
+                    if o not in _cache:
+                        _cache[o] = split_chunks(shard_views_balanced(V, world, rank, o), self.cps, c)
+                    return _cache[o]
+            else:
+                mine = shard_views(V, world, rank)
+                self.cps = math.ceil(math.ceil(V / world) / c)               # chunks per scene on every rank (ranks stay in lock step)
+                plain = [mine[j * c:(j + 1) * c] for j in range(self.cps)]   # the last chunk of a scene is short (40 = 13 x 3 + 1), gc_pipeline.py:190
+                chunks_of = lambda scene: plain
+            self.chunks_of = chunks_of
+            self.mine = list(range(V))              # cameras of every view (the balanced shards move with the owner)
         else:
             # raster-only (configs[4]): every rank renders its own V random cameras of the same 4 M-Gaussian scene
             cams = syn.make_cameras(V * world, seed=1)[rank * V:(rank + 1) * V]
             self.mine = list(range(V))
             self.cps = math.ceil(V / c)
+            self.chunks_of = lambda scene: [self.mine[j * c:(j + 1) * c] for j in range(self.cps)]
         self.ref_idx = [min(i, V - 1) for i in (4, 11, 29, 31)]                    # gc_pipeline.py:109-113 for V=40
         self.cams = {v: camera_to_gsplat(cams[v], K["fx"], K["fy"], K["cx"], K["cy"], W, H)
                      for v in sorted(set(self.mine) | (set(self.ref_idx) if self.edit else set()))}
@@ -191,7 +211,6 @@ class Bench:
         # the chunk's summed leaf gradients: six views of ONE flat buffer that the backward kernel writes into and RCCL reduces in
         # place; two buffers alternate so the all-reduce of chunk k completes under the denoise of chunk k + 1
         self.grads = [FlatGrads(self.params), FlatGrads(self.params)] if world > 1 else [FlatGrads(self.params)]
-        self.ref_mode = args.ref_mode if (world > 1 and self.edit) else "local"
         self.bank_layers = None
         self.half_events = []           # (start, end of denoise half, end of step) HIP events of the timed steps
         self.record_halves = False
@@ -253,7 +272,7 @@ class Bench:
         step carries exactly its share of the reference work whatever K is."""
         st, c, cps, nsteps, p = self.state, self.c, self.cps, self.nsteps, self.params
         scene, j = divmod(s, cps)
-        views = self.mine[j * c:(j + 1) * c]      # the last chunk of a scene is short (40 = 13 x 3 + 1), gc_pipeline.py:190
+        views = self.chunks_of(scene)[j]
         st["views_done"] += len(views)
         ev = None
         if self.record_halves:
@@ -476,7 +495,8 @@ def main():
             ref_copies = world if args.ref_mode == "replicate" and world > 1 else 1
             flop = views_done * (nsteps * 2 * per_sample + VAE_DECODE_GFLOP * 1e9) + scenes * ref_copies * nsteps * 8 * per_sample
             mfma_util = flop / dt_s / (world * PEAK_TFLOPS[args.dtype] * 1e12)
-            par = (f"views of one scene sharded x{world} (v % N); reference bank: " +
+            par = (f"views of one scene sharded x{world}" + (" (load balanced: the bank owner edits ~4 views fewer)" if world > 1 and args.ref_mode != "replicate" else " (v % N)") +
+                   "; reference bank: " +
                    ({"rotate": "owner rotates per scene, per-DDIM-step async RCCL broadcast", "owner0": "rank 0 owns, per-DDIM-step async RCCL broadcast",
                      "replicate": "replicated on every rank (no collective)"}[args.ref_mode] if world > 1 else "local") +
                    "; flat async gradient all-reduce; ControlNet || UNet encoder on 2 HIP streams")
@@ -574,12 +594,13 @@ def raster_roofline(args, B, g, stats, HW):
     finally:
         L._lib = real
     Ms = [int(a.item()) for a, _ in stats["dev"][n_dev:]] or stats["M"][-8:]        # intersections of the instrumented views
-    nviews = max(1, sum(1 for n, _, _ in timer.rec if n == "gc_rasterize_bwd"))
+    nviews = max(1, sum(1 for n, _, _ in timer.rec if n.startswith("gc_rasterize_bwd")))
     M = float(np.mean(Ms))
     N = args.gaussians
     per = {}
+    alias = {"gc_rasterize_bwd_clamped": "gc_rasterize_bwd", "gc_raster_finalize_into": "gc_raster_finalize"}     # same kernels, round-3 entry points
     for name, s, e in timer.rec:
-        per.setdefault(name, []).append(s.elapsed_time(e) * 1e-3)
+        per.setdefault(alias.get(name, name), []).append(s.elapsed_time(e) * 1e-3)
     traffic = None
     for tname in ("r03_raster_traffic.json", "r02_raster_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", tname)

@@ -301,6 +301,10 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) S1[r] = -BIG;                  // exp2 -> 0: the pipeline starts with P1 = 0
         pf[1][0] = make_uint4(0, 0, 0, 0);
+        if (ABL && (abl & 128)) {       // P fragments hold non-trivial constants instead of zeros (with bit 6: is the cost the dependency or the data?)
+            const uint4 c = make_uint4(0x3F2A3E91u + lane, 0x3DD73F11u ^ (lane << 3), 0x3E4C3F60u, 0x3F053D9Au + 7 * lane);
+            pf[0][0] = c; pf[0][1] = c; pf[1][0] = c; pf[1][1] = c;
+        }
         for (int t = 0; t < ntiles; ++t) tile_step(t == 0);
         fold(s);
     }

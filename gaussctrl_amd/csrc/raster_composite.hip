@@ -199,6 +199,7 @@ __global__ __launch_bounds__(BLOCK) void k_rasterize_bwd(int H, int W, int tiles
                                                          const float *__restrict__ background,
                                                          const float *__restrict__ final_Ts, const int32_t *__restrict__ final_index,
                                                          const float *__restrict__ v_out, const float *__restrict__ v_out_alpha,
+                                                         const float *__restrict__ pre_clamp,
                                                          float *__restrict__ v_xy, float *__restrict__ v_conic,
                                                          float *__restrict__ v_colors, float *__restrict__ v_opacity)
 {
@@ -224,6 +225,9 @@ __global__ __launch_bounds__(BLOCK) void k_rasterize_bwd(int H, int W, int tiles
     float vo0 = 0.f, vo1 = 0.f, vo2 = 0.f, voa = 0.f;
     if (inside) {
         vo0 = v_out[3 * pix]; vo1 = v_out[3 * pix + 1]; vo2 = v_out[3 * pix + 2];
+        if (pre_clamp) {      // backward of rgb = min(rgb, 1) (gc_model.py:188): the gradient passes where the un-clamped value is <= 1
+            vo0 = pre_clamp[3 * pix] <= 1.f ? vo0 : 0.f; vo1 = pre_clamp[3 * pix + 1] <= 1.f ? vo1 : 0.f; vo2 = pre_clamp[3 * pix + 2] <= 1.f ? vo2 : 0.f;
+        }
         if (v_out_alpha) voa = v_out_alpha[pix];
     }
     const float bgdot = background[0] * vo0 + background[1] * vo1 + background[2] * vo2;
@@ -351,6 +355,21 @@ int gc_rasterize_fwd(int img_h, int img_w, int tiles_x, int tiles_y, const int32
     return gc::check_launch("gc_rasterize_fwd");
 }
 
+static int rasterize_bwd_impl(const char *what, int img_h, int img_w, int tiles_x, int tiles_y, const int32_t *gaussian_ids_sorted,
+                              const int32_t *tile_bins, const float *xys, const float *conics, const float *colors,
+                              const float *opacities, const float *background, const float *final_Ts, const int32_t *final_index,
+                              const float *v_out, const float *v_out_alpha, const float *pre_clamp, float *v_xy, float *v_conic,
+                              float *v_colors, float *v_opacity, void *stream)
+{
+    GC_REQUIRE(img_h > 0 && img_w > 0 && tiles_x == (img_w + TILE - 1) / TILE && tiles_y == (img_h + TILE - 1) / TILE,
+               "tile bounds do not match the image size");
+    dim3 grid(tiles_x, tiles_y), block(BLOCK);
+    hipLaunchKernelGGL(k_rasterize_bwd, grid, block, 0, gc::S(stream), img_h, img_w, tiles_x, gaussian_ids_sorted, tile_bins,
+                       xys, conics, colors, opacities, background, final_Ts, final_index, v_out, v_out_alpha, pre_clamp, v_xy, v_conic,
+                       v_colors, v_opacity);
+    return gc::check_launch(what);
+}
+
 int gc_rasterize_bwd(int img_h, int img_w, int tiles_x, int tiles_y, int64_t N, const int32_t *gaussian_ids_sorted,
                      const int32_t *tile_bins, const float *xys, const float *conics, const float *colors,
                      const float *opacities, const float *background, const float *final_Ts, const int32_t *final_index,
@@ -358,13 +377,21 @@ int gc_rasterize_bwd(int img_h, int img_w, int tiles_x, int tiles_y, int64_t N, 
                      float *v_opacity, void *stream)
 {
     (void)N;
-    GC_REQUIRE(img_h > 0 && img_w > 0 && tiles_x == (img_w + TILE - 1) / TILE && tiles_y == (img_h + TILE - 1) / TILE,
-               "tile bounds do not match the image size");
-    dim3 grid(tiles_x, tiles_y), block(BLOCK);
-    hipLaunchKernelGGL(k_rasterize_bwd, grid, block, 0, gc::S(stream), img_h, img_w, tiles_x, gaussian_ids_sorted, tile_bins,
-                       xys, conics, colors, opacities, background, final_Ts, final_index, v_out, v_out_alpha, v_xy, v_conic,
-                       v_colors, v_opacity);
-    return gc::check_launch("gc_rasterize_bwd");
+    return rasterize_bwd_impl("gc_rasterize_bwd", img_h, img_w, tiles_x, tiles_y, gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities,
+                              background, final_Ts, final_index, v_out, v_out_alpha, nullptr, v_xy, v_conic, v_colors, v_opacity, stream);
+}
+
+/* the same with the backward of get_outputs' rgb clamp folded into the pixel load: v_out is masked where pre_clamp > 1 */
+int gc_rasterize_bwd_clamped(int img_h, int img_w, int tiles_x, int tiles_y, int64_t N, const int32_t *gaussian_ids_sorted,
+                             const int32_t *tile_bins, const float *xys, const float *conics, const float *colors,
+                             const float *opacities, const float *background, const float *final_Ts, const int32_t *final_index,
+                             const float *v_out, const float *v_out_alpha, const float *pre_clamp, float *v_xy, float *v_conic,
+                             float *v_colors, float *v_opacity, void *stream)
+{
+    (void)N;
+    GC_REQUIRE(pre_clamp, "pre_clamp image required (gc_rasterize_bwd is the form without the clamp)");
+    return rasterize_bwd_impl("gc_rasterize_bwd_clamped", img_h, img_w, tiles_x, tiles_y, gaussian_ids_sorted, tile_bins, xys, conics, colors,
+                              opacities, background, final_Ts, final_index, v_out, v_out_alpha, pre_clamp, v_xy, v_conic, v_colors, v_opacity, stream);
 }
 
 }  // extern "C"

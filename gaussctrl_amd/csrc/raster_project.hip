@@ -498,14 +498,17 @@ __global__ __launch_bounds__(256) void k_project_sh_bwd(int64_t N, Cam cam, int 
     }
 }
 
-__global__ __launch_bounds__(256) void k_finalize(int64_t npix, float *__restrict__ img, float *__restrict__ extra,
+// img_out == img_raw: in place.  Otherwise the un-clamped image stays where the compositing wrote it (the backward needs it for the
+// clamp's gradient mask) and the clamped one goes to img_out: no separate copy pass.
+__global__ __launch_bounds__(256) void k_finalize(int64_t npix, const float *img_raw, float *img_out, float *__restrict__ extra,
                                                   const float *__restrict__ final_T, float *__restrict__ alpha)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npix) return;
     float a = 1.f - final_T[i];
     alpha[i] = a;
-    img[3 * i] = fminf(img[3 * i], 1.f); img[3 * i + 1] = fminf(img[3 * i + 1], 1.f); img[3 * i + 2] = fminf(img[3 * i + 2], 1.f);
+    const float r = img_raw[3 * i], g = img_raw[3 * i + 1], b = img_raw[3 * i + 2];
+    img_out[3 * i] = fminf(r, 1.f); img_out[3 * i + 1] = fminf(g, 1.f); img_out[3 * i + 2] = fminf(b, 1.f);
     if (extra) extra[i] = a > 0.f ? extra[i] / a : 1000.f;
 }
 
@@ -648,9 +651,19 @@ int gc_raster_finalize(int64_t num_pixels, float *out_img, float *out_extra, con
                        void *stream)
 {
     if (num_pixels == 0) return GC_OK;
-    hipLaunchKernelGGL(k_finalize, dim3(gc::cdiv(num_pixels, 256)), dim3(256), 0, gc::S(stream), num_pixels, out_img,
+    hipLaunchKernelGGL(k_finalize, dim3(gc::cdiv(num_pixels, 256)), dim3(256), 0, gc::S(stream), num_pixels, (const float *)out_img, out_img,
                        out_extra, final_Ts, alpha);
     return gc::check_launch("gc_raster_finalize");
+}
+
+int gc_raster_finalize_into(int64_t num_pixels, const float *img_raw, float *img_clamped, float *out_extra, const float *final_Ts,
+                            float *alpha, void *stream)
+{
+    if (num_pixels == 0) return GC_OK;
+    GC_REQUIRE(img_raw && img_clamped && img_raw != img_clamped, "needs two distinct image buffers (gc_raster_finalize is the in-place form)");
+    hipLaunchKernelGGL(k_finalize, dim3(gc::cdiv(num_pixels, 256)), dim3(256), 0, gc::S(stream), num_pixels, img_raw, img_clamped,
+                       out_extra, final_Ts, alpha);
+    return gc::check_launch("gc_raster_finalize_into");
 }
 
 }  // extern "C"

@@ -24,6 +24,43 @@ def shard_views(n_views: int, world_size: int, rank: int) -> list[int]:
     return [v for v in range(n_views) if v % world_size == rank]
 
 
+REF_VIEW_EQUIV = 4.0      # the 4-view reference trajectory (CFG batch 8, 20 steps) costs about what editing 4 views costs
+
+
+def shard_views_balanced(n_views: int, world_size: int, rank: int, owner: int = -1, ref_equiv: float = REF_VIEW_EQUIV) -> list[int]:
+    """View sharding that accounts for the reference trajectory: the rank that computes a scene's (or the next scene's) reference bank
+    while the others edit (`owner`) gets ref_equiv fewer views, everybody else correspondingly more -- so that all ranks finish a
+    scene together instead of N - 1 ranks waiting for the owner.  owner < 0 (replicated bank / single rank): plain v % N sharding.
+    Deterministic, contiguous in rank order, the same on every rank."""
+    if world_size <= 1 or owner < 0:
+        return shard_views(n_views, world_size, rank)
+    share = (n_views + ref_equiv) / world_size                      # work per rank in view units
+    n_owner = max(0, min(n_views, int(round(share - ref_equiv))))
+    rest, others = n_views - n_owner, world_size - 1
+    counts = []
+    for r in range(world_size):
+        if r == owner:
+            counts.append(n_owner)
+        else:
+            j = r if r < owner else r - 1                           # index among the non-owners
+            counts.append(rest // others + (1 if j < rest % others else 0))
+    start = sum(counts[:rank])
+    return list(range(start, start + counts[rank]))
+
+
+def split_chunks(views: list, n_chunks: int, chunk_size: int) -> list[list]:
+    """a rank's views as exactly n_chunks chunks of <= chunk_size views, sizes as even as possible (ranks run their chunks in lock
+    step: the gradient all-reduce after every chunk is a rendez-vous), empty chunks last"""
+    n = len(views)
+    assert n <= n_chunks * chunk_size, (n, n_chunks, chunk_size)
+    base, extra = divmod(n, n_chunks)
+    out, o = [], 0
+    for j in range(n_chunks):
+        k = base + (1 if j < extra else 0)
+        out.append(list(views[o:o + k])); o += k
+    return out
+
+
 def allreduce_gradients(params, world_size: int, average: bool = True) -> None:
     """Flat all-reduce of every .grad in `params` (in place)."""
     if world_size <= 1:

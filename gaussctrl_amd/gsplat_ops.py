@@ -221,14 +221,21 @@ def _rasterize_fwd(H, W, tb, ids_s, bins, xys, conics, colors, opac, extra, back
     return out, out_e, fT, fi
 
 
-def _rasterize_bwd(H, W, tb, N, ids_s, bins, xys, conics, colors, opac, background, fT, fi, v_out, v_alpha):
+def _rasterize_bwd(H, W, tb, N, ids_s, bins, xys, conics, colors, opac, background, fT, fi, v_out, v_alpha, pre_clamp=None):
+    """pre_clamp: the un-clamped composited image -> the clamp(max=1) backward of gc_model.py:188 happens in the kernel's pixel load"""
     dev = xys.device
     v_xy = torch.zeros(N, 2, device=dev); v_conic = torch.zeros(N, 3, device=dev)
     v_col = torch.zeros(N, 3, device=dev); v_op = torch.zeros(N, device=dev)
-    L.check(L.lib().gc_rasterize_bwd(L.i32(H), L.i32(W), L.i32(tb[0]), L.i32(tb[1]), L.i64(N), L.ptr(ids_s), L.ptr(bins),
-                                     L.ptr(xys), L.ptr(conics), L.ptr(colors), L.ptr(opac), L.ptr(background), L.ptr(fT),
-                                     L.ptr(fi), L.ptr(v_out), L.ptr(v_alpha), L.ptr(v_xy), L.ptr(v_conic), L.ptr(v_col),
-                                     L.ptr(v_op), L.stream_ptr()), "gc_rasterize_bwd")
+    if pre_clamp is None:
+        L.check(L.lib().gc_rasterize_bwd(L.i32(H), L.i32(W), L.i32(tb[0]), L.i32(tb[1]), L.i64(N), L.ptr(ids_s), L.ptr(bins),
+                                         L.ptr(xys), L.ptr(conics), L.ptr(colors), L.ptr(opac), L.ptr(background), L.ptr(fT),
+                                         L.ptr(fi), L.ptr(v_out), L.ptr(v_alpha), L.ptr(v_xy), L.ptr(v_conic), L.ptr(v_col),
+                                         L.ptr(v_op), L.stream_ptr()), "gc_rasterize_bwd")
+    else:
+        L.check(L.lib().gc_rasterize_bwd_clamped(L.i32(H), L.i32(W), L.i32(tb[0]), L.i32(tb[1]), L.i64(N), L.ptr(ids_s), L.ptr(bins),
+                                                 L.ptr(xys), L.ptr(conics), L.ptr(colors), L.ptr(opac), L.ptr(background), L.ptr(fT),
+                                                 L.ptr(fi), L.ptr(v_out), L.ptr(v_alpha), L.ptr(pre_clamp), L.ptr(v_xy), L.ptr(v_conic),
+                                                 L.ptr(v_col), L.ptr(v_op), L.stream_ptr()), "gc_rasterize_bwd_clamped")
     return v_xy, v_conic, v_col, v_op
 
 
@@ -320,9 +327,14 @@ class _RenderView(torch.autograd.Function):
         extra = depths if want_depth else None
         img, dep, fT, fi = _rasterize_fwd(H, W, tb, ids_s, bins, xys, conics, rgbs, opac, extra, bg)
         alpha = torch.empty(H, W, device=dev)
-        pre_clamp = img.clone() if any(ctx.needs_input_grad[:6]) else None
-        L.check(lib.gc_raster_finalize(L.i64(H * W), L.ptr(img), L.ptr(dep), L.ptr(fT), L.ptr(alpha), st),
-                "gc_raster_finalize")
+        if any(ctx.needs_input_grad[:6]):        # differentiable: the raw image stays for the clamp's backward, no copy pass
+            pre_clamp, img = img, torch.empty_like(img)
+            L.check(lib.gc_raster_finalize_into(L.i64(H * W), L.ptr(pre_clamp), L.ptr(img), L.ptr(dep), L.ptr(fT), L.ptr(alpha), st),
+                    "gc_raster_finalize_into")
+        else:
+            pre_clamp = None
+            L.check(lib.gc_raster_finalize(L.i64(H * W), L.ptr(img), L.ptr(dep), L.ptr(fT), L.ptr(alpha), st),
+                    "gc_raster_finalize")
         if aux is not None:
             aux.xys, aux.radii, aux.num_tiles_hit, aux.M, aux.depths = xys, radii, nth, M, depths
             aux.gaussian_ids_sorted, aux.tile_bins, aux.final_index, aux.isect_ids_sorted = ids_s, bins, fi, keys_s
@@ -342,9 +354,9 @@ class _RenderView(torch.autograd.Function):
         H, W = cam["H"], cam["W"]
         dev = m.device
         vo = _c(v_img) if v_img is not None else torch.zeros(H, W, 3, device=dev)
-        vo = vo * (pre_clamp <= 1.0)                       # clamp(max=1) backward, gc_model.py:188
         va = _c(v_alpha) if v_alpha is not None else None
-        v_xy, v_conic, v_col, v_op = _rasterize_bwd(H, W, tb, N, ids_s, bins, xys, conics, rgbs, opac, bg, fT, fi, vo, va)
+        # (clamp(max=1) backward, gc_model.py:188: applied by the kernel when it loads the pixel's gradient)
+        v_xy, v_conic, v_col, v_op = _rasterize_bwd(H, W, tb, N, ids_s, bins, xys, conics, rgbs, opac, bg, fT, fi, vo, va, pre_clamp)
         if ctx.aux is not None:
             ctx.aux.xys_grad = v_xy
         into = ctx.aux.grad_into if ctx.aux is not None else None

@@ -143,6 +143,14 @@ int gc_rasterize_bwd(int img_h, int img_w, int tiles_x, int tiles_y, int64_t N,
                      const float *background, const float *final_Ts, const int32_t *final_index,
                      const float *v_out, const float *v_out_alpha,
                      float *v_xy, float *v_conic, float *v_colors, float *v_opacity, void *stream);
+/* The same with the backward of get_outputs' `rgb = clamp(rgb, max=1)` (gaussctrl/gc_model.py:188) folded into the pixel load:
+ * v_out is taken as 0 where pre_clamp[H,W,3] (the un-clamped composited image) exceeds 1. */
+int gc_rasterize_bwd_clamped(int img_h, int img_w, int tiles_x, int tiles_y, int64_t N,
+                             const int32_t *gaussian_ids_sorted, const int32_t *tile_bins,
+                             const float *xys, const float *conics, const float *colors, const float *opacities,
+                             const float *background, const float *final_Ts, const int32_t *final_index,
+                             const float *v_out, const float *v_out_alpha, const float *pre_clamp,
+                             float *v_xy, float *v_conic, float *v_colors, float *v_opacity, void *stream);
 
 /* Fused per-Gaussian front end of GaussCtrlModel.get_outputs (gaussctrl/gc_model.py:138-169,181):
  * exp(scales), quat normalisation, projection, view directions, SH(+0.5, clamp min 0), sigmoid(opacity)
@@ -183,6 +191,10 @@ int gc_project_sh_bwd_accumulate(int64_t N, const float *means, const float *log
  * depth = alpha>0 ? depth/alpha : 1000.  In place on out_img / out_extra; writes alpha[H,W]. */
 int gc_raster_finalize(int64_t num_pixels, float *out_img, float *out_extra, const float *final_Ts,
                        float *alpha, void *stream);
+/* Out-of-place form for a differentiable render: img_raw (as gc_rasterize_fwd wrote it) is kept for gc_rasterize_bwd_clamped,
+ * the clamped image goes to img_clamped (same epilogue otherwise; reference: gaussctrl/gc_model.py:188,197-204). */
+int gc_raster_finalize_into(int64_t num_pixels, const float *img_raw, float *img_clamped, float *out_extra,
+                            const float *final_Ts, float *alpha, void *stream);
 
 /* Loss + optimiser of the splat optimisation that follows the edit (reference:
  * SplatfactoModel.get_loss_dict inherited via gaussctrl/gc_pipeline.py:284-285, Adam groups gaussctrl/gc_config.py:58-87,

@@ -82,7 +82,8 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "abl":           # timing ablations of k_attn5 (results wrong by construction)
         names = {0: "everything (instrumented build)", 1: "no v_exp", 2: "no exp units (no v_exp, no v_cvt_pk)", 4: "no s_barrier", 8: "no LDS-DMA",
                  16: "no LDS fragment reads", 24: "no DMA, no fragment reads", 26: "MFMA only (+ barrier)", 30: "MFMA only",
-                 32: "units read a constant, not S", 64: "units write a sink, not P", 96: "units detached from both MFMAs", 120: "detached units, no LDS traffic"}
+                 32: "units read a constant, not S", 64: "units write a sink, not P", 96: "units detached from both MFMAs", 120: "detached units, no LDS traffic",
+                 192: "units write a sink, P = non-zero constants", 130: "no units, P = non-zero constants", 2 + 128 + 24: "no units, P constants, no LDS traffic"}
         timing(torch.bfloat16, 16)
         for bits, nm in names.items():
             print(f"ablation {bits:2d} {nm:40s}", end=" ")

@@ -108,6 +108,25 @@ def test_view_sharding_partitions():
             assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
 
 
+def test_balanced_sharding_accounts_for_the_reference_trajectory():
+    from gaussctrl_amd.dist import shard_views_balanced, split_chunks
+    for n, w in ((40, 8), (40, 4), (40, 2), (80, 8), (7, 4), (3, 8)):
+        for owner in range(w):
+            parts = [shard_views_balanced(n, w, r, owner) for r in range(w)]
+            assert sorted(sum(parts, [])) == list(range(n))                       # a partition of the views
+            others = [len(p) for r, p in enumerate(parts) if r != owner]
+            assert max(others) - min(others) <= 1
+            assert len(parts[owner]) <= min(others)                              # the owner edits fewer: it also runs the references
+            if n >= 4 * w:
+                assert abs((len(parts[owner]) + 4) - sum(others) / len(others)) <= 1.0
+    assert [len(shard_views_balanced(40, 8, r, 3)) for r in range(8)] == [6, 6, 6, 2, 5, 5, 5, 5]
+    assert shard_views_balanced(40, 8, 2, -1) == [2, 10, 18, 26, 34]              # no owner: plain v % N
+    assert shard_views_balanced(40, 1, 0, 0) == list(range(40))
+    assert [len(c) for c in split_chunks(list(range(7)), 4, 3)] == [2, 2, 2, 1]
+    assert [len(c) for c in split_chunks(list(range(2)), 2, 3)] == [1, 1]
+    assert split_chunks([], 2, 3) == [[], []]
+
+
 def test_gloo_world2_collectives():
     world = 2
     mgr = mp.Manager()

@@ -52,8 +52,13 @@ def _worker(rank, world, port, owner, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("owner", [-1, 0])
-def test_two_ranks_one_gpu_match_single_rank(owner):
+@pytest.mark.parametrize("owner,invariant", [(-1, False), (0, False), (0, True)])
+def test_two_ranks_one_gpu_match_single_rank(owner, invariant, monkeypatch):
+    """invariant: batch-invariant kernel planning (sd.ops.BATCH_INVARIANT; the spawned ranks read GC_BATCH_INVARIANT) -- the edited images
+    of the 2-rank run are then BIT-identical to the single-rank run, although the chunks hold other views."""
+    from gaussctrl_amd.sd import ops as sdops
+    monkeypatch.setenv("GC_BATCH_INVARIANT", "1" if invariant else "0")
+    monkeypatch.setattr(sdops, "BATCH_INVARIANT", invariant)
     pipe, model = _build(1, 0, -1)
     ref_imgs, ref_losses, ref_means = _run(pipe, model)
     del pipe, model
@@ -69,6 +74,8 @@ def test_two_ranks_one_gpu_match_single_rank(owner):
         # depends on the batch size (different fp32 accumulation orders, amplified by the random-weight network); measured on MI355X
         # (3 DDIM steps, f16): mean |diff| 1.7e-3, max 3e-2 on images in [0, 1]
         d = np.abs(imgs - ref_imgs.numpy())
+        if invariant:
+            assert np.array_equal(imgs, ref_imgs.numpy()), (d.mean(), d.max())
         assert d.mean() < 5e-3 and d.max() < 0.1, (d.mean(), d.max())
         # same views, averaged gradients of identical renders = the single-rank gradients: same losses / parameters up to atomics noise
         assert np.allclose(losses, ref_losses, rtol=2e-2, atol=1e-3), (losses, ref_losses)
