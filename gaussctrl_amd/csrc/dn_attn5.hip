@@ -4,6 +4,9 @@
 #include "dn_attn_common.h"
 
 namespace {
+#ifdef ATTN5_DEBUG
+__device__ unsigned g_attn5_dbg = 0;
+#endif
 // ------------------------------------------------------------------------------------------------------------------------
 // k_attn5 (round 3; D = 40, Lk % 64 == 0, Lq % 256 == 0): the k_attn4 arithmetic with the work of a 64-key tile split so that every
 // LDS fragment feeds TWO MFMAs.  Why: per 64-key tile k_attn4's eight co-resident waves (two workgroups of four) issue 8 x 14
@@ -67,6 +70,11 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
         if (hg == HS) qf[qb][KSS].x = pack2<T>(0.f, -BIG);
     }
     const float c2 = a.scale_log2e;
+    // Experiment hook (kernel_variant bits 16..20, default 0): P = exp2(s - m0 - cshift).  In f16 P must stay below 2^16, so a row whose
+    // later keys beat the first block's maximum by 16 binades sends its workgroup to the safe body; a positive shift widens that margin
+    // but P below 2^-14 is FLUSHED on this path (measured, profiles/r03_attn5_f16_window.txt: relative L2 error 3e-4 -> 5e-3 -> 8e-2 at
+    // shift 0 / 4 / 8), so f16 keeps shift 0 and its data-dependent fallback rate; bf16's 8-bit exponent never gets there.
+    const float cshift = (float)((a.abl >> 8) & 31) / (PRE ? 1.f : c2);
     const int abl = ABL ? __builtin_amdgcn_readfirstlane(a.abl) : 0;
     float abl_x = -(float)(lane & 7);
     unsigned abl_sink = 0;
@@ -111,13 +119,17 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
     ck.p = tab(kb_tab, 0); ck.tile = 0; ck.s = 0; ck.dst = ldsK + wid * 1024;
     cv.p = tab(vb_tab, 0); cv.tile = 0; cv.s = 0; cv.dst = ldsV + wid * (VSH * 16);
     const int64_t kstride = (int64_t)128 * a.ldk;
-    auto issue_kv = [&]() __attribute__((always_inline)) {
-        glds16_s(ck.p, (unsigned)k_off, ck.dst, k_msk);
-        ck.dst = ck.dst + KBYTES == ldsK + wid * 1024 + NST * KBYTES ? ldsK + wid * 1024 : ck.dst + KBYTES;
+    // dslot >= 0: the ring slot is a compile-time constant (the tile loop is unrolled NST times when ntiles % NST == 0: every LDS
+    // address is then an immediate and the per-tile pointer-wrap SALU disappears -- the kernel is sensitive to issue slots: the
+    // instrumented build's extra branches alone cost 30 %)
+    auto issue_kv = [&](auto dslot_) __attribute__((always_inline)) {
+        constexpr int DS = decltype(dslot_)::value;
+        glds16_s(ck.p, (unsigned)k_off, DS >= 0 ? ldsK + wid * 1024 + DS * KBYTES : ck.dst, k_msk);
+        if (DS < 0) ck.dst = ck.dst + KBYTES == ldsK + wid * 1024 + NST * KBYTES ? ldsK + wid * 1024 : ck.dst + KBYTES;
         ck.p += kstride;
         if (++ck.tile == ntiles) { ck.tile = 0; ck.s = ck.s + 1 < a.nsets ? ck.s + 1 : ck.s; ck.p = tab(kb_tab, ck.s); }
-        glds16_s(cv.p, (unsigned)v_off, cv.dst, v_msk);
-        cv.dst = cv.dst + VBYTES == ldsV + wid * (VSH * 16) + NST * VBYTES ? ldsV + wid * (VSH * 16) : cv.dst + VBYTES;
+        glds16_s(cv.p, (unsigned)v_off, DS >= 0 ? ldsV + wid * (VSH * 16) + DS * VBYTES : cv.dst, v_msk);
+        if (DS < 0) cv.dst = cv.dst + VBYTES == ldsV + wid * (VSH * 16) + NST * VBYTES ? ldsV + wid * (VSH * 16) : cv.dst + VBYTES;
         cv.p += 128;
         if (++cv.tile == ntiles) { cv.tile = 0; cv.s = cv.s + 1 < a.nsets ? cv.s + 1 : cv.s; cv.p = tab(vb_tab, cv.s); }
     };
@@ -183,13 +195,16 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) kf[ks] = *reinterpret_cast<const uint4 *>(kb_ + kfo[ks]);
     };
-    auto tile_step = [&](bool first) __attribute__((always_inline)) {
+    auto tile_step = [&](bool first, auto slot_) __attribute__((always_inline)) {
+        constexpr int SLOT = decltype(slot_)::value;                       // ring slot of this tile, or -1: dynamic ring pointers
         wait_vmcnt<(PD - 2) * GRP>();
         if (!(ABL && (abl & 4))) __builtin_amdgcn_s_barrier();
-        if (!(ABL && (abl & 8))) issue_kv();
-        const unsigned char *kb_ = rk, *vb_ = rv;
-        rk = rk + KBYTES == sK + NST * KBYTES ? sK : rk + KBYTES;
-        rv = rv + VBYTES == sV + NST * VBYTES ? sV : rv + VBYTES;
+        if (!(ABL && (abl & 8))) issue_kv(std::integral_constant<int, SLOT < 0 ? -1 : (SLOT + PD) % NST>{});
+        const unsigned char *kb_ = SLOT < 0 ? rk : sK + SLOT * KBYTES, *vb_ = SLOT < 0 ? rv : sV + SLOT * VBYTES;
+        if (SLOT < 0) {
+            rk = rk + KBYTES == sK + NST * KBYTES ? sK : rk + KBYTES;
+            rv = rv + VBYTES == sV + NST * VBYTES ? sV : rv + VBYTES;
+        }
         if (first) {
             // first tile of a K/V set: the row maximum over its FIRST key block becomes the set's offset -- evaluated by both waves of
             // a pair on the same data, so they agree bit for bit without an exchange
@@ -206,7 +221,7 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
                 const unsigned x = __float_as_uint(t);
                 const auto r1 = __builtin_amdgcn_permlane32_swap(x, x, false, false);
                 t = fmaxf(__uint_as_float(r1[0]), __uint_as_float(r1[1]));
-                const float mq = T::to_f(T::from_f(t));
+                const float mq = T::to_f(T::from_f(t + cshift));
                 if (hg == HS) qf[qb][KSS].x = pack2<T>(-mq, -BIG);
             }
         }
@@ -246,7 +261,7 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
         S1 = T::mfma32(kf[2], qf[1][2], S1);
         unit(S0, pf[0][1], 3, 1);
         __builtin_amdgcn_sched_barrier(0);
-        rd_kf(rk);                                      // tile i+1 (landed: the barrier above waited for it)
+        rd_kf(SLOT < 0 ? rk : sK + ((SLOT + 1) % NST) * KBYTES);      // tile i+1 (landed: the barrier above waited for it)
         os[0][0] = T::mfma32(vf[0][0], pf[0][0], os[0][0]);      // G
         __builtin_amdgcn_sched_barrier(0);
         os[0][1] = T::mfma32(vf[0][1], pf[0][0], os[0][1]);
@@ -276,6 +291,10 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
         for (int qb = 0; qb < QB; ++qb) {
             const float l = xl[(wid * QB + qb) * 32 + qi] + xl[((wid ^ 1) * QB + qb) * 32 + qi];
             bad |= !(l > 0.f && l < 1e37f);
+#ifdef ATTN5_DEBUG
+            if (!(l > 0.f && l < 1e37f) && hg == 0 && atomicAdd(&g_attn5_dbg, 1u) < 24u)
+                printf("bad: wg %d wave %d qb %d q %d set %d: l_mine %g l_partner %g\n", (int)blockIdx.x, wid, qb, qi, s, xl[(wid * QB + qb) * 32 + qi], xl[((wid ^ 1) * QB + qb) * 32 + qi]);
+#endif
             const float inv = a.set_w[s] / l;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { otot0[qb][r] += os[qb][0][r] * inv; os[qb][0][r] = 0.f; }
@@ -288,8 +307,8 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
 
     // ---- prologue: PD tiles in flight
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < PD; ++j) issue_kv();
+    static_for<0, PD>([&](auto j_) __attribute__((always_inline)) { issue_kv(std::integral_constant<int, decltype(j_)::value>{}); });
+    ck.dst = ldsK + wid * 1024 + PD * KBYTES; cv.dst = ldsV + wid * (VSH * 16) + PD * VBYTES;      // (dynamic form: next slot)
     wait_vmcnt<(PD - 1) * GRP>();
     __builtin_amdgcn_s_barrier();
     rd_kf(rk);                          // K fragments run one tile ahead of the loop
@@ -305,7 +324,12 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
             const uint4 c = make_uint4(0x3F2A3E91u + lane, 0x3DD73F11u ^ (lane << 3), 0x3E4C3F60u, 0x3F053D9Au + 7 * lane);
             pf[0][0] = c; pf[0][1] = c; pf[1][0] = c; pf[1][1] = c;
         }
-        for (int t = 0; t < ntiles; ++t) tile_step(t == 0);
+        if (ntiles % NST == 0) {        // every set starts at ring slot 0: unrolled, static slots
+            for (int t = 0; t < ntiles; t += NST)
+                static_for<0, NST>([&](auto k_) __attribute__((always_inline)) { tile_step(t + decltype(k_)::value == 0, k_); });
+        } else {
+            for (int t = 0; t < ntiles; ++t) tile_step(t == 0, std::integral_constant<int, -1>{});
+        }
         fold(s);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -363,15 +387,9 @@ void launch_attn5(const AttnArgs &a, int B, hipStream_t s)
 // depth: stages of the K / V^T LDS ring (4, 6 or 8: the DMA of a tile is issued depth - 1 tiles before its barrier)
 void gc_dn_launch_attn5(const void *args, int dtype, int B, int depth, hipStream_t s)
 {
+    (void)depth;       // ring depths 4 / 6 / 8 measured equal (profiles/r03_attn5_ablation.txt): 4 stages, which divides the 64 tiles of L = 4096
     const AttnArgs &a = *static_cast<const AttnArgs *>(args);
-    if (a.abl) { launch_attn5_<BF16, true, 6, true>(a, B, s); return; }
-    if (dtype == DT_BF16) {
-        if (depth == 4) launch_attn5<BF16, 4>(a, B, s);
-        else if (depth == 8) launch_attn5<BF16, 8>(a, B, s);
-        else launch_attn5<BF16, 6>(a, B, s);
-    } else {
-        if (depth == 4) launch_attn5<F16, 4>(a, B, s);
-        else if (depth == 8) launch_attn5<F16, 8>(a, B, s);
-        else launch_attn5<F16, 6>(a, B, s);
-    }
+    if (a.abl & 0xff) { launch_attn5_<BF16, true, 4, true>(a, B, s); return; }
+    if (dtype == DT_BF16) launch_attn5<BF16, 4>(a, B, s);
+    else launch_attn5<F16, 4>(a, B, s);
 }

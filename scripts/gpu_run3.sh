@@ -4,7 +4,7 @@ R=$PWD
 mkdir -p gpurun_out/r3c
 export TMPDIR=/tmp
 python scripts/attn5_check.py abl 2>&1 | grep "timing\|ablation" > gpurun_out/r3c/attn5_ablation.txt
-timeout 1200 python -m pytest tests -m gpu -x -q -k "raster or fused_render or model_get_outputs or accumulates" 2>&1 | tail -6 > gpurun_out/r3c/tests_raster.log
+timeout 1200 python -m pytest tests -m gpu -x -q -k "dist_gpu" 2>&1 | tail -6 > gpurun_out/r3c/tests_raster.log
 cat gpurun_out/r3c/tests_raster.log
 GC_BENCH_ONE_GPU=1 GC_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 8 --warmup 1 > gpurun_out/r3c/bench2_gloo.json 2> gpurun_out/r3c/bench2_gloo.err
 tail -3 gpurun_out/r3c/bench2_gloo.err
@@ -19,7 +19,7 @@ ls -R gpurun_out/r3c/prof | head -20
 DB=$(find gpurun_out/r3c/prof -name "*.db" | head -1)
 if [ -n "$DB" ]; then python scripts/rocpd_stats.py $DB 70 > gpurun_out/r3c/bench_kernel_stats.txt; else find gpurun_out/r3c/prof -name "*kernel_stats*" | head; fi
 head -30 gpurun_out/r3c/bench_kernel_stats.txt
-rm -rf gpurun_out/r3c/prof/*/*.db 2>/dev/null
+rm -rf gpurun_out/r3c/prof
 timeout 600 python bench.py --workload raster --gaussians 1000000 --steps 20 --warmup 2 --no-cpu-baseline > gpurun_out/r3c/raster_1m.json 2> gpurun_out/r3c/raster_1m.err
 timeout 600 python bench.py --workload raster --gaussians 4000000 --steps 20 --warmup 2 --no-cpu-baseline > gpurun_out/r3c/raster_4m.json 2> gpurun_out/r3c/raster_4m.err
 python - <<'P'
