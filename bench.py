@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="edit", choices=["edit", "raster"])
     ap.add_argument("--ref-mode", default="rotate", choices=["rotate", "owner0", "replicate"])    # N > 1: who computes the reference bank
+    ap.add_argument("--inflight", type=int, default=2)         # chunks in flight on independent HIP stream pairs (1: strictly one after the other)
     ap.add_argument("--no-secondary", action="store_true")     # skip the short f16 secondary measurement (default workload, N = 1)
     ap.add_argument("--mask", action="store_true")   # BASELINE configs[3]: edits composited through a (synthetic elliptical) mask, gc_pipeline.py:226-234
     return ap.parse_args()
@@ -210,8 +211,15 @@ class Bench:
         self.edit_mask = torch.tensor(syn.elliptical_mask(H, W, soft=True), device=dev, dtype=torch.float32) if args.mask else None
         # the chunk's summed leaf gradients: six views of ONE flat buffer that the backward kernel writes into and RCCL reduces in
         # place; two buffers alternate so the all-reduce of chunk k completes under the denoise of chunk k + 1
-        self.grads = [FlatGrads(self.params), FlatGrads(self.params)] if world > 1 else [FlatGrads(self.params)]
+        self.grads = [FlatGrads(self.params) for _ in range(max(2 if world > 1 else 1, max(1, args.inflight) if args.workload == "edit" else 1))]
         self.bank_layers = None
+        # consecutive chunks are independent given the reference bank: each runs on its own stream (pair), `inflight` of them at a time,
+        # so the part-filled grids and the fill / drain phases of one chunk's kernels are covered by the other's; the next scene's
+        # reference trajectory has a stream of its own
+        self.inflight = max(1, args.inflight) if self.edit else 1
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.inflight)] if self.inflight > 1 else [None]
+        self.ref_stream = torch.cuda.Stream(device=dev) if self.inflight > 1 else None
+        self.bank_ready = None          # event on ref_stream: the bank the chunks are about to use is complete
         self.half_events = []           # (start, end of denoise half, end of step) HIP events of the timed steps
         self.record_halves = False
         self.rank0_only = False
@@ -267,6 +275,13 @@ class Bench:
         return tr.finish() if done else None
 
     def step(self, s):
+        st_ = self.streams[s % len(self.streams)]
+        if st_ is None:
+            return self._step(s)
+        with torch.cuda.stream(st_):
+            return self._step(s)
+
+    def _step(self, s):
         """Chunk s of an endless stream of scenes (cps chunks per scene on every rank).  A scene's reference trajectory (4 views x 20
         DDIM steps, shared by its chunks) is computed while the PREVIOUS scene is edited, 20 / cps DDIM steps per chunk, so every
         step carries exactly its share of the reference work whatever K is."""
@@ -279,12 +294,18 @@ class Bench:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
             ev[0].record()
         if self.edit:
-            if st["bank"] is None:                # the very first scene (setup): its whole reference trajectory at once
-                st["bank"] = self.advance_bank(self.begin_bank(scene), None)
-            if st["next"] is None:                # the following scene's references start with this scene
-                st["next"] = self.begin_bank(scene + 1)
-            quota = (nsteps * (j + 1)) // cps - (nsteps * j) // cps
-            done = self.advance_bank(st["next"], quota)          # owner: compute + post sends; others: post receives (they arrive under (b))
+            cur = torch.cuda.current_stream()
+            refs = self.ref_stream if self.ref_stream is not None else cur
+            with torch.cuda.stream(refs):
+                if st["bank"] is None:                # the very first scene (setup): its whole reference trajectory at once
+                    st["bank"] = self.advance_bank(self.begin_bank(scene), None)
+                    self.bank_ready = torch.cuda.Event(); self.bank_ready.record()
+                if st["next"] is None:                # the following scene's references start with this scene
+                    st["next"] = self.begin_bank(scene + 1)
+                quota = (nsteps * (j + 1)) // cps - (nsteps * j) // cps
+                done = self.advance_bank(st["next"], quota)          # owner: compute + post sends; others: post receives (they arrive under (b))
+            if self.bank_ready is not None:
+                cur.wait_event(self.bank_ready)       # (no-op on the stream that recorded it)
             evals = [self.render_eval(i) for i in views]                                                    # (a)
             if views:
                 disp = torch.stack([self.disparity_of(e[1]) for e in evals])
@@ -292,12 +313,16 @@ class Bench:
                 edited = self.pipe.decode(lat)                                                              # (c)
             if j == cps - 1:
                 assert done is not None
+                st["prev_bank"] = st["bank"]          # chunks still in flight on other streams read it: keep it alive for one more scene
                 st["bank"], st["next"] = done, None
+                if self.ref_stream is not None:
+                    self.bank_ready = torch.cuda.Event()
+                    self.bank_ready.record(self.ref_stream)
         else:
             edited = [None] * len(views)
         if ev:
             ev[1].record()
-        fg = self.grads[s % len(self.grads)]
+        fg = self.grads[s % len(self.grads)]            # (same index -> same stream when chunks are in flight on several streams)
         fg.wait()                                 # the all-reduce posted two chunks ago (N > 1) has finished before its buffer is rewritten
         for jj, i in enumerate(views):                                                                      # (d)
             aux = self.new_aux()
@@ -322,6 +347,11 @@ class Bench:
     def finish(self):
         for fg in self.grads:
             fg.wait()
+        for st_ in self.streams:
+            if st_ is not None:
+                torch.cuda.current_stream().wait_stream(st_)
+        if self.ref_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.ref_stream)
 
     def barrier(self):
         torch.cuda.synchronize()
@@ -334,8 +364,10 @@ class Bench:
         state), `warmup` untimed steps, then EXACTLY `steps` timed steps between barriers; returns (seconds = max over ranks,
         views edited by this rank in the timed region, training renders in it)"""
         g = 0
-        for _ in range(2 + warmup):
+        for i in range(2 + warmup):
             self.step(g); g += 1
+            if i < 2:
+                torch.cuda.synchronize()      # the priming chunks also fill the per-prompt / per-timestep caches every stream reads later
         self.finish()
         self.barrier()
         v0, r0 = self.state["views_done"], self.state["renders_done"]
@@ -408,6 +440,7 @@ def main():
     pipe, stats, state = B.pipe, B.stats, B.state
     z0, ctx_neg, ctx_pos = B.z0, B.ctx_neg, B.ctx_pos
     chunks_per_scene = B.cps
+    B0_inflight = B.inflight
     dt_s, my_views, my_renders = B.run(args.warmup, args.steps)
     g = B.next_step
     if dist is not None:
@@ -499,7 +532,7 @@ def main():
                    "; reference bank: " +
                    ({"rotate": "owner rotates per scene, per-DDIM-step async RCCL broadcast", "owner0": "rank 0 owns, per-DDIM-step async RCCL broadcast",
                      "replicate": "replicated on every rank (no collective)"}[args.ref_mode] if world > 1 else "local") +
-                   "; flat async gradient all-reduce; ControlNet || UNet encoder on 2 HIP streams")
+                   f"; flat async gradient all-reduce; {B0_inflight} chunk(s) in flight on independent stream pairs; ControlNet || UNet encoder on 2 HIP streams")
         else:
             flop, mfma_util = None, None
             par = f"every rank renders its own {V} cameras (x{world}); flat async gradient all-reduce"
@@ -519,7 +552,8 @@ def main():
                "denoise_views_per_s": round(my_views / dn_s, 4) if (args.workload == "edit" and dn_s > 0) else None,
                "raster_fwd_bwd_iters_per_s": round(my_renders / rs_s, 2) if rs_s > 0 else None,
                "halves": {"denoise_s": round(dn_s, 4), "raster_train_s": round(rs_s, 4), "views_rank0": my_views, "train_renders_rank0": my_renders,
-                          "note": "denoise half = eval renders + disparity + 20-step denoise + VAE decode + reference share; raster half = training render fwd + L1/SSIM + bwd"},
+                          "spans_overlap": B0_inflight > 1,
+                          "note": "(with several chunks in flight the per-chunk spans overlap in time: each half's rate is then a lower bound) denoise half = eval renders + disparity + 20-step denoise + VAE decode + reference share; raster half = training render fwd + L1/SSIM + bwd"},
                "mfma_util_step": None if mfma_util is None else round(mfma_util, 4),
                "algorithmic_tflop_timed_region": None if flop is None else round(flop / 1e12, 1),
                "secondary": secondary,

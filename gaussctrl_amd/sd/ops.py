@@ -401,9 +401,10 @@ _disp_ws = {}
 def depth_to_disparity(depth, dtype):
     """depth fp32 [H,W] -> disparity [H,W,8] (3 used) in the activation dtype: 1/(d+1e-5) / max (gc_pipeline.py:258-266)."""
     _gpu(depth)
-    ws = _disp_ws.get(depth.device)
+    key = (depth.device, torch.cuda.current_stream().cuda_stream)          # scratch per stream: independent chunks may run concurrently
+    ws = _disp_ws.get(key)
     if ws is None:
-        ws = _disp_ws[depth.device] = torch.zeros(1, dtype=torch.int32, device=depth.device)
+        ws = _disp_ws[key] = torch.zeros(1, dtype=torch.int32, device=depth.device)
     d = depth.contiguous()
     out = torch.empty(d.shape[0], d.shape[1], 8, dtype=dtype, device=d.device)
     L.check(L.lib().gc_dn_depth_to_disparity(DT[dtype], _p(d), C.c_int64(d.numel()), _p(out), _p(ws), _stream()),
