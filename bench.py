@@ -505,10 +505,10 @@ def main():
         del B, pipe, state, z0, step
         torch.cuda.empty_cache()
         B2 = Bench(args, "f16", rank, world, dev, None, None)
-        n2 = min(args.steps, 7)
+        n2 = min(args.steps, B2.cps)           # up to one whole scene, so that the short last chunk and the reference share weigh as in `value`
         t2, v2, _ = B2.run(1, n2)
         secondary = {"dtype": "f16", "value": round(v2 / t2, 4), "unit": "views/s", "steps": n2, "warmup": 1,
-                     "note": "same workload with f16 activations (latents within 1e-3 rel of the fp32 oracle, tests/test_fullgeom_gpu.py); short sample"}
+                     "note": "same workload with f16 activations (latents within 1e-3 rel of the fp32 oracle, tests/test_fullgeom_gpu.py)"}
         del B2
         torch.cuda.empty_cache()
 
@@ -549,11 +549,13 @@ def main():
                           "ref_trajectory_in_timed_region": bool(args.workload == "edit"),
                           "ref_trajectory_share_per_step": f"{nsteps}/{chunks_per_scene} DDIM steps of the next scene's 4 reference views" if args.workload == "edit" else None},
                # the two halves separately (GPU time of rank 0's launch stream between HIP events in the timed steps)
-               "denoise_views_per_s": round(my_views / dn_s, 4) if (args.workload == "edit" and dn_s > 0) else None,
-               "raster_fwd_bwd_iters_per_s": round(my_renders / rs_s, 2) if rs_s > 0 else None,
+               # (the wall time of the timed region is apportioned to the halves by their share of the per-chunk GPU spans: with one
+               # chunk in flight that is the measured span itself, with several the spans overlap but their ratio stands)
+               "denoise_views_per_s": round(my_views / (dt_s * dn_s / (dn_s + rs_s)), 4) if (args.workload == "edit" and dn_s > 0) else None,
+               "raster_fwd_bwd_iters_per_s": round(my_renders / (dt_s * rs_s / (dn_s + rs_s)), 2) if rs_s > 0 else None,
                "halves": {"denoise_s": round(dn_s, 4), "raster_train_s": round(rs_s, 4), "views_rank0": my_views, "train_renders_rank0": my_renders,
                           "spans_overlap": B0_inflight > 1,
-                          "note": "(with several chunks in flight the per-chunk spans overlap in time: each half's rate is then a lower bound) denoise half = eval renders + disparity + 20-step denoise + VAE decode + reference share; raster half = training render fwd + L1/SSIM + bwd"},
+                          "note": "spans = GPU time between HIP events on each chunk's launch stream (they overlap when several chunks are in flight; the rates above apportion the wall time by their ratio); denoise half = eval renders + disparity + 20-step denoise + VAE decode + reference share; raster half = training render fwd + L1/SSIM + bwd"},
                "mfma_util_step": None if mfma_util is None else round(mfma_util, 4),
                "algorithmic_tflop_timed_region": None if flop is None else round(flop / 1e12, 1),
                "secondary": secondary,

@@ -16,6 +16,9 @@ __device__ unsigned g_attn5_dbg = 0;
 // the tile's 64 keys).  Per tile and wave: S'^T = 3 k-steps x 2 query blocks (6 MFMAs, 3 K fragments), O^T += 2 row blocks x 2
 // k-steps x 2 query blocks (8 MFMAs, 4 V^T fragments): the same 14 MFMAs per (32 queries x 64 keys) with 7 fragment reads instead of
 // 14 and one DMA'd tile instead of two -- 36-48 % LDS occupancy instead of 72-96 %.
+// (Tried and removed, round 3: deferring the P V MFMAs by a whole tile -- P and V^T fragments double-buffered, the cross-set sums parked
+// in LDS to pay for the registers -- is bit-identical and 1.7 % SLOWER (712 vs 700 us): the cost the ablations attribute to the
+// S -> exp -> P -> PV chain is not the latency of late exp units.)
 // The two key-half waves of a pair use the SAME offset (both evaluate the first key block of a set's first tile), so their partial
 // numerators and denominators simply add: the denominators are exchanged through LDS at the end of each set (w_s / (l_a + l_b)
 // scales both partial O^T), the partial weighted sums once at the end of the kernel.

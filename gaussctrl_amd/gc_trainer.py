@@ -42,7 +42,13 @@ if HAVE_NERFSTUDIO:  # pragma: no cover - executed with nerfstudio (or tests/fak
                 self.pipeline.edit_images()
 
         def train(self) -> None:
-            # gc_trainer.py:186-187: `render_rate` iterations from the loaded checkpoint's step (max_num_iterations is ignored there)
+            # gc_trainer.py:186-187: `render_rate` iterations from the loaded checkpoint's step (max_num_iterations is ignored there).
+            # nerfstudio 1.0.0 (the reference's pin) loops `range(start, start + max_num_iterations)`; later releases loop to an ABSOLUTE
+            # max_num_iterations, which would give zero iterations from a step-30000 checkpoint: refuse rather than train nothing.
+            import nerfstudio  # type: ignore
+            ver = getattr(nerfstudio, "__version__", None)
+            if ver is not None and not str(ver).startswith("1.0."):
+                raise RuntimeError(f"gaussctrl_amd's trainer follows nerfstudio 1.0.x's training loop (found {ver}); see INTEGRATION.md 3")
             keep = self.config.max_num_iterations
             self.config.max_num_iterations = self.pipeline.config.render_rate
             try:

@@ -131,5 +131,5 @@ if __name__ == "__main__":
     for qs in (0.25, 0.35):
         for v in (16, 0):
             timing(torch.float16, v, qscale=qs)
-    for v in (0, 32, 64, 16, 0, 32, 64):       # k_attn5 with ring depth 6 (default) / 4 / 8; 16 = k_attn4
+    for v in (0, 16, 0, 16):       # k_attn5, k_attn4
         timing(torch.bfloat16, v)
