@@ -497,6 +497,7 @@ def main():
             roof_raster = {"bound": "hbm", "unit": "GB/s", "peak": 8000.0, "achieved": rr["chain"]["GBps"], "frac": rr["chain"]["frac"],
                            "kernel_us_per_view": rr["chain"]["kernel_us_per_view"], "algorithmic_MB_per_view": rr["chain"]["algorithmic_MB_per_view"],
                            "traffic_ratio": rr["chain"].get("traffic_ratio"), "N": rr["chain"]["N"], "M_mean": rr["chain"]["M_mean"],
+                           "M_processed_mean": rr["chain"]["M_processed_mean"], "frac_processed_pairs": rr["chain"]["frac_processed_pairs"],
                            "formula": rr["chain"]["formula"], "dominant_stage": rr["kernel"], "dominant_stage_frac": rr["frac"]}
 
     # ---------------------------------------------------------------- secondary: the f16 activation path (the dtype that meets north_star's 1e-3)
@@ -629,12 +630,26 @@ def raster_roofline(args, B, g, stats, HW):
         torch.cuda.synchronize()
     finally:
         L._lib = real
-    Ms = [int(a.item()) for a, _ in stats["dev"][n_dev:]] or stats["M"][-8:]        # intersections of the instrumented views
+    Ms = [int(a.item()) for a, _ in stats["dev"][n_dev:]] or stats["M"][-8:]        # pairs the instrumented views really binned (tight boxes)
     nviews = max(1, sum(1 for n, _, _ in timer.rec if n.startswith("gc_rasterize_bwd")))
-    M = float(np.mean(Ms))
+    M_proc = float(np.mean(Ms))
+    # The SURVEY 8d byte formula counts the intersections of the reference's lists (gsplat's 3-sigma boxes): that M is measured here on
+    # the same cameras with the tight boxes switched off (untimed); `frac` prices the chain against it, `frac_processed_pairs` against
+    # the shorter lists the product path really moves.
+    scene, j = divmod(g - g % B.cps if args.workload != "raster" else g, B.cps)
+    Mg = []
+    for i in B.chunks_of(scene)[j]:
+        auxg = B.gops.RenderAux(); auxg.tight_boxes = False
+        with torch.no_grad():
+            p_ = B.params
+            B.gops.render_view(p_["means"], p_["scales"], p_["quats"], p_["opacities"], p_["features_dc"], p_["features_rest"], B.cams[i],
+                               B.bg, False, 3, auxg)
+        Mg.append(int(auxg.M))
+    M = float(np.mean(Mg)) if Mg else M_proc
     N = args.gaussians
     per = {}
-    alias = {"gc_rasterize_bwd_clamped": "gc_rasterize_bwd", "gc_raster_finalize_into": "gc_raster_finalize"}     # same kernels, round-3 entry points
+    alias = {"gc_rasterize_bwd_clamped": "gc_rasterize_bwd", "gc_raster_finalize_into": "gc_raster_finalize",          # same kernels, round-3 entry points
+             "gc_project_sh_fwd_boxes": "gc_project_sh_fwd", "gc_raster_bin_tiles_boxes": "gc_raster_bin_tiles_dev"}
     for name, s, e in timer.rec:
         per.setdefault(alias.get(name, name), []).append(s.elapsed_time(e) * 1e-3)
     traffic = None
@@ -664,7 +679,9 @@ def raster_roofline(args, B, g, stats, HW):
             "avg_launch_us": d["avg_us"], "algorithmic_bytes_per_launch": d["algorithmic_MB"] * 1e6,
             "chain": {"algorithmic_MB_per_view": round(tot_b / 1e6, 1), "kernel_us_per_view": round(tot_s * 1e6, 1),
                       "GBps": round(tot_b / tot_s / 1e9, 1), "frac": round(tot_b / tot_s / 8e12, 4), "views_in_sample": nviews,
-                      "N": N, "M_mean": int(M), "traffic_ratio": traffic_ratio, "formula": "N*660 + M*124 + HW*44 bytes per view (SURVEY.md 8d with the SH record no longer re-read in the backward)"},
+                      "N": N, "M_mean": int(M), "M_processed_mean": int(M_proc),
+                      "frac_processed_pairs": round((tot_b - 124.0 * (M - M_proc)) / tot_s / 8e12, 4),
+                      "traffic_ratio": traffic_ratio, "formula": "N*660 + M*124 + HW*44 bytes per view (SURVEY.md 8d with the SH record no longer re-read in the backward); M = intersections of gsplat's boxes (the reference's lists), M_processed = pairs binned on the tight boxes"},
             "stages": stages}
 
 

@@ -293,6 +293,7 @@ __global__ __launch_bounds__(256) void k_gather_tiles(int64_t N, const uint32_t 
 constexpr int EW = 4096;
 __global__ __launch_bounds__(256) void k_emit_sorted(int64_t N, int64_t M_cap, const uint32_t *__restrict__ order,
                                                      const float *__restrict__ xys, const int32_t *__restrict__ radii,
+                                                     const uint32_t *__restrict__ tile_box /* packed boxes instead of (xys, radii), or NULL */,
                                                      const int32_t *__restrict__ cum_sorted, int tiles_x, int tiles_y,
                                                      uint32_t *__restrict__ tile_keys, uint32_t *__restrict__ gids,
                                                      unsigned dmask, int nblocks, int32_t *__restrict__ hist /* [digits][nblocks], zeroed */)
@@ -312,7 +313,17 @@ __global__ __launch_bounds__(256) void k_emit_sorted(int64_t N, int64_t M_cap, c
     int64_t lo = 0, hi = 0;                       // this Gaussian's output range
     if (j < N) {
         g = order[j];
-        const int r = radii[g];
+        if (tile_box) {            // tight boxes written by gc_project_sh_fwd_boxes (0 = no tile)
+            const uint32_t bx = tile_box[g];
+            minx = (int)(bx & 255u); miny = (int)((bx >> 16) & 255u);
+            w = (int)((bx >> 8) & 255u) - minx;
+            const int hgt = (int)(bx >> 24) - miny;
+            if (w > 0 && hgt > 0) {
+                lo = j == 0 ? 0 : cum_sorted[j - 1];
+                hi = lo + (int64_t)w * hgt;
+            } else w = 0;
+        }
+        const int r = tile_box ? 0 : radii[g];
         if (r > 0) {
             // same float expressions as the projection kernel / oracle (bit-exact tile box)
             const float tcx = xys[2 * (size_t)g] / (float)TILE, tcy = xys[2 * (size_t)g + 1] / (float)TILE, tr = (float)r / (float)TILE;
@@ -479,7 +490,8 @@ size_t gc_raster_bin_workspace_bytes(int64_t M) { return make_plan(M > 0 ? M : 1
 
 namespace {
 int bin_tiles_impl(int64_t N, int64_t M, const int32_t *m_dev, int32_t *overflow_dev, const int32_t *depth_order,
-                   const int32_t *cum_sorted, const float *xys, const float *depths, const int32_t *radii, int tiles_x, int tiles_y,
+                   const int32_t *cum_sorted, const float *xys, const float *depths, const int32_t *radii, const uint32_t *tile_boxes,
+                   int tiles_x, int tiles_y,
                    int32_t *gaussian_ids_sorted, int32_t *tile_bins, int64_t *isect_ids_sorted, void *workspace,
                    size_t workspace_bytes, void *stream, const char *what)
 {
@@ -489,7 +501,7 @@ int bin_tiles_impl(int64_t N, int64_t M, const int32_t *m_dev, int32_t *overflow
     if (overflow_dev && hipMemsetAsync(overflow_dev, 0, 4, s) != hipSuccess) return GC_ELAUNCH;
     if (M == 0 || N == 0) return GC_OK;
     if (num_tiles > 65536) { gc::set_error("%s: at most 65536 tiles", what); return GC_EINVAL; }
-    if (!(depth_order && cum_sorted && xys && depths && radii && gaussian_ids_sorted && workspace)) { gc::set_error("%s: null pointer", what); return GC_EINVAL; }
+    if (!(depth_order && cum_sorted && ((xys && radii) || tile_boxes) && depths && gaussian_ids_sorted && workspace)) { gc::set_error("%s: null pointer", what); return GC_EINVAL; }
     const Plan p = make_plan(M);
     if (workspace_bytes < p.total) { gc::set_error("%s: workspace too small", what); return GC_ENOSPC; }
     set_attr();
@@ -506,7 +518,7 @@ int bin_tiles_impl(int64_t N, int64_t M, const int32_t *m_dev, int32_t *overflow
     const bool fused_hist = dbits <= 6;          // the emission also counts the first pass's digits (64 LDS counters per 4096-block)
     if (fused_hist && hipMemsetAsync(w + p.off_hist, 0, sizeof(int32_t) * ((size_t)1 << dbits) * p.nb, s) != hipSuccess) return GC_ELAUNCH;
     hipLaunchKernelGGL(k_emit_sorted, dim3(gc::cdiv(N, 256)), dim3(256), 0, s, N, M, (const uint32_t *)depth_order, xys, radii,
-                       cum_sorted, tiles_x, tiles_y, k0, v0, fused_hist ? (1u << dbits) - 1u : 0u, fused_hist ? p.nb : 0,
+                       tile_boxes, cum_sorted, tiles_x, tiles_y, k0, v0, fused_hist ? (1u << dbits) - 1u : 0u, fused_hist ? p.nb : 0,
                        (int32_t *)(w + p.off_hist));
     uint32_t *ks = k0, *vs = v0;
     for (int pass = 0; pass < passes; ++pass) {
@@ -531,7 +543,7 @@ int gc_raster_bin_tiles(int64_t N, int64_t M, const int32_t *depth_order, const 
                         int32_t *tile_bins, int64_t *isect_ids_sorted, void *workspace, size_t workspace_bytes, void *stream)
 {
     GC_REQUIRE(N >= 0 && M >= 0 && tile_bins, "bad arguments");
-    return bin_tiles_impl(N, M, nullptr, nullptr, depth_order, cum_sorted, xys, depths, radii, tiles_x, tiles_y, gaussian_ids_sorted,
+    return bin_tiles_impl(N, M, nullptr, nullptr, depth_order, cum_sorted, xys, depths, radii, nullptr, tiles_x, tiles_y, gaussian_ids_sorted,
                           tile_bins, isect_ids_sorted, workspace, workspace_bytes, stream, "gc_raster_bin_tiles");
 }
 
@@ -545,8 +557,22 @@ int gc_raster_bin_tiles_dev(int64_t N, int64_t M_cap, const int32_t *count_dev, 
                             void *workspace, size_t workspace_bytes, void *stream)
 {
     GC_REQUIRE(N >= 0 && M_cap >= 0 && tile_bins && count_dev && overflow_dev, "bad arguments");
-    return bin_tiles_impl(N, M_cap, count_dev, overflow_dev, depth_order, cum_sorted, xys, depths, radii, tiles_x, tiles_y,
+    return bin_tiles_impl(N, M_cap, count_dev, overflow_dev, depth_order, cum_sorted, xys, depths, radii, nullptr, tiles_x, tiles_y,
                           gaussian_ids_sorted, tile_bins, isect_ids_sorted, workspace, workspace_bytes, stream, "gc_raster_bin_tiles_dev");
+}
+
+/* Phase 2 on the tight tile boxes of gc_project_sh_fwd_boxes (instead of the boxes recomputed from xys / radii).  count_dev == NULL:
+ * M is the exact intersection count (the form of gc_raster_bin_tiles); otherwise the sync-free form of gc_raster_bin_tiles_dev
+ * (M = capacity, overflow_dev required). */
+int gc_raster_bin_tiles_boxes(int64_t N, int64_t M, const int32_t *count_dev, int32_t *overflow_dev, const int32_t *depth_order,
+                              const int32_t *cum_sorted, const uint32_t *tile_boxes, const float *depths, int tiles_x, int tiles_y,
+                              int32_t *gaussian_ids_sorted, int32_t *tile_bins, int64_t *isect_ids_sorted, void *workspace,
+                              size_t workspace_bytes, void *stream)
+{
+    GC_REQUIRE(N >= 0 && M >= 0 && tile_bins && tile_boxes && ((count_dev == nullptr) == (overflow_dev == nullptr)), "bad arguments");
+    GC_REQUIRE(tiles_x <= 255 && tiles_y <= 255, "packed boxes hold at most 255 x 255 tiles");
+    return bin_tiles_impl(N, M, count_dev, overflow_dev, depth_order, cum_sorted, nullptr, depths, nullptr, tile_boxes, tiles_x, tiles_y,
+                          gaussian_ids_sorted, tile_bins, isect_ids_sorted, workspace, workspace_bytes, stream, "gc_raster_bin_tiles_boxes");
 }
 
 }  // extern "C"

@@ -224,7 +224,15 @@ def test_fused_render_view(oracle_c, N, W, H, fx, sm, training):
     # integer state: identical up to exp()/sqrt ulp differences in the fused front end
     mism = (aux.radii.cpu().numpy() != o["radii"]).mean()
     assert mism < 1e-4, mism
-    assert abs(aux.M - o["M"]) <= max(4, 1e-4 * o["M"])
+    # the product path bins on TIGHT tile boxes (RenderAux.tight_boxes, default on): fewer (tile, Gaussian) pairs than gsplat's lists ...
+    assert aux.tile_boxes is not None and aux.M <= o["M"] + 4
+    # ... and with gsplat's boxes the SAME image bit for bit, on lists of gsplat's length
+    auxg = ops.RenderAux(); auxg.tight_boxes = False
+    with torch.no_grad():
+        rgb_g, alpha_g, depth_g = ops.render_view(tp["means"], tp["scales"], tp["quats"], tp["opacities"], tp["features_dc"],
+                                                  tp["features_rest"], cam, _t(BG), not training, 3, auxg)
+    assert abs(auxg.M - o["M"]) <= max(4, 1e-4 * o["M"])
+    assert torch.equal(rgb_g, rgb.detach()) and torch.equal(alpha_g, alpha.detach()) and (training or torch.equal(depth_g, depth))
     if not training:
         d = depth.cpu().numpy(); od = o["depth"][..., 0]
         far = (od == 1000.0)
@@ -302,7 +310,8 @@ def _full_parity(oracle_c, P, c2w, K, training, seed=5):
     mse = float(((rgb.detach().cpu().numpy().astype(np.float64) - o["rgb"]) ** 2).mean())
     assert 10 * math.log10(1.0 / max(mse, 1e-20)) >= 45.0
     assert (aux.radii.cpu().numpy() != o["radii"]).mean() < 1e-4
-    assert abs(aux.M - o["M"]) <= max(4, 1e-4 * o["M"])
+    assert aux.M <= o["M"] + 4            # tight tile boxes: never more pairs than gsplat's box (the oracle's M)
+    print(f"tight tile boxes: M = {aux.M} of gsplat's {o['M']} ({aux.M / max(o['M'], 1):.3f})")
     if not training:
         d = depth.cpu().numpy(); od = o["depth"][..., 0]
         far = (od == 1000.0)
@@ -358,7 +367,8 @@ def test_config5_raster_4m(oracle_c):
                                             tp["features_rest"], cam, _t(BG), True, 3, aux)
         assert bool(torch.isfinite(rgb).all()) and float(alpha.min()) >= 0.0 and float(alpha.max()) <= 1.0
         nth = aux.num_tiles_hit
-        Mi, keys, ids, bins, cum = ops.bin_and_sort_gaussians(N, aux.xys, aux.depths, aux.radii, nth, tb, want_keys=True)
+        Mi, keys, ids, bins, cum = ops.bin_and_sort_gaussians(N, aux.xys, aux.depths, aux.radii, nth, tb, want_keys=True,
+                                                              tile_boxes=aux.tile_boxes)
         assert Mi == aux.M == int(nth.sum())
         k = keys.cpu().numpy()
         assert np.all(k[1:] >= k[:-1])                                    # tile-major, depth-minor order
@@ -374,6 +384,38 @@ def test_config5_raster_4m(oracle_c):
         # every intersection's Gaussian is visible and its depth is the key's low word
         dbits = aux.depths.cpu().numpy().view(np.int32)[idn[:: max(1, Mi // 100000)]]
         assert np.array_equal(dbits.astype(np.int64), (k[:: max(1, Mi // 100000)] & 0xFFFFFFFF))
+
+
+def test_tight_tile_boxes_same_images_and_gradients():
+    """Tight tile boxes (gc_project_sh_fwd_boxes / gc_raster_bin_tiles_boxes) vs gsplat's 3-sigma boxes on scenes that stress the box:
+    needles, giants, faint and sub-pixel Gaussians, opacities around the 1/255 threshold.  Images must be BIT-identical (a dropped tile
+    contains no pixel that passes the per-pixel test); gradients agree to the noise of the float atomics; the lists get shorter."""
+    from gaussctrl_amd import gsplat_ops as ops
+    from gaussctrl_amd.camera import camera_to_gsplat
+    W, H = 320, 240
+    for seed, sm in ((0, 0.02), (1, 0.08), (2, 0.004)):
+        P = syn.make_gaussians(60000, seed=seed, scale_mean=sm)
+        g = np.random.default_rng(seed)
+        P["scales"][::7, 0] += 2.0                              # needles
+        P["scales"][::11] += 1.5                                # giants
+        P["opacities"][::5] = g.normal(-5.0, 1.0, size=P["opacities"][::5].shape).astype(np.float32)    # around / below 1/255
+        P["opacities"][::13] = 8.0                              # opaque: the alpha >= 1/255 ellipse exceeds gsplat's 3-sigma box
+        cam = camera_to_gsplat(syn.make_cameras(2, seed=seed + 3)[1], 300.0, 290.0, 161.3, 118.2, W, H)
+        v = torch.randn(H, W, 3, generator=torch.Generator().manual_seed(seed)).to(DEV)
+        out = {}
+        for tight in (True, False):
+            tp = {k: _t(x).requires_grad_(True) for k, x in P.items()}
+            aux = ops.RenderAux(); aux.tight_boxes = tight
+            rgb, alpha, _ = ops.render_view(tp["means"], tp["scales"], tp["quats"], tp["opacities"], tp["features_dc"], tp["features_rest"],
+                                            cam, _t(BG), False, 3, aux)
+            ((rgb * v).sum() + alpha.sum()).backward()
+            out[tight] = (rgb.detach(), alpha.detach(), {k: t.grad.clone() for k, t in tp.items()}, aux.M)
+        assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
+        assert out[True][3] < out[False][3]
+        scale = max(float(t.abs().max()) for t in out[False][2].values())
+        for k in out[False][2]:
+            _grad_close(out[True][2][k].cpu().numpy(), out[False][2][k].cpu().numpy(), scale)
+        print(f"seed {seed}: M tight {out[True][3]} / gsplat {out[False][3]} = {out[True][3] / out[False][3]:.3f}")
 
 
 def test_sh_degree0_sigmoid_colour(oracle_c):
