@@ -15,7 +15,8 @@ namespace {
 
 constexpr int WIN = 11, HALF = 5;
 constexpr int TS = 16;   // output tile
-constexpr int NSLOT = 32;  // partial-sum slots of the two loss scalars
+constexpr int NSLOT = 32;  // partial-sum slots of the two loss scalars ...
+constexpr int SLOT_PITCH = 32;   // ... one 128-byte line each: atomics to one cache line serialise in its L2 channel whatever the address
 
 struct Gauss { float w[WIN]; };
 
@@ -92,8 +93,8 @@ __global__ __launch_bounds__(256) void k_ssim_stats(const float *__restrict__ x,
     __syncthreads();
     if (tid == 0) {
         const int slot = (int)((blockIdx.x + blockIdx.y * 5 + blockIdx.z * 11) & (NSLOT - 1));
-        unsafeAtomicAdd(ssim_sum + slot, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-        unsafeAtomicAdd(l1_sum + slot, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        unsafeAtomicAdd(ssim_sum + slot * SLOT_PITCH, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        unsafeAtomicAdd(l1_sum + slot * SLOT_PITCH, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
     }
 }
 
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) void k_ssim_grad(const float *__restrict__ x, 
                                                    float *__restrict__ v_x, const float *__restrict__ slots, float *__restrict__ loss_out)
 {
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 64) {      // fold the partial sums of k_ssim_stats
-        float v = slots[threadIdx.x];                  // [0, NSLOT): SSIM, [NSLOT, 2 NSLOT): L1
+        float v = slots[threadIdx.x * SLOT_PITCH];     // slots [0, NSLOT): SSIM, [NSLOT, 2 NSLOT): L1
 #pragma unroll
         for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
         if ((threadIdx.x & 31) == 0) loss_out[threadIdx.x >> 5] = v;
@@ -179,7 +180,7 @@ Gauss make_window()
 
 extern "C" {
 
-size_t gc_l1_ssim_workspace_bytes(int H, int W, int C) { return sizeof(float) * (3 * (size_t)H * W * C + 2 + 2 * NSLOT); }
+size_t gc_l1_ssim_workspace_bytes(int H, int W, int C) { return sizeof(float) * (3 * (size_t)H * W * C + 32 + 2 * NSLOT * SLOT_PITCH); }
 
 /* loss = (1-lambda)*mean|x-y| + lambda*(1 - mean SSIM(x,y)); pred x / target y: float32 [H,W,C] channels-last.
  * valid_window = 1: SSIM averaged over the (H-10) x (W-10) x C pixels with a full window (pytorch_msssim, splatfacto's loss);
@@ -194,13 +195,13 @@ int gc_l1_ssim_fwd_bwd(const float *pred, const float *target, int H, int W, int
     if (workspace_bytes < gc_l1_ssim_workspace_bytes(H, W, C)) { gc::set_error("gc_l1_ssim_fwd_bwd: workspace too small"); return GC_ENOSPC; }
     hipStream_t s = gc::S(stream);
     const size_t n = (size_t)H * W * C;
-    float *dmu = (float *)workspace, *dxx = dmu + n, *dxy = dxx + n, *slots = dxy + n + 2;
+    float *dmu = (float *)workspace, *dxx = dmu + n, *dxy = dxx + n, *slots = dxy + (n + 31) / 32 * 32;        // (the slot lines start on a 128-byte boundary of the float array)
     static_assert(2 * NSLOT == 64, "k_ssim_grad folds the slots with one wave");
-    if (hipMemsetAsync(slots, 0, 2 * NSLOT * sizeof(float), s) != hipSuccess) return GC_ELAUNCH;
+    if (hipMemsetAsync(slots, 0, 2 * NSLOT * SLOT_PITCH * sizeof(float), s) != hipSuccess) return GC_ELAUNCH;
     const Gauss gw = make_window();
     dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, C);
     const size_t n_ssim = valid_window ? (size_t)(H - 2 * HALF) * (W - 2 * HALF) * C : n;
-    hipLaunchKernelGGL(k_ssim_stats, grid, dim3(256), 0, s, pred, target, H, W, C, valid_window, gw, slots, dmu, dxx, dxy, slots + NSLOT);
+    hipLaunchKernelGGL(k_ssim_stats, grid, dim3(256), 0, s, pred, target, H, W, C, valid_window, gw, slots, dmu, dxx, dxy, slots + NSLOT * SLOT_PITCH);
     hipLaunchKernelGGL(k_ssim_grad, grid, dim3(256), 0, s, pred, target, H, W, C, gw, dmu, dxx, dxy, lambda_, 1.f / (float)n,
                        1.f / (float)n_ssim, grad_scale, v_pred, slots, loss_out);
     return gc::check_launch("gc_l1_ssim_fwd_bwd");

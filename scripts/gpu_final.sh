@@ -25,6 +25,9 @@ timeout 600 python bench.py --workload raster --gaussians 4000000 --steps 20 --w
 GC_BENCH_ONE_GPU=1 GC_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 14 --warmup 1 > $O/bench2_gloo.json 2> $O/bench2_gloo.err
 GC_BENCH_ONE_GPU=1 GC_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29514 bench.py --gpus 2 --steps 14 --warmup 1 --ref-mode replicate > $O/bench2_gloo_replicate.json 2> $O/bench2_gloo_replicate.err
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
+# HBM traffic of the rasterizer stages (PMC, calibrated), 1 M and 4 M Gaussians
+timeout 1200 python scripts/pmc_traffic.py 1000000 4 $O/raster_traffic_1m.json > $O/raster_traffic_1m.log 2>&1
+timeout 1500 python scripts/pmc_traffic.py 4000000 4 $O/raster_traffic_4m.json > $O/raster_traffic_4m.log 2>&1
 tail -3 $O/smoke.log
 python - <<'P'
 import json, glob
