@@ -181,6 +181,12 @@ def test_image2latent_and_pipeline_flow(oracle_c):
     assert all(np.isfinite(losses)) and not torch.equal(before, model.means.detach())
     with pytest.raises(NotImplementedError):
         pipe.forward()
+    # chunks in flight on independent streams (inflight_chunks, default 2) edit exactly what strictly serial chunks edit
+    two = [t["image"].clone() for t in td]
+    pipe.config.inflight_chunks = 1
+    pipe.edit_images()
+    assert all(torch.equal(a, t["image"]) for a, t in zip(two, td))
+    pipe.config.inflight_chunks = 2
     # round_like_reference: rgb / depth rounded to fp16 where the reference does it (gc_pipeline.py:132-133), disparity evaluated in fp16
     assert pipe.device == torch.device(DEV)
     pipe.config.round_like_reference = True
