@@ -385,6 +385,29 @@ def attention(q, k, vt, heads, sets, frames_per_half, Lk=None, kref=None, vtref=
     return o
 
 
+class TailDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("channels", C.c_int), ("heads", C.c_int), ("M", C.c_int64), ("rows_per_frame", C.c_int64),
+                ("frames_per_half", C.c_int), ("text_len", C.c_int), ("ln_eps", C.c_float), ("attn_out", C.c_void_p), ("resid", C.c_void_p),
+                ("x_in", C.c_void_p), ("out", C.c_void_p), ("w_a", C.c_void_p), ("w_kv", C.c_void_p), ("w_b", C.c_void_p),
+                ("params", C.c_void_p), ("stop_after", C.c_int)]
+
+
+def transformer_tail(attn_out, resid, x_in, seg_a, seg_kv, seg_b, params, heads, frames_per_half, text_len, eps=1e-5, stop_after=0):
+    """Everything of a level-0 transformer block after the self-attention, one launch (gc_dn_transformer_tail): attn_out / resid / x_in
+    [B, HW, 320]; seg_* / params from weights.tail_streams / weights.tail_text_stream."""
+    _gpu(attn_out, resid, x_in, seg_a, seg_kv, seg_b, params)
+    B, HW, Cc = attn_out.shape
+    assert attn_out.is_contiguous() and resid.is_contiguous() and x_in.is_contiguous()
+    out = torch.empty_like(attn_out)
+    d = TailDesc()
+    d.dtype = _dt(attn_out); d.channels = Cc; d.heads = heads; d.M = B * HW; d.rows_per_frame = HW
+    d.frames_per_half = frames_per_half; d.text_len = text_len; d.ln_eps = eps
+    d.attn_out = attn_out.data_ptr(); d.resid = resid.data_ptr(); d.x_in = x_in.data_ptr(); d.out = out.data_ptr()
+    d.w_a = seg_a.data_ptr(); d.w_kv = seg_kv.data_ptr(); d.w_b = seg_b.data_ptr(); d.params = params.data_ptr(); d.stop_after = stop_after
+    L.check(L.lib().gc_dn_transformer_tail(C.byref(d), _stream()), "gc_dn_transformer_tail")
+    return out
+
+
 def cfg_ddim_step(eps, latents, xin, guidance, cfg, alpha_t, alpha_prev, nrep):
     """eps fp32 [(2)f, H, W, ld]; latents fp32 [f,H,W,4] (in place); xin dtype [nrep*f,H,W,8] (rewritten)."""
     _gpu(eps, latents, xin)

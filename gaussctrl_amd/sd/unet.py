@@ -17,10 +17,12 @@ Differences from the reference's execution that do not change results:
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 
 from . import ops
+from . import weights as weights_mod
 
 CFG_SD15 = dict(block_out_channels=(320, 640, 1280, 1280), layers_per_block=2, heads=8, cross_dim=768,
                 groups=32, attn_levels=(True, True, True, False), n_cond_blocks=6)
@@ -109,6 +111,9 @@ class SDNet:
                                                                     # measured neutral (7.02 vs 6.97 views/s) and it gives up the shifted sums
         self.fp8 = bool(weights.get("_fp8_convs", False))           # resnet 3x3 convs on e4m3 operands (weights.add_fp8_convs)
         self.fp8_a_scale = 127                                      # E8M0 byte of the conv inputs (GroupNorm + SiLU outputs are O(1): 2^0)
+        # level-0 transformer blocks: everything after the self-attention in ONE launch (ops.transformer_tail, csrc/dn_ttail.hip).  Opt-in
+        # (GC_FUSED_TAIL=1): measured 197 vs 226 us per block alone, but the kernel owns its 192 CUs completely
+        self.fused_tail = os.environ.get("GC_FUSED_TAIL", "0") == "1"
         self._arenas = {}
         self.arena = None
 
@@ -232,6 +237,14 @@ class SDNet:
             actx.text_kv[key] = (k, vt, Lt)
         return actx.text_kv[key]
 
+    def _text_stream(self, p, ctx, actx: AttnCtx):
+        """the text K / V^T of attention layer `p` as MFMA operand blocks per CFG half (stream segment of the fused tail)"""
+        key = (actx.net, p, "stream")
+        if key not in actx.text_kv:
+            k, vt, Lt = self._text_kv(p, ctx, actx)
+            actx.text_kv[key] = weights_mod.tail_text_stream(k, vt, Lt, self.cfg["heads"])
+        return actx.text_kv[key]
+
     def transformer(self, p, x, xs, ctx, actx: AttnCtx):
         """Transformer2DModel on (x, xs) -> (out, channel sums of out).  With folded LayerNorms (weights.prepare(fold_ln=True)) the
         three LayerNorm launches disappear: each producer GEMM leaves the row sums of its output, the consumer GEMM (whose weights
@@ -247,6 +260,11 @@ class SDNet:
             o = self._self_attention(t + ".attn1", h, actx, ln=(rs, w[t + ".attn1.to_qkv.colsum"], 1e-5))
         else:
             o = self._self_attention(t + ".attn1", ops.layernorm(h, w[t + ".norm1.weight"], w[t + ".norm1.bias"]), actx)
+        if self.fused_tail and (p + ".tail.a") in w and not fold and not self.fuse_stats and (H * W_) % 128 == 0 and ctx.shape[1] <= 96:
+            kv = self._text_stream(t + ".attn2", ctx, actx)
+            out = ops.transformer_tail(o, h, x.view(B, H * W_, Cc), w[p + ".tail.a"], kv, w[p + ".tail.b"], w[p + ".tail.params"],
+                                       self.cfg["heads"], B // kv.shape[0], ctx.shape[1])
+            return out.view(B, H, W_, Cc), None
         rs = ops.RowStats() if fold else None
         h = ops.linear(o, w[t + ".attn1.to_out.0.weight"], w[t + ".attn1.to_out.0.bias"], residual=h, row_stats=rs)
         if fold:

@@ -43,6 +43,73 @@ def geglu_permute(w, b):
 
 LOG2E = 1.4426950408889634
 
+# ---- operand streams of the fused transformer tail (csrc/dn_ttail.hip) -------------------------------------------------------
+# One MFMA (v_mfma_f32_32x32x16) of a wave consumes one 1 KB block: lane l = 32 hg + row holds A[row][8 hg .. 8 hg + 8) of a 32 x 16
+# tile.  The k-values of a tile are stored in the order PERM16, so that k-slot 8 hg + t of lane (m, hg) is the channel the lane already
+# holds in register t (t < 4) / 4 + t of the previous GEMM's 32x32 accumulator (rows 8 g + 4 hg + c in register 4 g + c).
+PERM16 = [0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15]
+
+
+def mfma_blocks(w):
+    """w [R, K] (R % 32 == 0, K % 16 == 0) -> [K/16, R/32, 64 lanes, 8] operand blocks (k-step major)."""
+    R, K = w.shape
+    assert R % 32 == 0 and K % 16 == 0
+    t = w.reshape(R // 32, 32, K // 16, 16)[..., PERM16].reshape(R // 32, 32, K // 16, 2, 8)
+    return t.permute(2, 0, 3, 1, 4).contiguous().reshape(K // 16, R // 32, 64, 8)
+
+
+def lane_order(v):
+    """per-channel vector [N] (N % 32 == 0) -> the order lane (m, hg) reads it: index 32 nb + 16 hg + 4 g + c <-> channel 32 nb + 8 g + 4 hg + c"""
+    N = v.shape[0]
+    return v.reshape(N // 32, 4, 2, 4).permute(0, 2, 1, 3).contiguous().reshape(N)
+
+
+def tail_streams(out, sd_f32, p, heads, dtype):
+    """Stream segments A / B and the parameter table of transformer `p` (C = 320 only).  sd_f32(name) returns the fp32 master of a tensor
+    (softmax scale folded into attn2.to_q when the network was prepared with `heads`).  Rounded ONCE to `dtype`, like the per-op weights."""
+    t = p + ".transformer_blocks.0"
+    W = lambda n: sd_f32(n).to(dtype)
+    Cc = sd_f32(p + ".proj_out.weight").shape[0]
+    assert Cc == 320 and heads == 8
+    seg_a = torch.cat([mfma_blocks(W(t + ".attn1.to_out.0.weight")).reshape(-1), mfma_blocks(W(t + ".attn2.to_q.weight")).reshape(-1)])
+    up = W(t + ".ff.net.0.proj.weight")                      # [2 * 1280, 320] = [hidden | gate]
+    n = up.shape[0] // 2
+    # rows of up-block nb: [hidden 16 nb .. +8 | their gates | hidden 16 nb + 8 .. +8 | their gates]
+    idx = torch.arange(n, device=up.device).reshape(n // 16, 2, 8)
+    rows = torch.stack([idx, idx + n], dim=2).reshape(-1)     # [nb][half][hidden|gate][8]
+    upb = mfma_blocks(up[rows])                               # [20 ks][80 nb]
+    dnb = mfma_blocks(W(t + ".ff.net.2.weight"))              # [80 ks][10 nb]
+    nit = n // 64
+    upb = upb.reshape(20, nit, 4, 64, 8).permute(1, 0, 2, 3, 4)      # [it][ks][j]
+    dnb = dnb.reshape(nit, 4, 10, 64, 8)                               # [it][j][nb]
+    ffs = torch.cat([upb.reshape(nit, -1), dnb.reshape(nit, -1)], dim=1).reshape(-1)
+    po = W(p + ".proj_out.weight").reshape(Cc, Cc)
+    seg_b = torch.cat([mfma_blocks(W(t + ".attn2.to_out.0.weight")).reshape(-1), ffs, mfma_blocks(po).reshape(-1)])
+    f = lambda name: sd_f32(name).float()
+    params = torch.cat([lane_order(f(t + ".attn1.to_out.0.bias")), lane_order(f(t + ".norm2.weight")), lane_order(f(t + ".norm2.bias")),
+                        lane_order(f(t + ".attn2.to_out.0.bias")), lane_order(f(t + ".norm3.weight")), lane_order(f(t + ".norm3.bias")),
+                        lane_order(f(t + ".ff.net.2.bias")), lane_order(f(p + ".proj_out.bias")),
+                        lane_order(f(t + ".ff.net.0.proj.bias")[rows])])
+    out[p + ".tail.a"] = seg_a.contiguous(); out[p + ".tail.b"] = seg_b.contiguous(); out[p + ".tail.params"] = params.contiguous()
+
+
+def tail_text_stream(k, vt, Lt, heads):
+    """text K [halves, Lt, C] / V^T [halves, C, >= Lt] -> the per-half K / V^T segment of the tail stream: per head 9 K blocks
+    (k-step major over d padded 40 -> 48, 3 key blocks of 32) and 12 V^T blocks (key k-step major, 2 channel blocks; channel row 40 = ones,
+    so that the P V MFMAs also produce the softmax denominator)."""
+    Hh, _, Cc = k.shape
+    D = Cc // heads
+    segs = []
+    for hf in range(Hh):
+        for h in range(heads):
+            km = torch.zeros(96, 48, dtype=k.dtype, device=k.device)
+            km[:Lt, :D] = k[hf, :Lt, h * D:(h + 1) * D]
+            vm = torch.zeros(64, 96, dtype=k.dtype, device=k.device)
+            vm[:D, :Lt] = vt[hf, h * D:(h + 1) * D, :Lt]
+            vm[D, :Lt] = 1
+            segs += [mfma_blocks(km).reshape(-1), mfma_blocks(vm).reshape(-1)]
+    return torch.cat(segs).reshape(Hh, -1).contiguous()
+
 
 def prepare(sd: dict, dtype, device, heads=None, fold_ln=False) -> dict:
     """Generic pass over a diffusers state dict.  `heads` (attention heads of the network) folds the softmax scale
@@ -68,6 +135,13 @@ def prepare(sd: dict, dtype, device, heads=None, fold_ln=False) -> dict:
             out[k] = v.float().contiguous()       # norm affine, linear / 1x1 biases
     out["_attn_q_prescaled"] = bool(heads)
     out["_ln_folded"] = bool(fold_ln)
+    if heads == 8 and not fold_ln:                     # level-0 transformers (C = 320): operand streams of the one-launch tail (dn_ttail.hip)
+        def master(name):
+            v = sd[name].to(device).float()
+            return v * ((v.shape[0] // heads) ** -0.5 * LOG2E) if name.endswith(".attn2.to_q.weight") else v
+        for k in list(sd.keys()):
+            if k.endswith(".transformer_blocks.0.attn1.to_q.weight") and sd[k].shape[0] == 320:
+                tail_streams(out, master, k[:-len(".transformer_blocks.0.attn1.to_q.weight")], heads, dtype)
     for k in list(out.keys()):
         if k.endswith(".attn1.to_q.weight"):            # fused Q|K|V projection of the self-attention layers
             a = k[:-len("to_q.weight")]

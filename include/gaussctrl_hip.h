@@ -322,6 +322,32 @@ typedef struct gc_attn_desc {
 } gc_attn_desc;
 int gc_dn_attention(const gc_attn_desc *desc, void *stream);
 
+/* The tail of a level-0 transformer block (C = 320, 8 heads) in ONE launch: attn1.to_out + residual, LayerNorm, attn2 (text cross-
+ * attention: to_q, softmax over <= 96 text tokens, to_out + residual), LayerNorm, GEGLU feed-forward + residual, proj_out + the block's
+ * input.  Replaces nine launches of the per-op path (diffusers BasicTransformerBlock.forward / Transformer2DModel.forward behind the
+ * reference's gc_pipeline.py:224-227); rows stay in registers, the weights arrive as a host-prepared linear stream of 1 KB MFMA operand
+ * blocks (gaussctrl_amd/sd/weights.py::tail_streams documents the layout; gc_dn_transformer_tail_layout returns its sizes). */
+typedef struct gc_ttail_desc {
+    int dtype;
+    int channels, heads;             /* 320, 8 */
+    int64_t M;                       /* token rows = frames * rows_per_frame */
+    int64_t rows_per_frame;          /* % 128 == 0 */
+    int frames_per_half;             /* frame b reads the text K / V^T of CFG half b / frames_per_half (<= 2 halves) */
+    int text_len;                    /* valid text tokens (77), <= 96 */
+    float ln_eps;
+    const void *attn_out;            /* [M][320] output of the self-attention (before to_out) */
+    const void *resid;               /* [M][320] residual stream entering the block (proj_in output) */
+    const void *x_in;                /* [M][320] input of the Transformer2DModel (proj_out residual) */
+    void *out;                       /* [M][320] */
+    const void *w_a;                 /* stream segment A: attn1.to_out, attn2.to_q */
+    const void *w_kv;                /* [halves][blocks_kv KB] text K / V^T per CFG half */
+    const void *w_b;                 /* stream segment B: attn2.to_out, feed-forward, proj_out */
+    const float *params;             /* biases / LayerNorm affine in lane order */
+    int stop_after;                  /* 0; tests: 1..5 = `out` receives the intermediate after that stage */
+} gc_ttail_desc;
+int gc_dn_transformer_tail(const gc_ttail_desc *desc, void *stream);
+void gc_dn_transformer_tail_layout(int64_t *blocks_a, int64_t *blocks_kv, int64_t *blocks_b, int64_t *param_floats);
+
 /* GroupNorm(G groups, eps)(+SiLU) on [B][HW][C]; stats_ws: gc_dn_groupnorm_workspace_bytes(B, HW, C) bytes of scratch. */
 size_t gc_dn_groupnorm_workspace_bytes(int64_t B, int64_t HW, int C);
 int gc_dn_groupnorm(int dtype, const void *x, void *y, int64_t B, int64_t HW, int C, int G, const float *gamma,

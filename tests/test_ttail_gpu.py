@@ -1,0 +1,103 @@
+"""The one-launch transformer tail (gc_dn_transformer_tail, csrc/dn_ttail.hip) against (a) a plain PyTorch fp32 restatement of the same
+nine operations (diffusers BasicTransformerBlock.forward after attn1 + Transformer2DModel.proj_out: what the reference's UNet executes
+behind gaussctrl/gc_pipeline.py:224-227) and (b) the per-op HIP path it replaces; then through the UNet (GC_FUSED_TAIL)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+C, H, FFN, CTX = 320, 8, 1280, 768
+P = "tb"; T = P + ".transformer_blocks.0"
+
+
+def _sd(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    sd = {P + ".proj_in.weight": r(C, C, 1, 1, sc=C ** -0.5), P + ".proj_in.bias": r(C, sc=0.1),
+          P + ".proj_out.weight": r(C, C, 1, 1, sc=C ** -0.5), P + ".proj_out.bias": r(C, sc=0.1),
+          T + ".ff.net.0.proj.weight": r(2 * FFN, C, sc=C ** -0.5), T + ".ff.net.0.proj.bias": r(2 * FFN, sc=0.1),
+          T + ".ff.net.2.weight": r(C, FFN, sc=FFN ** -0.5), T + ".ff.net.2.bias": r(C, sc=0.1)}
+    for n in ("norm1", "norm2", "norm3"):
+        sd[T + f".{n}.weight"] = 1 + r(C, sc=0.1); sd[T + f".{n}.bias"] = r(C, sc=0.1)
+    for a, kin in (("attn1", C), ("attn2", CTX)):
+        sd[T + f".{a}.to_q.weight"] = r(C, C, sc=C ** -0.5 * 2)
+        sd[T + f".{a}.to_k.weight"] = r(C, kin, sc=kin ** -0.5 * 2); sd[T + f".{a}.to_v.weight"] = r(C, kin, sc=kin ** -0.5)
+        sd[T + f".{a}.to_out.0.weight"] = r(C, C, sc=C ** -0.5); sd[T + f".{a}.to_out.0.bias"] = r(C, sc=0.1)
+    return sd
+
+
+def _torch_tail(sd, o1, h, x, ctx, f):
+    """fp32, unfused, straight from the module definitions"""
+    F = torch.nn.functional
+    W = lambda n: sd[n].float().to(o1.device)
+    o1, h, x, ctx = o1.float(), h.float(), x.float(), ctx.float()
+    B, HW, _ = o1.shape
+    h1 = F.linear(o1, W(T + ".attn1.to_out.0.weight"), W(T + ".attn1.to_out.0.bias")) + h
+    n2 = F.layer_norm(h1, (C,), W(T + ".norm2.weight"), W(T + ".norm2.bias"), 1e-5)
+    q = F.linear(n2, W(T + ".attn2.to_q.weight")).view(B, HW, H, C // H).transpose(1, 2)
+    cx = ctx.repeat_interleave(f, 0)                                   # frame b reads the text of its CFG half
+    k = F.linear(cx, W(T + ".attn2.to_k.weight")).view(B, -1, H, C // H).transpose(1, 2)
+    v = F.linear(cx, W(T + ".attn2.to_v.weight")).view(B, -1, H, C // H).transpose(1, 2)
+    o = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(C // H), -1) @ v
+    h2 = F.linear(o.transpose(1, 2).reshape(B, HW, C), W(T + ".attn2.to_out.0.weight"), W(T + ".attn2.to_out.0.bias")) + h1
+    n3 = F.layer_norm(h2, (C,), W(T + ".norm3.weight"), W(T + ".norm3.bias"), 1e-5)
+    hid, gate = F.linear(n3, W(T + ".ff.net.0.proj.weight"), W(T + ".ff.net.0.proj.bias")).chunk(2, -1)
+    h3 = F.linear(hid * F.gelu(gate), W(T + ".ff.net.2.weight"), W(T + ".ff.net.2.bias")) + h2
+    return F.linear(h3, W(P + ".proj_out.weight").view(C, C), W(P + ".proj_out.bias")) + x
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,HW,f,Lt", [(2, 256, 1, 77), (4, 128, 2, 50), (6, 384, 3, 96)])
+def test_tail_matches_torch_and_the_per_op_path(dtype, B, HW, f, Lt):
+    from gaussctrl_amd.sd import ops, weights
+    dev = "cuda:0"
+    sd = _sd()
+    w = weights.prepare(sd, dtype, dev, heads=H)
+    g = torch.Generator().manual_seed(1)
+    o1, h, x = (torch.randn(B, HW, C, generator=g).to(dtype).to(dev) for _ in range(3))
+    ctx = torch.randn(B // f, Lt, CTX, generator=g).to(dtype).to(dev)
+    Lp = (Lt + 7) // 8 * 8
+    k = ops.linear(ctx, w[T + ".attn2.to_k.weight"])
+    vt = torch.zeros(B // f, C, Lp, dtype=dtype, device=dev)
+    ops.linear(ctx, w[T + ".attn2.to_v.weight"], want_out=False, rows_per_batch=Lt, out_t=vt, ldt=Lp, t_batch_stride=C * Lp)
+    kv = weights.tail_text_stream(k, vt, Lt, H)
+    got = ops.transformer_tail(o1, h, x, w[P + ".tail.a"], kv, w[P + ".tail.b"], w[P + ".tail.params"], H, f, Lt).float()
+    # (a) fp32 torch: the error is the 16-bit rounding of the intermediates (per-op path measured the same way below)
+    ref = _torch_tail(sd, o1, h, x, ctx, f)
+    # (b) the nine launches it replaces
+    h1 = ops.linear(o1, w[T + ".attn1.to_out.0.weight"], w[T + ".attn1.to_out.0.bias"], residual=h)
+    q = ops.linear(ops.layernorm(h1, w[T + ".norm2.weight"], w[T + ".norm2.bias"]), w[T + ".attn2.to_q.weight"])
+    o = ops.attention(q, k, vt, H, [(-2, 1.0)], f, Lk=Lt, q_prescaled=True)
+    h2 = ops.linear(o, w[T + ".attn2.to_out.0.weight"], w[T + ".attn2.to_out.0.bias"], residual=h1)
+    ff = ops.linear(ops.layernorm(h2, w[T + ".norm3.weight"], w[T + ".norm3.bias"]), w[T + ".ff.net.0.proj.weight"],
+                    w[T + ".ff.net.0.proj.bias"], geglu=True)
+    h3 = ops.linear(ff, w[T + ".ff.net.2.weight"], w[T + ".ff.net.2.bias"], residual=h2)
+    per_op = ops.linear(h3, w[P + ".proj_out.weight"], w[P + ".proj_out.bias"], residual=x).float()
+    scale = ref.abs().max()
+    e_fused, e_per_op = (got - ref).abs().max() / scale, (per_op - ref).abs().max() / scale
+    bar = 2e-2 if dtype == torch.bfloat16 else 3e-3            # of the output range: ~2.5 ulp of the 16-bit format at the largest value
+    assert e_fused < bar, (e_fused, e_per_op)
+    assert e_fused < 2 * e_per_op + 1e-3, (e_fused, e_per_op)  # no worse than the path it replaces
+    assert (got - per_op).abs().max() / scale < bar
+
+
+def test_unet_with_fused_tail_matches_per_op_unet():
+    """the whole UNet (random SD1.5-shaped weights, 2 frames = one per CFG half, 32x32 latents -> 1024 tokens at level 0) with the five
+    level-0 transformer tails fused vs per-op: same eps up to the 16-bit rounding of the intermediates"""
+    from gaussctrl_amd.sd import arch, unet as U, weights
+    dev = "cuda:0"
+    sd = arch.random_state_dict(arch.unet_shapes(), 0, dev)
+    w = weights.prepare(sd, torch.bfloat16, dev, heads=8)
+    assert "down_blocks.0.attentions.0.tail.a" in w and "down_blocks.1.attentions.0.tail.a" not in w       # C = 320 only
+    net = U.UNet(w)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 32, 32, 8, generator=g).to(torch.bfloat16).to(dev)
+    ctx = torch.randn(2, 77, 768, generator=g).to(torch.bfloat16).to(dev)
+    outs = []
+    for fused in (False, True):
+        net.fused_tail = fused
+        actx = U.AttnCtx("plain", 0.0, 1, {}, None, "unet")
+        outs.append(net.forward(x, 500.0, ctx, None, None, actx)[..., :4].float())
+    d = (outs[0] - outs[1]).abs().max() / outs[0].abs().max()
+    assert 0 < d < 3e-2, d                          # different kernels (not bit-equal), same function
