@@ -61,9 +61,7 @@ __global__ __launch_bounds__(256, 1) void k_ttail(const TailArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     float *prm = reinterpret_cast<float *>(smem + NSLOT * SLOT);
     const int m = lane & 31, hg = lane >> 5;
-    const float *prm_l = prm + 16 * hg;    // this lane's half of every 32-channel group: all table reads are base + immediate
     const int64_t row0 = (int64_t)blockIdx.x * 128;
-    const int64_t row = row0 + wid * 32 + m;
     const int half = (int)(row0 / a.rows_per_frame) / a.f;
     const unsigned char *wkv = a.wkv + (size_t)half * BLK_KV * 1024;
 
@@ -79,9 +77,9 @@ __global__ __launch_bounds__(256, 1) void k_ttail(const TailArgs a)
     const unsigned voff = lane * 16;
     auto issue = [&](int ring_slot, bool mid = false) {      // mid: inside segment B for sure (the feed-forward loop)
         const unsigned dst = lds0 + ring_slot * SLOT + 2 * wid * 1024;
-        if (!(ABL & 1)) {
-            glds16_s(isrc, voff, dst, ~0ull);
-            glds16_s(isrc + 1024, voff, dst + 1024, ~0ull);
+        if (!(ABL & 1)) {          // EXEC is all ones here: no mask juggling around the DMA (dn_attn_common.h's glds16_s writes EXEC twice per call)
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(isrc), "s"(dst) : "memory");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(isrc + 1024), "s"(dst + 1024) : "memory");
         }
         ++issue_slot;
         isrc += SLOT;
@@ -120,8 +118,19 @@ __global__ __launch_bounds__(256, 1) void k_ttail(const TailArgs a)
     for (int i = tid; i < P_TOTAL / 4; i += 256) reinterpret_cast<float4 *>(prm)[i] = reinterpret_cast<const float4 *>(a.params)[i];
 
     // ---------------- activations: uint4[KS] in lane order (word w of k-step ks = channels 16 ks + {4 hg + 2 w', 8 + 4 hg + 2 w'})
+    // Long-lived per-lane values (row pointers, table offsets) are recomputed where they are used: kept in a register across a stage
+    // they get spilled, and a scratch reload's s_waitcnt vmcnt(0) drains the whole DMA queue
+    auto fresh_lane = [&]() -> unsigned {
+        unsigned l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
+    };
+    auto row_off = [&]() -> int64_t {      // element offset of this lane's 4-channel group 0 in a [M][320] tensor
+        const unsigned l = fresh_lane();
+        return (row0 + wid * 32 + (l & 31)) * TC + 4 * (l >> 5);
+    };
     auto load_rows = [&](const unsigned short *p, uint4 *dst) {
-        const unsigned short *r = p + (row < a.M ? row : 0) * TC + 4 * hg;
+        const unsigned short *r = p + row_off();
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const uint2 lo = *reinterpret_cast<const uint2 *>(r + 16 * ks), hi = *reinterpret_cast<const uint2 *>(r + 16 * ks + 8);
@@ -129,8 +138,7 @@ __global__ __launch_bounds__(256, 1) void k_ttail(const TailArgs a)
         }
     };
     auto store_rows = [&](const uint4 *src) {
-        if (row >= a.M) return;
-        unsigned short *r = a.out + row * TC + 4 * hg;
+        unsigned short *r = a.out + row_off();
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             *reinterpret_cast<uint2 *>(r + 16 * ks) = make_uint2(src[ks].x, src[ks].y);
@@ -170,22 +178,30 @@ __global__ __launch_bounds__(256, 1) void k_ttail(const TailArgs a)
         epi(NB - 2);
         epi(NB - 1);
     };
-    // dst k-steps 2 nb, 2 nb + 1 = round(acc[nb] + bias + residual) in lane order
-    auto epi_block = [&](int pbias, uint4 r0, uint4 r1, uint4 *dst, int nb) {
-        float bv[16];
+    // acc = bias + residual (lane order): every residual connection enters as the accumulators' initial value -- fp32, added before the
+    // products like the per-op epilogue adds it after them, one rounding at the end -- so the epilogues only round, and no residual has
+    // to wait anywhere (parked in memory its reload would cost a vmcnt(0), i.e. a drained DMA queue)
+    auto init_acc = [&](int pbias, const uint4 *res) {
+        const float *prm_l = prm + 16 * (fresh_lane() >> 5);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4 *>(bv + 4 * q) = *reinterpret_cast<const float4 *>(prm_l + (pbias + 32 * nb + 4 * q));
+        for (int nb = 0; nb < NB; ++nb) {
+            float bv[16];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const uint4 rr = j ? r1 : r0;
-            const unsigned rw[4] = {rr.x, rr.y, rr.z, rr.w};
-            unsigned ow[4];
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<float4 *>(bv + 4 * q) = *reinterpret_cast<const float4 *>(prm_l + (pbias + 32 * nb + 4 * q));
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const int r = 8 * j + 2 * w;
-                ow[w] = pack2<T>(acc[nb][r] + bv[r] + lo_f(rw[w]), acc[nb][r + 1] + bv[r + 1] + hi_f(rw[w]));
+            for (int j = 0; j < 2; ++j) {
+                const uint4 rr = res[2 * nb + j];
+                unsigned rw[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                for (int w = 0; w < 4; ++w) asm volatile("" : "+v"(rw[w]));      // unpack here (not CSE'd with a LayerNorm pass 160 registers ago)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    acc[nb][8 * j + 2 * w] = bv[8 * j + 2 * w] + lo_f(rw[w]);
+                    acc[nb][8 * j + 2 * w + 1] = bv[8 * j + 2 * w + 1] + hi_f(rw[w]);
+                }
             }
-            dst[2 * nb + j] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+            asm volatile("" : "+a"(acc[nb]));          // into the AGPRs now (left to itself hipcc keeps VGPR copies and spills them)
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     auto frag_block = [&](uint4 *dst, int nb) {        // round the accumulators (no bias) into lane order
@@ -194,14 +210,9 @@ __global__ __launch_bounds__(256, 1) void k_ttail(const TailArgs a)
             dst[2 * nb + j] = make_uint4(pack2<T>(acc[nb][8 * j], acc[nb][8 * j + 1]), pack2<T>(acc[nb][8 * j + 2], acc[nb][8 * j + 3]),
                                          pack2<T>(acc[nb][8 * j + 4], acc[nb][8 * j + 5]), pack2<T>(acc[nb][8 * j + 6], acc[nb][8 * j + 7]));
     };
-    auto load_block = [&](const unsigned short *p, int nb, uint4 &r0, uint4 &r1) {     // k-steps 2 nb, 2 nb + 1 of this lane's row
-        const unsigned short *r = p + row * TC + 4 * hg + 32 * nb;
-        const uint2 a0 = *reinterpret_cast<const uint2 *>(r), a1 = *reinterpret_cast<const uint2 *>(r + 8);
-        const uint2 b0 = *reinterpret_cast<const uint2 *>(r + 16), b1 = *reinterpret_cast<const uint2 *>(r + 24);
-        r0 = make_uint4(a0.x, a0.y, a1.x, a1.y); r1 = make_uint4(b0.x, b0.y, b1.x, b1.y);
-    };
     // dst = round(LayerNorm(src) * gamma + beta); a row's 320 channels live in the lane pair (m, 0) / (m, 1)
     auto layernorm = [&](const uint4 *src, int pg, int pb, uint4 *dst) {
+        const float *prm_l = prm + 16 * (fresh_lane() >> 5);
         float s = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -246,15 +257,14 @@ __global__ __launch_bounds__(256, 1) void k_ttail(const TailArgs a)
     };
     // ---------------- 1: h1 = to_out1(o1) + h
     STAMP(0);
-    zero_acc();
-    gemm(G_O1, xf, [&](int nb) { epi_block(P_BO1, hres[2 * nb], hres[2 * nb + 1], hres, nb); });
+    init_acc(P_BO1, hres);
+    gemm(G_O1, xf, [&](int nb) { frag_block(hres, nb); });
     STAMP(1);
     STAMP(2);
     if constexpr (STOP == 1) { store_rows(hres); wait_vmcnt<0>(); return; }
 
     // ---------------- 2: q2 = to_q2(LN2(h1));  o2 = softmax(q2 Kt^T) Vt per head;  h2 = to_out2(o2) + h1
     layernorm(hres, P_G2, P_B2, xf);
-    store_rows(hres);                      // h1 waits in `out` (this lane's own bytes): attention needs the registers
     STAMP(3);
     uint4 qf[KS];                          // q2 (already scaled by D^-1/2 log2 e on the host), lane order
     zero_acc();
@@ -262,6 +272,15 @@ __global__ __launch_bounds__(256, 1) void k_ttail(const TailArgs a)
     STAMP(4);
     STAMP(5);
     if constexpr (STOP == 2) { store_rows(qf); wait_vmcnt<0>(); return; }
+    // h1 waits in 80 AGPRs while the attention needs the VGPRs (explicitly: hipcc would spill it to scratch instead)
+    unsigned park[4 * KS];
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+        asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(park[4 * i]) : "v"(hres[i].x));
+        asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(park[4 * i + 1]) : "v"(hres[i].y));
+        asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(park[4 * i + 2]) : "v"(hres[i].z));
+        asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(park[4 * i + 3]) : "v"(hres[i].w));
+    }
     {
         uint4 *of = xf;                    // LN2's output is dead: the attention output takes its registers
         // 8-channel group `grp` (channels 8 grp .. 8 grp + 7): this lane's 4 of them are 2 words of a lane-order array
@@ -330,9 +349,15 @@ __global__ __launch_bounds__(256, 1) void k_ttail(const TailArgs a)
         });
         if constexpr (STOP == 3) { store_rows(of); wait_vmcnt<0>(); return; }
         STAMP(6);
-        load_rows(a.out, hres);            // h1 back; lands under the GEMM
-        zero_acc();
-        gemm(G_O2, of, [&](int nb) { epi_block(P_BO2, hres[2 * nb], hres[2 * nb + 1], hres, nb); });
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(hres[i].x) : "a"(park[4 * i]));
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(hres[i].y) : "a"(park[4 * i + 1]));
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(hres[i].z) : "a"(park[4 * i + 2]));
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(hres[i].w) : "a"(park[4 * i + 3]));
+        }
+        init_acc(P_BO2, hres);
+        gemm(G_O2, of, [&](int nb) { frag_block(hres, nb); });
     }
     STAMP(7);
     if constexpr (STOP == 4) { store_rows(hres); wait_vmcnt<0>(); return; }
@@ -340,8 +365,7 @@ __global__ __launch_bounds__(256, 1) void k_ttail(const TailArgs a)
     // ---------------- 3: h3 = down(GEGLU(up(LN3(h2)))) + h2
     layernorm(hres, P_G3, P_B3, xf);
     STAMP(8);
-    store_rows(hres);                      // h2 waits in `out` (this lane's own bytes) while the feed-forward needs the registers
-    zero_acc();
+    init_acc(P_BDN, hres);                 // h2 + bias: the down projection accumulates on top of them
     // one iteration = 64 inner channels: 4 up-blocks (80 MFMAs), GEGLU, 4 k-steps of the down projection (40 MFMAs).  The last one is
     // peeled: h2 comes back from `out` while its MFMAs run, and the epilogue of every finished accumulator block runs in their shadow.
     auto ff_iter = [&](int it, auto last_c) {
@@ -381,33 +405,32 @@ __global__ __launch_bounds__(256, 1) void k_ttail(const TailArgs a)
             __builtin_amdgcn_sched_barrier(0);         // one block at a time (16 bias + 16 accumulator registers, not 128)
         }
         STAMP(12 + 3 * it);
-        if constexpr (LAST) load_rows(a.out, hres);    // h2 (LN3's output in xf is dead from here on: xf receives h3)
+        if constexpr (LAST) load_rows(a.x, xf);        // the block's input for proj_out's residual (LN3's output in xf is dead from here on)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 acc[nb] = mma(blk(G_FF, KS * 4 + j * NB + nb, !LAST), ff[j], acc[nb]);
                 if constexpr (LAST)
-                    if (j == 3 && nb >= 2) epi_block(P_BDN, hres[2 * (nb - 2)], hres[2 * (nb - 2) + 1], xf, nb - 2);
+                    if (j == 3 && nb >= 2) frag_block(hres, nb - 2);
             }
         if constexpr (LAST) {
-            epi_block(P_BDN, hres[2 * (NB - 2)], hres[2 * (NB - 2) + 1], xf, NB - 2);
-            epi_block(P_BDN, hres[2 * (NB - 1)], hres[2 * (NB - 1) + 1], xf, NB - 1);
+            frag_block(hres, NB - 2);
+            frag_block(hres, NB - 1);
         }
     };
 #pragma unroll 1
     for (int it = 0; it < FF_IT - 1; ++it) ff_iter(it, std::false_type{});
     ff_iter(FF_IT - 1, std::true_type{});
     STAMP(9);
-    if constexpr (STOP == 5) { store_rows(xf); wait_vmcnt<0>(); return; }
+    if constexpr (STOP == 5) { store_rows(hres); wait_vmcnt<0>(); return; }
 
     // ---------------- 4: out = proj_out(h3) + x
     STAMP(60);
-    load_rows(a.x, hres);
-    zero_acc();
-    gemm(G_PO, xf, [&](int nb) { epi_block(P_BPO, hres[2 * nb], hres[2 * nb + 1], hres, nb); });
+    init_acc(P_BPO, xf);
+    gemm(G_PO, hres, [&](int nb) { frag_block(xf, nb); });
     STAMP(61);
-    store_rows(hres);
+    store_rows(xf);
     STAMP(62);
 }
 
