@@ -10,6 +10,8 @@ unchanged (the reference loads them at /root/reference/gaussctrl/gc_pipeline.py:
 """
 from __future__ import annotations
 
+import math
+
 import torch
 
 
@@ -64,6 +66,16 @@ def lane_order(v):
     return v.reshape(N // 32, 4, 2, 4).permute(0, 2, 1, 3).contiguous().reshape(N)
 
 
+GELU_N, GELU_STEP = 2048, 128.0
+
+
+def gelu_table(device):
+    """(gelu(x_i), gelu(x_i+1) - gelu(x_i)) for x_i = (i - GELU_N / 2) / GELU_STEP, exact erf in float64: the fused tail interpolates it linearly"""
+    x = (torch.arange(GELU_N + 1, dtype=torch.float64) - GELU_N // 2) / GELU_STEP
+    g = 0.5 * x * (1 + torch.erf(x / math.sqrt(2.0)))
+    return torch.stack([g[:-1], g[1:] - g[:-1]], 1).reshape(-1).float().to(device)
+
+
 def tail_streams(out, sd_f32, p, heads, dtype):
     """Stream segments A / B and the parameter table of transformer `p` (C = 320 only).  sd_f32(name) returns the fp32 master of a tensor
     (softmax scale folded into attn2.to_q when the network was prepared with `heads`).  Rounded ONCE to `dtype`, like the per-op weights."""
@@ -89,7 +101,7 @@ def tail_streams(out, sd_f32, p, heads, dtype):
     params = torch.cat([lane_order(f(t + ".attn1.to_out.0.bias")), lane_order(f(t + ".norm2.weight")), lane_order(f(t + ".norm2.bias")),
                         lane_order(f(t + ".attn2.to_out.0.bias")), lane_order(f(t + ".norm3.weight")), lane_order(f(t + ".norm3.bias")),
                         lane_order(f(t + ".ff.net.2.bias")), lane_order(f(p + ".proj_out.bias")),
-                        lane_order(f(t + ".ff.net.0.proj.bias")[rows])])
+                        lane_order(f(t + ".ff.net.0.proj.bias")[rows]), gelu_table(sd_f32(p + ".proj_out.bias").device)])
     out[p + ".tail.a"] = seg_a.contiguous(); out[p + ".tail.b"] = seg_b.contiguous(); out[p + ".tail.params"] = params.contiguous()
 
 

@@ -92,7 +92,10 @@ def test_tail_stream_sizes_and_geglu_pairing():
     weights.tail_streams(out, lambda n: sd[n].float().reshape(sd[n].shape[0], -1).squeeze(-1) if sd[n].dim() == 4 else sd[n].float(), p, 8, torch.float32)
     assert out[p + ".tail.a"].numel() == 400 * 512 and out[p + ".tail.b"].numel() == 2800 * 512      # 1 KB blocks of 512 2-byte elements
     prm = out[p + ".tail.params"]
-    assert prm.numel() == 2560 + 2560
+    assert prm.numel() == 2560 + 2560 + 2 * weights.GELU_N
+    x = torch.tensor([-3.0, -0.5, 0.0, 0.75, 2.5])          # table entries at x * 128 + 1024
+    tab = prm[5120:].reshape(-1, 2)
+    assert torch.allclose(tab[(x * 128 + 1024).long(), 0], torch.nn.functional.gelu(x), atol=1e-6)
     # GEGLU bias, lane order of up-block 0: registers 0..3 / 8..11 hold hidden channels, 4..7 / 12..15 their gates (hidden + 1280)
     bup = prm[2560:2560 + 32].reshape(2, 16)
     for hg in range(2):
