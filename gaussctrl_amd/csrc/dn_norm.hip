@@ -589,6 +589,27 @@ int gc_dn_groupnorm(int dtype, const void *x, void *y, int64_t B, int64_t HW, in
     return gc::check_launch("gc_dn_groupnorm");
 }
 
+int gc_dn_groupnorm_coef(int dtype, const void *x, int64_t B, int64_t HW, int C, int G, const float *gamma, const float *beta, float eps,
+                         float *stats_ws, float *coef, void *stream)
+{
+    GC_REQUIRE(C % 8 == 0 && C % G == 0 && stats_ws && coef, "groupnorm_coef: C must be a multiple of 8 and of G; workspace and output required");
+    GC_REQUIRE(C / G <= 256 && B * HW * (C / 8) < (int64_t)1 << 31, "groupnorm_coef: group too wide / tensor too large");
+    hipStream_t s = gc::S(stream);
+    int nslab, ppb, ny, nchb;
+    gn_plan(B, HW, C, &nslab, &ppb, &ny, &nchb);
+    float *part = stats_ws;
+    const int lanes = 256 / nchb;
+    dim3 grid((unsigned)nslab, ny, (unsigned)B);
+    const size_t lds = sizeof(float) * 16 * (size_t)lanes * nchb;
+    DN_DISPATCH(dtype,
+                hipLaunchKernelGGL((k_gn_partial<BF16>), grid, dim3(256), lds, s, (const unsigned short *)x, (int)HW, C, nchb, ppb, part),
+                hipLaunchKernelGGL((k_gn_partial<F16>), grid, dim3(256), lds, s, (const unsigned short *)x, (int)HW, C, nchb, ppb, part));
+    DN_DISPATCH(dtype,
+                hipLaunchKernelGGL((k_gn_finalize<BF16>), dim3((unsigned)(B * G)), dim3(256), 0, s, (const unsigned short *)x, (int)HW, C, G, nslab, part, gamma, beta, eps, coef),
+                hipLaunchKernelGGL((k_gn_finalize<F16>), dim3((unsigned)(B * G)), dim3(256), 0, s, (const unsigned short *)x, (int)HW, C, G, nslab, part, gamma, beta, eps, coef));
+    return gc::check_launch("gc_dn_groupnorm_coef");
+}
+
 int gc_dn_groupnorm_apply(int dtype, const void *x, void *y, int64_t B, int64_t HW, int C, int G, const float *gamma,
                           const float *beta, float eps, int act, const float *group_stats, void *stream)
 {

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256, 1) void k_ttail(const TailArgs a)
     const unsigned char *isrc = a.wa + (size_t)wid * 2048;      // this wave's 2 KB of it
     const unsigned char *isrc_kv = wkv + (size_t)wid * 2048, *isrc_b = a.wb + (size_t)wid * 2048;
     const unsigned voff = lane * 16;
-    auto issue = [&](int ring_slot, bool mid = false) {      // mid: inside segment B for sure (the feed-forward loop)
+    auto issue = [&](int ring_slot, bool mid = false) __attribute__((always_inline)) {      // mid: inside segment B for sure (the feed-forward loop)
         const unsigned dst = lds0 + ring_slot * SLOT + 2 * wid * 1024;
         if (!(ABL & 1)) {          // EXEC is all ones here: no mask juggling around the DMA (dn_attn_common.h's glds16_s writes EXEC twice per call)
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(isrc), "s"(dst) : "memory");
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256, 1) void k_ttail(const TailArgs a)
     };
     uint4 pre[SLOT_BLK];
     const unsigned char *my = smem + lane * 16, *my_hi = my + 65536;       // two bases: every block offset fits the 16-bit immediate
-    auto fetch = [&](int g, bool mid = false) {        // g: stream index of the block to read (compile-time after unrolling, up to a ring revolution)
+    auto fetch = [&](int g, bool mid = false) __attribute__((always_inline)) {        // g: stream index of the block to read (compile-time after unrolling, up to a ring revolution)
         if ((g & (SLOT_BLK - 1)) == 0) {   // entering slot g / 8; mid: far from the end of the stream (the feed-forward loop)
             if (mid || issue_slot < NSLOTS_TOTAL) {
                 wait_vmcnt<2 * (NSLOT - 3)>();
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256, 1) void k_ttail(const TailArgs a)
         const int o = (g % RING_BLK) * 1024;
         if (!(ABL & 4) || g < SLOT_BLK) pre[g & (SLOT_BLK - 1)] = *reinterpret_cast<const uint4 *>(o < 65536 ? my + o : my_hi + (o - 65536));
     };
-    auto blk = [&](int base, int i, bool mid = false) -> uint4 {       // base: the stage's first block (a multiple of 8), i: block inside the stage
+    auto blk = [&](int base, int i, bool mid = false) __attribute__((always_inline)) -> uint4 {       // base: the stage's first block (a multiple of 8), i: block inside the stage
         const uint4 v = pre[i & (SLOT_BLK - 1)];
         if (base + i + SLOT_BLK < NSLOTS_TOTAL * SLOT_BLK) fetch(base + i + SLOT_BLK, mid);
         __builtin_amdgcn_sched_barrier(0);           // keep the look-ahead where it is: hipcc would sink every read next to its MFMA
@@ -125,16 +125,16 @@ __global__ __launch_bounds__(256, 1) void k_ttail(const TailArgs a)
     // ---------------- activations: uint4[KS] in lane order (word w of k-step ks = channels 16 ks + {4 hg + 2 w', 8 + 4 hg + 2 w'})
     // Long-lived per-lane values (row pointers, table offsets) are recomputed where they are used: kept in a register across a stage
     // they get spilled, and a scratch reload's s_waitcnt vmcnt(0) drains the whole DMA queue
-    auto fresh_lane = [&]() -> unsigned {
+    auto fresh_lane = [&]() __attribute__((always_inline)) -> unsigned {
         unsigned l;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
         return l;
     };
-    auto row_off = [&]() -> int64_t {      // element offset of this lane's 4-channel group 0 in a [M][320] tensor
+    auto row_off = [&]() __attribute__((always_inline)) -> int64_t {      // element offset of this lane's 4-channel group 0 in a [M][320] tensor
         const unsigned l = fresh_lane();
         return (row0 + wid * 32 + (l & 31)) * TC + 4 * (l >> 5);
     };
-    auto load_rows = [&](const unsigned short *p, uint4 *dst) {
+    auto load_rows = [&](const unsigned short *p, uint4 *dst) __attribute__((always_inline)) {
         const unsigned short *r = p + row_off();
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256, 1) void k_ttail(const TailArgs a)
             dst[ks] = make_uint4(lo.x, lo.y, hi.x, hi.y);
         }
     };
-    auto store_rows = [&](const uint4 *src) {
+    auto store_rows = [&](const uint4 *src) __attribute__((always_inline)) {
         unsigned short *r = a.out + row_off();
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -150,8 +150,8 @@ __global__ __launch_bounds__(256, 1) void k_ttail(const TailArgs a)
             *reinterpret_cast<uint2 *>(r + 16 * ks + 8) = make_uint2(src[ks].z, src[ks].w);
         }
     };
-    auto lo_f = [](unsigned w) { return T::to_f((unsigned short)(w & 0xffff)); };
-    auto hi_f = [](unsigned w) { return T::to_f((unsigned short)(w >> 16)); };
+    auto lo_f = [](unsigned w) __attribute__((always_inline)) { return T::to_f((unsigned short)(w & 0xffff)); };
+    auto hi_f = [](unsigned w) __attribute__((always_inline)) { return T::to_f((unsigned short)(w >> 16)); };
 
     uint4 xf[KS], hres[KS];
     f32x16 acc[NB];
@@ -159,11 +159,11 @@ __global__ __launch_bounds__(256, 1) void k_ttail(const TailArgs a)
     load_rows(a.h, hres);
     __syncthreads();                       // parameter table visible
 
-    auto mma = [&](uint4 wv, uint4 xv, f32x16 c) -> f32x16 {
+    auto mma = [&](uint4 wv, uint4 xv, f32x16 c) __attribute__((always_inline)) -> f32x16 {
         if (ABL & 8) { c[0] += __uint_as_float(wv.x ^ xv.x); return c; }
         return T::mfma32(wv, xv, c);
     };
-    auto zero_acc = [&]() {
+    auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256, 1) void k_ttail(const TailArgs a)
     // acc[nb] += W[32 nb ..][k] x[k], blocks in (ks, nb) order.  epi(nb) is called as soon as block nb is complete (two MFMAs later, so
     // that its result is out of the pipeline): the epilogue's VALU work runs in the shadow of the last MFMAs, and the accumulators are
     // read out of the AGPRs block by block (read all at once they would need 160 more registers than there are)
-    auto gemm = [&](int base, const uint4 *x, auto &&epi) {
+    auto gemm = [&](int base, const uint4 *x, auto &&epi) __attribute__((always_inline)) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256, 1) void k_ttail(const TailArgs a)
     // acc = bias + residual (lane order): every residual connection enters as the accumulators' initial value -- fp32, added before the
     // products like the per-op epilogue adds it after them, one rounding at the end -- so the epilogues only round, and no residual has
     // to wait anywhere (parked in memory its reload would cost a vmcnt(0), i.e. a drained DMA queue)
-    auto init_acc = [&](int pbias, const uint4 *res) {
+    auto init_acc = [&](int pbias, const uint4 *res) __attribute__((always_inline)) {
         const float *prm_l = prm + 16 * (fresh_lane() >> 5);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -209,14 +209,14 @@ __global__ __launch_bounds__(256, 1) void k_ttail(const TailArgs a)
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto frag_block = [&](uint4 *dst, int nb) {        // round the accumulators (no bias) into lane order
+    auto frag_block = [&](uint4 *dst, int nb) __attribute__((always_inline)) {        // round the accumulators (no bias) into lane order
 #pragma unroll
         for (int j = 0; j < 2; ++j)
             dst[2 * nb + j] = make_uint4(pack2<T>(acc[nb][8 * j], acc[nb][8 * j + 1]), pack2<T>(acc[nb][8 * j + 2], acc[nb][8 * j + 3]),
                                          pack2<T>(acc[nb][8 * j + 4], acc[nb][8 * j + 5]), pack2<T>(acc[nb][8 * j + 6], acc[nb][8 * j + 7]));
     };
     // dst = round(LayerNorm(src) * gamma + beta); a row's 320 channels live in the lane pair (m, 0) / (m, 1)
-    auto layernorm = [&](const uint4 *src, int pg, int pb, uint4 *dst) {
+    auto layernorm = [&](const uint4 *src, int pg, int pb, uint4 *dst) __attribute__((always_inline)) {
         const float *prm_l = prm + 16 * (fresh_lane() >> 5);
         float s = 0.f;
 #pragma unroll
@@ -289,11 +289,11 @@ __global__ __launch_bounds__(256, 1) void k_ttail(const TailArgs a)
     {
         uint4 *of = xf;                    // LN2's output is dead: the attention output takes its registers
         // 8-channel group `grp` (channels 8 grp .. 8 grp + 7): this lane's 4 of them are 2 words of a lane-order array
-        auto grp_get = [&](const uint4 *p, int grp, unsigned &w0, unsigned &w1) {
+        auto grp_get = [&](const uint4 *p, int grp, unsigned &w0, unsigned &w1) __attribute__((always_inline)) {
             const uint4 v = p[grp >> 1];
             if (grp & 1) { w0 = v.z; w1 = v.w; } else { w0 = v.x; w1 = v.y; }
         };
-        auto grp_set = [&](uint4 *p, int grp, unsigned w0, unsigned w1) {
+        auto grp_set = [&](uint4 *p, int grp, unsigned w0, unsigned w1) __attribute__((always_inline)) {
             if (grp & 1) { p[grp >> 1].z = w0; p[grp >> 1].w = w1; } else { p[grp >> 1].x = w0; p[grp >> 1].y = w1; }
         };
         static_for<0, TH>([&](auto hc) {
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256, 1) void k_ttail(const TailArgs a)
     init_acc(P_BDN, hres);                 // h2 + bias: the down projection accumulates on top of them
     // one iteration = 64 inner channels: 4 up-blocks (80 MFMAs), GEGLU, 4 k-steps of the down projection (40 MFMAs).  The last one is
     // peeled: h2 comes back from `out` while its MFMAs run, and the epilogue of every finished accumulator block runs in their shadow.
-    auto ff_iter = [&](int it, auto last_c) {
+    auto ff_iter = [&](int it, auto last_c) __attribute__((always_inline)) {
         constexpr bool LAST = decltype(last_c)::value;
         STAMP(10 + 3 * it);
         f32x16 up[4];

@@ -408,6 +408,45 @@ def transformer_tail(attn_out, resid, x_in, seg_a, seg_kv, seg_b, params, heads,
     return out
 
 
+class HeadDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("channels", C.c_int), ("M", C.c_int64), ("rows_per_frame", C.c_int64), ("ln_eps", C.c_float),
+                ("x", C.c_void_p), ("gn_coef", C.c_void_p), ("h", C.c_void_p), ("qk", C.c_void_p), ("vt", C.c_void_p), ("ldvt", C.c_int64),
+                ("vt_batch_stride", C.c_int64), ("w", C.c_void_p), ("params", C.c_void_p)]
+
+
+def groupnorm_coef(x, gamma, beta, groups, eps):
+    """x [B,HW,C] -> coef fp32 [B,C,2]: GroupNorm(x)[b,:,c] = x * coef[b,c,0] + coef[b,c,1] (the statistics passes of groupnorm only)"""
+    _gpu(x)
+    B, Cc = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * Cc)
+    key = (x.device, B, HW, Cc, torch.cuda.current_stream().cuda_stream)
+    ws = _gn_ws.get(key)
+    if ws is None:
+        nbytes = L.lib().gc_dn_groupnorm_workspace_bytes(C.c_int64(B), C.c_int64(HW), Cc)
+        ws = _gn_ws[key] = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    coef = torch.empty(B, Cc, 2, dtype=torch.float32, device=x.device)
+    L.check(L.lib().gc_dn_groupnorm_coef(_dt(x), _p(x), C.c_int64(B), C.c_int64(HW), Cc, groups, _p(gamma), _p(beta), C.c_float(eps),
+                                         _p(ws), _p(coef), _stream()), "gc_dn_groupnorm_coef")
+    return coef
+
+
+def transformer_head(x, coef, w_stream, params, eps=1e-5):
+    """GroupNorm apply + proj_in + LayerNorm1 + Q | K | V of a level-0 transformer block, one launch (gc_dn_transformer_head).
+    x [B, HW, 320], coef from groupnorm_coef -> (h [B,HW,320], qk [B,HW,640], vt [B,320,HW])"""
+    _gpu(x, coef, w_stream, params)
+    B, HW, Cc = x.shape
+    assert x.is_contiguous()
+    h = torch.empty_like(x)
+    qk = torch.empty(B, HW, 2 * Cc, dtype=x.dtype, device=x.device)
+    vt = torch.empty(B, Cc, HW, dtype=x.dtype, device=x.device)
+    d = HeadDesc()
+    d.dtype = _dt(x); d.channels = Cc; d.M = B * HW; d.rows_per_frame = HW; d.ln_eps = eps
+    d.x = x.data_ptr(); d.gn_coef = coef.data_ptr(); d.h = h.data_ptr(); d.qk = qk.data_ptr(); d.vt = vt.data_ptr()
+    d.ldvt = HW; d.vt_batch_stride = Cc * HW; d.w = w_stream.data_ptr(); d.params = params.data_ptr()
+    L.check(L.lib().gc_dn_transformer_head(C.byref(d), _stream()), "gc_dn_transformer_head")
+    return h, qk, vt
+
+
 def cfg_ddim_step(eps, latents, xin, guidance, cfg, alpha_t, alpha_prev, nrep):
     """eps fp32 [(2)f, H, W, ld]; latents fp32 [f,H,W,4] (in place); xin dtype [nrep*f,H,W,8] (rewritten)."""
     _gpu(eps, latents, xin)

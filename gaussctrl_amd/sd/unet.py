@@ -114,6 +114,8 @@ class SDNet:
         # level-0 transformer blocks: everything after the self-attention in ONE launch (ops.transformer_tail, csrc/dn_ttail.hip): 148 us
         # against 225 us for the nine per-op launches at 6 x 4096 tokens, +4.3 % views/s end to end.  GC_FUSED_TAIL=0: per-op.
         self.fused_tail = os.environ.get("GC_FUSED_TAIL", "1") == "1"
+        # the same for everything before the self-attention (GroupNorm apply, proj_in, LayerNorm1, Q | K | V: ops.transformer_head, csrc/dn_thead.hip)
+        self.fused_head = os.environ.get("GC_FUSED_HEAD", "1") == "1"
         self._arenas = {}
         self.arena = None
 
@@ -211,7 +213,12 @@ class SDNet:
         # one GEMM for Q | K | V: columns [0,2C) -> qk [B,L,2C], columns [2C,3C) -> V^T [B,C,Lp]
         qk = ops.linear(n, w[p + ".to_qkv.weight"], w.get(p + ".to_qkv.bias") if ln is not None else None, rows_per_batch=L, out_t=vt,
                         ldt=Lp, t_batch_stride=Cc * Lp, t_col0=2 * Cc, out_cols=2 * Cc, ln=ln)
-        q, k = qk[..., :Cc], qk[..., Cc:]
+        return self._attend(p, qk[..., :Cc], qk[..., Cc:], vt, actx)
+
+    def _attend(self, p, q, k, vt, actx: AttnCtx):
+        """the attention processor proper on projected Q / K / V^T (utils.py:60-117)"""
+        heads = self.cfg["heads"]
+        L = q.shape[1]
         if actx.mode == "plain":
             return ops.attention(q, k, vt, heads, [(-1, 1.0)], actx.f, Lk=L, q_prescaled=self.qpre)
         a = actx.coeff
@@ -251,15 +258,21 @@ class SDNet:
         carry gamma / beta) normalises in its epilogue -- 11 launches per block instead of 16."""
         w = self.w
         B, H, W_, Cc = x.shape
-        h = self.gn(x, xs, p + ".norm", 1e-6, False)
         t = p + ".transformer_blocks.0"
         fold = self.ln_folded
-        rs = ops.RowStats() if fold else None
-        h = ops.linear(h.view(B, H * W_, Cc), w[p + ".proj_in.weight"], w[p + ".proj_in.bias"], row_stats=rs)
-        if fold:
-            o = self._self_attention(t + ".attn1", h, actx, ln=(rs, w[t + ".attn1.to_qkv.colsum"], 1e-5))
+        if self.fused_head and (p + ".head.w") in w and not fold and xs is None and (H * W_) % 128 == 0:
+            x3 = x.view(B, H * W_, Cc)
+            coef = ops.groupnorm_coef(x3, w[p + ".norm.weight"], w[p + ".norm.bias"], self.cfg["groups"], 1e-6)
+            h, qk, vt = ops.transformer_head(x3, coef, w[p + ".head.w"], w[p + ".head.params"])
+            o = self._attend(t + ".attn1", qk[..., :Cc], qk[..., Cc:], vt, actx)
         else:
-            o = self._self_attention(t + ".attn1", ops.layernorm(h, w[t + ".norm1.weight"], w[t + ".norm1.bias"]), actx)
+            h = self.gn(x, xs, p + ".norm", 1e-6, False)
+            rs = ops.RowStats() if fold else None
+            h = ops.linear(h.view(B, H * W_, Cc), w[p + ".proj_in.weight"], w[p + ".proj_in.bias"], row_stats=rs)
+            if fold:
+                o = self._self_attention(t + ".attn1", h, actx, ln=(rs, w[t + ".attn1.to_qkv.colsum"], 1e-5))
+            else:
+                o = self._self_attention(t + ".attn1", ops.layernorm(h, w[t + ".norm1.weight"], w[t + ".norm1.bias"]), actx)
         if self.fused_tail and (p + ".tail.a") in w and not fold and not self.fuse_stats and (H * W_) % 128 == 0 and ctx.shape[1] <= 96:
             kv = self._text_stream(t + ".attn2", ctx, actx)
             out = ops.transformer_tail(o, h, x.view(B, H * W_, Cc), w[p + ".tail.a"], kv, w[p + ".tail.b"], w[p + ".tail.params"],

@@ -105,6 +105,19 @@ def tail_streams(out, sd_f32, p, heads, dtype):
     out[p + ".tail.a"] = seg_a.contiguous(); out[p + ".tail.b"] = seg_b.contiguous(); out[p + ".tail.params"] = params.contiguous()
 
 
+def head_stream(out, sd_f32, p, heads, dtype):
+    """Operand stream and parameter table of the fused head of transformer `p` (csrc/dn_thead.hip): proj_in, attn1.to_q (softmax scale
+    folded in), to_k, to_v as MFMA blocks; proj_in bias and LayerNorm1 affine in lane order."""
+    t = p + ".transformer_blocks.0"
+    W = lambda n: sd_f32(n).to(dtype)
+    Cc = sd_f32(p + ".proj_in.weight").shape[0]
+    assert Cc == 320
+    out[p + ".head.w"] = torch.cat([mfma_blocks(W(p + ".proj_in.weight").reshape(Cc, Cc)).reshape(-1), mfma_blocks(W(t + ".attn1.to_q.weight")).reshape(-1),
+                                    mfma_blocks(W(t + ".attn1.to_k.weight")).reshape(-1), mfma_blocks(W(t + ".attn1.to_v.weight")).reshape(-1)]).contiguous()
+    f = lambda name: sd_f32(name).float()
+    out[p + ".head.params"] = torch.cat([lane_order(f(p + ".proj_in.bias")), lane_order(f(t + ".norm1.weight")), lane_order(f(t + ".norm1.bias"))]).contiguous()
+
+
 def tail_text_stream(k, vt, Lt, heads):
     """text K [halves, Lt, C] / V^T [halves, C, >= Lt] -> the per-half K / V^T segment of the tail stream: per head 9 K blocks
     (k-step major over d padded 40 -> 48, 3 key blocks of 32) and 12 V^T blocks (key k-step major, 2 channel blocks; channel row 40 = ones,
@@ -150,10 +163,12 @@ def prepare(sd: dict, dtype, device, heads=None, fold_ln=False) -> dict:
     if heads == 8 and not fold_ln:                     # level-0 transformers (C = 320): operand streams of the one-launch tail (dn_ttail.hip)
         def master(name):
             v = sd[name].to(device).float()
-            return v * ((v.shape[0] // heads) ** -0.5 * LOG2E) if name.endswith(".attn2.to_q.weight") else v
+            return v * ((v.shape[0] // heads) ** -0.5 * LOG2E) if name.endswith((".attn1.to_q.weight", ".attn2.to_q.weight")) else v
         for k in list(sd.keys()):
             if k.endswith(".transformer_blocks.0.attn1.to_q.weight") and sd[k].shape[0] == 320:
                 tail_streams(out, master, k[:-len(".transformer_blocks.0.attn1.to_q.weight")], heads, dtype)
+                if not any(kk.endswith("attn1.to_q.bias") for kk in sd):            # SD1.5: no bias on the attention projections
+                    head_stream(out, master, k[:-len(".transformer_blocks.0.attn1.to_q.weight")], heads, dtype)
     for k in list(out.keys()):
         if k.endswith(".attn1.to_q.weight"):            # fused Q|K|V projection of the self-attention layers
             a = k[:-len("to_q.weight")]

@@ -348,10 +348,34 @@ typedef struct gc_ttail_desc {
 int gc_dn_transformer_tail(const gc_ttail_desc *desc, void *stream);
 void gc_dn_transformer_tail_layout(int64_t *blocks_a, int64_t *blocks_kv, int64_t *blocks_b, int64_t *param_floats);
 
+/* The head of a level-0 transformer block (C = 320) in ONE launch: GroupNorm apply (coefficients from gc_dn_groupnorm_coef), proj_in,
+ * LayerNorm1 and the attn1 Q / K / V projections (Transformer2DModel.forward + BasicTransformerBlock.forward up to the attention
+ * processor call, behind the reference's gc_pipeline.py:224-227).  Rows stay in registers as in gc_dn_transformer_tail; the weights are one
+ * operand stream (gaussctrl_amd/sd/weights.py::head_stream). */
+typedef struct gc_thead_desc {
+    int dtype;
+    int channels;                    /* 320 */
+    int64_t M;                       /* token rows = frames * rows_per_frame */
+    int64_t rows_per_frame;          /* % 128 == 0 */
+    float ln_eps;
+    const void *x;                   /* [M][320] input of the Transformer2DModel (before its GroupNorm) */
+    const float *gn_coef;            /* [frames][320][2] */
+    void *h;                         /* [M][320] proj_in output (the block's residual stream) */
+    void *qk;                        /* [M][640] = Q | K (Q scaled on the host as for gc_attn_desc.q_prescaled) */
+    void *vt;                        /* [frames][320][ldvt] V transposed, token-contiguous */
+    int64_t ldvt, vt_batch_stride;
+    const void *w;                   /* operand stream: proj_in, to_q, to_k, to_v */
+    const float *params;             /* proj_in bias, LayerNorm1 gamma / beta in lane order */
+} gc_thead_desc;
+int gc_dn_transformer_head(const gc_thead_desc *desc, void *stream);
+
 /* GroupNorm(G groups, eps)(+SiLU) on [B][HW][C]; stats_ws: gc_dn_groupnorm_workspace_bytes(B, HW, C) bytes of scratch. */
 size_t gc_dn_groupnorm_workspace_bytes(int64_t B, int64_t HW, int C);
 int gc_dn_groupnorm(int dtype, const void *x, void *y, int64_t B, int64_t HW, int C, int G, const float *gamma,
                     const float *beta, float eps, int act, float *stats_ws, void *stream);
+/* The first two passes of gc_dn_groupnorm only: coef[B][C][2] = (a, d) with GroupNorm(x)[b, :, c] = x * a + d.  Input of gc_dn_transformer_head. */
+int gc_dn_groupnorm_coef(int dtype, const void *x, int64_t B, int64_t HW, int C, int G, const float *gamma, const float *beta, float eps,
+                         float *stats_ws, float *coef, void *stream);
 /* GroupNorm(+SiLU) from producer-side statistics: group_stats[B][G][2] = per (batch, group) (sum, sum of squares) over the HW pixels and
  * the C / G channels of the group, accumulated by the kernel that wrote x (gc_gemm_desc.out_group_stats, gc_dn_concat_add).
  * One launch instead of three. */

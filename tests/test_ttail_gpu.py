@@ -83,8 +83,8 @@ def test_tail_matches_torch_and_the_per_op_path(dtype, B, HW, f, Lt):
 
 
 def test_unet_with_fused_tail_matches_per_op_unet():
-    """the whole UNet (random SD1.5-shaped weights, 2 frames = one per CFG half, 32x32 latents -> 1024 tokens at level 0) with the five
-    level-0 transformer tails fused vs per-op: same eps up to the 16-bit rounding of the intermediates"""
+    """the whole UNet (random SD1.5-shaped weights, 2 frames = one per CFG half, 32x32 latents -> 1024 tokens at level 0) with the heads and tails of the five
+    level-0 transformer blocks fused vs per-op: same eps up to the 16-bit rounding of the intermediates"""
     from gaussctrl_amd.sd import arch, unet as U, weights
     dev = "cuda:0"
     sd = arch.random_state_dict(arch.unet_shapes(), 0, dev)
@@ -96,8 +96,43 @@ def test_unet_with_fused_tail_matches_per_op_unet():
     ctx = torch.randn(2, 77, 768, generator=g).to(torch.bfloat16).to(dev)
     outs = []
     for fused in (False, True):
-        net.fused_tail = fused
+        net.fused_tail = net.fused_head = fused
         actx = U.AttnCtx("plain", 0.0, 1, {}, None, "unet")
         outs.append(net.forward(x, 500.0, ctx, None, None, actx)[..., :4].float())
     d = (outs[0] - outs[1]).abs().max() / outs[0].abs().max()
     assert 0 < d < 3e-2, d                          # different kernels (not bit-equal), same function
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,HW", [(2, 256), (3, 1024)])
+def test_head_matches_torch_and_the_per_op_path(dtype, B, HW):
+    """gc_dn_transformer_head (GroupNorm apply, proj_in, LayerNorm1, Q | K | V^T) vs fp32 torch and vs the four launches it replaces"""
+    from gaussctrl_amd.sd import ops, weights
+    F = torch.nn.functional
+    dev = "cuda:0"
+    sd = _sd()
+    sd[P + ".norm.weight"] = 1 + 0.1 * torch.randn(C, generator=torch.Generator().manual_seed(5)); sd[P + ".norm.bias"] = 0.1 * torch.randn(C, generator=torch.Generator().manual_seed(6))
+    w = weights.prepare(sd, dtype, dev, heads=H)
+    assert P + ".head.w" in w
+    g = torch.Generator().manual_seed(2)
+    x = (torch.randn(B, HW, C, generator=g) * 1.5 + 0.3).to(dtype).to(dev)
+    coef = ops.groupnorm_coef(x, w[P + ".norm.weight"], w[P + ".norm.bias"], 32, 1e-6)
+    h, qk, vt = ops.transformer_head(x, coef, w[P + ".head.w"], w[P + ".head.params"])
+    # per-op path
+    xn = ops.groupnorm(x, w[P + ".norm.weight"], w[P + ".norm.bias"], 32, 1e-6, False)
+    h_ref = ops.linear(xn, w[P + ".proj_in.weight"], w[P + ".proj_in.bias"])
+    n1 = ops.layernorm(h_ref, w[T + ".norm1.weight"], w[T + ".norm1.bias"])
+    vt_ref = torch.empty(B, C, HW, dtype=dtype, device=dev)
+    qk_ref = ops.linear(n1, w[T + ".attn1.to_qkv.weight"], None, rows_per_batch=HW, out_t=vt_ref, ldt=HW, t_batch_stride=C * HW, t_col0=2 * C, out_cols=2 * C)
+    # fp32 torch (Q carries the folded softmax scale: D^-1/2 log2 e)
+    W = lambda n: sd[n].float().to(dev)
+    xt = F.group_norm(x.float().transpose(1, 2), 32, W(P + ".norm.weight"), W(P + ".norm.bias"), 1e-6).transpose(1, 2)
+    ht = F.linear(xt, W(P + ".proj_in.weight").view(C, C), W(P + ".proj_in.bias"))
+    nt = F.layer_norm(ht, (C,), W(T + ".norm1.weight"), W(T + ".norm1.bias"), 1e-5)
+    qt = F.linear(nt, W(T + ".attn1.to_q.weight")) * ((C // H) ** -0.5 * 1.4426950408889634)
+    kt = F.linear(nt, W(T + ".attn1.to_k.weight")); vtt = F.linear(nt, W(T + ".attn1.to_v.weight")).transpose(1, 2)
+    bar = 2e-2 if dtype == torch.bfloat16 else 3e-3
+    for name, got, ref, tt in (("h", h, h_ref, ht), ("q", qk[..., :C], qk_ref[..., :C], qt), ("k", qk[..., C:], qk_ref[..., C:], kt), ("vt", vt, vt_ref, vtt)):
+        sc = tt.abs().max()
+        e_f, e_p = (got.float() - tt).abs().max() / sc, (ref.float() - tt).abs().max() / sc
+        assert e_f < bar and e_f < 2 * e_p + 1e-3, (name, float(e_f), float(e_p))
