@@ -16,6 +16,7 @@ namespace {
 
 constexpr int TC = 320, NB = TC / 32, KS = TC / 16;
 constexpr int SLOT_BLK = 8, SLOT = SLOT_BLK * 1024, NSLOT = 15, RING_BLK = NSLOT * SLOT_BLK;
+static_assert(NSLOT == 15 && KS * NB == 200, "the store windows in fetch() are written for 13 slots in flight and 200-block GEMMs");
 constexpr int G_IN = 0, G_Q = KS * NB, G_K = 2 * KS * NB, G_V = 3 * KS * NB, BLK_TOTAL = 4 * KS * NB, NSLOTS_TOTAL = BLK_TOTAL / SLOT_BLK;
 // parameter table (floats): bias of proj_in, LayerNorm1 gamma / beta in lane order (dn_ttail.hip), then this image's GroupNorm coefficients
 // (a, d) per channel in natural order
@@ -28,7 +29,7 @@ struct HeadArgs {
     unsigned short *h, *qk, *vt;           // [M][320], [M][640] = Q | K, [B][320][ldvt]
     const unsigned char *w;                // operand stream: proj_in, to_q, to_k, to_v (BLK_TOTAL KB)
     const float *params;                   // [P_TABLE]
-    int M, rows_per_frame;
+    int M, rows_per_frame, h_frags;
     int64_t ldvt, vt_bs;
     float eps;
 };
@@ -61,15 +62,16 @@ __global__ __launch_bounds__(256, 1) void k_thead(const HeadArgs a)
         ++issue_slot;
         isrc += SLOT;
     };
-    uint4 pre0, pre1, pre2, pre3, pre4, pre5, pre6, pre7;      // (as an array hipcc left the look-ahead in scratch memory in this kernel)
-    auto PRE = [&](int i) __attribute__((always_inline)) -> uint4 & {
-        switch (i & 7) { case 0: return pre0; case 1: return pre1; case 2: return pre2; case 3: return pre3; case 4: return pre4; case 5: return pre5; case 6: return pre6; default: return pre7; }
-    };
+    uint4 pre[SLOT_BLK];
     const unsigned char *my = smem + lane * 16, *my_hi = my + 65536;       // two bases: every block offset fits the 16-bit immediate
     auto fetch = [&](int g) __attribute__((always_inline)) {
         if ((g & (SLOT_BLK - 1)) == 0) {
             if (issue_slot < NSLOTS_TOTAL) {
-                wait_vmcnt<2 * (NSLOT - 3)>();
+                // vmcnt retires in order and counts stores too: the 20 row stores after a GEMM are YOUNGER than the DMA of the next 13 slots
+                // to be entered, so those waits may leave them outstanding (else 20 stores + 4 DMAs fill the allowance: the stream starves)
+                const int s = g / SLOT_BLK;
+                const bool after_store = (s >= 26 && s <= 38) || (s >= 51 && s <= 63) || (s >= 76 && s <= 88);
+                if (after_store) wait_vmcnt<2 * (NSLOT - 3) + KS>(); else wait_vmcnt<2 * (NSLOT - 3)>();
                 __builtin_amdgcn_s_barrier();
                 issue((g / SLOT_BLK + NSLOT - 2) % NSLOT);
             } else {
@@ -78,10 +80,10 @@ __global__ __launch_bounds__(256, 1) void k_thead(const HeadArgs a)
             }
         }
         const int o = (g % RING_BLK) * 1024;
-        PRE(g) = *reinterpret_cast<const uint4 *>(o < 65536 ? my + o : my_hi + (o - 65536));
+        pre[g & (SLOT_BLK - 1)] = *reinterpret_cast<const uint4 *>(o < 65536 ? my + o : my_hi + (o - 65536));
     };
     auto blk = [&](int base, int i) __attribute__((always_inline)) -> uint4 {
-        const uint4 v = PRE(i);
+        const uint4 v = pre[i & (SLOT_BLK - 1)];
         if (base + i + SLOT_BLK < BLK_TOTAL) fetch(base + i + SLOT_BLK);
         __builtin_amdgcn_sched_barrier(0);
         return v;
@@ -103,16 +105,26 @@ __global__ __launch_bounds__(256, 1) void k_thead(const HeadArgs a)
     auto lo_f = [](unsigned w) __attribute__((always_inline)) { return T::to_f((unsigned short)(w & 0xffff)); };
     auto hi_f = [](unsigned w) __attribute__((always_inline)) { return T::to_f((unsigned short)(w >> 16)); };
     // rows in lane order (dn_ttail.hip): word w of k-step ks = channels 16 ks + {4 hg + 2 w', 8 + 4 hg + 2 w'}
+    // one 16-byte store per k-step: the lane pair (m, 0) / (m, 1) first trades halves, so that hg = 0 owns channels 16 ks .. + 7 and hg = 1
+    // channels 16 ks + 8 .. + 15 (stores are issue-bound here: 20 dwordx4 cost half of 40 dwordx2)
     auto store_rows = [&](const uint4 *src, unsigned short *p, int ld) __attribute__((always_inline)) {
         const unsigned l = fresh_lane();
-        unsigned short *r = p + (row0 + wid * 32 + (l & 31)) * ld + 4 * (l >> 5);
+        const bool up = (l >> 5) != 0;
+        unsigned short *r = p + (row0 + wid * 32 + (l & 31)) * ld + 8 * (l >> 5);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            *reinterpret_cast<uint2 *>(r + 16 * ks) = make_uint2(src[ks].x, src[ks].y);
-            *reinterpret_cast<uint2 *>(r + 16 * ks + 8) = make_uint2(src[ks].z, src[ks].w);
+            const unsigned s0 = up ? src[ks].x : src[ks].z, s1 = up ? src[ks].y : src[ks].w;      // what the partner is missing
+            const unsigned r0 = __shfl_xor(s0, 32, 64), r1 = __shfl_xor(s1, 32, 64);
+            *reinterpret_cast<uint4 *>(r + 16 * ks) = up ? make_uint4(r0, r1, src[ks].z, src[ks].w) : make_uint4(src[ks].x, src[ks].y, r0, r1);
         }
     };
-
+    // the residual stream h goes to the tail kernel only: stored as the fragments themselves ([32-row block][k-step][lane][16 bytes]),
+    // 1 KB contiguous per store instruction
+    auto store_frags = [&](const uint4 *src, unsigned short *p) __attribute__((always_inline)) {
+        uint4 *r = reinterpret_cast<uint4 *>(p) + ((row0 >> 5) + wid) * (KS * 64) + fresh_lane();
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) r[ks * 64] = src[ks];
+    };
     uint4 xf[KS], hf[KS];
     f32x16 acc[NB];
     {
@@ -192,7 +204,7 @@ __global__ __launch_bounds__(256, 1) void k_thead(const HeadArgs a)
     }
     gemm(std::integral_constant<int, G_IN>{}, xf, [&](int nb) { frag_block(hf, nb); });
     STAMP(3);
-    store_rows(hf, a.h, TC);
+    if (a.h_frags) store_frags(hf, a.h); else store_rows(hf, a.h, TC);
     STAMP(4);
 
     // ---------------- n1 = LayerNorm1(h) (a row's 320 channels live in the lane pair (m, 0) / (m, 1))
@@ -305,7 +317,7 @@ extern "C" int gc_dn_transformer_head(const gc_thead_desc *d, void *stream)
     HeadArgs a;
     a.x = (const unsigned short *)d->x; a.coef = d->gn_coef; a.h = (unsigned short *)d->h; a.qk = (unsigned short *)d->qk; a.vt = (unsigned short *)d->vt;
     a.w = (const unsigned char *)d->w; a.params = d->params; a.M = (int)d->M; a.rows_per_frame = (int)d->rows_per_frame;
-    a.ldvt = d->ldvt; a.vt_bs = d->vt_batch_stride; a.eps = d->ln_eps;
+    a.ldvt = d->ldvt; a.vt_bs = d->vt_batch_stride; a.eps = d->ln_eps; a.h_frags = d->h_fragment_layout;
     if (d->dtype == DT_BF16) return launch<BF16>(a, (hipStream_t)stream);
     if (d->dtype == DT_F16) return launch<F16>(a, (hipStream_t)stream);
     GC_REQUIRE(false, "dtype");

@@ -44,7 +44,7 @@ struct TailArgs {
     unsigned short *out;                   // [M][320]
     const unsigned char *wa, *wkv, *wb;    // stream segments; wkv: [2 halves][BLK_KV KB]
     const float *params;                   // [P_TOTAL]
-    int M, rows_per_frame, f, Lt;
+    int M, rows_per_frame, f, Lt, h_frags;
     float eps;
     int stop;                              // tests: 0 = whole tail; 1..5 = write the intermediate after that many stages to `out` and leave
 };
@@ -156,7 +156,11 @@ __global__ __launch_bounds__(256, 1) void k_ttail(const TailArgs a)
     uint4 xf[KS], hres[KS];
     f32x16 acc[NB];
     load_rows(a.o1, xf);
-    load_rows(a.h, hres);
+    if (a.h_frags) {                       // written by the head kernel as the fragments themselves: 1 KB per load instruction
+        const uint4 *r = reinterpret_cast<const uint4 *>(a.h) + ((row0 >> 5) + wid) * (KS * 64) + fresh_lane();
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) hres[ks] = r[ks * 64];
+    } else load_rows(a.h, hres);
     __syncthreads();                       // parameter table visible
 
     auto mma = [&](uint4 wv, uint4 xv, f32x16 c) __attribute__((always_inline)) -> f32x16 {
@@ -463,7 +467,7 @@ extern "C" int gc_dn_transformer_tail(const gc_ttail_desc *d, void *stream)
     a.out = (unsigned short *)d->out;
     a.wa = (const unsigned char *)d->w_a; a.wkv = (const unsigned char *)d->w_kv; a.wb = (const unsigned char *)d->w_b;
     a.params = d->params; a.M = (int)d->M; a.rows_per_frame = (int)d->rows_per_frame; a.f = d->frames_per_half; a.Lt = d->text_len;
-    a.eps = d->ln_eps; a.stop = d->stop_after & 7;
+    a.eps = d->ln_eps; a.stop = d->stop_after & 7; a.h_frags = d->resid_fragment_layout;
 #ifdef TTAIL_ABLATIONS
     if (d->dtype == DT_BF16 && (d->stop_after & 7)) {
         switch (d->stop_after & 7) {

@@ -389,10 +389,10 @@ class TailDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("channels", C.c_int), ("heads", C.c_int), ("M", C.c_int64), ("rows_per_frame", C.c_int64),
                 ("frames_per_half", C.c_int), ("text_len", C.c_int), ("ln_eps", C.c_float), ("attn_out", C.c_void_p), ("resid", C.c_void_p),
                 ("x_in", C.c_void_p), ("out", C.c_void_p), ("w_a", C.c_void_p), ("w_kv", C.c_void_p), ("w_b", C.c_void_p),
-                ("params", C.c_void_p), ("stop_after", C.c_int)]
+                ("params", C.c_void_p), ("stop_after", C.c_int), ("resid_fragment_layout", C.c_int)]
 
 
-def transformer_tail(attn_out, resid, x_in, seg_a, seg_kv, seg_b, params, heads, frames_per_half, text_len, eps=1e-5, stop_after=0):
+def transformer_tail(attn_out, resid, x_in, seg_a, seg_kv, seg_b, params, heads, frames_per_half, text_len, eps=1e-5, stop_after=0, resid_frags=False):
     """Everything of a level-0 transformer block after the self-attention, one launch (gc_dn_transformer_tail): attn_out / resid / x_in
     [B, HW, 320]; seg_* / params from weights.tail_streams / weights.tail_text_stream."""
     _gpu(attn_out, resid, x_in, seg_a, seg_kv, seg_b, params)
@@ -404,6 +404,7 @@ def transformer_tail(attn_out, resid, x_in, seg_a, seg_kv, seg_b, params, heads,
     d.frames_per_half = frames_per_half; d.text_len = text_len; d.ln_eps = eps
     d.attn_out = attn_out.data_ptr(); d.resid = resid.data_ptr(); d.x_in = x_in.data_ptr(); d.out = out.data_ptr()
     d.w_a = seg_a.data_ptr(); d.w_kv = seg_kv.data_ptr(); d.w_b = seg_b.data_ptr(); d.params = params.data_ptr(); d.stop_after = stop_after
+    d.resid_fragment_layout = int(resid_frags)
     L.check(L.lib().gc_dn_transformer_tail(C.byref(d), _stream()), "gc_dn_transformer_tail")
     return out
 
@@ -411,7 +412,7 @@ def transformer_tail(attn_out, resid, x_in, seg_a, seg_kv, seg_b, params, heads,
 class HeadDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("channels", C.c_int), ("M", C.c_int64), ("rows_per_frame", C.c_int64), ("ln_eps", C.c_float),
                 ("x", C.c_void_p), ("gn_coef", C.c_void_p), ("h", C.c_void_p), ("qk", C.c_void_p), ("vt", C.c_void_p), ("ldvt", C.c_int64),
-                ("vt_batch_stride", C.c_int64), ("w", C.c_void_p), ("params", C.c_void_p)]
+                ("vt_batch_stride", C.c_int64), ("w", C.c_void_p), ("params", C.c_void_p), ("h_fragment_layout", C.c_int)]
 
 
 def groupnorm_coef(x, gamma, beta, groups, eps):
@@ -430,7 +431,7 @@ def groupnorm_coef(x, gamma, beta, groups, eps):
     return coef
 
 
-def transformer_head(x, coef, w_stream, params, eps=1e-5):
+def transformer_head(x, coef, w_stream, params, eps=1e-5, h_frags=False):
     """GroupNorm apply + proj_in + LayerNorm1 + Q | K | V of a level-0 transformer block, one launch (gc_dn_transformer_head).
     x [B, HW, 320], coef from groupnorm_coef -> (h [B,HW,320], qk [B,HW,640], vt [B,320,HW])"""
     _gpu(x, coef, w_stream, params)
@@ -442,7 +443,7 @@ def transformer_head(x, coef, w_stream, params, eps=1e-5):
     d = HeadDesc()
     d.dtype = _dt(x); d.channels = Cc; d.M = B * HW; d.rows_per_frame = HW; d.ln_eps = eps
     d.x = x.data_ptr(); d.gn_coef = coef.data_ptr(); d.h = h.data_ptr(); d.qk = qk.data_ptr(); d.vt = vt.data_ptr()
-    d.ldvt = HW; d.vt_batch_stride = Cc * HW; d.w = w_stream.data_ptr(); d.params = params.data_ptr()
+    d.ldvt = HW; d.vt_batch_stride = Cc * HW; d.w = w_stream.data_ptr(); d.params = params.data_ptr(); d.h_fragment_layout = int(h_frags)
     L.check(L.lib().gc_dn_transformer_head(C.byref(d), _stream()), "gc_dn_transformer_head")
     return h, qk, vt
 

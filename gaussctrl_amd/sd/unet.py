@@ -260,10 +260,13 @@ class SDNet:
         B, H, W_, Cc = x.shape
         t = p + ".transformer_blocks.0"
         fold = self.ln_folded
+        tail = self.fused_tail and (p + ".tail.a") in w and not fold and not self.fuse_stats and (H * W_) % 128 == 0 and ctx.shape[1] <= 96
+        hfr = False
         if self.fused_head and (p + ".head.w") in w and not fold and xs is None and (H * W_) % 128 == 0:
             x3 = x.view(B, H * W_, Cc)
             coef = ops.groupnorm_coef(x3, w[p + ".norm.weight"], w[p + ".norm.bias"], self.cfg["groups"], 1e-6)
-            h, qk, vt = ops.transformer_head(x3, coef, w[p + ".head.w"], w[p + ".head.params"])
+            hfr = tail                       # h goes from one fused kernel to the other: stored as MFMA fragments
+            h, qk, vt = ops.transformer_head(x3, coef, w[p + ".head.w"], w[p + ".head.params"], h_frags=hfr)
             o = self._attend(t + ".attn1", qk[..., :Cc], qk[..., Cc:], vt, actx)
         else:
             h = self.gn(x, xs, p + ".norm", 1e-6, False)
@@ -273,10 +276,10 @@ class SDNet:
                 o = self._self_attention(t + ".attn1", h, actx, ln=(rs, w[t + ".attn1.to_qkv.colsum"], 1e-5))
             else:
                 o = self._self_attention(t + ".attn1", ops.layernorm(h, w[t + ".norm1.weight"], w[t + ".norm1.bias"]), actx)
-        if self.fused_tail and (p + ".tail.a") in w and not fold and not self.fuse_stats and (H * W_) % 128 == 0 and ctx.shape[1] <= 96:
+        if tail:
             kv = self._text_stream(t + ".attn2", ctx, actx)
             out = ops.transformer_tail(o, h, x.view(B, H * W_, Cc), w[p + ".tail.a"], kv, w[p + ".tail.b"], w[p + ".tail.params"],
-                                       self.cfg["heads"], B // kv.shape[0], ctx.shape[1])
+                                       self.cfg["heads"], B // kv.shape[0], ctx.shape[1], resid_frags=hfr)
             return out.view(B, H, W_, Cc), None
         rs = ops.RowStats() if fold else None
         h = ops.linear(o, w[t + ".attn1.to_out.0.weight"], w[t + ".attn1.to_out.0.bias"], residual=h, row_stats=rs)

@@ -344,6 +344,7 @@ typedef struct gc_ttail_desc {
     const void *w_b;                 /* stream segment B: attn2.to_out, feed-forward, proj_out */
     const float *params;             /* biases / LayerNorm affine in lane order */
     int stop_after;                  /* 0; tests: 1..5 = `out` receives the intermediate after that stage */
+    int resid_fragment_layout;       /* 1: `resid` was written by gc_dn_transformer_head with h_fragment_layout = 1 */
 } gc_ttail_desc;
 int gc_dn_transformer_tail(const gc_ttail_desc *desc, void *stream);
 void gc_dn_transformer_tail_layout(int64_t *blocks_a, int64_t *blocks_kv, int64_t *blocks_b, int64_t *param_floats);
@@ -366,6 +367,7 @@ typedef struct gc_thead_desc {
     int64_t ldvt, vt_batch_stride;
     const void *w;                   /* operand stream: proj_in, to_q, to_k, to_v */
     const float *params;             /* proj_in bias, LayerNorm1 gamma / beta in lane order */
+    int h_fragment_layout;           /* 1: h is written as MFMA fragments ([M / 32][20][64 lanes][8]), readable only by gc_dn_transformer_tail */
 } gc_thead_desc;
 int gc_dn_transformer_head(const gc_thead_desc *desc, void *stream);
 

@@ -136,3 +136,25 @@ def test_head_matches_torch_and_the_per_op_path(dtype, B, HW):
         sc = tt.abs().max()
         e_f, e_p = (got.float() - tt).abs().max() / sc, (ref.float() - tt).abs().max() / sc
         assert e_f < bar and e_f < 2 * e_p + 1e-3, (name, float(e_f), float(e_p))
+
+
+def test_head_to_tail_fragment_layout_is_the_same_function():
+    """h handed from the head kernel to the tail kernel as MFMA fragments (h_fragment_layout) or as rows: identical tail output"""
+    from gaussctrl_amd.sd import ops, weights
+    dev, dtype, B, HW, f, Lt = "cuda:0", torch.bfloat16, 4, 256, 2, 77
+    sd = _sd()
+    sd[P + ".norm.weight"] = torch.ones(C); sd[P + ".norm.bias"] = torch.zeros(C)
+    w = weights.prepare(sd, dtype, dev, heads=H)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, HW, C, generator=g).to(dtype).to(dev); o1 = torch.randn(B, HW, C, generator=g).to(dtype).to(dev)
+    ctx = torch.randn(B // f, Lt, CTX, generator=g).to(dtype).to(dev)
+    k = ops.linear(ctx, w[T + ".attn2.to_k.weight"])
+    vt = torch.zeros(B // f, C, 80, dtype=dtype, device=dev)
+    ops.linear(ctx, w[T + ".attn2.to_v.weight"], want_out=False, rows_per_batch=Lt, out_t=vt, ldt=80, t_batch_stride=C * 80)
+    kv = weights.tail_text_stream(k, vt, Lt, H)
+    coef = ops.groupnorm_coef(x, w[P + ".norm.weight"], w[P + ".norm.bias"], 32, 1e-6)
+    outs = []
+    for fr in (False, True):
+        h, qk, vtt = ops.transformer_head(x, coef, w[P + ".head.w"], w[P + ".head.params"], h_frags=fr)
+        outs.append((ops.transformer_tail(o1, h, x, w[P + ".tail.a"], kv, w[P + ".tail.b"], w[P + ".tail.params"], H, f, Lt, resid_frags=fr), qk, vtt))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
