@@ -548,6 +548,8 @@ def main():
                           "views_per_step": round(views_done / args.steps, 3), "chunks_per_scene_per_rank": chunks_per_scene, "parallelism": par,
                           "mean_intersections_M": int(np.mean(stats["M"])) if stats["M"] else 0,
                           "ref_trajectory_in_timed_region": bool(args.workload == "edit"),
+                          "level0_transformer_blocks": ("one-launch head + tail" if os.environ.get("GC_FUSED_HEAD", "1") == "1" and os.environ.get("GC_FUSED_TAIL", "1") == "1"
+                                                        else f"GC_FUSED_HEAD={os.environ.get('GC_FUSED_HEAD', '1')} GC_FUSED_TAIL={os.environ.get('GC_FUSED_TAIL', '1')}") if args.workload == "edit" else None,
                           "ref_trajectory_share_per_step": f"{nsteps}/{chunks_per_scene} DDIM steps of the next scene's 4 reference views" if args.workload == "edit" else None},
                # the two halves separately (GPU time of rank 0's launch stream between HIP events in the timed steps)
                # (the wall time of the timed region is apportioned to the halves by their share of the per-chunk GPU spans: with one

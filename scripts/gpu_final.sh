@@ -20,6 +20,12 @@ timeout 600 python bench.py --chunk-size 8 --mask --no-cpu-baseline --no-seconda
 timeout 600 python bench.py --gaussians 2000000 --views 10 --no-cpu-baseline --no-secondary > $O/bench_config3_one_shard.json 2> $O/bench_config3.err
 timeout 600 python bench.py --inflight 1 --no-cpu-baseline --no-secondary > $O/bench_bf16_inflight1.json 2> $O/bench_inflight1.err
 GC_ATTN_V=4 timeout 600 python bench.py --no-cpu-baseline --no-secondary > $O/bench_bf16_attn4.json 2> $O/bench_attn4.err
+GC_FUSED_HEAD=0 GC_FUSED_TAIL=0 timeout 600 python bench.py --no-cpu-baseline --no-secondary > $O/bench_bf16_perop_blocks.json 2> $O/bench_perop_blocks.err
+GC_FUSED_HEAD=0 timeout 600 python bench.py --no-cpu-baseline --no-secondary > $O/bench_bf16_tail_only.json 2> $O/bench_tail_only.err
+PYTHONPATH=. timeout 300 python scripts/ttail_check.py bf16 time > $O/ttail_check_bf16.txt 2>&1
+PYTHONPATH=. timeout 300 python scripts/ttail_check.py f16 time > $O/ttail_check_f16.txt 2>&1
+PYTHONPATH=. timeout 300 python scripts/thead_check.py > $O/thead_check_bf16.txt 2>&1
+PYTHONPATH=. timeout 300 python scripts/thead_check.py f16 > $O/thead_check_f16.txt 2>&1
 timeout 600 python bench.py --workload raster --gaussians 1000000 --steps 20 --warmup 2 > $O/raster_1m.json 2> $O/raster_1m.err
 timeout 600 python bench.py --workload raster --gaussians 4000000 --steps 20 --warmup 2 --no-cpu-baseline > $O/raster_4m.json 2> $O/raster_4m.err
 GC_BENCH_ONE_GPU=1 GC_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 14 --warmup 1 > $O/bench2_gloo.json 2> $O/bench2_gloo.err
