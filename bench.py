@@ -69,6 +69,7 @@ class GemmProfiler:
 
     def wrap(self, ops):
         self._lin, self._conv, self._att = ops.linear, ops.conv3x3, ops.attention
+        self._tail, self._head = ops.transformer_tail, ops.transformer_head
         prof = self
 
         def att(q, k, vt, heads, sets, fph, Lk=None, **kw):
@@ -111,10 +112,30 @@ class GemmProfiler:
             prof.rec.append((f"gemm<{prof.dt},conv3x3{'' if mode == 2 else ' generic'},BN={32 * ntw}>", 2.0 * (out.numel() // out.shape[-1]) * N * w.shape[1], s, e))
             return out
 
+        def tail(o, h, x, *a, **k):      # level-0 block after the attention, one launch: 2 * rows * 1.6896 M weights (incl. the 77-key text attention)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = prof._tail(o, h, x, *a, **k)
+            e.record()
+            C_ = o.shape[-1]
+            prof.rec.append((f"k_ttail<{prof.dt}> (row-resident block tail)", 2.0 * (o.numel() // C_) * (4 * C_ * C_ + 12 * C_ * C_ + 2 * 77 * C_), s, e))
+            return out
+
+        def head(x, *a, **k):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = prof._head(x, *a, **k)
+            e.record()
+            C_ = x.shape[-1]
+            prof.rec.append((f"k_thead<{prof.dt}> (row-resident block head)", 2.0 * (x.numel() // C_) * 4 * C_ * C_, s, e))
+            return out
+
         ops.linear, ops.conv3x3, ops.attention = lin, conv, att
+        ops.transformer_tail, ops.transformer_head = tail, head
 
     def unwrap(self, ops):
         ops.linear, ops.conv3x3, ops.attention = self._lin, self._conv, self._att
+        ops.transformer_tail, ops.transformer_head = self._tail, self._head
 
     def summary(self):
         torch.cuda.synchronize()

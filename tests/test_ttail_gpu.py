@@ -158,3 +158,41 @@ def test_head_to_tail_fragment_layout_is_the_same_function():
         h, qk, vtt = ops.transformer_head(x, coef, w[P + ".head.w"], w[P + ".head.params"], h_frags=fr)
         outs.append((ops.transformer_tail(o1, h, x, w[P + ".tail.a"], kv, w[P + ".tail.b"], w[P + ".tail.params"], H, f, Lt, resid_frags=fr), qk, vtt))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
+@pytest.mark.parametrize("dtype,bar", [(torch.float16, 2e-3), (torch.bfloat16, 1.5e-2)])
+@pytest.mark.parametrize("mode", ["xview", "plain"])
+def test_level0_block_against_the_oracle(dtype, bar, mode):
+    """A whole level-0 transformer block in its product wiring -- GroupNorm statistics, one-launch head, the (cross-view) attention kernel,
+    one-launch tail -- against the CPU oracle's restatement of the reference block (oracle/sd15_torch.py::transformer: Transformer2DModel
+    + BasicTransformerBlock with CrossViewAttnProcessor, utils.py:44-133), SD1.5 level-0 shapes: C = 320, 8 heads, 77 x 768 text."""
+    from gaussctrl_amd.sd import unet as U, weights
+    from oracle import sd15_torch as sd
+    dev = "cuda:0"
+    f, Hh, Ww = 5, 8, 16                                        # 2 CFG halves x 5 frames, 128 tokens each
+    B = 2 * f
+    sdw = _sd(seed=7)
+    g = torch.Generator().manual_seed(8)
+    sdw[P + ".norm.weight"] = 1 + 0.1 * torch.randn(C, generator=g); sdw[P + ".norm.bias"] = 0.1 * torch.randn(C, generator=g)
+    r16 = lambda v: v.to(dtype).float()
+    wq = {k: r16(v) for k, v in sdw.items()}                    # the oracle sees the 16-bit weights the kernels get
+    x = torch.randn(B, C, Hh, Ww, generator=g) * 1.2
+    ctx = torch.randn(2, 77, CTX, generator=g)
+    cfg = dict(groups=32, heads=H)
+    ref = sd.transformer(wq, P, r16(x), r16(ctx).repeat_interleave(f, 0), cfg, mode, 0.6)              # [B, C, H, W]
+    w = weights.prepare(sdw, dtype, dev, heads=H)
+    w["conv_in.weight"] = torch.zeros(1, dtype=dtype, device=dev)                                       # SDNet reads its dtype here
+    net = U.SDNet(w, dict(U.CFG_SD15), "unet")
+    assert net.fused_head and net.fused_tail
+    net.begin_forward(dev)
+    actx = U.AttnCtx(mode, 0.6, f, {}, None, "unet")
+    xg = x.permute(0, 2, 3, 1).contiguous().to(dtype).to(dev)
+    out, _ = net.transformer(P, xg, None, ctx.to(dtype).to(dev), actx)
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    rel = float((got - ref).norm() / ref.norm())
+    assert rel < bar, rel
+    # and the per-op launches give the same answer within the same bar
+    net.fused_head = net.fused_tail = False
+    out2, _ = net.transformer(P, xg, None, ctx.to(dtype).to(dev), U.AttnCtx(mode, 0.6, f, {}, None, "unet"))
+    rel2 = float((out2.float().cpu().permute(0, 3, 1, 2) - ref).norm() / ref.norm())
+    assert rel2 < bar and rel < 2 * rel2 + 1e-4, (rel, rel2)
