@@ -76,6 +76,9 @@ def host_floats(values):
 
 def stream_ptr():
     import torch
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)       # ~0.3 us instead of ~8 us through torch.cuda.current_stream()
+    if raw is not None:
+        return C.c_void_p(raw(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -89,8 +89,19 @@ def _gpu(*ts):
             raise L.GaussCtrlHipError("denoise ops need GPU tensors (HIP path only; no CPU fallback)")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def stream_handle():
+    """raw hipStream_t of torch's current stream on the current device.  The host enqueues ~13 000 launches per 3-view chunk: through
+    torch.cuda.current_stream() this lookup alone was 84 of the 275 ms of host time per chunk (scripts/cpu_bound_check.py)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
+    return torch.cuda.current_stream().cuda_stream
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(stream_handle())
 
 
 _zero_page = {}
@@ -205,7 +216,7 @@ def groupnorm(x, gamma, beta, groups, eps, silu):
     _gpu(x)
     B, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * Cc)
-    key = (x.device, B, HW, Cc, torch.cuda.current_stream().cuda_stream)      # scratch is per stream: two networks may run concurrently
+    key = (x.device, B, HW, Cc, stream_handle())      # scratch is per stream: two networks may run concurrently
     ws = _gn_ws.get(key)
     if ws is None:
         nbytes = L.lib().gc_dn_groupnorm_workspace_bytes(C.c_int64(B), C.c_int64(HW), Cc)
@@ -420,7 +431,7 @@ def groupnorm_coef(x, gamma, beta, groups, eps):
     _gpu(x)
     B, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * Cc)
-    key = (x.device, B, HW, Cc, torch.cuda.current_stream().cuda_stream)
+    key = (x.device, B, HW, Cc, stream_handle())
     ws = _gn_ws.get(key)
     if ws is None:
         nbytes = L.lib().gc_dn_groupnorm_workspace_bytes(C.c_int64(B), C.c_int64(HW), Cc)
@@ -464,7 +475,7 @@ _disp_ws = {}
 def depth_to_disparity(depth, dtype):
     """depth fp32 [H,W] -> disparity [H,W,8] (3 used) in the activation dtype: 1/(d+1e-5) / max (gc_pipeline.py:258-266)."""
     _gpu(depth)
-    key = (depth.device, torch.cuda.current_stream().cuda_stream)          # scratch per stream: independent chunks may run concurrently
+    key = (depth.device, stream_handle())          # scratch per stream: independent chunks may run concurrently
     ws = _disp_ws.get(key)
     if ws is None:
         ws = _disp_ws[key] = torch.zeros(1, dtype=torch.int32, device=depth.device)

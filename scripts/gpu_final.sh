@@ -26,6 +26,8 @@ PYTHONPATH=. timeout 300 python scripts/ttail_check.py bf16 time > $O/ttail_chec
 PYTHONPATH=. timeout 300 python scripts/ttail_check.py f16 time > $O/ttail_check_f16.txt 2>&1
 PYTHONPATH=. timeout 300 python scripts/thead_check.py > $O/thead_check_bf16.txt 2>&1
 PYTHONPATH=. timeout 300 python scripts/thead_check.py f16 > $O/thead_check_f16.txt 2>&1
+PYTHONPATH=. timeout 300 python scripts/gn_shapes.py > $O/gn_shapes.txt 2>&1
+PYTHONPATH=. timeout 600 python scripts/cpu_bound_check.py 2>&1 | grep -E 'host enqueue' > $O/host_enqueue.txt
 timeout 600 python bench.py --workload raster --gaussians 1000000 --steps 20 --warmup 2 > $O/raster_1m.json 2> $O/raster_1m.err
 timeout 600 python bench.py --workload raster --gaussians 4000000 --steps 20 --warmup 2 --no-cpu-baseline > $O/raster_4m.json 2> $O/raster_4m.err
 GC_BENCH_ONE_GPU=1 GC_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 14 --warmup 1 > $O/bench2_gloo.json 2> $O/bench2_gloo.err
