@@ -27,6 +27,8 @@ PYTHONPATH=. timeout 300 python scripts/ttail_check.py f16 time > $O/ttail_check
 PYTHONPATH=. timeout 300 python scripts/thead_check.py > $O/thead_check_bf16.txt 2>&1
 PYTHONPATH=. timeout 300 python scripts/thead_check.py f16 > $O/thead_check_f16.txt 2>&1
 PYTHONPATH=. timeout 300 python scripts/gn_shapes.py > $O/gn_shapes.txt 2>&1
+PYTHONPATH=$R timeout 900 python scripts/pmc.py 'k_ttail|k_thead' -- python $R/scripts/ttail_check.py bf16 time > $O/ttail_pmc.txt 2>&1
+PYTHONPATH=$R timeout 900 python scripts/pmc.py 'k_thead' -- python $R/scripts/thead_check.py > $O/thead_pmc.txt 2>&1
 PYTHONPATH=. timeout 600 python scripts/cpu_bound_check.py 2>&1 | grep -E 'host enqueue' > $O/host_enqueue.txt
 timeout 600 python bench.py --workload raster --gaussians 1000000 --steps 20 --warmup 2 > $O/raster_1m.json 2> $O/raster_1m.err
 timeout 600 python bench.py --workload raster --gaussians 4000000 --steps 20 --warmup 2 --no-cpu-baseline > $O/raster_4m.json 2> $O/raster_4m.err
