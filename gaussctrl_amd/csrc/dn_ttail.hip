@@ -25,7 +25,7 @@ constexpr int TC = 320, TH = 8, TD = 40;                 // channels, heads, hea
 constexpr int NB = TC / 32, KS = TC / 16;                // accumulator blocks / k-steps of a C-wide GEMM
 constexpr int FF = 4 * TC, FF_IT = FF / 64;              // GEGLU inner width; 64 inner channels (= 4 up-blocks = 4 down k-steps) per iteration
 // GELU by table: (gelu(x_i), gelu(x_i+1) - gelu(x_i)) at x_i = (i - GELU_N / 2) / GELU_STEP, exact erf on the host, linear interpolation
-// (|error| <= h^2 / 8 max|gelu''| = 8.6e-6; beyond +-8 the end segments extrapolate gelu's asymptotes x and 0): 6 VALU + one ds_read_b64
+// (|error| <= h^2 / 8 max|gelu''| = 8.6e-6; beyond +-8 the end segments extrapolate gelu's asymptotes x and 0): 7 VALU + one ds_read_b64
 // per value instead of the 14 of erf by Abramowitz-Stegun -- at one wave per SIMD every VALU instruction is matrix-core idle time
 constexpr int GELU_N = 2048;
 constexpr float GELU_STEP = 128.f;
@@ -408,15 +408,16 @@ __global__ __launch_bounds__(256, 1) void k_ttail(const TailArgs a)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const float hid = up[j][8 * pr + c] + bv[8 * pr + c], gate = up[j][8 * pr + 4 + c] + bv[8 * pr + 4 + c];
-                    const float t = __builtin_amdgcn_fmed3f(__builtin_fmaf(gate, GELU_STEP, 0.5f * GELU_N), 0.f, GELU_N - 0.001f);
-                    const float2 e = reinterpret_cast<const float2 *>(prm + P_LUT)[(int)t];
-                    o[4 * pr + c] = hid * __builtin_fmaf(__builtin_amdgcn_fractf(t), e.y, e.x);
+                    // segment index clamped, the fraction NOT: beyond +-8 the end segments extrapolate (slopes 1 and 0 to 1e-14: gelu's asymptotes)
+                    const float t = __builtin_fmaf(gate, GELU_STEP, 0.5f * GELU_N);
+                    const float ti = __builtin_floorf(__builtin_amdgcn_fmed3f(t, 0.f, (float)(GELU_N - 1)));
+                    const float2 e = reinterpret_cast<const float2 *>(prm + P_LUT)[(int)ti];
+                    o[4 * pr + c] = hid * __builtin_fmaf(t - ti, e.y, e.x);
                 }
             ff[j] = pack8<T>(o);
             __builtin_amdgcn_sched_barrier(0);         // one block at a time (16 bias + 16 accumulator registers, not 128)
         }
         STAMP(12 + 3 * it);
-        if constexpr (LAST) load_rows(a.x, xf);        // the block's input for proj_out's residual (LN3's output in xf is dead from here on)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -438,6 +439,8 @@ __global__ __launch_bounds__(256, 1) void k_ttail(const TailArgs a)
 
     // ---------------- 4: out = proj_out(h3) + x
     STAMP(60);
+    load_rows(a.x, xf);                    // the block's input (proj_out's residual); loaded here, not under the last MFMAs: 80 more live
+                                           // registers there spill, and a spill reload drains the DMA queue
     init_acc(P_BPO, xf);
     gemm(G_PO, hres, [&](int nb) { frag_block(xf, nb); });
     STAMP(61);

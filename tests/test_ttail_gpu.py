@@ -11,13 +11,17 @@ C, H, FFN, CTX = 320, 8, 1280, 768
 P = "tb"; T = P + ".transformer_blocks.0"
 
 
-def _sd(seed=0):
+def _sd(seed=0, gate_shift=0.0):
+    """gate_shift: added to the GEGLU gate biases (half of them negated): pushes gates beyond the +-8 of the tail kernel's GELU table"""
     g = torch.Generator().manual_seed(seed)
     r = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
     sd = {P + ".proj_in.weight": r(C, C, 1, 1, sc=C ** -0.5), P + ".proj_in.bias": r(C, sc=0.1),
           P + ".proj_out.weight": r(C, C, 1, 1, sc=C ** -0.5), P + ".proj_out.bias": r(C, sc=0.1),
           T + ".ff.net.0.proj.weight": r(2 * FFN, C, sc=C ** -0.5), T + ".ff.net.0.proj.bias": r(2 * FFN, sc=0.1),
           T + ".ff.net.2.weight": r(C, FFN, sc=FFN ** -0.5), T + ".ff.net.2.bias": r(C, sc=0.1)}
+    if gate_shift:
+        sgn = torch.where(torch.arange(FFN) % 2 == 0, 1.0, -1.0)
+        sd[T + ".ff.net.0.proj.bias"][FFN:] += gate_shift * sgn
     for n in ("norm1", "norm2", "norm3"):
         sd[T + f".{n}.weight"] = 1 + r(C, sc=0.1); sd[T + f".{n}.bias"] = r(C, sc=0.1)
     for a, kin in (("attn1", C), ("attn2", CTX)):
@@ -48,11 +52,12 @@ def _torch_tail(sd, o1, h, x, ctx, f):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("B,HW,f,Lt", [(2, 256, 1, 77), (4, 128, 2, 50), (6, 384, 3, 96)])
-def test_tail_matches_torch_and_the_per_op_path(dtype, B, HW, f, Lt):
+@pytest.mark.parametrize("B,HW,f,Lt,gate_shift", [(2, 256, 1, 77, 0.0), (4, 128, 2, 50, 0.0), (6, 384, 3, 96, 0.0), (2, 128, 1, 77, 14.0)])
+def test_tail_matches_torch_and_the_per_op_path(dtype, B, HW, f, Lt, gate_shift):
+    """gate_shift = 14: GEGLU gates around +-14, far outside the GELU table's +-8 (gelu(x) = x / 0 there: the end segments extrapolate)"""
     from gaussctrl_amd.sd import ops, weights
     dev = "cuda:0"
-    sd = _sd()
+    sd = _sd(gate_shift=gate_shift)
     w = weights.prepare(sd, dtype, dev, heads=H)
     g = torch.Generator().manual_seed(1)
     o1, h, x = (torch.randn(B, HW, C, generator=g).to(dtype).to(dev) for _ in range(3))
