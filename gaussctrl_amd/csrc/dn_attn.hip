@@ -32,6 +32,22 @@ __global__ __launch_bounds__(256, 2) void k_attn(const AttnArgs a)
     attn_safe_body<T, D, QT>(a, qblk, h, b, sK, sV);
 }
 
+// out = round(sum_s part[s]) in a fixed order: the second launch of a set-split attention (below)
+template <class T>
+__global__ __launch_bounds__(256) void k_attn_combine(const float *__restrict__ part, int nsets, int64_t n4, int64_t set_stride4, unsigned short *__restrict__ O,
+                                                      int64_t ldo, int64_t o_bs, int64_t row4, int64_t rows_per_batch)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 v = reinterpret_cast<const float4 *>(part)[i];
+        for (int s = 1; s < nsets; ++s) {
+            const float4 w = reinterpret_cast<const float4 *>(part)[i + s * set_stride4];
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
+        const int64_t row = i / row4, c4 = i - row * row4, b = row / rows_per_batch, q = row - b * rows_per_batch;
+        *reinterpret_cast<uint2 *>(O + b * o_bs + q * ldo + c4 * 4) = make_uint2(pack2<T>(v.x, v.y), pack2<T>(v.z, v.w));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
 // k_attn3: static-offset, software-pipelined form for head sizes with two spare contraction columns (D % 32 != 0: 40, 80).
 //
@@ -784,12 +800,20 @@ int launch_attn(const AttnArgs &a, int D, int B, bool fast, int variant, hipStre
         default: break;
         }
     }
+    // Few workgroups and several K/V sets (D = 160 at 16x16 / 8x8: 192 / 48 workgroups of one wave per SIMD, nobody to hide the
+    // S -> max -> exp -> P V dependency chain): one workgroup per (query block, set) + a fixed-order fp32 combine
 #define GC_ATT(DD, QQ)                                                                                  \
     do {                                                                                                \
         AttnArgs aa = a;                                                                                \
         aa.nqb = (a.Lq + 64 * QQ - 1) / (64 * QQ);                                                      \
-        dim3 grid((unsigned)(aa.nqb * a.H * B));                                                        \
-        hipLaunchKernelGGL((k_attn<T, DD, QQ>), grid, dim3(256), 0, s, aa);                             \
+        const unsigned nwg = (unsigned)(aa.nqb * a.H * B);                                              \
+        if (a.part && a.nsets > 1 && nwg < 512) {                                                       \
+            hipLaunchKernelGGL((k_attn<T, DD, QQ>), dim3(nwg, (unsigned)a.nsets), dim3(256), 0, s, aa); \
+            const int64_t n4 = (int64_t)B * a.Lq * (a.H * DD) / 4;                                      \
+            hipLaunchKernelGGL((k_attn_combine<T>), dim3((unsigned)std::min<int64_t>((n4 + 255) / 256, 2048)), dim3(256), 0, s, a.part, a.nsets, \
+                               n4, n4, a.O, a.ldo, a.o_bs, (int64_t)(a.H * DD) / 4, (int64_t)a.Lq);     \
+        } else                                                                                          \
+            hipLaunchKernelGGL((k_attn<T, DD, QQ>), dim3(nwg), dim3(256), 0, s, aa);                    \
     } while (0)
     switch (D) {
     case 8: GC_ATT(8, 2); break;
@@ -806,6 +830,12 @@ int launch_attn(const AttnArgs &a, int D, int B, bool fast, int variant, hipStre
 }
 
 }  // namespace
+
+extern "C" size_t gc_dn_attention_workspace_bytes(const gc_attn_desc *d)
+{
+    if (!d || d->nsets <= 1 || d->head_dim != 160) return 0;        // the set-split form serves the head size that has no static-offset kernel
+    return sizeof(float) * (size_t)d->nsets * (size_t)d->batch * (size_t)d->Lq * (size_t)d->heads * (size_t)d->head_dim;
+}
 
 extern "C" int gc_dn_attention(const gc_attn_desc *d, void *stream)
 {
@@ -829,6 +859,7 @@ extern "C" int gc_dn_attention(const gc_attn_desc *d, void *stream)
     for (int i = 0; i < d->nsets; ++i) GC_REQUIRE(d->set_kind[i] >= -2 && d->set_kind[i] < a.ref_fph, "bad set_kind");
     a.scale_log2e = d->q_prescaled ? 1.f : d->scale * 1.4426950408889634f;
     a.abl = d->kernel_variant >> 8;
+    a.part = (d->workspace && d->workspace_bytes >= gc_dn_attention_workspace_bytes(d)) ? (float *)d->workspace : nullptr;
     const bool fast = !(d->kernel_variant & 1);      // kernel_variant bit 0: online-softmax kernel everywhere (tests)
     int rc = d->dtype == DT_BF16 ? launch_attn<BF16>(a, d->head_dim, d->batch, fast, d->kernel_variant, gc::S(stream))
              : d->dtype == DT_F16 ? launch_attn<F16>(a, d->head_dim, d->batch, fast, d->kernel_variant, gc::S(stream)) : GC_EINVAL;

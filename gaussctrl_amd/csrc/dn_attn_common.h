@@ -22,6 +22,7 @@ struct AttnArgs {
     float scale_log2e;
     int nqb;                                         // query blocks per (batch, head)
     int abl;                                         // timing ablations of k_attn5's instrumented instantiation (kernel_variant >> 8; 0 in production)
+    float *part;                                     // set-split launches (k_attn, gridDim.y = nsets): fp32 [nsets][B][Lq][H*D] weighted per-set outputs
 };
 
 // 1-D grid, XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the id is remapped
@@ -120,7 +121,11 @@ __device__ __forceinline__ void attn_safe_body(const AttnArgs &a, int qblk, int 
     const int ntiles = (a.Lk + 63) / 64;
     const int lk8 = (a.Lk + 7) / 8 * 8;
     const float c2 = a.scale_log2e;
-    for (int s = 0; s < a.nsets; ++s) {
+    // set-split launch: this workgroup handles K/V set blockIdx.y only and leaves its weighted output in a.part (the sets are independent
+    // attentions, out = sum_s w_s O_s: k_attn_combine adds them in a fixed order)
+    const bool split = gridDim.y > 1;
+    const int s_begin = split ? (int)blockIdx.y : 0, s_end = split ? s_begin + 1 : a.nsets;
+    for (int s = s_begin; s < s_end; ++s) {
         const int kind = a.set_kind[s];
         const unsigned short *Kb, *Vb;
         if (kind >= 0) {
@@ -272,6 +277,22 @@ __device__ __forceinline__ void attn_safe_body(const AttnArgs &a, int qblk, int 
         }
     }
     // ---- store: lane owns O[q = fr][d = 16*dt + 4*g .. +4]
+    if (split) {
+        float *pb = a.part + (((int64_t)s_begin * gridDim.x / (a.nqb * a.H) + b) * a.Lq) * (int64_t)(a.H * D);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const int q = q_wave0 + qt * 16 + fr;
+            if (q >= a.Lq) continue;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d = dt * 16 + g * 4;
+                if (d + 4 > D) continue;
+                *reinterpret_cast<float4 *>(pb + (int64_t)q * (a.H * D) + h * D + d) =
+                    make_float4(otot[dt][qt][0], otot[dt][qt][1], otot[dt][qt][2], otot[dt][qt][3]);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         const int q = q_wave0 + qt * 16 + fr;

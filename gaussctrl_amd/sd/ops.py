@@ -40,7 +40,7 @@ class AttnDesc(C.Structure):
                 ("O", C.c_void_p), ("ldo", C.c_int64), ("o_batch_stride", C.c_int64),
                 ("Kref", C.c_void_p), ("kref_batch_stride", C.c_int64), ("Vtref", C.c_void_p),
                 ("vtref_batch_stride", C.c_int64), ("ref_frames_per_half", C.c_int), ("q_prescaled", C.c_int),
-                ("kernel_variant", C.c_int)]
+                ("kernel_variant", C.c_int), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
 def _variant_from_env():
@@ -392,6 +392,10 @@ def attention(q, k, vt, heads, sets, frames_per_half, Lk=None, kref=None, vtref=
     if kref is not None:
         d.Kref = kref.data_ptr(); d.kref_batch_stride = kref.stride(0)
         d.Vtref = vtref.data_ptr(); d.vtref_batch_stride = vtref.stride(0); d.ref_frames_per_half = ref_fph
+    wsb = L.lib().gc_dn_attention_workspace_bytes(C.byref(d))      # head size 160 with several K/V sets: one workgroup per (query block, set)
+    if wsb:
+        ws = torch.empty(wsb, dtype=torch.uint8, device=q.device)
+        d.workspace = ws.data_ptr(); d.workspace_bytes = wsb
     L.check(L.lib().gc_dn_attention(C.byref(d), _stream()), "gc_dn_attention")
     return o
 

@@ -319,7 +319,10 @@ typedef struct gc_attn_desc {
     int kernel_variant;              /* 0 = automatic; bit 0: online-softmax kernel for every shape (tests); bit 1: head_dim 40 on the
                                         16x16x32 kernel (k_attn3) instead of the 32x32x16 one (k_attn4); bit 2: k_attn4 with 8 waves; bit 3: k_attn4 with 64 queries
                                         per wave, one wave per SIMD (measured 25 % slower: DESIGN.md 7.1) */
+    void *workspace;                 /* optional, >= gc_dn_attention_workspace_bytes(desc): lets small grids with several K/V sets (head_dim 160) run */
+    size_t workspace_bytes;          /* one workgroup per (query block, set) + a fixed-order fp32 combine; NULL: one launch as before */
 } gc_attn_desc;
+size_t gc_dn_attention_workspace_bytes(const gc_attn_desc *desc);
 int gc_dn_attention(const gc_attn_desc *desc, void *stream);
 
 /* The tail of a level-0 transformer block (C = 320, 8 heads) in ONE launch: attn1.to_out + residual, LayerNorm, attn2 (text cross-
