@@ -195,6 +195,33 @@ def bin_and_sort(xys, depths, radii, num_tiles_hit, tile_bounds):
 
 
 # ------------------------------------------------------------------ A.4 rasterize (differentiable)
+def composite_tile(xys, conics, colors, opacities, gid, s, h0, h1, w0, w1, extra=None):
+    """Front-to-back compositing of the splats `gid` (already in list order; `s` = list position of gid[0]) over the pixel block
+    [h0,h1) x [w0,w1).  Returns (img[P,C] WITHOUT background, T_final[P], last contributing list index[P], extra[P] or None)."""
+    dt = xys.dtype
+    py, px = torch.meshgrid(torch.arange(h0, h1, dtype=dt), torch.arange(w0, w1, dtype=dt), indexing="ij")
+    px, py = px.reshape(-1, 1), py.reshape(-1, 1)                 # [P,1]
+    dx = xys[gid, 0][None, :] - px
+    dy = xys[gid, 1][None, :] - py
+    cn = conics[gid]
+    sigma = 0.5 * (cn[:, 0] * dx * dx + cn[:, 2] * dy * dy) + cn[:, 1] * dx * dy
+    alpha = torch.clamp(opacities[gid][None, :] * torch.exp(-sigma), max=ALPHA_CAP)
+    valid = (sigma >= 0) & (alpha >= ALPHA_MIN)
+    a_eff = torch.where(valid, alpha, torch.zeros_like(alpha))
+    one_m = 1 - a_eff
+    T_incl = torch.cumprod(one_m, dim=1)                          # T after k
+    T_excl = torch.cat([torch.ones_like(T_incl[:, :1]), T_incl[:, :-1]], 1)
+    stop = valid & (T_incl <= T_STOP)                             # first such k terminates the pixel
+    alive = torch.cumsum(stop.to(torch.int32), 1) == 0            # k strictly before the stop
+    contrib = valid & alive
+    wgt = torch.where(contrib, a_eff * T_excl, torch.zeros_like(a_eff))
+    img = wgt @ colors[gid]
+    Tfin = torch.prod(torch.where(contrib, one_m, torch.ones_like(one_m)), 1)
+    kk = torch.arange(s, s + gid.numel(), dtype=torch.int32)[None, :].expand_as(contrib)
+    last = torch.where(contrib, kk, torch.zeros_like(kk)).max(1).values
+    return img, Tfin, last, (wgt @ extra[gid] if extra is not None else None)
+
+
 def rasterize(xys, conics, colors, opacities, gaussian_ids_sorted, tile_bins, H, W, tile_bounds, background,
               extra=None):
     """Vectorised per tile.  colors [N,C]; returns (out_img[H,W,C], out_alpha[H,W], final_index[H,W],
@@ -219,28 +246,9 @@ def rasterize(xys, conics, colors, opacities, gaussian_ids_sorted, tile_bins, H,
                 cols_e.append(torch.zeros(ph, pw, dtype=dt)); cols_i.append(torch.zeros(ph, pw, dtype=torch.int32))
                 continue
             gid = gaussian_ids_sorted[s:e].to(torch.int64)
-            py, px = torch.meshgrid(torch.arange(h0, h1, dtype=dt), torch.arange(w0, w1, dtype=dt), indexing="ij")
-            px, py = px.reshape(-1, 1), py.reshape(-1, 1)                 # [P,1]
-            dx = xys[gid, 0][None, :] - px
-            dy = xys[gid, 1][None, :] - py
-            cn = conics[gid]
-            sigma = 0.5 * (cn[:, 0] * dx * dx + cn[:, 2] * dy * dy) + cn[:, 1] * dx * dy
-            alpha = torch.clamp(opacities[gid][None, :] * torch.exp(-sigma), max=ALPHA_CAP)
-            valid = (sigma >= 0) & (alpha >= ALPHA_MIN)
-            a_eff = torch.where(valid, alpha, torch.zeros_like(alpha))
-            one_m = 1 - a_eff
-            T_incl = torch.cumprod(one_m, dim=1)                          # T after k
-            T_excl = torch.cat([torch.ones_like(T_incl[:, :1]), T_incl[:, :-1]], 1)
-            stop = valid & (T_incl <= T_STOP)                             # first such k terminates the pixel
-            alive = torch.cumsum(stop.to(torch.int32), 1) == 0            # k strictly before the stop
-            contrib = valid & alive
-            wgt = torch.where(contrib, a_eff * T_excl, torch.zeros_like(a_eff))
-            img = wgt @ colors[gid]
-            Tfin = torch.prod(torch.where(contrib, one_m, torch.ones_like(one_m)), 1)
-            kk = torch.arange(s, e, dtype=torch.int32)[None, :].expand_as(contrib)
-            last = torch.where(contrib, kk, torch.zeros_like(kk)).max(1).values
+            img, Tfin, last, ext = composite_tile(xys, conics, colors, opacities, gid, s, h0, h1, w0, w1, extra)
             cols_img.append(img.reshape(ph, pw, C)); cols_T.append(Tfin.reshape(ph, pw)); cols_i.append(last.reshape(ph, pw))
-            cols_e.append((wgt @ extra[gid]).reshape(ph, pw) if extra is not None else torch.zeros(ph, pw, dtype=dt))
+            cols_e.append(ext.reshape(ph, pw) if extra is not None else torch.zeros(ph, pw, dtype=dt))
         rows.append((torch.cat(cols_img, 1), torch.cat(cols_T, 1), torch.cat(cols_e, 1), torch.cat(cols_i, 1)))
     out = torch.cat([r[0] for r in rows], 0)
     out_T = torch.cat([r[1] for r in rows], 0)
@@ -279,3 +287,48 @@ def get_outputs(params, c2w, fx, fy, cx, cy, W, H, background, training, sh_degr
         depth_im = torch.where(pos, depth_im / torch.where(pos, alpha, torch.ones_like(alpha)), torch.full_like(depth_im, 1000.0))
     return {"rgb": rgb, "depth": depth_im, "accumulation": alpha, "xys": xys, "radii": radii,
             "gaussian_ids_sorted": ids, "tile_bins": bins, "final_index": fidx}
+
+
+# ------------------------------------------------------------------ fp64 gradients at scene sizes the vectorised form cannot hold
+def render_grads_tiled(params, c2w, fx, fy, cx, cy, W, H, background, v_rgb, gaussian_ids_sorted, tile_bins, sh_degree_to_use=3,
+                       alpha_weight=1.0, dtype=torch.float64, device="cpu"):
+    """d/d(params) of  sum(rgb * v_rgb) + alpha_weight * sum(alpha)  for the TRAINING render of get_outputs above (rgb clamped to <= 1,
+    gc_model.py:188), evaluated tile by tile so that a 60 k-Gaussian stress scene with multi-million-entry lists fits: the per-tile
+    compositing graph (same expressions as `rasterize`) is differentiated on its own down to (xys, conics, rgbs, opacities) and the
+    sums are pushed through projection / SH / sigmoid once.  `gaussian_ids_sorted` / `tile_bins`: the gsplat-box lists (bit-exact
+    between the C oracle and the HIP binning, tests/test_raster_gpu.py) -- the per-pixel tests do not depend on the lists' length.
+    `device` may be a GPU: this is the checker running in float64 there, not the product."""
+    with torch.device(device):
+        p = {k: torch.as_tensor(v).to(device=device, dtype=dtype).requires_grad_(True) for k, v in params.items()}
+        c2w_t = torch.as_tensor(c2w).to(device=device, dtype=dtype)[:3]
+        viewmat, projmat, full = camera_to_gsplat(c2w_t, fx, fy, W, H, dtype)
+        tb = ((W + TILE - 1) // TILE, (H + TILE - 1) // TILE, 1)
+        colors = torch.cat([p["features_dc"][:, None, :], p["features_rest"]], 1)
+        quats = p["quats"] / p["quats"].norm(dim=-1, keepdim=True)
+        xys, depths, radii, conics, nth, _ = project_gaussians(p["means"], torch.exp(p["scales"]), 1.0, quats, viewmat[:3], full,
+                                                               fx, fy, cx, cy, H, W, tb)
+        viewdirs = p["means"].detach() - c2w_t[:3, 3]
+        viewdirs = viewdirs / viewdirs.norm(dim=-1, keepdim=True)
+        rgbs = torch.clamp(spherical_harmonics(sh_degree_to_use, viewdirs, colors) + 0.5, min=0.0)
+        opac = torch.sigmoid(p["opacities"])[:, 0]
+        mid = [t.detach().requires_grad_(True) for t in (xys, conics, rgbs, opac)]
+        acc = [torch.zeros_like(t) for t in mid]
+        bg = torch.as_tensor(background).to(device=device, dtype=dtype)
+        v = torch.as_tensor(v_rgb).to(device=device, dtype=dtype)
+        ids = torch.as_tensor(gaussian_ids_sorted).to(device=device, dtype=torch.int64)
+        bins_h = torch.as_tensor(tile_bins).cpu().numpy()
+        for ty in range(tb[1]):
+            for tx in range(tb[0]):
+                s, e = int(bins_h[ty * tb[0] + tx, 0]), int(bins_h[ty * tb[0] + tx, 1])
+                if e <= s:
+                    continue
+                h0, w0 = ty * TILE, tx * TILE
+                h1, w1 = min(h0 + TILE, H), min(w0 + TILE, W)
+                img, Tfin, _, _ = composite_tile(mid[0], mid[1], mid[2], mid[3], ids[s:e], s, h0, h1, w0, w1)
+                rgb = torch.clamp(img + Tfin[:, None] * bg, max=1.0).reshape(h1 - h0, w1 - w0, 3)
+                loss = (rgb * v[h0:h1, w0:w1]).sum() + alpha_weight * (1 - Tfin).sum()
+                for a, g in zip(acc, torch.autograd.grad(loss, mid)):
+                    a += g
+        torch.autograd.backward([xys, conics, rgbs, opac], acc)
+    return {k: t.grad.detach().cpu() for k, t in p.items()}
+

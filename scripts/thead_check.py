@@ -1,7 +1,9 @@
 """fused transformer head (csrc/dn_thead.hip) against the four per-op launches: timing at B = 6, 4096 tokens. python scripts/thead_check.py [f16]"""
+import os
 import sys
 import torch
-sys.path.insert(0, "tests")
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, "tests"))
 from test_ttail_gpu import _sd, P, T, C, H
 from gaussctrl_amd.sd import ops, weights
 

@@ -17,3 +17,20 @@ def oracle_c():
     from oracle import raster_c
     raster_c.build()
     return raster_c
+
+
+def pytest_terminal_summary(terminalreporter):
+    """Numeric checks that came within 2x of their bar (tests/_margins.py), and the full list as JSON lines if asked for."""
+    import json
+    from _margins import RECORDS
+    if not RECORDS:
+        return
+    tight = sorted(((v / b if b else float("inf")), t, n, v, b) for t, n, v, b in RECORDS if b == 0 or v / b > 0.5)
+    terminalreporter.write_line(f"margins: {len(RECORDS)} numeric checks recorded, {len(tight)} used more than half of their bar")
+    for r, t, n, v, b in tight[::-1][:40]:
+        terminalreporter.write_line(f"  x{r:.3f}  {v:.4g} / {b:.4g}  {n}  [{t}]")
+    path = os.environ.get("GC_TEST_MARGINS")
+    if path:
+        with open(path, "a") as f:
+            for t, n, v, b in RECORDS:
+                f.write(json.dumps({"test": t, "check": n, "value": v, "bar": b}) + "\n")

@@ -3,6 +3,7 @@ references of the same op evaluated on the SAME 2-byte-rounded inputs.  Toleranc
 the activation dtype (bf16: 2^-8, f16: 2^-11 relative) plus accumulation-order noise."""
 import numpy as np
 import pytest
+from _margins import within
 import torch
 import torch.nn.functional as F
 
@@ -13,12 +14,13 @@ EPS = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}
 
 
 def _close(got, ref, dt, extra=1.0):
+    """|err| <= tol * |ref| (ONE output rounding of the activation dtype: deterministic, can be used up entirely at the bottom of a
+    binade) + 0.05 * tol * max|ref| + 1e-6 (slack for accumulation-order noise).  The recorded margin is the share of that SLACK in use."""
     got = got.double().cpu(); ref = ref.double().cpu()
     tol = EPS[dt] * extra
     err = (got - ref).abs()
-    bound = tol * ref.abs() + tol * ref.abs().max() * 0.05 + 1e-6
-    bad = (err > bound)
-    assert not bad.any(), f"max err {err.max().item():.3e} (ref max {ref.abs().max().item():.3e}), {bad.sum().item()} / {bad.numel()} beyond tolerance"
+    slack = tol * ref.abs().max() * 0.05 + 1e-6
+    within("kernel output: (err - one rounding) / accumulation slack", ((err - tol * ref.abs()) / slack).clamp_min(0).max().item(), 1.0)
 
 
 def _rand(shape, dt, scale=1.0, seed=0):

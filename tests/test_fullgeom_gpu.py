@@ -10,6 +10,7 @@ import os
 
 import numpy as np
 import pytest
+from _margins import within
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -71,7 +72,7 @@ def test_edit_f7_h64_all_20_steps(nets, dt):
     cur = _curve(trace, ref)
     print(f"\nedit f=7 h=64 {dt}: rel L2 error of the latents per DDIM step (in-batch references):\n  " +
           " ".join(f"{e:.2e}" for e in cur))
-    assert max(cur) <= BAR[dt], (max(cur), cur)
+    within("max(cur)", max(cur), BAR[dt])
     # product path: reference K / V^T from the bank, chunk frames only
     bank = pipe.build_ref_bank(lat[:4].to(DEV), disp[:4].to(DEV), cn.to(DEV), cp.to(DEV))
     trace_c = []
@@ -79,10 +80,10 @@ def test_edit_f7_h64_all_20_steps(nets, dt):
                            on_step=lambda i, l: trace_c.append(l.permute(0, 3, 1, 2).float().cpu()))
     cur_c = [_rel(t, torch.tensor(ref[i][4:])) for i, t in enumerate(trace_c)]
     print(f"edit f=7 h=64 {dt}: cached-reference path, chunk frames vs oracle:\n  " + " ".join(f"{e:.2e}" for e in cur_c))
-    assert max(cur_c) <= BAR[dt], (max(cur_c), cur_c)
+    within("max(cur_c)", max(cur_c), BAR[dt])
     d = _rel(trace_c[-1], trace[-1][4:])
     print(f"cached vs in-batch after 20 steps: {d:.2e}")
-    assert d <= BAR[dt]
+    within("d", d, BAR[dt])
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
@@ -100,7 +101,7 @@ def test_invert_f3_h64_all_20_steps(nets, dt):
                 on_step=lambda i, l: trace.append(l.permute(0, 3, 1, 2).float().cpu()))
     cur = _curve(trace, ref)
     print(f"\ninversion f=3 h=64 {dt}: rel L2 per step:\n  " + " ".join(f"{e:.2e}" for e in cur))
-    assert max(cur) <= BAR[dt], (max(cur), cur)
+    within("max(cur)", max(cur), BAR[dt])
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
@@ -121,7 +122,7 @@ def test_edit_f12_h64_config4_geometry(nets, dt):
                     on_step=lambda i, l: trace.append(l.permute(0, 3, 1, 2).float().cpu()))
     cur = _curve(trace, ref)
     print(f"\nedit f=12 h=64 {dt}: " + " ".join(f"{e:.2e}" for e in cur))
-    assert max(cur) <= BAR[dt], cur
+    within("max(cur)", max(cur), BAR[dt])
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
@@ -146,11 +147,11 @@ def test_vae_decode_h64(dt):
     got = dec.decode(to_nhwc8(zin.to(DEV), dt), postprocess=True)[..., :3].permute(0, 3, 1, 2).cpu()
     err = (got - ref).abs()
     print(f"\nvae decode h=64 {dt}: max abs {float(err.max()):.3e}  mean abs {float(err.mean()):.3e}  rel L2 {_rel(got, ref):.3e}")
-    assert _rel(got, ref) <= BAR[dt]
+    within("_rel(got, ref)", _rel(got, ref), BAR[dt])
     if dt == torch.float16:
-        assert float(err.max()) <= 1.0 / 255.0, float(err.max())
+        within("float(err.max())", float(err.max()), 1.0 / 255.0)
     else:
-        assert float(err.mean()) <= 1.0 / 255.0 and float(err.max()) <= 8.0 / 255.0, (float(err.mean()), float(err.max()))
+        within("float(err.mean())", float(err.mean()), 1.0 / 255.0); within("float(err.max())", float(err.max()), 8.0 / 255.0)
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
@@ -173,7 +174,7 @@ def test_vae_encode_h512(dt):
     got = (enc.encode_mean(to_nhwc8(x.to(DEV), dt))[..., :4] * 0.18215).permute(0, 3, 1, 2).float().cpu()
     rel = _rel(got, ref)
     print(f"\nvae encode 512x512 {dt}: rel L2 {rel:.3e}  max abs {float((got - ref).abs().max()):.3e}")
-    assert got.shape == (1, 4, H // 8, H // 8) and rel <= 2 * BAR[dt], rel
+    assert got.shape == (1, 4, H // 8, H // 8); within("rel", rel, 2 * BAR[dt])
 
 
 def _config4_run(nets, dt, fp8):
@@ -224,8 +225,8 @@ def _config4_run(nets, dt, fp8):
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_config4_f12_all_steps_decode_mask(nets, dt):
     cur, mean_e, max_e = _config4_run(nets, dt, False)
-    assert max(cur) <= BAR[dt], cur
-    assert mean_e <= 1.0 / 255.0 and max_e <= (2.0 if dt == torch.float16 else 16.0) / 255.0, (mean_e, max_e)
+    within("max(cur)", max(cur), BAR[dt])
+    within("mean_e", mean_e, 1.0 / 255.0); within("max_e", max_e, (2.0 if dt == torch.float16 else 16.0) / 255.0)
 
 
 def test_config4_f12_fp8_convs(nets):
@@ -233,8 +234,8 @@ def test_config4_f12_fp8_convs(nets):
     all 20 steps, decode, mask.  Own bars of the e4m3 path (3 mantissa bits): latents <= 6e-2 relative L2 at every step, composited
     image within 2 eight-bit levels on average."""
     cur, mean_e, max_e = _config4_run(nets, torch.bfloat16, True)
-    assert max(cur) <= 6e-2, cur
-    assert mean_e <= 2.0 / 255.0, (mean_e, max_e)
+    within("max(cur)", max(cur), 6e-2)
+    within("mean_e", mean_e, 2.0 / 255.0)
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
@@ -261,7 +262,7 @@ def test_batch_invariant_mode_bit_identical(nets, dt):
         # and it is still the same computation: within the dtype's bar of the default planning
         ops.BATCH_INVARIANT = False
         ref = pipe.edit_chunk_cached(to(lat[4:7]), to(disp[4:7]), to(cn), to(cp), bank, steps=3)
-        assert _rel(full, ref) <= BAR[dt]
+        within("_rel(full, ref)", _rel(full, ref), BAR[dt])
     finally:
         ops.BATCH_INVARIANT = keep
 
@@ -290,4 +291,4 @@ def test_edit_f7_h64_fp8_convs(nets):
                     on_step=lambda i, l: trace.append(l.permute(0, 3, 1, 2).float().cpu()))
     cur = _curve(trace, ref)
     print("\nedit f=7 h=64 fp8 convs: rel L2 per step:\n  " + " ".join(f"{e:.2e}" for e in cur))
-    assert max(cur) <= 6e-2, cur
+    within("max(cur)", max(cur), 6e-2)

@@ -104,6 +104,21 @@ def test_c_oracle_matches_torch_autograd(oracle_c, dtype):
         assert np.abs(gt - o["grads"][k]).max() <= 2e-5 * (np.abs(gt).max() + 1e-12), k
 
 
+def test_tiled_fp64_gradients_equal_whole_graph_autograd():
+    """render_grads_tiled (the fp64 checker of the stress-scene gradient tests on the GPU) == autograd of get_outputs in one graph."""
+    N, H, W = 300, 40, 56
+    P = syn.make_gaussians(N, seed=5, scale_mean=0.05)
+    c2w = syn.make_cameras(1, seed=6)[0]
+    fx = fy = 60.0; cx, cy = 28.0, 20.0
+    v = torch.randn(H, W, 3, generator=torch.Generator().manual_seed(0), dtype=torch.float64)
+    tp = {k: torch.tensor(x, dtype=torch.float64, requires_grad=True) for k, x in P.items()}
+    to = rt.get_outputs(tp, torch.tensor(c2w), fx, fy, cx, cy, W, H, torch.tensor(BG), training=True, dtype=torch.float64)
+    ((to["rgb"] * v).sum() + to["accumulation"].sum()).backward()
+    g = rt.render_grads_tiled(P, c2w, fx, fy, cx, cy, W, H, BG, v, to["gaussian_ids_sorted"], to["tile_bins"])
+    for k in P:
+        assert np.abs(g[k].numpy() - tp[k].grad.numpy()).max() <= 1e-12 * (np.abs(tp[k].grad.numpy()).max() + 1e-30), k
+
+
 def test_all_culled_returns_background(oracle_c):
     P, c2w = _one_gaussian()
     P["means"][0] = [0, -5.0, 0]           # behind the camera

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 import torch
 
+from _margins import within
 from gaussctrl_amd import synthetic as syn
 
 pytestmark = pytest.mark.gpu
@@ -36,15 +37,15 @@ def _img_close(got, ref, rel=1e-4, frac_max=1e-5):
     got = np.asarray(got, np.float64); ref = np.asarray(ref, np.float64)
     d = np.abs(got - ref); bound = rel * (np.abs(ref).max() + 1e-12)
     frac = float((d > bound).mean())
-    assert frac <= frac_max, f"fraction of values beyond {rel} rel: {frac}"
-    assert d.max() <= (1.0 / 255.0) * max(1.0, np.abs(ref).max()), d.max()
+    within(f"img: fraction of values beyond {rel} rel", frac, frac_max)
+    within("img: worst value (one dropped splat)", d.max(), (1.0 / 255.0) * max(1.0, np.abs(ref).max()))
 
 
 def _grad_close(got, ref, scale):
     """float-atomic accumulation order differs from the oracle: |diff| <= 1e-3 * max|ref| + 1e-6 * scale
     (scale = largest gradient magnitude of the whole parameter set; guards exactly-zero gradients)."""
     got = np.asarray(got, np.float64); ref = np.asarray(ref, np.float64)
-    assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-6 * scale, (np.abs(got - ref).max(), np.abs(ref).max())
+    within("grad max-norm", np.abs(got - ref).max(), 1e-3 * np.abs(ref).max() + 1e-6 * scale)
 
 
 @pytest.mark.parametrize("N,W,H,fx", [(5000, 200, 136, 180.0), (200000, 512, 512, 540.0), (1, 64, 64, 100.0)])
@@ -77,11 +78,11 @@ def test_sh_fwd_bwd(oracle_c):
         ref = oracle_c.spherical_harmonics(n, d, c)
         ct = _t(c).requires_grad_(True)
         out = ops.spherical_harmonics(n, _t(d), ct)
-        assert _relerr(out.detach().cpu().numpy(), ref) < 1e-6
+        within("_relerr(out.detach().cpu().numpy(), ref)", _relerr(out.detach().cpu().numpy(), ref), 1e-6, strict=True)
         v = g.normal(size=(N, 3)).astype(np.float32)
         out.backward(_t(v))
         refb = oracle_c.spherical_harmonics_bwd(n, d, K, v)
-        assert _relerr(ct.grad.cpu().numpy(), refb) < 1e-6
+        within("_relerr(ct.grad.cpu().numpy(), refb)", _relerr(ct.grad.cpu().numpy(), refb), 1e-6, strict=True)
 
 
 # tile counts chosen to take every branch of the tile passes (raster_sort.hip): 28 tiles -> one 5-bit staged pass, 63 -> one 6-bit,
@@ -169,8 +170,8 @@ def test_block_culling_edge_cases(oracle_c):
         got, ref = tp[k].grad.cpu().numpy().astype(np.float64), o["grads"][k].astype(np.float64)
         assert np.isfinite(got).all()
         d = np.abs(got[plain] - ref[plain])
-        assert d.max() <= 1e-2 * np.abs(ref[plain]).max() + 1e-6 * scale, (k, d.max(), np.abs(ref[plain]).max())
-        assert np.linalg.norm(got - ref) <= 5e-2 * np.linalg.norm(ref) + 1e-6 * scale, (k, np.linalg.norm(got - ref), np.linalg.norm(ref))
+        within("d.max()", d.max(), 1e-2 * np.abs(ref[plain]).max() + 1e-6 * scale)
+        within("np.linalg.norm(got - ref)", np.linalg.norm(got - ref), 5e-2 * np.linalg.norm(ref) + 1e-6 * scale)
 
 
 @pytest.mark.parametrize("N,W,H,fx,sm", [(5000, 200, 136, 180.0, 0.03), (100000, 512, 512, 540.0, 0.01), (3, 40, 24, 50.0, 0.2)])
@@ -389,10 +390,21 @@ def test_config5_raster_4m(oracle_c):
 def test_tight_tile_boxes_same_images_and_gradients():
     """Tight tile boxes (gc_project_sh_fwd_boxes / gc_raster_bin_tiles_boxes) vs gsplat's 3-sigma boxes on scenes that stress the box:
     needles, giants, faint and sub-pixel Gaussians, opacities around the 1/255 threshold.  Images must be BIT-identical (a dropped tile
-    contains no pixel that passes the per-pixel test); gradients agree to the noise of the float atomics; the lists get shorter."""
+    contains no pixel that passes the per-pixel test) and the lists get shorter.
+
+    Gradients.  These scenes are ill-conditioned on purpose: a needle's scale / rotation gradient is a cancelling sum whose fp32
+    float-atomic order noise is amplified by the projection backward.  Measured (scripts/tight_box_noise.py ->
+    profiles/r04_tight_box_noise.txt; same build, same box): the SAME variant run twice differs by up to 6.4e-4 of the tensor's max
+    (relative L2 2.9e-4), tight vs gsplat boxes by 1.03e-3 / 4.6e-4, and both sit 8.5e-4 / 5.0e-4 from the float64 gradients of the
+    independent restatement -- i.e. the two variants are equally far from the truth and the round-3 bar (1e-3 of max between the two
+    variants) sat inside the noise (a second box: same variant twice 1.47e-3 / 6.6e-4).  Criterion now: EACH variant within 1e-2 of max / 5e-3 relative L2 of the fp64 oracle
+    (oracle/raster_torch.py::render_grads_tiled, evaluated in float64 on the GPU), and the variants within the same bounds of each
+    other: >= 4.7x every distance measured on two boxes (worst: 2.1e-3 / 1.0e-3), all of it on ONE needle's scale / rotation rows."""
     from gaussctrl_amd import gsplat_ops as ops
     from gaussctrl_amd.camera import camera_to_gsplat
+    from oracle import raster_torch as rt
     W, H = 320, 240
+    K = dict(fx=300.0, fy=290.0, cx=161.3, cy=118.2)
     for seed, sm in ((0, 0.02), (1, 0.08), (2, 0.004)):
         P = syn.make_gaussians(60000, seed=seed, scale_mean=sm)
         g = np.random.default_rng(seed)
@@ -400,7 +412,8 @@ def test_tight_tile_boxes_same_images_and_gradients():
         P["scales"][::11] += 1.5                                # giants
         P["opacities"][::5] = g.normal(-5.0, 1.0, size=P["opacities"][::5].shape).astype(np.float32)    # around / below 1/255
         P["opacities"][::13] = 8.0                              # opaque: the alpha >= 1/255 ellipse exceeds gsplat's 3-sigma box
-        cam = camera_to_gsplat(syn.make_cameras(2, seed=seed + 3)[1], 300.0, 290.0, 161.3, 118.2, W, H)
+        c2w = syn.make_cameras(2, seed=seed + 3)[1]
+        cam = camera_to_gsplat(c2w, K["fx"], K["fy"], K["cx"], K["cy"], W, H)
         v = torch.randn(H, W, 3, generator=torch.Generator().manual_seed(seed)).to(DEV)
         out = {}
         for tight in (True, False):
@@ -409,12 +422,19 @@ def test_tight_tile_boxes_same_images_and_gradients():
             rgb, alpha, _ = ops.render_view(tp["means"], tp["scales"], tp["quats"], tp["opacities"], tp["features_dc"], tp["features_rest"],
                                             cam, _t(BG), False, 3, aux)
             ((rgb * v).sum() + alpha.sum()).backward()
-            out[tight] = (rgb.detach(), alpha.detach(), {k: t.grad.clone() for k, t in tp.items()}, aux.M)
+            out[tight] = (rgb.detach(), alpha.detach(), {k: t.grad.double().cpu().numpy() for k, t in tp.items()}, aux.M, aux)
         assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
         assert out[True][3] < out[False][3]
-        scale = max(float(t.abs().max()) for t in out[False][2].values())
-        for k in out[False][2]:
-            _grad_close(out[True][2][k].cpu().numpy(), out[False][2][k].cpu().numpy(), scale)
+        ref = rt.render_grads_tiled(P, c2w, K["fx"], K["fy"], K["cx"], K["cy"], W, H, BG, v.cpu(), out[False][4].gaussian_ids_sorted,
+                                    out[False][4].tile_bins, device=DEV)
+        scale = max(float(t.abs().max()) for t in ref.values())
+        for k in ref:
+            r = ref[k].numpy()
+            for name, a, b in (("tight vs fp64", out[True][2][k], r), ("gsplat boxes vs fp64", out[False][2][k], r),
+                               ("tight vs gsplat boxes", out[True][2][k], out[False][2][k])):
+                d = a - b
+                within(f"{k} {name} max-norm", np.abs(d).max(), 1e-2 * np.abs(r).max() + 1e-6 * scale)
+                within(f"{k} {name} rel L2", np.linalg.norm(d), 5e-3 * np.linalg.norm(r) + 1e-6 * scale)
         print(f"seed {seed}: M tight {out[True][3]} / gsplat {out[False][3]} = {out[True][3] / out[False][3]:.3f}")
 
 

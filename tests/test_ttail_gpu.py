@@ -4,6 +4,7 @@ behind gaussctrl/gc_pipeline.py:224-227) and (b) the per-op HIP path it replaces
 import math
 
 import pytest
+from _margins import within
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -82,9 +83,9 @@ def test_tail_matches_torch_and_the_per_op_path(dtype, B, HW, f, Lt, gate_shift)
     scale = ref.abs().max()
     e_fused, e_per_op = (got - ref).abs().max() / scale, (per_op - ref).abs().max() / scale
     bar = 2e-2 if dtype == torch.bfloat16 else 3e-3            # of the output range: ~2.5 ulp of the 16-bit format at the largest value
-    assert e_fused < bar, (e_fused, e_per_op)
-    assert e_fused < 2 * e_per_op + 1e-3, (e_fused, e_per_op)  # no worse than the path it replaces
-    assert (got - per_op).abs().max() / scale < bar
+    within("e_fused", e_fused, bar, strict=True)
+    within("e_fused", e_fused, 2 * e_per_op + 1e-3, strict=True)  # no worse than the path it replaces
+    within("(got - per_op).abs().max() / scale", (got - per_op).abs().max() / scale, bar, strict=True)
 
 
 def test_unet_with_fused_tail_matches_per_op_unet():
@@ -140,7 +141,7 @@ def test_head_matches_torch_and_the_per_op_path(dtype, B, HW):
     for name, got, ref, tt in (("h", h, h_ref, ht), ("q", qk[..., :C], qk_ref[..., :C], qt), ("k", qk[..., C:], qk_ref[..., C:], kt), ("vt", vt, vt_ref, vtt)):
         sc = tt.abs().max()
         e_f, e_p = (got.float() - tt).abs().max() / sc, (ref.float() - tt).abs().max() / sc
-        assert e_f < bar and e_f < 2 * e_p + 1e-3, (name, float(e_f), float(e_p))
+        within("e_f", e_f, bar, strict=True); within("e_f", e_f, 2 * e_p + 1e-3, strict=True)
 
 
 def test_head_to_tail_fragment_layout_is_the_same_function():
@@ -195,9 +196,9 @@ def test_level0_block_against_the_oracle(dtype, bar, mode):
     out, _ = net.transformer(P, xg, None, ctx.to(dtype).to(dev), actx)
     got = out.float().cpu().permute(0, 3, 1, 2)
     rel = float((got - ref).norm() / ref.norm())
-    assert rel < bar, rel
+    within("rel", rel, bar, strict=True)
     # and the per-op launches give the same answer within the same bar
     net.fused_head = net.fused_tail = False
     out2, _ = net.transformer(P, xg, None, ctx.to(dtype).to(dev), U.AttnCtx(mode, 0.6, f, {}, None, "unet"))
     rel2 = float((out2.float().cpu().permute(0, 3, 1, 2) - ref).norm() / ref.norm())
-    assert rel2 < bar and rel < 2 * rel2 + 1e-4, (rel, rel2)
+    within("rel2", rel2, bar, strict=True); within("rel", rel, 2 * rel2 + 1e-4, strict=True)
