@@ -109,7 +109,8 @@ class GemmProfiler:
             N = w.shape[0]
             ntw = 5 if (N % 160 == 0 and N % 128 != 0) else 4
             mode = 2 if x.shape[-1] % 64 == 0 else 1
-            prof.rec.append((f"gemm<{prof.dt},conv3x3{'' if mode == 2 else ' generic'},BN={32 * ntw}>", 2.0 * (out.numel() // out.shape[-1]) * N * w.shape[1], s, e))
+            o = out[0] if isinstance(out, tuple) else out              # (out, ChanParts) when the producer statistics were asked for
+            prof.rec.append((f"gemm<{prof.dt},conv3x3{'' if mode == 2 else ' generic'},BN={32 * ntw}>", 2.0 * (o.numel() // o.shape[-1]) * N * w.shape[1], s, e))
             return out
 
         def tail(o, h, x, *a, **k):      # level-0 block after the attention, one launch: 2 * rows * 1.6896 M weights (incl. the 77-key text attention)
@@ -453,6 +454,7 @@ def main():
         dist = None
 
     from gaussctrl_amd.sd import ops as sdops
+    sdops.configure(sdops.options_from_env())       # experiment switches (GC_FUSED_TAIL=0, GC_ATTN_V=4, GC_ABLATE=gn, ...): default = product
     if args.views is None:
         args.views = 40 if args.workload == "edit" else 256
     c, V, nsteps = args.chunk_size, args.views, args.denoise_steps
@@ -569,8 +571,8 @@ def main():
                           "views_per_step": round(views_done / args.steps, 3), "chunks_per_scene_per_rank": chunks_per_scene, "parallelism": par,
                           "mean_intersections_M": int(np.mean(stats["M"])) if stats["M"] else 0,
                           "ref_trajectory_in_timed_region": bool(args.workload == "edit"),
-                          "level0_transformer_blocks": ("one-launch head + tail" if os.environ.get("GC_FUSED_HEAD", "1") == "1" and os.environ.get("GC_FUSED_TAIL", "1") == "1"
-                                                        else f"GC_FUSED_HEAD={os.environ.get('GC_FUSED_HEAD', '1')} GC_FUSED_TAIL={os.environ.get('GC_FUSED_TAIL', '1')}") if args.workload == "edit" else None,
+                          "level0_transformer_blocks": ("one-launch head + tail" if sdops.OPTIONS.fused_head and sdops.OPTIONS.fused_tail
+                                                        else f"fused_head={sdops.OPTIONS.fused_head} fused_tail={sdops.OPTIONS.fused_tail}") if args.workload == "edit" else None,
                           "ref_trajectory_share_per_step": f"{nsteps}/{chunks_per_scene} DDIM steps of the next scene's 4 reference views" if args.workload == "edit" else None},
                # the two halves separately (GPU time of rank 0's launch stream between HIP events in the timed steps)
                # (the wall time of the timed region is apportioned to the halves by their share of the per-chunk GPU spans: with one

@@ -859,7 +859,8 @@ extern "C" int gc_dn_attention(const gc_attn_desc *d, void *stream)
     for (int i = 0; i < d->nsets; ++i) GC_REQUIRE(d->set_kind[i] >= -2 && d->set_kind[i] < a.ref_fph, "bad set_kind");
     a.scale_log2e = d->q_prescaled ? 1.f : d->scale * 1.4426950408889634f;
     a.abl = d->kernel_variant >> 8;
-    a.part = (d->workspace && d->workspace_bytes >= gc_dn_attention_workspace_bytes(d)) ? (float *)d->workspace : nullptr;
+    const size_t ws_need = gc_dn_attention_workspace_bytes(d);          // 0: this shape never takes the set-split form, whatever is passed
+    a.part = (d->workspace && ws_need > 0 && d->workspace_bytes >= ws_need) ? (float *)d->workspace : nullptr;
     const bool fast = !(d->kernel_variant & 1);      // kernel_variant bit 0: online-softmax kernel everywhere (tests)
     int rc = d->dtype == DT_BF16 ? launch_attn<BF16>(a, d->head_dim, d->batch, fast, d->kernel_variant, gc::S(stream))
              : d->dtype == DT_F16 ? launch_attn<F16>(a, d->head_dim, d->batch, fast, d->kernel_variant, gc::S(stream)) : GC_EINVAL;

@@ -273,7 +273,9 @@ __device__ __forceinline__ void attn_safe_body(const AttnArgs &a, int qblk, int 
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) otot[dt][qt][r] += os[dt][qt][r] * inv;
+                // (explicit multiply THEN add, never an FMA: the set-split launch stores round(os * inv) per set and k_attn_combine adds the
+                // sets in this order, so the two forms agree bit for bit whatever grid size picked between them)
+                for (int r = 0; r < 4; ++r) otot[dt][qt][r] = __fadd_rn(otot[dt][qt][r], __fmul_rn(os[dt][qt][r], inv));
         }
     }
     // ---- store: lane owns O[q = fr][d = 16*dt + 4*g .. +4]

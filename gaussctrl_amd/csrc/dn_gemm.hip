@@ -60,7 +60,7 @@ extern "C" size_t gc_dn_gemm_workspace_bytes(const gc_gemm_desc *d)
 namespace {
 // kernel choice of one problem (shared by the launcher and the row-statistics layout query)
 struct Sel { int mode, ntw, splits, tps, mt8; };     // mt8 > 0: 8-wave kernel with MT = mt8; 0: 4-wave kernel
-int select(const gc_gemm_desc *d, Sel *o)
+int select(const gc_gemm_desc *d, Sel *o, bool want_parts)
 {
     int mode = 0;
     if (d->mode == 1) mode = (d->Cin % 64 == 0) ? 2 : 1;
@@ -92,7 +92,7 @@ int select(const gc_gemm_desc *d, Sel *o)
         if (!mt && mode == 0 && !force_mt) mt = 2;       // small linears: the 8-wave kernel's fill + epilogue is the shorter one (12.6 vs 20.9 us at M = 384)
         // part-filled single-round grids of short-K linears: 64-row tiles, two workgroups per CU (all resident when <= 512 tiles)
         if (mode == 0 && !force_mt && ntw == 4 && d->K % 64 == 0 && !d->geglu && !d->out_t && !(kv & 0x100) &&
-            !(d->ln_row_stats || d->out_row_stats || d->out_group_stats)) {
+            !(d->ln_row_stats || d->out_row_stats || d->out_group_stats) && !want_parts) {
             const int64_t t1 = ((d->M + 63) / 64) * nbn, t2 = ((d->M + 127) / 128) * nbn;
             if (mt == 2 && t2 <= 256 && t1 <= 512 && t1 > 128 && nk_host <= 24) mt = 1;      // (same accumulation order as MT 2)
         }
@@ -117,8 +117,37 @@ extern "C" int gc_dn_gemm_row_stat_slots(const gc_gemm_desc *d)
     if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
     if (d->fp8) { const int ntw = (d->N % 160 == 0 && d->N % 128 != 0) ? 5 : 4; return (int)((d->N + 16 * ntw - 1) / (16 * ntw)); }
     Sel sel;
-    select(d, &sel);
+    select(d, &sel, false);
     return sel.splits > 1 ? (int)((d->N / 4 + 63) / 64) : (int)((d->N + 16 * sel.ntw - 1) / (16 * sel.ntw));
+}
+
+namespace {
+// channel-partial layout of one problem: rows per slab (0 = unsupported) and slab slots per batch
+void chan_parts_layout(const gc_gemm_desc *d, const Sel &sel, int64_t *rows, int *nslab)
+{
+    *rows = 0; *nslab = 0;
+    const int64_t rpb = d->rows_per_batch;
+    if (d->fp8 || d->geglu || d->out_t || !d->out || d->out_f32 || d->ln_row_stats || d->out_row_stats || d->out_group_stats) return;
+    if (rpb < 256 || rpb % 32 != 0 || d->M % rpb != 0) return;
+    if (sel.splits > 1) { *rows = CS_RB; *nslab = (int)(rpb / CS_RB); return; }           // the reduce-epilogue kernel produces them
+    if (!sel.mt8) return;
+    if ((d->mode == 1 && d->upsample) || (d->mode == 0 && d->K % 64 != 0)) return;
+    const int64_t bm = 64 * (sel.mt8 < 2 ? 2 : sel.mt8);
+    if (bm > rpb) return;
+    *rows = bm;
+    *nslab = (int)(rpb % bm == 0 ? rpb / bm : (rpb + bm - 1) / bm + 1);
+}
+}  // namespace
+
+extern "C" int gc_dn_gemm_chan_parts_layout(const gc_gemm_desc *d, int64_t *rows_per_slab, int *nslab)
+{
+    GC_REQUIRE(d && rows_per_slab && nslab, "null argument");
+    *rows_per_slab = 0; *nslab = 0;
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->rows_per_batch <= 0) return GC_OK;
+    Sel sel;
+    select(d, &sel, true);
+    chan_parts_layout(d, sel, rows_per_slab, nslab);
+    return GC_OK;
 }
 
 extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
@@ -157,7 +186,15 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
     const int force_mt = d->kernel_variant & 7;
     GC_REQUIRE(force_mt >= 0 && force_mt <= 4, "kernel_variant: MT must be 0 .. 4");
     Sel sel;
-    select(d, &sel);
+    select(d, &sel, d->out_chan_parts != nullptr);
+    g.chan_parts = d->out_chan_parts; g.cp_nslab = 0; g.cp_rows = 0;
+    if (d->out_chan_parts) {
+        int64_t rows; int ns;
+        chan_parts_layout(d, sel, &rows, &ns);
+        GC_REQUIRE(rows > 0, "out_chan_parts: this problem cannot produce channel partials (see gc_dn_gemm_chan_parts_layout)");
+        g.cp_nslab = ns; g.cp_rows = (int)rows;
+        if (sel.mt8 == 1) sel.mt8 = 2;
+    }
     if (fuse_of(g) && sel.mt8) {     // the 8-wave kernel carries the fused epilogue for conv (generic / fast) and K % 64 == 0 linears only
         const bool upsampled = d->mode == 1 && d->upsample, ragged = d->mode == 0 && d->K % 64 != 0;
         GC_REQUIRE(!upsampled && !ragged, "row / group statistics and LayerNorm folding: not with upsample-fused convs or K % 64 != 0 linears");
@@ -185,7 +222,7 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
     const int bn = 32 * sel.ntw;
     const int64_t nbn = (d->N + bn - 1) / bn;
     g.persist = 0;
-    if (sel.mt8 == 4 && sel.ntw == 4 && sel.mode == 0 && sel.splits == 1 && d->K % 64 == 0 && d->K <= 64 * 24 && !fuse_of(g) &&
+    if (sel.mt8 == 4 && sel.ntw == 4 && sel.mode == 0 && sel.splits == 1 && d->K % 64 == 0 && d->K <= 64 * 24 && !fuse_of(g) && !g.chan_parts &&
         !g.rowvec && !g.out_t && !g.out_f32 && g.out && g.act != 2 && !(d->kernel_variant & 0x200)) {
         // multi-round short-K linear (the GEGLU FF-up projections): persistent workgroups, next tile's fill under this tile's epilogue
         const int64_t tiles = ((d->M + 255) / 256) * nbn;
@@ -194,12 +231,14 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
     if (sel.mt8) {
         const int64_t nbm8 = (d->M + 64 * sel.mt8 - 1) / (64 * sel.mt8);
         const dim3 grid8((unsigned)(nbm8 * nbn), (unsigned)sel.splits);
-        if (fuse_of(g)) dn_gemm_launch_fuse(g, d->dtype, sel.mode, sel.ntw, sel.mt8, grid8, s); else dn_gemm_launch_plain(g, d->dtype, sel.mode, sel.ntw, sel.mt8, grid8, s);
+        if (fuse_of(g)) dn_gemm_launch_fuse(g, d->dtype, sel.mode, sel.ntw, sel.mt8, grid8, s);
+        else if (g.chan_parts && sel.splits == 1) dn_gemm_launch_cs(g, d->dtype, sel.mode, sel.ntw, sel.mt8, grid8, s);
+        else dn_gemm_launch_plain(g, d->dtype, sel.mode, sel.ntw, sel.mt8, grid8, s);
     } else {
         const int64_t nbm = (d->M + BM - 1) / BM;
         const dim3 grid((unsigned)(nbm * nbn), (unsigned)sel.splits);
         if (fuse_of(g)) dn_gemm_launch_fuse(g, d->dtype, sel.mode, sel.ntw, 0, grid, s); else dn_gemm_launch_plain(g, d->dtype, sel.mode, sel.ntw, 0, grid, s);
     }
-    if (sel.splits > 1) dn_gemm_launch_splitk_epilogue(g, d->dtype, s);
+    if (sel.splits > 1) { if (g.chan_parts) dn_gemm_launch_splitk_epilogue_cs(g, d->dtype, s); else dn_gemm_launch_splitk_epilogue(g, d->dtype, s); }
     return gc::check_launch("gc_dn_gemm");
 }

@@ -53,6 +53,11 @@ struct GemmArgs {
     const unsigned char *w_scale;       // fp8 path: E8M0 scale byte per weight row [N] (weights stored as e4m3 * 2^(127 - byte))
     int a_scale;                        // fp8 path: E8M0 scale byte of the whole activation tensor
     int dbg;                            // experiment switches (kernel_variant bits 8..): 1 no global group atomics, 2 no LDS atomics, 4 no DPP
+    // per-CHANNEL partial sums of the stored output, the input of a following GroupNorm (k_gemm8 CS = true, k_splitk_epilogue_cs):
+    // chan_parts[b][slab][n] = (sum, sum^2) over the rows of batch b inside the slab-th row tile (cp_rows rows each, tiles counted over
+    // all M rows) that overlaps batch b.  PLAIN stores: no atomics (round 2's per-(batch, group) float atomics cost 26 ms per chunk in
+    // same-line contention), no zero-init; gc_dn_groupnorm_apply_parts adds the slabs up in its prologue.
+    float *chan_parts; int cp_nslab; int cp_rows;
 };
 }  // namespace dng
 
@@ -700,9 +705,10 @@ __device__ __forceinline__ void glds16_s(const void *sbase, unsigned voff, unsig
 // MODE 3 (k_gemm8 only): linear with K % 64 == 0 -- rows past M / N re-read the last valid row (their outputs are never stored),
 // so a k-tile's DMA is a uniform base + constant per-lane offset: no VALU at all in the issue path.
 // MT: m-tiles (of 16) per wave: workgroup tile (64 MT) x (32 NTW), waves 4 (M) x 2 (N), wave tile (16 MT) x (16 NTW).
-template <class T, int MODE, int NTW, int MT, bool FUSE>
+template <class T, int MODE, int NTW, int MT, bool FUSE, bool CS = false>
 __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g)
 {
+    static_assert(!(FUSE && CS), "one statistics epilogue at a time");
     constexpr int BM = 64 * MT;
     constexpr bool CONVF = MODE == 2 || MODE == 4, UPS = MODE == 4;   // MODE 4 = MODE 2 + fused nearest-x2 upsample
     constexpr int BN = 32 * NTW;
@@ -726,6 +732,10 @@ __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g
     float *srow = reinterpret_cast<float *>(smem + NS * STAGE);          // FUSE: [BM][2] row sums of the LayerNorm-folded consumer
     if constexpr (FUSE) {
         if (g.row_stats && g.splits == 1) row_stats_prologue<BM>(g, m_base, srow);
+    }
+    float *ctab = reinterpret_cast<float *>(smem + NS * STAGE);          // CS: [2 batch slots][BN][2] channel sums of this tile, behind the ring
+    if constexpr (CS) {      // zeroed here: the k loop's barriers order it before the epilogue's LDS adds
+        for (int i = tid; i < 4 * BN; i += 512) ctab[i] = 0.f;
     }
 
     // ---- per-lane DMA coordinates
@@ -977,9 +987,45 @@ __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g
         const int64_t n = n_lane + nt * 16;
         bia[nt] = (g.bias && n < g.N) ? *reinterpret_cast<const float4 *>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // CS: per-lane channel sums over the wave's rows of ONE batch; a 16-row m-tile never straddles batches (rows_per_batch % 16 == 0)
+    // and a workgroup tile at most one boundary (BM <= rows_per_batch): slot 0 = the batch of the tile's first row, slot 1 the next
+    float cs[CS ? NTW : 1][4], cq[CS ? NTW : 1][4];
+    int cs_slot = -1;
+    int64_t m_split = 0;
+    if constexpr (CS) {
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { cs[nt][r] = 0.f; cq[nt][r] = 0.f; }
+        m_split = (m_base / g.rows_per_batch + 1) * g.rows_per_batch;          // first row of the next batch
+    }
+    auto cs_flush = [&]() __attribute__((always_inline)) {
+        if constexpr (CS) {
+            float *tb = ctab + (cs_slot * BN + wn * (16 * NTW) + fc * 4) * 2;
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float sa = row16_sum(cs[nt][r]), sb = row16_sum(cq[nt][r]);
+                    if (fr == 0) {
+                        __hip_atomic_fetch_add(tb + (nt * 16 + r) * 2, sa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(tb + (nt * 16 + r) * 2 + 1, sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    cs[nt][r] = 0.f; cq[nt][r] = 0.f;
+                }
+        }
+    };
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int64_t m = m_base + wm * (16 * MT) + mt * 16 + fr;
+        if constexpr (CS) {
+            const int64_t m_tile = m_base + wm * (16 * MT) + mt * 16;         // wave-uniform
+            if (m_tile < g.M) {
+                const int slot = m_tile >= m_split ? 1 : 0;
+                if (cs_slot >= 0 && slot != cs_slot) cs_flush();
+                cs_slot = slot;
+            }
+        }
         if (m >= g.M) continue;
         float4 rv[NTW];
         uint2 rs[NTW];
@@ -1021,17 +1067,39 @@ __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g
                 v[2] += T::to_f((unsigned short)(rs[nt].y & 0xffff)); v[3] += T::to_f((unsigned short)(rs[nt].y >> 16));
             }
             const bool to_t = g.out_t && on >= g.t_col0;
+            const uint2 pk = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
             if (g.out && !(to_t && g.t_col0 > 0)) {
                 if (g.out_f32)
                     *reinterpret_cast<float4 *>((float *)g.out + m * g.ldc + on) = make_float4(v[0], v[1], v[2], v[3]);
                 else
-                    *reinterpret_cast<uint2 *>((unsigned char *)g.out + (m * g.ldc + on) * 2) = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
+                    *reinterpret_cast<uint2 *>((unsigned char *)g.out + (m * g.ldc + on) * 2) = pk;
             }
             if (to_t) {
                 const int64_t b = m / g.rows_per_batch, tok = m - b * g.rows_per_batch;
                 unsigned short *o = (unsigned short *)g.out_t + b * g.t_batch_stride + tok;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[(on - g.t_col0 + r) * g.ldt] = T::from_f(v[r]);
+            }
+            if constexpr (CS) {      // statistics of the values as STORED (rounded to the activation type)
+                const float t0 = T::to_f((unsigned short)(pk.x & 0xffff)), t1 = T::to_f((unsigned short)(pk.x >> 16));
+                const float t2 = T::to_f((unsigned short)(pk.y & 0xffff)), t3 = T::to_f((unsigned short)(pk.y >> 16));
+                cs[nt][0] += t0; cq[nt][0] += t0 * t0; cs[nt][1] += t1; cq[nt][1] += t1 * t1;
+                cs[nt][2] += t2; cq[nt][2] += t2 * t2; cs[nt][3] += t3; cq[nt][3] += t3 * t3;
+            }
+        }
+    }
+    if constexpr (CS) {
+        if (cs_slot >= 0) cs_flush();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the LDS adds; NOT the output stores still in flight
+        __builtin_amdgcn_s_barrier();
+        const int64_t b0 = m_base / g.rows_per_batch;
+        const int64_t m_end = m_base + BM < g.M ? m_base + BM : g.M;
+        for (int i = tid; i < 2 * BN; i += 512) {
+            const int slot = i >= BN ? 1 : 0, nl = i - slot * BN;
+            const int64_t n = n_base + nl, b = b0 + slot;
+            if (n < g.N && (slot == 0 || m_split < m_end)) {
+                const int64_t slab = mblk - (b * g.rows_per_batch) / BM;       // tiles are counted over all M rows
+                *reinterpret_cast<float2 *>(g.chan_parts + ((b * g.cp_nslab + slab) * g.N + n) * 2) = *reinterpret_cast<const float2 *>(ctab + i * 2);
             }
         }
     }
@@ -1619,6 +1687,64 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const GemmArgs g)
 }
 
 
+// the plain reduce-epilogue + per-channel partial sums of the stored output (GemmArgs::chan_parts, slabs of CS_RB rows; rows_per_batch %
+// CS_RB == 0 so a slab never straddles batches): workgroup = 16 column quads (64 columns) x 16 row lanes over CS_RB rows -- 2 rows per
+// thread, all slab loads of a thread in flight together (the first version, 64 quads x 4 row lanes x 8 rows, ran 19.5 us against 7.9 us
+// for the plain grid-stride kernel: a chain of dependent round trips on 240 workgroups)
+constexpr int CS_RB = 32;
+template <class T>
+__global__ __launch_bounds__(256) void k_splitk_epilogue_cs(const GemmArgs g)
+{
+    __shared__ float red[16][16][8];
+    constexpr int RPT = CS_RB / 16;
+    const int64_t nq = g.N / 4;
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int64_t cq4 = (int64_t)blockIdx.x * 16 + cl;
+    const int64_t m0 = (int64_t)blockIdx.y * CS_RB;
+    const bool okc = cq4 < nq;
+    const int64_t n = (okc ? cq4 : 0) * 4;
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float v[RPT][4];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) { v[i][0] = 0.f; v[i][1] = 0.f; v[i][2] = 0.f; v[i][3] = 0.f; }
+    if (okc) {
+        for (int z = 0; z < g.splits; ++z) {
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const int64_t m = m0 + rl + 16 * i;
+                if (m < g.M) {
+                    const float4 a = *reinterpret_cast<const float4 *>(g.ws + ((int64_t)z * g.M + m) * g.N + n);
+                    v[i][0] += a.x; v[i][1] += a.y; v[i][2] += a.z; v[i][3] += a.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int64_t m = m0 + rl + 16 * i;
+            if (m >= g.M) break;
+            float gate[4] = {0.f, 0.f, 0.f, 0.f};
+            epilogue_store<T>(g, m, n, n, v[i], gate);      // on return v holds the values as stored
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { cs[2 * r] += v[i][r]; cs[2 * r + 1] += v[i][r] * v[i][r]; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[rl][cl][j] = cs[j];
+    __syncthreads();
+    if (threadIdx.x < 128) {           // thread = (column quad, value): sum over the 16 row lanes
+        const int c2 = threadIdx.x >> 3, j = threadIdx.x & 7;
+        const int64_t cq = (int64_t)blockIdx.x * 16 + c2;
+        if (cq < nq && m0 < g.M) {
+            float o = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o += red[r][c2][j];
+            const int64_t b = m0 / g.rows_per_batch, slab = (m0 - b * g.rows_per_batch) / CS_RB;
+            g.chan_parts[((b * g.cp_nslab + slab) * g.N + cq * 4) * 2 + j] = o;
+        }
+    }
+}
+
+
 inline bool fuse_of(const GemmArgs &g) { return g.row_stats || g.out_row_stats || g.out_group_stats; }
 
 // ---- launch templates: instantiated with FUSE = false in dn_gemm_plain.hip and FUSE = true in dn_gemm_fuse.hip (one translation
@@ -1632,14 +1758,34 @@ void launch4(const GemmArgs &g, dim3 grid, hipStream_t s)
     hipLaunchKernelGGL((k_gemm<T, MODE, NTW, FUSE>), grid, dim3(NT), lds, s, g);
 }
 
-template <class T, int MODE, int NTW, int MT, bool FUSE>
+template <class T, int MODE, int NTW, int MT, bool FUSE, bool CS = false>
 void launch8(const GemmArgs &g, dim3 grid, hipStream_t s)
 {
-    constexpr size_t lds = 3 * (64 * MT * 128 + 32 * NTW * 128) + (FUSE ? 64 * MT * 8 : 0);     // FUSE: + the row-sum array of row_stats_prologue
+    // FUSE: + the row-sum array of row_stats_prologue; CS: + the [2][BN][2] channel-sum table
+    constexpr size_t lds = 3 * (64 * MT * 128 + 32 * NTW * 128) + (FUSE ? 64 * MT * 8 : 0) + (CS ? 32 * NTW * 16 : 0);
     static_assert(lds <= 160 * 1024, "LDS ring");
     static gc::AttrOnce once;
-    gc::ensure_dynamic_lds(once, (const void *)k_gemm8<T, MODE, NTW, MT, FUSE>, (int)lds);
-    hipLaunchKernelGGL((k_gemm8<T, MODE, NTW, MT, FUSE>), grid, dim3(512), lds, s, g);
+    gc::ensure_dynamic_lds(once, (const void *)k_gemm8<T, MODE, NTW, MT, FUSE, CS>, (int)lds);
+    hipLaunchKernelGGL((k_gemm8<T, MODE, NTW, MT, FUSE, CS>), grid, dim3(512), lds, s, g);
+}
+
+// channel-partial epilogue (CS): the modes whose output feeds a GroupNorm -- generic conv (conv_in), fast conv, K % 64 == 0 linear (proj_out)
+template <class T, int NTW, int MT>
+void dispatch8cs_m(const GemmArgs &g, int mode, dim3 grid, hipStream_t s)
+{
+    if (mode == 0) launch8<T, 3, NTW, MT, false, true>(g, grid, s);
+    else if (mode == 1) launch8<T, 1, NTW, MT, false, true>(g, grid, s);
+    else launch8<T, 2, NTW, MT, false, true>(g, grid, s);
+}
+template <class T>
+void dispatch8cs(const GemmArgs &g, int mode, int ntw, int mt, dim3 grid, hipStream_t s)
+{
+    if (mt < 2) mt = 2;
+    if (ntw == 5) {
+        if (mt == 4) dispatch8cs_m<T, 5, 4>(g, mode, grid, s); else if (mt == 3) dispatch8cs_m<T, 5, 3>(g, mode, grid, s); else dispatch8cs_m<T, 5, 2>(g, mode, grid, s);
+    } else {
+        if (mt == 4) dispatch8cs_m<T, 4, 4>(g, mode, grid, s); else if (mt == 3) dispatch8cs_m<T, 4, 3>(g, mode, grid, s); else dispatch8cs_m<T, 4, 2>(g, mode, grid, s);
+    }
 }
 
 template <class T, int NTW, int MT, bool FUSE>
@@ -1691,3 +1837,5 @@ void dn_gemm_launch_plain(const GemmArgs &g, int dtype, int mode, int ntw, int m
 void dn_gemm_launch_fuse(const GemmArgs &g, int dtype, int mode, int ntw, int mt8, dim3 grid, hipStream_t s);
 void dn_gemm_launch_fp8(const GemmArgs &g, int dtype, int mode, int ntw, int mt, dim3 grid, hipStream_t s);
 void dn_gemm_launch_splitk_epilogue(const GemmArgs &g, int dtype, hipStream_t s);
+void dn_gemm_launch_cs(const GemmArgs &g, int dtype, int mode, int ntw, int mt8, dim3 grid, hipStream_t s);     // 8-wave kernel + channel partials
+void dn_gemm_launch_splitk_epilogue_cs(const GemmArgs &g, int dtype, hipStream_t s);

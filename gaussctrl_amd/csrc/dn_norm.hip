@@ -210,6 +210,53 @@ __global__ __launch_bounds__(256) void k_gn_apply_stats(const unsigned short *__
     }
 }
 
+// GroupNorm from per-CHANNEL partial sums that the PRODUCER of x left per row slab (gc_gemm_desc.out_chan_parts: the conv / linear epilogue,
+// the split-K reduce kernel, gc_dn_concat_add_parts): parts[b][slab][c] = (sum x, sum x^2) over the rows of batch b inside slab `slab`.
+// Plain stores on the producer side -- no atomics, no zero-init; the slabs are added up HERE, in the prologue of the apply kernel
+// (a few tens of independent 8-byte loads per thread from L2), then the group moments, then the coefficients, all in LDS.
+// slab_mode 0: slabs are the producer's row tiles of R rows counted over all B * HW rows (a tile that straddles two batches has a slab
+// in each); slab_mode 1: slabs restart at every batch.  Raw (unshifted) fp32 sums: relative error of the variance ~ 1e-7 * mean^2 / var.
+__device__ __forceinline__ int parts_count(unsigned b, unsigned HW, unsigned R, int mode)
+{
+    if (mode) return (int)((HW + R - 1) / R);
+    const unsigned long long r0 = (unsigned long long)b * HW, r1 = r0 + HW - 1;
+    return (int)(r1 / R - r0 / R) + 1;
+}
+
+// finalize pass over the producer's partials: one workgroup per (batch, group); thread = (channel of the group, slab subset), every
+// thread issues its few slab loads back to back; -> coef[b][c] = (a_c = rstd_g gamma_c, beta_c - mean_g a_c), the input of k_gn_apply.
+// (Tried first: the slab sums, group moments and coefficients in the PROLOGUE of the apply kernel -- one launch per GroupNorm -- but every
+// one of its ~500 workgroups then re-reads nslab x C x 8 bytes and re-adds them in LDS: 64 us instead of 23 us at 64 x 64 x 320.)
+__global__ __launch_bounds__(256) void k_gn_finalize_parts(unsigned HW, unsigned C, int G, const float *__restrict__ parts, int nslab, unsigned R, int mode,
+                                                           const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float *__restrict__ coef)
+{
+    __shared__ float red[2][4];
+    const unsigned b = blockIdx.x / G, gi = blockIdx.x % G, cpg = C / G, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int ns = parts_count(b, HW, R, mode);
+    const unsigned ci = tid % cpg, sub = tid / cpg, nsub = 256 / cpg;   // cpg <= 256
+    float s1 = 0.f, s2 = 0.f;
+    if (sub < nsub) {
+        const float2 *pb = reinterpret_cast<const float2 *>(parts) + ((size_t)b * nslab) * C + gi * cpg + ci;
+        int sl = (int)sub;
+        for (; sl + 3 * (int)nsub < ns; sl += 4 * (int)nsub) {
+            const float2 v0 = pb[(size_t)sl * C], v1 = pb[(size_t)(sl + nsub) * C], v2 = pb[(size_t)(sl + 2 * nsub) * C], v3 = pb[(size_t)(sl + 3 * nsub) * C];
+            s1 += (v0.x + v1.x) + (v2.x + v3.x); s2 += (v0.y + v1.y) + (v2.y + v3.y);
+        }
+        for (; sl < ns; sl += (int)nsub) { const float2 v = pb[(size_t)sl * C]; s1 += v.x; s2 += v.y; }
+    }
+    s1 = wave_sum_f(s1); s2 = wave_sum_f(s2);
+    if (lane == 0) { red[0][wid] = s1; red[1][wid] = s2; }
+    __syncthreads();
+    const float n = (float)HW * (float)cpg;
+    const float mu = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / n;
+    const float var = fmaxf(((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / n - mu * mu, 0.f);
+    const float rstd = rsqrtf(var + eps);
+    for (unsigned c = gi * cpg + tid; c < (gi + 1) * cpg; c += 256) {
+        const float a = rstd * gamma[c];
+        *reinterpret_cast<float2 *>(coef + ((size_t)b * C + c) * 2) = make_float2(a, beta[c] - mu * a);
+    }
+}
+
 // The same GroupNorm(+SiLU) with an OCP fp8 (e4m3) OUTPUT for the fp8 convolution path (k_gemm8q): y8[b][p][Cp] bytes, Cp = C rounded
 // up to a multiple of 128 (one 3x3 tap per 128-byte k-tile), padding channels written as zero; stored value = y * qscale (a power of
 // two: the tensor-wide E8M0 activation scale), saturated to +-448.
@@ -332,6 +379,80 @@ __global__ __launch_bounds__(256) void k_concat_add_stats(const unsigned short *
     for (int i = tid; i < 2 * G; i += 256) {
         const float v = grp[i];
         if (v != 0.f) unsafeAtomicAdd(stats + (size_t)b * G * 2 + i, v);
+    }
+}
+
+// out[b][p][C1+C2] = [a | b (+ c)] + the per-CHANNEL partial sums of the output per pixel slab, plain stores (parts[b][slab][C][2],
+// slab_mode 1 of gc_dn_groupnorm_apply_parts).  A thread owns one 16-byte channel chunk and walks the pixels of its slab FOUR at a time
+// (independent loads in flight; the one-at-a-time walk of k_concat_add_stats over 128-pixel slabs ran 41 us against 9 us for the plain
+// concat), slabs of 16 / 32 pixels so that the grid has several workgroups per CU.
+template <class T>
+__global__ __launch_bounds__(256) void k_concat_add_parts(const unsigned short *__restrict__ a, int C1, const unsigned short *__restrict__ bsrc,
+                                                          const unsigned short *__restrict__ c, int C2, unsigned short *__restrict__ out,
+                                                          int HW, int nchb, int pix_per_block, float *__restrict__ parts)
+{
+    extern __shared__ float sp[];   // [lanes][nchb][16]
+    const int b = blockIdx.z, C = C1 + C2;
+    const int lanes = 256 / nchb;
+    const int tid = threadIdx.x;
+    const int cch = tid % nchb, pl = tid / nchb;
+    const int c0 = (blockIdx.y * nchb + cch) * 8;
+    const size_t row0 = (size_t)b * HW;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    if (pl < lanes) {
+        const int p0 = blockIdx.x * pix_per_block;
+        const int p1 = min(p0 + pix_per_block, HW);
+        const bool first = c0 < C1;
+        const unsigned short *src = first ? a + c0 : bsrc + (c0 - C1);
+        const unsigned short *src2 = (!first && c) ? c + (c0 - C1) : nullptr;
+        const int ld = first ? C1 : C2;
+        for (int p = p0 + pl; p < p1; p += 4 * lanes) {
+            uint4 v[4], w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int pp = p + u * lanes;
+                const size_t m = row0 + (pp < p1 ? pp : p);
+                v[u] = *reinterpret_cast<const uint4 *>(src + m * ld);
+                if (src2) w[u] = *reinterpret_cast<const uint4 *>(src2 + m * ld);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int pp = p + u * lanes;
+                if (pp >= p1) break;
+                float f[8];
+                unpack8<T>(v[u], f);
+                if (src2) {
+                    float fc[8];
+                    unpack8<T>(w[u], fc);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] += fc[j];
+                    v[u] = pack8<T>(f);
+                    unpack8<T>(v[u], f);        // statistics of the values as stored
+                }
+                *reinterpret_cast<uint4 *>(out + (row0 + pp) * C + c0) = v[u];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s1[j] += f[j]; s2[j] += f[j] * f[j]; }
+            }
+        }
+        float *o = sp + ((size_t)pl * nchb + cch) * 16;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { o[2 * j] = s1[j]; o[2 * j + 1] = s2[j]; }
+    }
+    __syncthreads();
+    if (pl == 0) {
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+        for (int l = 0; l < lanes; ++l) {
+            const float *o = sp + ((size_t)l * nchb + cch) * 16;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] += o[j];
+        }
+        float *dst = parts + (((size_t)b * gridDim.x + blockIdx.x) * C + c0) * 2;
+#pragma unroll
+        for (int j = 0; j < 16; j += 4) *reinterpret_cast<float4 *>(dst + j) = make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]);
     }
 }
 
@@ -690,6 +811,71 @@ int gc_dn_concat_add(int dtype, const void *a, int C1, const void *b, const void
                 hipLaunchKernelGGL((k_concat_add<F16>), dim3(ew_grid(chunks)), dim3(256), 0, gc::S(stream), (const unsigned short *)a, C1,
                                    (const unsigned short *)b, (const unsigned short *)c, C2, (unsigned short *)out, (unsigned)chunks));
     return gc::check_launch("gc_dn_concat_add");
+}
+
+int gc_dn_groupnorm_coef_parts(int64_t B, int64_t HW, int C, int G, const float *gamma, const float *beta, float eps, const float *parts,
+                               int64_t rows_per_slab, int nslab, int slab_mode, float *coef, void *stream)
+{
+    GC_REQUIRE(C % G == 0 && C / G <= 256 && parts && gamma && beta && coef && rows_per_slab > 0 && nslab > 0, "groupnorm_coef_parts: bad arguments");
+    hipLaunchKernelGGL(k_gn_finalize_parts, dim3((unsigned)(B * G)), dim3(256), 0, gc::S(stream), (unsigned)HW, (unsigned)C, G, parts, nslab,
+                       (unsigned)rows_per_slab, slab_mode, gamma, beta, eps, coef);
+    return gc::check_launch("gc_dn_groupnorm_coef_parts");
+}
+
+int gc_dn_groupnorm_apply_parts(int dtype, const void *x, void *y, int64_t B, int64_t HW, int C, int G, const float *gamma, const float *beta,
+                                float eps, int act, const float *parts, int64_t rows_per_slab, int nslab, int slab_mode, float *coef_ws, void *stream)
+{
+    GC_REQUIRE(C % 8 == 0 && coef_ws, "groupnorm_apply_parts: C must be a multiple of 8; coefficient workspace [B][C][2] required");
+    GC_REQUIRE(B * HW * (int64_t)(C / 8) < (int64_t)1 << 31, "groupnorm_apply_parts: tensor too large");
+    const int rc = gc_dn_groupnorm_coef_parts(B, HW, C, G, gamma, beta, eps, parts, rows_per_slab, nslab, slab_mode, coef_ws, stream);
+    if (rc != GC_OK) return rc;
+    const int64_t chunks = B * HW * (C / 8);
+    hipStream_t s = gc::S(stream);
+    DN_DISPATCH(dtype,
+                hipLaunchKernelGGL((k_gn_apply<BF16>), dim3(ew_grid(chunks)), dim3(256), 0, s, (const unsigned short *)x,
+                                   (unsigned short *)y, (unsigned)HW, (unsigned)C, coef_ws, act, (unsigned)chunks),
+                hipLaunchKernelGGL((k_gn_apply<F16>), dim3(ew_grid(chunks)), dim3(256), 0, s, (const unsigned short *)x,
+                                   (unsigned short *)y, (unsigned)HW, (unsigned)C, coef_ws, act, (unsigned)chunks));
+    return gc::check_launch("gc_dn_groupnorm_apply_parts");
+}
+
+static void concat_parts_plan(int64_t HW, int C, int *nslab, int *ppb, int *ny, int *nchb)
+{
+    const int nch = C / 8;
+    int y = 1;
+    while (nch % y != 0 || nch / y > 256) ++y;
+    *ny = y; *nchb = nch / y;
+    const int lanes = 256 / *nchb;
+    int p = HW >= 4096 ? 32 : 16;
+    if (p < lanes) p = lanes;
+    *ppb = p; *nslab = (int)((HW + p - 1) / p);
+}
+
+int gc_dn_concat_parts_layout(int64_t rows_per_batch, int C, int64_t *rows_per_slab, int *nslab)
+{
+    GC_REQUIRE(rows_per_slab && nslab && rows_per_batch > 0 && C % 8 == 0, "concat_parts_layout: bad arguments");
+    int ns, ppb, ny, nchb;
+    concat_parts_plan(rows_per_batch, C, &ns, &ppb, &ny, &nchb);
+    *rows_per_slab = ppb; *nslab = ns;
+    return GC_OK;
+}
+
+int gc_dn_concat_add_parts(int dtype, const void *a, int C1, const void *b, const void *c, int C2, void *out, int64_t M, int64_t rows_per_batch,
+                           float *parts, void *stream)
+{
+    GC_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && parts && out, "concat_parts: channel counts must be multiples of 8; output and partials buffer required");
+    GC_REQUIRE(rows_per_batch > 0 && M % rows_per_batch == 0 && M / rows_per_batch <= 65535, "concat_parts: M must be B * rows_per_batch");
+    int nslab, ppb, ny, nchb;
+    concat_parts_plan(rows_per_batch, C1 + C2, &nslab, &ppb, &ny, &nchb);
+    const int lanes = 256 / nchb;
+    dim3 grid((unsigned)nslab, ny, (unsigned)(M / rows_per_batch));
+    const size_t lds = sizeof(float) * 16 * (size_t)lanes * nchb;
+    DN_DISPATCH(dtype,
+                hipLaunchKernelGGL((k_concat_add_parts<BF16>), grid, dim3(256), lds, gc::S(stream), (const unsigned short *)a, C1,
+                                   (const unsigned short *)b, (const unsigned short *)c, C2, (unsigned short *)out, (int)rows_per_batch, nchb, ppb, parts),
+                hipLaunchKernelGGL((k_concat_add_parts<F16>), grid, dim3(256), lds, gc::S(stream), (const unsigned short *)a, C1,
+                                   (const unsigned short *)b, (const unsigned short *)c, C2, (unsigned short *)out, (int)rows_per_batch, nchb, ppb, parts));
+    return gc::check_launch("gc_dn_concat_add_parts");
 }
 
 int gc_dn_group_stats(int dtype, const void *x, int64_t B, int64_t HW, int C, int G, float *group_stats, void *stream)

@@ -67,6 +67,8 @@ class GaussCtrlPipelineConfig(_PipelineConfigBase):
                                        # read-only reference bank; 1 = strictly one after the other, as the reference runs them)
     round_like_reference: bool = False  # True: round the rendered rgb / depth to fp16 before inversion, disparity and the mask composite,
                                        # exactly where the reference does (gc_pipeline.py:132-133,155); False keeps the fp32 renders
+    batch_invariant: bool = False      # kernel planning that makes a view's result independent of its chunk / rank count (sd.ops.KernelOptions)
+    kernel_options: Optional[object] = None   # a gaussctrl_amd.sd.ops.KernelOptions replacing the process-wide kernel switches (None: keep)
     synthetic_weights: bool = False    # True: seeded random SD1.5-shaped weights + hashed prompt embeddings (bench / tests; there
                                        # are no checkpoints on the build machines).  False: checkpoints are REQUIRED -- no silent fallback.
 
@@ -127,6 +129,10 @@ class GaussCtrlPipeline(_PipelineBase):
             arch.check_state_dict(sd, shapes)
             self.weights_source.setdefault(name, "caller-supplied state dict")
             return sd
+        if config.kernel_options is not None:
+            sdops.configure(options=config.kernel_options)
+        if config.batch_invariant:
+            sdops.configure(batch_invariant=True)
         self.pipe = DenoisePipeline(prepare(get("unet", arch.unet_shapes(), 100), self.dtype, dev, heads=8),
                                     prepare(get("controlnet", arch.controlnet_shapes(), 200), self.dtype, dev, heads=8),
                                     prepare_vae_weights(get("vae_decoder", arch.vae_decoder_shapes(), 300), self.dtype, dev),
@@ -218,10 +224,13 @@ class GaussCtrlPipeline(_PipelineBase):
         # fill / drain phases are covered by the other's kernels (bench.py --inflight: +3 % views/s at chunk_size 3)
         main = torch.cuda.current_stream()
         n_fly = max(1, int(self.config.inflight_chunks)) if (bank is not None and self._dev.type == "cuda") else 1
-        if n_fly > 1 and getattr(self, "_chunk_streams", None) is None:
+        if n_fly > 1 and len(getattr(self, "_chunk_streams", None) or ()) != n_fly:      # (inflight_chunks may change between calls)
             self._chunk_streams = [torch.cuda.Stream(device=self._dev) for _ in range(n_fly)]
         ready = torch.cuda.Event() if n_fly > 1 else None
         if ready is not None:
+            # the chunk streams are ordered after `main` only: everything they share must be complete there first.  With a bank
+            # received by broadcast nothing has touched the pipeline's lazily filled caches yet (text K / V^T, time-embedding rows).
+            self.pipe.warm_caches(cn, cp)
             ready.record(main)
         for ci, s in enumerate(range(0, len(views), self.chunk_size)):
             chunk = views[s:s + self.chunk_size]

@@ -7,6 +7,7 @@ kernel behind the C ABI.  No CPU / eager fallback exists.
 from __future__ import annotations
 
 import ctypes as C
+import dataclasses
 import os
 
 import torch
@@ -27,7 +28,7 @@ class GemmDesc(C.Structure):
                 ("ln_row_stats", C.c_void_p), ("ln_row_stat_slots", C.c_int), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float),
                 ("out_row_stats", C.c_void_p), ("out_group_stats", C.c_void_p), ("gn_groups", C.c_int),
                 ("fp8", C.c_int), ("w_scale", C.c_void_p), ("a_scale", C.c_int),
-                ("kernel_variant", C.c_int), ("plan_rows", C.c_int64)]
+                ("kernel_variant", C.c_int), ("out_chan_parts", C.c_void_p), ("plan_rows", C.c_int64)]
 
 
 class AttnDesc(C.Structure):
@@ -43,33 +44,85 @@ class AttnDesc(C.Structure):
                 ("kernel_variant", C.c_int), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
-def _variant_from_env():
-    """Kernel-selection overrides for tests / experiments.  The library itself holds no such state: they travel in the descriptors
-    (gc_gemm_desc.kernel_variant / gc_attn_desc.kernel_variant); this host layer reads them once from the environment."""
-    import os
-    g = int(os.environ.get("GC_GEMM_MT", "0")) & 7
-    use8 = os.environ.get("GC_GEMM8")
+@dataclasses.dataclass
+class KernelOptions:
+    """Every switch of the denoise host layer in ONE object (the C library holds no such state: kernel-selection overrides travel in the
+    descriptors, gc_gemm_desc.kernel_variant / gc_attn_desc.kernel_variant / plan_rows).  The product default is `KernelOptions()`;
+    GaussCtrlPipelineConfig.kernel_options / bench.py flags / tests pass other values through `configure(...)`.  Nothing on the product
+    path reads the process environment: `options_from_env()` is the bridge the benchmark and experiment scripts call explicitly."""
+    gemm_variant: int = 0            # gc_gemm_desc.kernel_variant (tile-height / kernel-family overrides, A/B and tests)
+    attn_variant: int = 0            # gc_attn_desc.kernel_variant
+    # Batch-invariant kernel planning (gc_gemm_desc.plan_rows, GroupNorm act bit 8): every output row is accumulated in an order that
+    # depends on the layer's shape only, so a view's latents are bit-identical whatever shares its chunk or however many ranks shard
+    # the scene (SURVEY.md 8e "bit-compatible with the single-GPU result").  Costs throughput (k-slices sized for one frame).
+    batch_invariant: bool = False
+    fused_head: bool = True          # level-0 transformer blocks: GroupNorm apply .. Q | K | V^T in one launch (csrc/dn_thead.hip)
+    fused_tail: bool = True          # ... and everything after the self-attention in one launch (csrc/dn_ttail.hip)
+    two_streams: bool = True         # ControlNet || UNet encoder on two HIP streams inside a denoise step
+    gn_parts: bool = True            # GroupNorm statistics from the producer's epilogue (per-channel partials, plain stores): the
+                                     # stand-alone statistics + finalize launches disappear (1 launch per GroupNorm instead of 3)
+    ablate: frozenset = frozenset()  # TIMING ablations (results wrong by construction; scripts/ablate_classes.sh): op classes whose
+                                     # launches are skipped -- {"gn", "ln", "attn", "linear", "conv", "head", "tail"}
+
+
+OPTIONS = KernelOptions()
+
+
+def configure(options: KernelOptions | None = None, **kw) -> KernelOptions:
+    """Replace (options=) or update (**kw) the process-wide kernel options; returns the active object."""
+    global OPTIONS, BATCH_INVARIANT
+    if options is not None:
+        OPTIONS = options
+    if kw:
+        OPTIONS = dataclasses.replace(OPTIONS, **kw)
+    BATCH_INVARIANT = OPTIONS.batch_invariant
+    KERNEL_VARIANT["gemm"], KERNEL_VARIANT["attn"] = OPTIONS.gemm_variant, OPTIONS.attn_variant
+    return OPTIONS
+
+
+def options_from_env(env=None) -> KernelOptions:
+    """The experiment switches of bench.py / scripts / the spawned ranks of the tests, decoded from GC_* variables (NOT called on
+    import and never by the plugin path):  GC_GEMM_MT / GC_GEMM8 / GC_GEMM_CONVSPLIT / GC_GEMM_DBG -> gemm_variant;  GC_ATTN_SAFE /
+    GC_ATTN_16 / GC_ATTN_V -> attn_variant;  GC_BATCH_INVARIANT, GC_FUSED_HEAD, GC_FUSED_TAIL, GC_DN_STREAMS, GC_GN_PARTS, GC_ABLATE=a,b,c."""
+    e = os.environ if env is None else env
+    on = lambda k, d: e.get(k, d) not in ("", "0")
+    g = int(e.get("GC_GEMM_MT", "0")) & 7
+    use8 = e.get("GC_GEMM8")
     if use8 == "0":
         g |= 0x10
     elif use8 == "2":
         g |= 0x20
-    cs = os.environ.get("GC_GEMM_CONVSPLIT")
+    cs = e.get("GC_GEMM_CONVSPLIT")
     if cs == "0":
         g |= 0x40
     elif cs == "2":
         g |= 0x80
-    g |= (int(os.environ.get("GC_GEMM_DBG", "0")) & 0xff) << 8
-    return {"gemm": g, "attn": (1 if os.environ.get("GC_ATTN_SAFE", "0") not in ("", "0") else 0) | (2 if os.environ.get("GC_ATTN_16", "0") not in ("", "0") else 0) | (int(os.environ.get("GC_ATTN_V", "0")) << 2)}
+    g |= (int(e.get("GC_GEMM_DBG", "0")) & 0xff) << 8
+    a = (1 if on("GC_ATTN_SAFE", "0") else 0) | (2 if on("GC_ATTN_16", "0") else 0) | (int(e.get("GC_ATTN_V", "0")) << 2)
+    return KernelOptions(gemm_variant=g, attn_variant=a, batch_invariant=on("GC_BATCH_INVARIANT", "0"),
+                         fused_head=on("GC_FUSED_HEAD", "1"), fused_tail=on("GC_FUSED_TAIL", "1"), two_streams=on("GC_DN_STREAMS", "1"),
+                         gn_parts=on("GC_GN_PARTS", "1"),
+                         ablate=frozenset(x for x in e.get("GC_ABLATE", "").split(",") if x))
 
 
-KERNEL_VARIANT = _variant_from_env()
-# Batch-invariant kernel planning (gc_gemm_desc.plan_rows, GroupNorm act bit 8): every output row is accumulated in an order that
-# depends on the layer's shape only, so a view's latents are bit-identical whatever shares its chunk or however many ranks shard
-# the scene (SURVEY.md 8e "bit-compatible with the single-GPU result").  Costs throughput (k-slices sized for one frame); off by default.
-BATCH_INVARIANT = os.environ.get("GC_BATCH_INVARIANT", "0") not in ("", "0")
+KERNEL_VARIANT = {"gemm": 0, "attn": 0}     # mirrors of OPTIONS kept as module attributes (read on every launch; tests patch them)
+BATCH_INVARIANT = False
 
 
 DT = {torch.bfloat16: 0, torch.float16: 1}
+_abl_cache = {}
+
+
+def _ablated(cls, shape, dtype, device):
+    """TIMING ablation (KernelOptions.ablate): the op class is skipped and a cached all-zero tensor of the output's shape is handed on
+    (results wrong by construction; zeros keep every downstream kernel on its normal code path).  None when the class is live."""
+    if cls not in OPTIONS.ablate:
+        return None
+    key = (cls, tuple(shape), dtype, device, stream_handle())
+    t = _abl_cache.get(key)
+    if t is None:
+        t = _abl_cache[key] = torch.zeros(tuple(shape), dtype=dtype, device=device)
+    return t
 
 
 def _dt(t):
@@ -107,6 +160,16 @@ def _stream():
 _zero_page = {}
 
 
+class ChanParts:
+    """Per-channel partial (sum, sum^2) of a tensor per row slab, left by its PRODUCER (gc_gemm_desc.out_chan_parts / gc_dn_concat_add_parts)
+    for the GroupNorm that follows (groupnorm(..., parts=)): buf fp32 [B, nslab, C, 2]; rows = rows per slab; mode 0: slabs are the
+    producer's row tiles counted over all rows, 1: slabs restart at every batch."""
+    __slots__ = ("buf", "rows", "nslab", "mode")
+
+    def __init__(self, buf, rows, nslab, mode):
+        self.buf, self.rows, self.nslab, self.mode = buf, rows, nslab, mode
+
+
 class RowStats:
     """(sum, sum^2) of every output row of a GEMM, left by its epilogue as [slots][M][2] partials over column slabs (plain stores: no
     zero-init); handed to the GEMM that has the following LayerNorm folded in (linear(..., ln=(row_stats, colsum, eps)))."""
@@ -116,7 +179,8 @@ class RowStats:
         self.buf, self.slots = None, 0
 
 
-def _run_gemm(d, dev, what, row_stats=None):
+def _run_gemm(d, dev, what, row_stats=None, want_parts=False):
+    """-> ChanParts of the output when want_parts and the kernel this problem selects can produce them, else None"""
     lib = L.lib()
     z = _zero_page.get(dev)
     if z is None:
@@ -132,7 +196,15 @@ def _run_gemm(d, dev, what, row_stats=None):
         row_stats.slots = int(lib.gc_dn_gemm_row_stat_slots(C.byref(d)))
         row_stats.buf = torch.empty(row_stats.slots, d.M, 2, dtype=torch.float32, device=dev)
         d.out_row_stats = row_stats.buf.data_ptr()
+    parts = None
+    if want_parts and d.rows_per_batch >= 256:
+        rows, ns = C.c_int64(0), C.c_int(0)
+        L.check(lib.gc_dn_gemm_chan_parts_layout(C.byref(d), C.byref(rows), C.byref(ns)), "gc_dn_gemm_chan_parts_layout")
+        if rows.value > 0:
+            parts = ChanParts(torch.empty(d.M // d.rows_per_batch, ns.value, d.N, 2, dtype=torch.float32, device=dev), rows.value, ns.value, 0)
+            d.out_chan_parts = parts.buf.data_ptr()
     L.check(lib.gc_dn_gemm(C.byref(d), _stream()), what)
+    return parts
 
 
 def _stats_args(d, ln, group_stats):
@@ -144,8 +216,9 @@ def _stats_args(d, ln, group_stats):
 
 def linear(x, w, bias=None, residual=None, act=0, geglu=False, out_f32=False, scale=1.0, rowvec=None, rows_per_batch=0,
            ld_rowvec=None, out=None, want_out=True, out_t=None, ldt=0, t_batch_stride=0, t_col0=0, out_cols=None,
-           ln=None, row_stats=None, group_stats=None):
+           ln=None, row_stats=None, group_stats=None, chan_parts=False):
     """x [..., K] (last dim contiguous, rows strided by x.stride(-2)) @ w[N,K]^T with fused epilogue.
+    chan_parts=True: returns (out, ChanParts | None) -- the per-channel partial sums of the output for a following GroupNorm (needs rows_per_batch);
     ln=(RowStats of x, colsum [N], eps): LayerNorm folded in (w carries gamma, bias carries W beta);
     row_stats: a RowStats() that receives the per-row (sum, sum^2) partials of the stored output;
     group_stats: zeroed fp32 [B, G, 2] that receives the per-(batch, GroupNorm group) sums (needs rows_per_batch)."""
@@ -164,6 +237,11 @@ def linear(x, w, bias=None, residual=None, act=0, geglu=False, out_f32=False, sc
     if BATCH_INVARIANT and x.dim() >= 3:
         d.plan_rows = M // x.shape[0]                 # the rows one frame contributes
     No = N // 2 if geglu else (N if out_cols is None else out_cols)
+    if OPTIONS.ablate and out is None and row_stats is None and M >= 256:
+        z = _ablated("linear", x.shape[:-1] + (No,), torch.float32 if out_f32 else x.dtype, x.device)
+        z = _ablated(f"linear_k{K}", x.shape[:-1] + (No,), torch.float32 if out_f32 else x.dtype, x.device) if z is None else z
+        if z is not None:
+            return ((z if want_out else None), None) if chan_parts else (z if want_out else None)
     if residual is not None:
         d.residual = residual.data_ptr(); d.ldr = residual.stride(-2)
     d.out_scale = scale; d.act = act; d.geglu = int(geglu)
@@ -174,19 +252,24 @@ def linear(x, w, bias=None, residual=None, act=0, geglu=False, out_f32=False, sc
     if out_t is not None:
         d.out_t = out_t.data_ptr(); d.ldt = ldt; d.t_batch_stride = t_batch_stride; d.t_col0 = t_col0
     _stats_args(d, ln, group_stats)
-    _run_gemm(d, x.device, "gc_dn_gemm", row_stats)
-    return out
+    parts = _run_gemm(d, x.device, "gc_dn_gemm", row_stats, want_parts=chan_parts and not BATCH_INVARIANT)
+    return (out, parts) if chan_parts else out
 
 
 def conv3x3(x, w, bias=None, stride=1, upsample=False, rowvec=None, ld_rowvec=None, residual=None, act=0, scale=1.0,
-            out_f32=False, pad_lo=1, group_stats=None):
-    """x [B,H,W,Cin] NHWC, w [N, 9*Cin] ((tap, cin) order), pad 1."""
+            out_f32=False, pad_lo=1, group_stats=None, chan_parts=False):
+    """x [B,H,W,Cin] NHWC, w [N, 9*Cin] ((tap, cin) order), pad 1.  chan_parts=True: returns (out, ChanParts | None)."""
     _gpu(x, w)
     B, H, W_, Cin = x.shape
     Hin, Win = (2 * H, 2 * W_) if upsample else (H, W_)
     # pad_lo=1: Conv2d(padding=1); pad_lo=0: F.pad(x,(0,1,0,1)) + Conv2d(padding=0) (VAE encoder downsample)
     Ho, Wo = (Hin + pad_lo + 1 - 3) // stride + 1, (Win + pad_lo + 1 - 3) // stride + 1
     N = w.shape[0]
+    if OPTIONS.ablate:
+        z = _ablated("conv", (B, Ho, Wo, N), torch.float32 if out_f32 else x.dtype, x.device)
+        z = _ablated(f"conv_hw{Ho}", (B, Ho, Wo, N), torch.float32 if out_f32 else x.dtype, x.device) if z is None else z
+        if z is not None:
+            return (z, None) if chan_parts else z
     out = torch.empty(B, Ho, Wo, N, dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
     d = GemmDesc()
     d.dtype = _dt(x); d.mode = 1; d.M, d.N, d.K = B * Ho * Wo, N, 9 * Cin
@@ -204,18 +287,32 @@ def conv3x3(x, w, bias=None, stride=1, upsample=False, rowvec=None, ld_rowvec=No
     d.out_scale = scale; d.act = act
     d.out = out.data_ptr(); d.ldc = N; d.out_f32 = int(out_f32)
     _stats_args(d, None, group_stats)
-    _run_gemm(d, x.device, "gc_dn_gemm(conv3x3)")
-    return out
+    parts = _run_gemm(d, x.device, "gc_dn_gemm(conv3x3)", want_parts=chan_parts and not BATCH_INVARIANT)
+    return (out, parts) if chan_parts else out
 
 
 _gn_ws = {}
 
 
-def groupnorm(x, gamma, beta, groups, eps, silu):
-    """x [B,H,W,C] (or [B,HW,C])"""
+def groupnorm(x, gamma, beta, groups, eps, silu, parts=None):
+    """x [B,H,W,C] (or [B,HW,C]).  parts: the ChanParts x's producer left -> finalize + apply (gc_dn_groupnorm_apply_parts): no statistics pass over x."""
     _gpu(x)
     B, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * Cc)
+    if OPTIONS.ablate:
+        z = _ablated("gn", x.shape, x.dtype, x.device)
+        if z is not None:
+            return z
+    if parts is not None:
+        y = torch.empty_like(x)
+        key = (x.device, B, Cc, stream_handle(), "coef")          # coefficient scratch, per stream
+        ws = _gn_ws.get(key)
+        if ws is None:
+            ws = _gn_ws[key] = torch.empty(B, Cc, 2, dtype=torch.float32, device=x.device)
+        L.check(L.lib().gc_dn_groupnorm_apply_parts(_dt(x), _p(x), _p(y), C.c_int64(B), C.c_int64(HW), Cc, groups, _p(gamma), _p(beta), C.c_float(eps),
+                                                    int(silu), _p(parts.buf), C.c_int64(parts.rows), parts.nslab, parts.mode, _p(ws), _stream()),
+                "gc_dn_groupnorm_apply_parts")
+        return y
     key = (x.device, B, HW, Cc, stream_handle())      # scratch is per stream: two networks may run concurrently
     ws = _gn_ws.get(key)
     if ws is None:
@@ -328,19 +425,33 @@ def linear_fp8(x8, w8, w_scale, out_dtype, bias=None, residual=None, act=0, scal
 def layernorm(x, gamma, beta, eps=1e-5):
     _gpu(x)
     Cc = x.shape[-1]
+    if OPTIONS.ablate:
+        z = _ablated("ln", x.shape, x.dtype, x.device)
+        if z is not None:
+            return z
     y = torch.empty_like(x)
     L.check(L.lib().gc_dn_layernorm(_dt(x), _p(x), _p(y), C.c_int64(x.numel() // Cc), Cc, _p(gamma), _p(beta),
                                     C.c_float(eps), _stream()), "gc_dn_layernorm")
     return y
 
 
-def concat_add(a, b, c=None, group_stats=None):
+def concat_add(a, b, c=None, group_stats=None, chan_parts=False):
     """cat([a, b (+ c)], dim=-1) on channels-last tensors [B, ..., C]; group_stats (zeroed fp32 [B, G, 2]) receives the
-    per-(batch, GroupNorm group) (sum, sum^2) of the output."""
+    per-(batch, GroupNorm group) (sum, sum^2) of the output; chan_parts=True: returns (out, ChanParts | None) instead."""
     _gpu(a, b, c)
     C1, C2 = a.shape[-1], b.shape[-1]
     M = a.numel() // C1
     out = torch.empty(a.shape[:-1] + (C1 + C2,), dtype=a.dtype, device=a.device)
+    if chan_parts:
+        rpb = M // a.shape[0]
+        if rpb < 256 or BATCH_INVARIANT or "gn" in OPTIONS.ablate:
+            return concat_add(a, b, c), None
+        rows, ns = C.c_int64(0), C.c_int(0)
+        L.check(L.lib().gc_dn_concat_parts_layout(C.c_int64(rpb), C1 + C2, C.byref(rows), C.byref(ns)), "gc_dn_concat_parts_layout")
+        parts = ChanParts(torch.empty(a.shape[0], ns.value, C1 + C2, 2, dtype=torch.float32, device=a.device), rows.value, ns.value, 1)
+        L.check(L.lib().gc_dn_concat_add_parts(_dt(a), _p(a), C1, _p(b), _p(c), C2, _p(out), C.c_int64(M), C.c_int64(rpb), _p(parts.buf), _stream()),
+                "gc_dn_concat_add_parts")
+        return out, parts
     L.check(L.lib().gc_dn_concat_add(_dt(a), _p(a), C1, _p(b), _p(c), C2, _p(out), C.c_int64(M), C.c_int64(M // a.shape[0]),
                                      _p(group_stats), 0 if group_stats is None else group_stats.shape[-2], _stream()), "gc_dn_concat_add")
     return out
@@ -376,6 +487,11 @@ def attention(q, k, vt, heads, sets, frames_per_half, Lk=None, kref=None, vtref=
     B, Lq, Cc = q.shape
     D = Cc // heads
     Lk = k.shape[1] if Lk is None else Lk
+    if OPTIONS.ablate:
+        z = _ablated("attn", (B, Lq, Cc), q.dtype, q.device)
+        z = _ablated(f"attn{D}", (B, Lq, Cc), q.dtype, q.device) if z is None else z
+        if z is not None:
+            return z
     o = torch.empty(B, Lq, Cc, dtype=q.dtype, device=q.device)
     d = AttnDesc()
     d.dtype = _dt(q); d.batch, d.heads, d.head_dim, d.Lq, d.Lk = B, heads, D, Lq, Lk
@@ -413,6 +529,10 @@ def transformer_tail(attn_out, resid, x_in, seg_a, seg_kv, seg_b, params, heads,
     _gpu(attn_out, resid, x_in, seg_a, seg_kv, seg_b, params)
     B, HW, Cc = attn_out.shape
     assert attn_out.is_contiguous() and resid.is_contiguous() and x_in.is_contiguous()
+    if OPTIONS.ablate:
+        z = _ablated("tail", attn_out.shape, attn_out.dtype, attn_out.device)
+        if z is not None:
+            return z
     out = torch.empty_like(attn_out)
     d = TailDesc()
     d.dtype = _dt(attn_out); d.channels = Cc; d.heads = heads; d.M = B * HW; d.rows_per_frame = HW
@@ -430,16 +550,26 @@ class HeadDesc(C.Structure):
                 ("vt_batch_stride", C.c_int64), ("w", C.c_void_p), ("params", C.c_void_p), ("h_fragment_layout", C.c_int)]
 
 
-def groupnorm_coef(x, gamma, beta, groups, eps):
-    """x [B,HW,C] -> coef fp32 [B,C,2]: GroupNorm(x)[b,:,c] = x * coef[b,c,0] + coef[b,c,1] (the statistics passes of groupnorm only)"""
+def groupnorm_coef(x, gamma, beta, groups, eps, parts=None):
+    """x [B,HW,C] -> coef fp32 [B,C,2]: GroupNorm(x)[b,:,c] = x * coef[b,c,0] + coef[b,c,1] (the statistics passes of groupnorm only;
+    one tiny launch from the producer's ChanParts when given)"""
     _gpu(x)
     B, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * Cc)
+    if parts is not None and "gn" not in OPTIONS.ablate:
+        coef = torch.empty(B, Cc, 2, dtype=torch.float32, device=x.device)
+        L.check(L.lib().gc_dn_groupnorm_coef_parts(C.c_int64(B), C.c_int64(HW), Cc, groups, _p(gamma), _p(beta), C.c_float(eps), _p(parts.buf),
+                                                   C.c_int64(parts.rows), parts.nslab, parts.mode, _p(coef), _stream()), "gc_dn_groupnorm_coef_parts")
+        return coef
     key = (x.device, B, HW, Cc, stream_handle())
     ws = _gn_ws.get(key)
     if ws is None:
         nbytes = L.lib().gc_dn_groupnorm_workspace_bytes(C.c_int64(B), C.c_int64(HW), Cc)
         ws = _gn_ws[key] = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    if OPTIONS.ablate:
+        z = _ablated("gn", (B, Cc, 2), torch.float32, x.device)
+        if z is not None:
+            return z
     coef = torch.empty(B, Cc, 2, dtype=torch.float32, device=x.device)
     L.check(L.lib().gc_dn_groupnorm_coef(_dt(x), _p(x), C.c_int64(B), C.c_int64(HW), Cc, groups, _p(gamma), _p(beta), C.c_float(eps),
                                          _p(ws), _p(coef), _stream()), "gc_dn_groupnorm_coef")
@@ -452,6 +582,9 @@ def transformer_head(x, coef, w_stream, params, eps=1e-5, h_frags=False):
     _gpu(x, coef, w_stream, params)
     B, HW, Cc = x.shape
     assert x.is_contiguous()
+    if OPTIONS.ablate and "head" in OPTIONS.ablate:
+        return (_ablated("head", x.shape, x.dtype, x.device), _ablated("head", (B, HW, 2 * Cc), x.dtype, x.device),
+                _ablated("head", (B, Cc, HW), x.dtype, x.device))
     h = torch.empty_like(x)
     qk = torch.empty(B, HW, 2 * Cc, dtype=x.dtype, device=x.device)
     vt = torch.empty(B, Cc, HW, dtype=x.dtype, device=x.device)

@@ -8,8 +8,6 @@ prompt, outside the hot path.
 """
 from __future__ import annotations
 
-import os
-
 import numpy as np
 import torch
 
@@ -62,7 +60,7 @@ class DenoisePipeline:
         self.cn_scale = controlnet_conditioning_scale
         self.text_kv = {}          # per-layer text K / V^T cache, valid for one (negative, positive) prompt pair
         self._text_key = None
-        self.two_streams = os.environ.get("GC_DN_STREAMS", "1") != "0"     # ControlNet || UNet encoder on two HIP streams
+        self.two_streams = ops.OPTIONS.two_streams     # ControlNet || UNet encoder on two HIP streams
         self._side = {}
 
     def _side_stream(self, dev):
@@ -81,6 +79,27 @@ class DenoisePipeline:
             self._text_key = key
             self._ctx_tensor = ctx
         return self._ctx_tensor
+
+    def warm_caches(self, ctx_neg, ctx_pos, steps: int | None = None, inverse: bool = False):
+        """Fill, on the CURRENT stream, every lazily built cache a trajectory with these prompts reads: per-layer text K / V^T (and the
+        fused tail's text operand streams) of both networks, and the time-embedding rows of every timestep.  A caller that then runs
+        several trajectories on independent streams (GaussCtrlPipeline.edit_images, bench.py) orders those streams after this point and
+        no stream ever reads a cache entry another stream is still writing -- with a received reference bank nothing else would have
+        filled them before the first chunk (the bank owner fills them while it records the bank)."""
+        ctx = self._ctx(ctx_neg, ctx_pos)
+        ts = self.sched.timesteps(self.n, inverse)
+        ts = ts if steps is None else ts[:steps]
+        for net in (self.unet, self.controlnet):
+            a = AttnCtx("plain", 0.0, 1, self.text_kv, None, net.name)
+            for key in list(net.w):
+                if isinstance(key, str) and key.endswith(".attn2.to_k.weight"):
+                    p = key[:-len(".to_k.weight")]
+                    net._text_kv(p, ctx, a)
+                    if net.tail_eligible(p[:-len(".transformer_blocks.0.attn2")], ctx):
+                        net._text_stream(p, ctx, a)
+            for t in ts:
+                net.time_embed(t, ctx.device)
+        return ctx
 
     # ---------------------------------------------------------------------------------- core loop
     def _begin(self, latents, disparity, ctx, cfg: bool, mode: str, coeff_unet: float, coeff_cn: float,

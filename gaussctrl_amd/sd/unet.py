@@ -112,10 +112,12 @@ class SDNet:
         self.fp8 = bool(weights.get("_fp8_convs", False))           # resnet 3x3 convs on e4m3 operands (weights.add_fp8_convs)
         self.fp8_a_scale = 127                                      # E8M0 byte of the conv inputs (GroupNorm + SiLU outputs are O(1): 2^0)
         # level-0 transformer blocks: everything after the self-attention in ONE launch (ops.transformer_tail, csrc/dn_ttail.hip): 148 us
-        # against 225 us for the nine per-op launches at 6 x 4096 tokens, +4.3 % views/s end to end.  GC_FUSED_TAIL=0: per-op.
-        self.fused_tail = os.environ.get("GC_FUSED_TAIL", "1") == "1"
+        # against 225 us for the nine per-op launches at 6 x 4096 tokens, +4.3 % views/s end to end.  ops.KernelOptions.fused_tail.
+        self.fused_tail = ops.OPTIONS.fused_tail
         # the same for everything before the self-attention (GroupNorm apply, proj_in, LayerNorm1, Q | K | V: ops.transformer_head, csrc/dn_thead.hip)
-        self.fused_head = os.environ.get("GC_FUSED_HEAD", "1") == "1"
+        self.fused_head = ops.OPTIONS.fused_head
+        # GroupNorm statistics as per-channel partials from the producing conv / linear / concat (ops.ChanParts travel in the `xs` slot)
+        self.gn_parts = ops.OPTIONS.gn_parts
         self._arenas = {}
         self.arena = None
 
@@ -141,6 +143,8 @@ class SDNet:
         else the stand-alone statistics pass + a quantising apply"""
         w = self.w
         g = self.cfg["groups"]
+        if isinstance(xs, ops.ChanParts):
+            xs = None                        # (the e4m3 apply kernel takes per-group sums only)
         if xs is not None:
             return ops.groupnorm_apply_fp8(x, xs, w[p + ".weight"], w[p + ".bias"], g, eps, True, self.fp8_a_scale)
         return ops.groupnorm_fp8(x, w[p + ".weight"], w[p + ".bias"], g, eps, True, self.fp8_a_scale)
@@ -149,6 +153,8 @@ class SDNet:
         """GroupNorm(+SiLU): one launch when the producer of x left its channel sums (xs), else the three-kernel stand-alone path"""
         w = self.w
         g = self.cfg["groups"]
+        if isinstance(xs, ops.ChanParts):
+            return ops.groupnorm(x, w[p + ".weight"], w[p + ".bias"], g, eps, silu, parts=xs)
         if xs is not None:
             return ops.groupnorm_apply(x, xs, w[p + ".weight"], w[p + ".bias"], g, eps, silu)
         if self.gn_two_pass and x.numel() > (1 << 20):      # (<= 2 MB: the one-launch small-map kernel inside ops.groupnorm wins)
@@ -191,7 +197,10 @@ class SDNet:
                                 a_scale=self.fp8_a_scale, group_stats=hs)
         else:
             h = self.gn(x, xs, p + ".norm1", eps, True)
-            h = ops.conv3x3(h, w[p + ".conv1.weight"], w[p + ".conv1.bias"], rowvec=rv, ld_rowvec=0, group_stats=hs)
+            if self.gn_parts and hs is None:
+                h, hs = ops.conv3x3(h, w[p + ".conv1.weight"], w[p + ".conv1.bias"], rowvec=rv, ld_rowvec=0, chan_parts=True)
+            else:
+                h = ops.conv3x3(h, w[p + ".conv1.weight"], w[p + ".conv1.bias"], rowvec=rv, ld_rowvec=0, group_stats=hs)
         sc = x
         if (p + ".conv_shortcut.weight") in w:
             sc = ops.linear(x, w[p + ".conv_shortcut.weight"], w[p + ".conv_shortcut.bias"])
@@ -201,6 +210,8 @@ class SDNet:
             return ops.conv3x3_fp8(h8, w[p + ".conv2.w8"], w[p + ".conv2.w8_scale"], x.dtype, w[p + ".conv2.bias"], residual=sc,
                                    a_scale=self.fp8_a_scale, group_stats=os_), os_
         h = self.gn(h, hs, p + ".norm2", eps, True)
+        if self.gn_parts and os_ is None:
+            return ops.conv3x3(h, w[p + ".conv2.weight"], w[p + ".conv2.bias"], residual=sc, chan_parts=True)
         return ops.conv3x3(h, w[p + ".conv2.weight"], w[p + ".conv2.bias"], residual=sc, group_stats=os_), os_
 
     def _self_attention(self, p, n, actx: AttnCtx, ln=None):
@@ -252,6 +263,11 @@ class SDNet:
             actx.text_kv[key] = weights_mod.tail_text_stream(k, vt, Lt, self.cfg["heads"])
         return actx.text_kv[key]
 
+    def tail_eligible(self, p, ctx) -> bool:
+        """static part of the fused-tail predicate for transformer block `p` (the shape part is checked per call)"""
+        return bool(self.fused_tail and (p + ".tail.a") in self.w and not self.ln_folded and not self.fuse_stats
+                    and ctx.shape[1] <= 96 and ctx.shape[0] <= 2)
+
     def transformer(self, p, x, xs, ctx, actx: AttnCtx):
         """Transformer2DModel on (x, xs) -> (out, channel sums of out).  With folded LayerNorms (weights.prepare(fold_ln=True)) the
         three LayerNorm launches disappear: each producer GEMM leaves the row sums of its output, the consumer GEMM (whose weights
@@ -260,11 +276,13 @@ class SDNet:
         B, H, W_, Cc = x.shape
         t = p + ".transformer_blocks.0"
         fold = self.ln_folded
-        tail = self.fused_tail and (p + ".tail.a") in w and not fold and not self.fuse_stats and (H * W_) % 128 == 0 and ctx.shape[1] <= 96
+        # (the tail kernel reads one text block per CFG half: ctx rows <= 2 and an equal number of frames per row; anything else -- e.g. a
+        # direct caller with one ctx row per frame -- takes the per-op path)
+        tail = self.tail_eligible(p, ctx) and (H * W_) % 128 == 0 and B % ctx.shape[0] == 0
         hfr = False
-        if self.fused_head and (p + ".head.w") in w and not fold and xs is None and (H * W_) % 128 == 0:
+        if self.fused_head and (p + ".head.w") in w and not fold and (xs is None or isinstance(xs, ops.ChanParts)) and (H * W_) % 128 == 0:
             x3 = x.view(B, H * W_, Cc)
-            coef = ops.groupnorm_coef(x3, w[p + ".norm.weight"], w[p + ".norm.bias"], self.cfg["groups"], 1e-6)
+            coef = ops.groupnorm_coef(x3, w[p + ".norm.weight"], w[p + ".norm.bias"], self.cfg["groups"], 1e-6, parts=xs)
             hfr = tail                       # h goes from one fused kernel to the other: stored as MFMA fragments
             h, qk, vt = ops.transformer_head(x3, coef, w[p + ".head.w"], w[p + ".head.params"], h_frags=hfr)
             o = self._attend(t + ".attn1", qk[..., :Cc], qk[..., Cc:], vt, actx)
@@ -300,6 +318,10 @@ class SDNet:
                             w[t + ".ff.net.0.proj.bias"], geglu=True)
         h = ops.linear(ff, w[t + ".ff.net.2.weight"], w[t + ".ff.net.2.bias"], residual=h)
         os_ = self._cs(B, Cc, H * W_)
+        if self.gn_parts and os_ is None:
+            out, os_ = ops.linear(h, w[p + ".proj_out.weight"], w[p + ".proj_out.bias"], residual=x.view(B, H * W_, Cc), rows_per_batch=H * W_,
+                                  chan_parts=True)
+            return out.view(B, H, W_, Cc), os_
         out = ops.linear(h, w[p + ".proj_out.weight"], w[p + ".proj_out.bias"], residual=x.view(B, H * W_, Cc), rows_per_batch=H * W_,
                          group_stats=os_)
         return out.view(B, H, W_, Cc), os_
@@ -318,7 +340,10 @@ class SDNet:
             if i < n - 1:
                 p = f"down_blocks.{i}.downsamplers.0.conv"
                 xs = self._cs(x.shape[0], self.w[p + ".weight"].shape[0], (x.shape[1] // 2) * (x.shape[2] // 2))
-                x = ops.conv3x3(x, self.w[p + ".weight"], self.w[p + ".bias"], stride=2, group_stats=xs)
+                if self.gn_parts and xs is None:
+                    x, xs = ops.conv3x3(x, self.w[p + ".weight"], self.w[p + ".bias"], stride=2, chan_parts=True)
+                else:
+                    x = ops.conv3x3(x, self.w[p + ".weight"], self.w[p + ".bias"], stride=2, group_stats=xs)
                 skips.append(x)
         x, xs = self.resnet("mid_block.resnets.0", x, xs, temb_act)
         x, xs = self.transformer("mid_block.attentions.0", x, xs, ctx, actx)
@@ -343,7 +368,10 @@ class ControlNet(SDNet):
         self.begin_forward(xin.device)
         temb_act = self.time_embed(t, xin.device)
         xs = self._cs(xin.shape[0], w["conv_in.weight"].shape[0], xin.shape[1] * xin.shape[2])
-        x = ops.conv3x3(xin, w["conv_in.weight"], w["conv_in.bias"], residual=cond_emb, group_stats=xs)
+        if self.gn_parts and xs is None:
+            x, xs = ops.conv3x3(xin, w["conv_in.weight"], w["conv_in.bias"], residual=cond_emb, chan_parts=True)
+        else:
+            x = ops.conv3x3(xin, w["conv_in.weight"], w["conv_in.bias"], residual=cond_emb, group_stats=xs)
         x, _, skips = self.encoder(x, xs, temb_act, ctx, actx)
         down = []
         for n, s in enumerate(skips):
@@ -364,7 +392,10 @@ class UNet(SDNet):
         self.begin_forward(xin.device)
         temb_act = self.time_embed(t, xin.device)
         xs = self._cs(xin.shape[0], w["conv_in.weight"].shape[0], xin.shape[1] * xin.shape[2])
-        x = ops.conv3x3(xin, w["conv_in.weight"], w["conv_in.bias"], group_stats=xs)
+        if self.gn_parts and xs is None:
+            x, xs = ops.conv3x3(xin, w["conv_in.weight"], w["conv_in.bias"], chan_parts=True)
+        else:
+            x = ops.conv3x3(xin, w["conv_in.weight"], w["conv_in.bias"], group_stats=xs)
         x, _, skips = self.encoder(x, xs, temb_act, ctx, actx)
         return x, skips, temb_act
 
@@ -381,7 +412,10 @@ class UNet(SDNet):
                 s = skips.pop()
                 r = down_res.pop() if down_res is not None else None
                 xs = self._cs(x.shape[0], x.shape[-1] + s.shape[-1], 16, streaming=True)     # the concat streams every element anyway
-                x = ops.concat_add(x, s, r, group_stats=xs)   # cat([x, skip + controlnet residual]) + its channel sums
+                if self.gn_parts and xs is None:
+                    x, xs = ops.concat_add(x, s, r, chan_parts=True)   # cat([x, skip + controlnet residual]) + per-channel partials of it
+                else:
+                    x = ops.concat_add(x, s, r, group_stats=xs)   # cat([x, skip + controlnet residual]) + its channel sums
                 x, xs = self.resnet(f"up_blocks.{i}.resnets.{j}", x, xs, temb_act)
                 if rev_attn[i]:
                     x, xs = self.transformer(f"up_blocks.{i}.attentions.{j}", x, xs, ctx, actx)

@@ -285,12 +285,20 @@ typedef struct gc_gemm_desc {
     int a_scale;               /* E8M0 byte of the activation tensor */
     int kernel_variant;        /* 0 = automatic.  Overrides for tests / experiments: bits 0-2 force the 8-wave kernel's m-tiles per wave (2,3,4); */
                                /* 0x10 4-wave kernel only; 0x20 force the 8-wave kernel; 0x40 no k-slices for part-filled conv grids; 0x80 slice 8x8-map convs too */
+    float *out_chan_parts;     /* NULL or [M / rows_per_batch][nslab][N][2]: per-CHANNEL partial (sum, sum of squares) of the stored output per row slab */
+                               /* (layout: gc_dn_gemm_chan_parts_layout), PLAIN stores -- no atomics, no zero-init -> gc_dn_groupnorm_apply_parts /   */
+                               /* gc_dn_groupnorm_coef_parts: the statistics pass of the GroupNorm that follows this conv / linear for free        */
     int64_t plan_rows;         /* 0 = plan for M.  > 0 (the rows ONE frame contributes: tokens, or Ho * Wo): kernel family and split-K are planned as if */
                                /* M were plan_rows, so every output row is accumulated in the same order whatever else shares the batch */
                                /* (batch-invariant results: a view's latents do not depend on its chunk-mates or on the rank count) */
 } gc_gemm_desc;
 size_t gc_dn_gemm_workspace_bytes(const gc_gemm_desc *desc);
 int gc_dn_gemm_row_stat_slots(const gc_gemm_desc *desc);   /* column slabs per row this problem writes to out_row_stats (with desc->workspace set) */
+/* Layout of out_chan_parts for this problem (call with desc->workspace set, as for the launch): *rows_per_slab rows per slab (slabs =
+ * the kernel's row tiles, counted over all M rows; a tile that straddles two batches contributes a slab to each) and *nslab slab slots per
+ * batch.  *rows_per_slab = 0: the kernel this problem selects cannot produce them (GEGLU / transposed / fp32 / fp8 outputs, upsample-fused
+ * convs, rows_per_batch < 256 or not a multiple of 32, 4-wave kernel) -- run the stand-alone GroupNorm instead. */
+int gc_dn_gemm_chan_parts_layout(const gc_gemm_desc *desc, int64_t *rows_per_slab, int *nslab);
 int gc_dn_gemm(const gc_gemm_desc *desc, void *stream);
 
 /* Fused multi-K/V-set attention = CrossViewAttnProcessor core, gaussctrl/utils.py:86-117 (+ compute_attn :25-37). */
@@ -316,10 +324,14 @@ typedef struct gc_attn_desc {
     const void *Vtref; int64_t vtref_batch_stride;
     int ref_frames_per_half;
     int q_prescaled;                 /* Q is already multiplied by scale*log2(e) (folded into the Q projection weights): `scale` is ignored */
-    int kernel_variant;              /* 0 = automatic; bit 0: online-softmax kernel for every shape (tests); bit 1: head_dim 40 on the
-                                        16x16x32 kernel (k_attn3) instead of the 32x32x16 one (k_attn4); bit 2: k_attn4 with 8 waves; bit 3: k_attn4 with 64 queries
-                                        per wave, one wave per SIMD (measured 25 % slower: DESIGN.md 7.1) */
-    void *workspace;                 /* optional, >= gc_dn_attention_workspace_bytes(desc): lets small grids with several K/V sets (head_dim 160) run */
+    int kernel_variant;              /* 0 = automatic.  head_dim 40 then runs k_attn5 (key-split 8-wave kernel, csrc/dn_attn5.hip) when
+                                        Lk % 64 == 0 and Lq % 256 == 0 and nsets * ceil(Lk / 64) >= 4, else k_attn4; head_dim 80 k_attn3; every
+                                        other head_dim and short key streams the online-softmax kernel k_attn.  A/B and test overrides:
+                                        bit 0: k_attn for every shape; bit 1: head_dim 40 on the 16x16x32 kernel (k_attn3); bit 2: k_attn4 with
+                                        8 waves; bit 3: k_attn4 with 64 queries per wave (25 % slower: DESIGN.md 7.1); bit 4: k_attn4 instead of
+                                        k_attn5; bits 5 / 6: k_attn5 with an LDS ring of 4 / 8 tiles instead of 6; bits 8..: timing ablations of
+                                        instrumented builds (ignored by the product build) */
+    void *workspace;                 /* optional, >= gc_dn_attention_workspace_bytes(desc) (0 unless head_dim == 160 and nsets > 1; ignored when 0): lets small grids with several K/V sets run */
     size_t workspace_bytes;          /* one workgroup per (query block, set) + a fixed-order fp32 combine; NULL: one launch as before */
 } gc_attn_desc;
 size_t gc_dn_attention_workspace_bytes(const gc_attn_desc *desc);
@@ -399,6 +411,23 @@ int gc_dn_layernorm(int dtype, const void *x, void *y, int64_t M, int C, const f
  * group_stats (optional, caller-zeroed [M / rows_per_batch][gn_groups][2]): per (batch, GroupNorm group) (sum, sum of squares) of `out`. */
 int gc_dn_concat_add(int dtype, const void *a, int C1, const void *b, const void *c, int C2, void *out, int64_t M,
                      int64_t rows_per_batch, float *group_stats, int gn_groups, void *stream);
+
+/* GroupNorm(+SiLU) whose statistics pass was done by the PRODUCER of x: `parts` [B][nslab][C][2] are per-channel partial (sum, sum of
+ * squares) per row slab as left by gc_gemm_desc.out_chan_parts (slab_mode 0: slabs = the GEMM's row tiles of rows_per_slab rows counted
+ * over all B * HW rows) or gc_dn_concat_add_parts (slab_mode 1: slabs restart at every batch).  Two launches instead of three
+ * (gc_dn_groupnorm): a tiny finalize over the partials (coef_ws fp32 [B][C][2], caller-owned scratch) + the apply pass; the read of x for
+ * the statistics is gone.  Semantics = torch.nn.GroupNorm of diffusers' ResnetBlock2D / Transformer2DModel reached from
+ * /root/reference/gaussctrl/gc_pipeline.py:142-145,209-219. */
+int gc_dn_groupnorm_apply_parts(int dtype, const void *x, void *y, int64_t B, int64_t HW, int C, int G, const float *gamma, const float *beta,
+                                float eps, int act, const float *parts, int64_t rows_per_slab, int nslab, int slab_mode, float *coef_ws, void *stream);
+/* the coefficients alone: coef [B][C][2], y = x * coef[.][c][0] + coef[.][c][1] (input of gc_dn_transformer_head) */
+int gc_dn_groupnorm_coef_parts(int64_t B, int64_t HW, int C, int G, const float *gamma, const float *beta, float eps, const float *parts,
+                               int64_t rows_per_slab, int nslab, int slab_mode, float *coef, void *stream);
+/* gc_dn_concat_add that also leaves the per-channel partials of its output: parts [M / rows_per_batch][nslab][C1 + C2][2], slab_mode 1,
+ * layout from gc_dn_concat_parts_layout(rows_per_batch, C1 + C2, ...) */
+int gc_dn_concat_parts_layout(int64_t rows_per_batch, int C, int64_t *rows_per_slab, int *nslab);
+int gc_dn_concat_add_parts(int dtype, const void *a, int C1, const void *b, const void *c, int C2, void *out, int64_t M, int64_t rows_per_batch,
+                           float *parts, void *stream);
 /* out = act(a*sa + b*sb) over n elements (b may be NULL). */
 int gc_dn_axpby(int dtype, const void *a, float sa, const void *b, float sb, int act, void *out, int64_t n, void *stream);
 /* float32 -> dtype with optional SiLU (time-embedding vectors). */

@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # kernel-selection experiment switches (GC_GEMM_MT, GC_ATTN_SAFE, ...: tests/test_gemm_variants_gpu.py forces them over a child
+    # pytest) reach the host layer through its explicit bridge; the product path itself never reads the environment
+    from gaussctrl_amd.sd import ops
+    ops.configure(ops.options_from_env())
 
 
 @pytest.fixture(scope="session")

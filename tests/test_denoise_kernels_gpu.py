@@ -118,6 +118,71 @@ def test_groupnorm(dt, B, HW, C, G):
     _close(ops.groupnorm(x, gamma, beta, G, 1e-5, True), F.silu(ref), dt, extra=2.0)
 
 
+def _parts_sums(parts, b, HW):
+    """add up the slabs of batch b the way gc_dn_groupnorm_apply_parts does -> [C, 2]"""
+    if parts.mode == 1:
+        ns = (HW + parts.rows - 1) // parts.rows
+    else:
+        ns = ((b + 1) * HW - 1) // parts.rows - (b * HW) // parts.rows + 1
+    assert ns <= parts.nslab
+    return parts.buf[b, :ns].double().sum(0)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("kind,B,H,Cin,Cout", [("conv", 6, 64, 320, 320),        # MT 3 tiles of 192 rows straddle the 4096-row batches
+                                               ("conv", 2, 32, 320, 640), ("conv", 6, 32, 640, 640), ("conv", 3, 64, 640, 320),
+                                               ("conv", 6, 16, 1280, 1280),      # split-K: the reduce-epilogue kernel leaves the partials
+                                               ("conv", 2, 16, 640, 1280), ("conv_in", 6, 64, 8, 320), ("down", 6, 64, 320, 320),
+                                               ("linear", 6, 32, 640, 640), ("linear", 6, 16, 1280, 1280), ("linear", 2, 64, 320, 320),
+                                               ("concat", 6, 64, 320, 320), ("concat", 6, 32, 640, 320), ("concat", 2, 16, 1280, 640)])
+def test_groupnorm_from_producer_partials(dt, kind, B, H, Cin, Cout):
+    """The statistics pass of a GroupNorm as per-channel partial sums left by the kernel that PRODUCED the tensor (conv / linear epilogue,
+    split-K reduce, concat): the partials add up to the channel sums of the stored output, and GroupNorm(+SiLU) from them equals the
+    stand-alone three-kernel GroupNorm and the fp64 reference (inputs with |mean| > std: raw fp32 sums must not cancel visibly)."""
+    from gaussctrl_amd.sd import ops
+    from gaussctrl_amd.sd.weights import conv3x3_weight
+    G = 32
+    if kind in ("conv", "conv_in", "down"):
+        x = _rand((B, H, H, Cin), dt, 1.0, 1)
+        w = _rand((Cout, Cin, 3, 3), dt, (9 * Cin) ** -0.5, 2)
+        b = torch.randn(Cout, device=DEV) * 2 + 1.5
+        res = _rand((B, H, H, Cout), dt, 1.0, 3) if kind == "conv" else None
+        out, parts = ops.conv3x3(x, conv3x3_weight(w, dt), b, stride=2 if kind == "down" else 1, residual=res, chan_parts=True)
+        plain = ops.conv3x3(x, conv3x3_weight(w, dt), b, stride=2 if kind == "down" else 1, residual=res)
+    elif kind == "linear":
+        x = _rand((B, H * H, Cin), dt, 1.0, 1)
+        w = _rand((Cout, Cin), dt, Cin ** -0.5, 2)
+        b = torch.randn(Cout, device=DEV) * 2 + 1.5
+        res = _rand((B, H * H, Cout), dt, 1.0, 3)
+        out, parts = ops.linear(x, w, b, residual=res, rows_per_batch=H * H, chan_parts=True)
+        plain = ops.linear(x, w, b, residual=res, rows_per_batch=H * H)
+    else:
+        a = (_rand((B, H, H, Cin), dt, 1.0, 1).float() + 2.0).to(dt); bb = _rand((B, H, H, Cout), dt, 1.0, 2); cc = _rand((B, H, H, Cout), dt, 1.0, 3)
+        out, parts = ops.concat_add(a, bb, cc, chan_parts=True)
+        plain = ops.concat_add(a, bb, cc)
+    assert parts is not None, "this shape must take the producer-statistics path"
+    assert torch.equal(out, plain)                          # the statistics epilogue does not change what is stored
+    Bo, Co = out.shape[0], out.shape[-1]
+    HW = out.numel() // (Bo * Co)
+    o64 = out.double().reshape(Bo, HW, Co)
+    for bi in range(Bo):
+        got = _parts_sums(parts, bi, HW)
+        want = torch.stack([o64[bi].sum(0), (o64[bi] ** 2).sum(0)], -1)
+        within(f"{kind}: channel partial sums vs fp64 (rel to sum |x| resp. sum x^2)",
+               ((got - want).abs() / torch.stack([o64[bi].abs().sum(0), (o64[bi] ** 2).sum(0)], -1).clamp_min(1e-6)).max().item(), 2e-6)
+    gamma = torch.randn(Co, device=DEV); beta = torch.randn(Co, device=DEV)
+    ref = F.group_norm(o64.transpose(1, 2), G, gamma.double(), beta.double(), 1e-5).transpose(1, 2).reshape(out.shape)
+    for silu in (False, True):
+        y = ops.groupnorm(out, gamma, beta, G, 1e-5, silu, parts=parts)
+        _close(y, F.silu(ref) if silu else ref, dt, extra=2.0)
+        y3 = ops.groupnorm(out, gamma, beta, G, 1e-5, silu)
+        within(f"{kind}: GroupNorm from partials vs the stand-alone kernels (max abs diff / max |y|)",
+               ((y.double() - y3.double()).abs().max() / y3.double().abs().max()).item(), 2 * EPS[dt])
+    coef = ops.groupnorm_coef(out.reshape(Bo, HW, Co), gamma, beta, G, 1e-5, parts=parts)
+    coef3 = ops.groupnorm_coef(out.reshape(Bo, HW, Co), gamma, beta, G, 1e-5)
+    within(f"{kind}: coefficients from partials vs stand-alone", ((coef - coef3).abs().max() / coef3.abs().max()).item(), 1e-4)
+
+
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("M,C", [(100, 320), (77, 640), (1000, 1280), (5, 64)])
 def test_layernorm(dt, M, C):

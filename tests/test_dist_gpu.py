@@ -44,6 +44,8 @@ def _run(pipe, model):
 def _worker(rank, world, port, owner, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gaussctrl_amd.sd import ops as sdops
+    sdops.configure(sdops.options_from_env())          # the spawned rank takes GC_BATCH_INVARIANT from the parent test
     try:
         pipe, model = _build(world, rank, owner)
         imgs, losses, means = _run(pipe, model)
