@@ -123,30 +123,37 @@ extern "C" int gc_dn_gemm_row_stat_slots(const gc_gemm_desc *d)
 
 namespace {
 // channel-partial layout of one problem: rows per slab (0 = unsupported) and slab slots per batch
-void chan_parts_layout(const gc_gemm_desc *d, const Sel &sel, int64_t *rows, int *nslab)
+void chan_parts_layout(const gc_gemm_desc *d, const Sel &sel, int64_t *rows, int *nslab, int *col_tile)
 {
-    *rows = 0; *nslab = 0;
+    *rows = 0; *nslab = 0; *col_tile = 0;
     const int64_t rpb = d->rows_per_batch;
-    if (d->fp8 || d->geglu || d->out_t || !d->out || d->out_f32 || d->ln_row_stats || d->out_row_stats || d->out_group_stats) return;
+    if (d->fp8 || d->geglu || d->act != 0 || d->out_t || !d->out || d->out_f32 || d->ln_row_stats || d->out_row_stats || d->out_group_stats) return;
     if (rpb < 256 || rpb % 32 != 0 || d->M % rpb != 0) return;
-    if (sel.splits > 1) { *rows = CS_RB; *nslab = (int)(rpb / CS_RB); return; }           // the reduce-epilogue kernel produces them
+    if (d->gn_groups < 1 || d->N % d->gn_groups != 0) return;
+    const int64_t cpg = d->N / d->gn_groups;
+    if (sel.splits > 1) {            // the reduce-epilogue kernel produces them (64-column blocks)
+        if (cpg > 64) return;
+        *rows = CS_RB; *nslab = (int)(rpb / CS_RB); *col_tile = 64;
+        return;
+    }
     if (!sel.mt8) return;
     if ((d->mode == 1 && d->upsample) || (d->mode == 0 && d->K % 64 != 0)) return;
     const int64_t bm = 64 * (sel.mt8 < 2 ? 2 : sel.mt8);
-    if (bm > rpb) return;
+    if (bm > rpb || cpg > 32 * sel.ntw) return;
     *rows = bm;
     *nslab = (int)(rpb % bm == 0 ? rpb / bm : (rpb + bm - 1) / bm + 1);
+    *col_tile = 32 * sel.ntw;
 }
 }  // namespace
 
-extern "C" int gc_dn_gemm_chan_parts_layout(const gc_gemm_desc *d, int64_t *rows_per_slab, int *nslab)
+extern "C" int gc_dn_gemm_chan_parts_layout(const gc_gemm_desc *d, int64_t *rows_per_slab, int *nslab, int *col_tile)
 {
-    GC_REQUIRE(d && rows_per_slab && nslab, "null argument");
-    *rows_per_slab = 0; *nslab = 0;
+    GC_REQUIRE(d && rows_per_slab && nslab && col_tile, "null argument");
+    *rows_per_slab = 0; *nslab = 0; *col_tile = 0;
     if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->rows_per_batch <= 0) return GC_OK;
     Sel sel;
     select(d, &sel, true);
-    chan_parts_layout(d, sel, rows_per_slab, nslab);
+    chan_parts_layout(d, sel, rows_per_slab, nslab, col_tile);
     return GC_OK;
 }
 
@@ -189,8 +196,8 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
     select(d, &sel, d->out_chan_parts != nullptr);
     g.chan_parts = d->out_chan_parts; g.cp_nslab = 0; g.cp_rows = 0;
     if (d->out_chan_parts) {
-        int64_t rows; int ns;
-        chan_parts_layout(d, sel, &rows, &ns);
+        int64_t rows; int ns, ct;
+        chan_parts_layout(d, sel, &rows, &ns, &ct);
         GC_REQUIRE(rows > 0, "out_chan_parts: this problem cannot produce channel partials (see gc_dn_gemm_chan_parts_layout)");
         g.cp_nslab = ns; g.cp_rows = (int)rows;
         if (sel.mt8 == 1) sel.mt8 = 2;
@@ -233,6 +240,7 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
         const dim3 grid8((unsigned)(nbm8 * nbn), (unsigned)sel.splits);
         if (fuse_of(g)) dn_gemm_launch_fuse(g, d->dtype, sel.mode, sel.ntw, sel.mt8, grid8, s);
         else if (g.chan_parts && sel.splits == 1) dn_gemm_launch_cs(g, d->dtype, sel.mode, sel.ntw, sel.mt8, grid8, s);
+        else if (lean_of(g, sel.mode) && g.persist == 0 && !(d->kernel_variant & 0x400)) dn_gemm_launch_lean(g, d->dtype, sel.mode, sel.ntw, sel.mt8, grid8, s);
         else dn_gemm_launch_plain(g, d->dtype, sel.mode, sel.ntw, sel.mt8, grid8, s);
     } else {
         const int64_t nbm = (d->M + BM - 1) / BM;

@@ -53,10 +53,12 @@ struct GemmArgs {
     const unsigned char *w_scale;       // fp8 path: E8M0 scale byte per weight row [N] (weights stored as e4m3 * 2^(127 - byte))
     int a_scale;                        // fp8 path: E8M0 scale byte of the whole activation tensor
     int dbg;                            // experiment switches (kernel_variant bits 8..): 1 no global group atomics, 2 no LDS atomics, 4 no DPP
-    // per-CHANNEL partial sums of the stored output, the input of a following GroupNorm (k_gemm8 CS = true, k_splitk_epilogue_cs):
-    // chan_parts[b][slab][n] = (sum, sum^2) over the rows of batch b inside the slab-th row tile (cp_rows rows each, tiles counted over
-    // all M rows) that overlaps batch b.  PLAIN stores: no atomics (round 2's per-(batch, group) float atomics cost 26 ms per chunk in
-    // same-line contention), no zero-init; gc_dn_groupnorm_apply_parts adds the slabs up in its prologue.
+    // partial GroupNorm-group sums of the stored output, the statistics pass of the GroupNorm that follows (k_gemm8 CS = true,
+    // k_splitk_epilogue_cs): chan_parts[b][slab][group][half] = (sum, sum^2) over the rows of batch b inside the slab-th row tile (cp_rows
+    // rows each, tiles counted over all M rows) that overlaps batch b and over the group's channels inside this workgroup's column tile:
+    // half 0 when the tile holds the group's first channel, half 1 for the rest of a group that straddles two column tiles (gn_cpg <= tile
+    // width: at most two).  PLAIN stores: no atomics (round 2's per-(batch, group) float atomics cost 26 ms per chunk in same-line
+    // contention), no zero-init; gc_dn_groupnorm_apply_parts adds them up in its prologue.
     float *chan_parts; int cp_nslab; int cp_rows;
 };
 }  // namespace dng
@@ -705,10 +707,15 @@ __device__ __forceinline__ void glds16_s(const void *sbase, unsigned voff, unsig
 // MODE 3 (k_gemm8 only): linear with K % 64 == 0 -- rows past M / N re-read the last valid row (their outputs are never stored),
 // so a k-tile's DMA is a uniform base + constant per-lane offset: no VALU at all in the issue path.
 // MT: m-tiles (of 16) per wave: workgroup tile (64 MT) x (32 NTW), waves 4 (M) x 2 (N), wave tile (16 MT) x (16 NTW).
-template <class T, int MODE, int NTW, int MT, bool FUSE, bool CS = false>
+// LEAN: the epilogue of the common case only -- bias / row-vector / scale / residual / 2-byte store (no GEGLU, no activation, no fp32 or
+// transposed output; checked by the launcher).  The full epilogue is ~470 instructions per accumulator block x MT NTW blocks (7 000 of the
+// kernel's 9 400 instructions, 56 KB: more than the instruction cache) although a launch executes a small part of it; every wave fetches
+// its way through the rest.  CS implies LEAN.
+template <class T, int MODE, int NTW, int MT, bool FUSE, bool CS = false, bool LEAN_ = false>
 __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g)
 {
     static_assert(!(FUSE && CS), "one statistics epilogue at a time");
+    constexpr bool LEAN = LEAN_ || CS;
     constexpr int BM = 64 * MT;
     constexpr bool CONVF = MODE == 2 || MODE == 4, UPS = MODE == 4;   // MODE 4 = MODE 2 + fused nearest-x2 upsample
     constexpr int BN = 32 * NTW;
@@ -987,45 +994,17 @@ __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g
         const int64_t n = n_lane + nt * 16;
         bia[nt] = (g.bias && n < g.N) ? *reinterpret_cast<const float4 *>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    // CS: per-lane channel sums over the wave's rows of ONE batch; a 16-row m-tile never straddles batches (rows_per_batch % 16 == 0)
-    // and a workgroup tile at most one boundary (BM <= rows_per_batch): slot 0 = the batch of the tile's first row, slot 1 the next
-    float cs[CS ? NTW : 1][4], cq[CS ? NTW : 1][4];
-    int cs_slot = -1;
-    int64_t m_split = 0;
+    // CS: the stored values of this lane (2-byte pairs; zero where nothing is stored) are kept for the statistics pass after the stores
+    uint2 pks[CS ? MT : 1][CS ? NTW : 1];
     if constexpr (CS) {
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { cs[nt][r] = 0.f; cq[nt][r] = 0.f; }
-        m_split = (m_base / g.rows_per_batch + 1) * g.rows_per_batch;          // first row of the next batch
+            for (int nt = 0; nt < NTW; ++nt) pks[mt][nt] = make_uint2(0u, 0u);
     }
-    auto cs_flush = [&]() __attribute__((always_inline)) {
-        if constexpr (CS) {
-            float *tb = ctab + (cs_slot * BN + wn * (16 * NTW) + fc * 4) * 2;
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float sa = row16_sum(cs[nt][r]), sb = row16_sum(cq[nt][r]);
-                    if (fr == 0) {
-                        __hip_atomic_fetch_add(tb + (nt * 16 + r) * 2, sa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(tb + (nt * 16 + r) * 2 + 1, sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                    cs[nt][r] = 0.f; cq[nt][r] = 0.f;
-                }
-        }
-    };
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int64_t m = m_base + wm * (16 * MT) + mt * 16 + fr;
-        if constexpr (CS) {
-            const int64_t m_tile = m_base + wm * (16 * MT) + mt * 16;         // wave-uniform
-            if (m_tile < g.M) {
-                const int slot = m_tile >= m_split ? 1 : 0;
-                if (cs_slot >= 0 && slot != cs_slot) cs_flush();
-                cs_slot = slot;
-            }
-        }
         if (m >= g.M) continue;
         float4 rv[NTW];
         uint2 rs[NTW];
@@ -1033,8 +1012,8 @@ __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
             const int64_t n = n_lane + nt * 16;
-            const bool okn = n < g.N && !(g.geglu && (nt & 1));
-            const int64_t on = g.geglu ? (n_base + wn * (16 * NTW) + nt * 16) / 2 + fc * 4 : n;
+            const bool okn = n < g.N && !(!LEAN && g.geglu && (nt & 1));
+            const int64_t on = (!LEAN && g.geglu) ? (n_base + wn * (16 * NTW) + nt * 16) / 2 + fc * 4 : n;
             rv[nt] = (g.rowvec && n < g.N) ? *reinterpret_cast<const float4 *>(g.rowvec + bidx * g.ld_rowvec + n) : make_float4(0.f, 0.f, 0.f, 0.f);
             rs[nt] = (g.residual && okn) ? *reinterpret_cast<const uint2 *>((const unsigned char *)g.residual + (m * g.ldr + on) * 2) : make_uint2(0u, 0u);
         }
@@ -1042,21 +1021,21 @@ __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g
         for (int nt = 0; nt < NTW; ++nt) {
             const int64_t n = n_lane + nt * 16;
             if (n >= g.N) continue;
-            if (g.geglu && (nt & 1)) continue;
+            if (!LEAN && g.geglu && (nt & 1)) continue;
             float v[4] = {acc[nt][mt][0] + bia[nt].x + rv[nt].x, acc[nt][mt][1] + bia[nt].y + rv[nt].y,
                           acc[nt][mt][2] + bia[nt].z + rv[nt].z, acc[nt][mt][3] + bia[nt].w + rv[nt].w};
             int64_t on = n;
-            if (g.geglu) {
+            if (!LEAN && g.geglu) {
                 constexpr int NP = NTW - 1;
                 const int np = nt + 1 < NTW ? nt + 1 : NP;
                 v[0] *= gelu_erf(acc[np][mt][0] + bia[np].x); v[1] *= gelu_erf(acc[np][mt][1] + bia[np].y);
                 v[2] *= gelu_erf(acc[np][mt][2] + bia[np].z); v[3] *= gelu_erf(acc[np][mt][3] + bia[np].w);
                 on = (n_base + wn * (16 * NTW) + nt * 16) / 2 + fc * 4;
             }
-            if (g.act == 1) {
+            if (!LEAN && g.act == 1) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = silu(v[r]);
-            } else if (g.act == 2) {
+            } else if (!LEAN && g.act == 2) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r] * 0.5f + 0.5f, 0.f), 1.f);
             }
@@ -1066,10 +1045,10 @@ __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g
                 v[0] += T::to_f((unsigned short)(rs[nt].x & 0xffff)); v[1] += T::to_f((unsigned short)(rs[nt].x >> 16));
                 v[2] += T::to_f((unsigned short)(rs[nt].y & 0xffff)); v[3] += T::to_f((unsigned short)(rs[nt].y >> 16));
             }
-            const bool to_t = g.out_t && on >= g.t_col0;
+            const bool to_t = !LEAN && g.out_t && on >= g.t_col0;
             const uint2 pk = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
             if (g.out && !(to_t && g.t_col0 > 0)) {
-                if (g.out_f32)
+                if (!LEAN && g.out_f32)
                     *reinterpret_cast<float4 *>((float *)g.out + m * g.ldc + on) = make_float4(v[0], v[1], v[2], v[3]);
                 else
                     *reinterpret_cast<uint2 *>((unsigned char *)g.out + (m * g.ldc + on) * 2) = pk;
@@ -1080,27 +1059,65 @@ __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[(on - g.t_col0 + r) * g.ldt] = T::from_f(v[r]);
             }
-            if constexpr (CS) {      // statistics of the values as STORED (rounded to the activation type)
-                const float t0 = T::to_f((unsigned short)(pk.x & 0xffff)), t1 = T::to_f((unsigned short)(pk.x >> 16));
-                const float t2 = T::to_f((unsigned short)(pk.y & 0xffff)), t3 = T::to_f((unsigned short)(pk.y >> 16));
-                cs[nt][0] += t0; cq[nt][0] += t0 * t0; cs[nt][1] += t1; cq[nt][1] += t1 * t1;
-                cs[nt][2] += t2; cq[nt][2] += t2 * t2; cs[nt][3] += t3; cq[nt][3] += t3 * t3;
-            }
+            if constexpr (CS) pks[mt][nt] = pk;      // statistics of the values as STORED (rounded to the activation type)
         }
     }
     if constexpr (CS) {
-        if (cs_slot >= 0) cs_flush();
+        // Statistics pass, ONE copy of the code (the first version flushed at every batch boundary inside the unrolled m loop: MT + 1
+        // copies of 40 DPP reductions, +3 000 instructions and +5.5 us per launch of pure instruction fetch): pass p sums the rows of batch
+        // slot p -- slot 0 = the batch of the tile's first row, slot 1 = the next one, present only in a tile that straddles a batch
+        // boundary (a 16-row m-tile never does: rows_per_batch % 16 == 0; BM <= rows_per_batch: at most one boundary).
+        const int64_t m_split = (m_base / g.rows_per_batch + 1) * g.rows_per_batch;          // first row of the next batch
+        const int64_t m_end = m_base + BM < g.M ? m_base + BM : g.M;
+        const int npass = m_split < m_end ? 2 : 1;
+#pragma unroll 1
+        for (int pass = 0; pass < npass; ++pass) {
+            float cs[NTW][4], cq[NTW][4];
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { cs[nt][r] = 0.f; cq[nt][r] = 0.f; }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int64_t m_tile = m_base + wm * (16 * MT) + mt * 16;             // wave-uniform
+                const float wgt = ((m_tile >= m_split ? 1 : 0) == pass) ? 1.f : 0.f;
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    const uint2 pk = pks[mt][nt];
+                    const float t0 = wgt * T::to_f((unsigned short)(pk.x & 0xffff)), t1 = wgt * T::to_f((unsigned short)(pk.x >> 16));
+                    const float t2 = wgt * T::to_f((unsigned short)(pk.y & 0xffff)), t3 = wgt * T::to_f((unsigned short)(pk.y >> 16));
+                    cs[nt][0] += t0; cq[nt][0] += t0 * t0; cs[nt][1] += t1; cq[nt][1] += t1 * t1;
+                    cs[nt][2] += t2; cq[nt][2] += t2 * t2; cs[nt][3] += t3; cq[nt][3] += t3 * t3;
+                }
+            }
+            float *tb = ctab + (pass * BN + wn * (16 * NTW) + fc * 4) * 2;
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float sa = row16_sum(cs[nt][r]), sb = row16_sum(cq[nt][r]);
+                    if (fr == 0) {
+                        __hip_atomic_fetch_add(tb + (nt * 16 + r) * 2, sa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(tb + (nt * 16 + r) * 2 + 1, sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the LDS adds; NOT the output stores still in flight
         __builtin_amdgcn_s_barrier();
         const int64_t b0 = m_base / g.rows_per_batch;
-        const int64_t m_end = m_base + BM < g.M ? m_base + BM : g.M;
-        for (int i = tid; i < 2 * BN; i += 512) {
-            const int slot = i >= BN ? 1 : 0, nl = i - slot * BN;
-            const int64_t n = n_base + nl, b = b0 + slot;
-            if (n < g.N && (slot == 0 || m_split < m_end)) {
-                const int64_t slab = mblk - (b * g.rows_per_batch) / BM;       // tiles are counted over all M rows
-                *reinterpret_cast<float2 *>(g.chan_parts + ((b * g.cp_nslab + slab) * g.N + n) * 2) = *reinterpret_cast<const float2 *>(ctab + i * 2);
-            }
+        const int cpg = g.gn_cpg, G = (int)(g.N / cpg);
+        const int n_hi = (int)(n_base + BN < g.N ? n_base + BN : g.N);
+        const int g_first = (int)n_base / cpg, ng = (n_hi - 1) / cpg - g_first + 1;        // groups that overlap this column tile (<= BN / cpg + 2)
+        for (int i = tid; i < 2 * ng; i += 512) {
+            const int slot = i >= ng ? 1 : 0, gg = g_first + i - slot * ng;
+            if (slot == 1 && !(m_split < m_end)) continue;
+            const int c_lo = gg * cpg > (int)n_base ? gg * cpg : (int)n_base, c_hi = (gg + 1) * cpg < n_hi ? (gg + 1) * cpg : n_hi;
+            float s1 = 0.f, s2 = 0.f;
+            for (int c = c_lo; c < c_hi; ++c) { const float2 t = *reinterpret_cast<const float2 *>(ctab + (slot * BN + c - (int)n_base) * 2); s1 += t.x; s2 += t.y; }
+            const int64_t b = b0 + slot;
+            const int64_t slab = mblk - (b * g.rows_per_batch) / BM;       // tiles are counted over all M rows
+            const int half = gg * cpg < (int)n_base ? 1 : 0;
+            *reinterpret_cast<float2 *>(g.chan_parts + ((((b * g.cp_nslab + slab) * G + gg) * 2 + half) * 2)) = make_float2(s1, s2);
         }
     }
 }
@@ -1731,15 +1748,27 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue_cs(const GemmArgs g)
 #pragma unroll
     for (int j = 0; j < 8; ++j) red[rl][cl][j] = cs[j];
     __syncthreads();
-    if (threadIdx.x < 128) {           // thread = (column quad, value): sum over the 16 row lanes
+    __shared__ float chs[64][2];
+    if (threadIdx.x < 128) {           // thread = (column, value): sum over the 16 row lanes
         const int c2 = threadIdx.x >> 3, j = threadIdx.x & 7;
-        const int64_t cq = (int64_t)blockIdx.x * 16 + c2;
-        if (cq < nq && m0 < g.M) {
-            float o = 0.f;
+        float o = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o += red[r][c2][j];
+        for (int r = 0; r < 16; ++r) o += red[r][c2][j];
+        chs[c2 * 4 + (j >> 1)][j & 1] = o;
+    }
+    __syncthreads();
+    if (m0 < g.M) {
+        const int cpg = g.gn_cpg, G = (int)(g.N / cpg);
+        const int n_base = (int)blockIdx.x * 64, n_hi = n_base + 64 < (int)g.N ? n_base + 64 : (int)g.N;
+        const int g_first = n_base / cpg, ng = (n_hi - 1) / cpg - g_first + 1;
+        if ((int)threadIdx.x < ng) {
+            const int gg = g_first + threadIdx.x;
+            const int c_lo = gg * cpg > n_base ? gg * cpg : n_base, c_hi = (gg + 1) * cpg < n_hi ? (gg + 1) * cpg : n_hi;
+            float s1 = 0.f, s2 = 0.f;
+            for (int c = c_lo; c < c_hi; ++c) { s1 += chs[c - n_base][0]; s2 += chs[c - n_base][1]; }
             const int64_t b = m0 / g.rows_per_batch, slab = (m0 - b * g.rows_per_batch) / CS_RB;
-            g.chan_parts[((b * g.cp_nslab + slab) * g.N + cq * 4) * 2 + j] = o;
+            const int half = gg * cpg < n_base ? 1 : 0;
+            *reinterpret_cast<float2 *>(g.chan_parts + ((((b * g.cp_nslab + slab) * G + gg) * 2 + half) * 2)) = make_float2(s1, s2);
         }
     }
 }
@@ -1758,15 +1787,36 @@ void launch4(const GemmArgs &g, dim3 grid, hipStream_t s)
     hipLaunchKernelGGL((k_gemm<T, MODE, NTW, FUSE>), grid, dim3(NT), lds, s, g);
 }
 
-template <class T, int MODE, int NTW, int MT, bool FUSE, bool CS = false>
+template <class T, int MODE, int NTW, int MT, bool FUSE, bool CS = false, bool LEAN = false>
 void launch8(const GemmArgs &g, dim3 grid, hipStream_t s)
 {
     // FUSE: + the row-sum array of row_stats_prologue; CS: + the [2][BN][2] channel-sum table
     constexpr size_t lds = 3 * (64 * MT * 128 + 32 * NTW * 128) + (FUSE ? 64 * MT * 8 : 0) + (CS ? 32 * NTW * 16 : 0);
     static_assert(lds <= 160 * 1024, "LDS ring");
     static gc::AttrOnce once;
-    gc::ensure_dynamic_lds(once, (const void *)k_gemm8<T, MODE, NTW, MT, FUSE, CS>, (int)lds);
-    hipLaunchKernelGGL((k_gemm8<T, MODE, NTW, MT, FUSE, CS>), grid, dim3(512), lds, s, g);
+    gc::ensure_dynamic_lds(once, (const void *)k_gemm8<T, MODE, NTW, MT, FUSE, CS, LEAN>, (int)lds);
+    hipLaunchKernelGGL((k_gemm8<T, MODE, NTW, MT, FUSE, CS, LEAN>), grid, dim3(512), lds, s, g);
+}
+
+// lean epilogue (no GEGLU / activation / fp32 / transposed output): fast conv, upsample-fused conv, K % 64 == 0 linear
+inline bool lean_of(const GemmArgs &g, int mode) { return !g.geglu && g.act == 0 && !g.out_f32 && !g.out_t && g.out && mode != 1 && (mode != 0 || g.K % 64 == 0); }
+template <class T, int NTW, int MT>
+void dispatch8lean_m(const GemmArgs &g, int mode, dim3 grid, hipStream_t s)
+{
+    if (mode == 0) launch8<T, 3, NTW, MT, false, false, true>(g, grid, s);
+    else if (g.ups) launch8<T, 4, NTW, MT, false, false, true>(g, grid, s);
+    else launch8<T, 2, NTW, MT, false, false, true>(g, grid, s);
+}
+template <class T>
+void dispatch8lean(const GemmArgs &g, int mode, int ntw, int mt, dim3 grid, hipStream_t s)
+{
+    if (mt == 1 && ntw == 4 && mode == 0) { launch8<T, 3, 4, 1, false, false, true>(g, grid, s); return; }
+    if (mt < 2) mt = 2;
+    if (ntw == 5) {
+        if (mt == 4) dispatch8lean_m<T, 5, 4>(g, mode, grid, s); else if (mt == 3) dispatch8lean_m<T, 5, 3>(g, mode, grid, s); else dispatch8lean_m<T, 5, 2>(g, mode, grid, s);
+    } else {
+        if (mt == 4) dispatch8lean_m<T, 4, 4>(g, mode, grid, s); else if (mt == 3) dispatch8lean_m<T, 4, 3>(g, mode, grid, s); else dispatch8lean_m<T, 4, 2>(g, mode, grid, s);
+    }
 }
 
 // channel-partial epilogue (CS): the modes whose output feeds a GroupNorm -- generic conv (conv_in), fast conv, K % 64 == 0 linear (proj_out)
@@ -1839,3 +1889,4 @@ void dn_gemm_launch_fp8(const GemmArgs &g, int dtype, int mode, int ntw, int mt,
 void dn_gemm_launch_splitk_epilogue(const GemmArgs &g, int dtype, hipStream_t s);
 void dn_gemm_launch_cs(const GemmArgs &g, int dtype, int mode, int ntw, int mt8, dim3 grid, hipStream_t s);     // 8-wave kernel + channel partials
 void dn_gemm_launch_splitk_epilogue_cs(const GemmArgs &g, int dtype, hipStream_t s);
+void dn_gemm_launch_lean(const GemmArgs &g, int dtype, int mode, int ntw, int mt8, dim3 grid, hipStream_t s);   // 8-wave kernel, lean epilogue

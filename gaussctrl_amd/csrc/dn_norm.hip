@@ -210,50 +210,140 @@ __global__ __launch_bounds__(256) void k_gn_apply_stats(const unsigned short *__
     }
 }
 
-// GroupNorm from per-CHANNEL partial sums that the PRODUCER of x left per row slab (gc_gemm_desc.out_chan_parts: the conv / linear epilogue,
-// the split-K reduce kernel, gc_dn_concat_add_parts): parts[b][slab][c] = (sum x, sum x^2) over the rows of batch b inside slab `slab`.
-// Plain stores on the producer side -- no atomics, no zero-init; the slabs are added up HERE, in the prologue of the apply kernel
-// (a few tens of independent 8-byte loads per thread from L2), then the group moments, then the coefficients, all in LDS.
+// GroupNorm whose statistics pass was done by the PRODUCER of x (gc_gemm_desc.out_chan_parts: the conv / linear epilogue, the split-K reduce
+// kernel; gc_dn_concat_add_parts): parts[b][slab][g][half] = (sum x, sum x^2) over the rows of batch b inside row slab `slab` and over the
+// channels of group g inside one column tile of the producer (half 1: the rest of a group that straddles two column tiles of `col_tile`
+// channels).  Plain stores on the producer side -- no atomics, no zero-init; the few KB of a batch are added up HERE, in the prologue
+// of the apply kernel (<= 8 independent 8-byte loads per thread), then the moments and the per-channel coefficients, all in LDS: ONE launch.
 // slab_mode 0: slabs are the producer's row tiles of R rows counted over all B * HW rows (a tile that straddles two batches has a slab
 // in each); slab_mode 1: slabs restart at every batch.  Raw (unshifted) fp32 sums: relative error of the variance ~ 1e-7 * mean^2 / var.
+// (Tried first: per-CHANNEL partials, summed in this prologue -- every one of the ~500 workgroups re-read nslab x C x 8 bytes and re-added
+// them in LDS: 64 us instead of 23 us at 64 x 64 x 320 -- and per-channel partials with a separate finalize launch: +1.8 % views/s.)
 __device__ __forceinline__ int parts_count(unsigned b, unsigned HW, unsigned R, int mode)
 {
     if (mode) return (int)((HW + R - 1) / R);
-    const unsigned long long r0 = (unsigned long long)b * HW, r1 = r0 + HW - 1;
+    const unsigned r0 = b * HW, r1 = r0 + HW - 1;          // B * HW < 2^31 (checked on the host)
     return (int)(r1 / R - r0 / R) + 1;
 }
 
-// finalize pass over the producer's partials: one workgroup per (batch, group); thread = (channel of the group, slab subset), every
-// thread issues its few slab loads back to back; -> coef[b][c] = (a_c = rstd_g gamma_c, beta_c - mean_g a_c), the input of k_gn_apply.
-// (Tried first: the slab sums, group moments and coefficients in the PROLOGUE of the apply kernel -- one launch per GroupNorm -- but every
-// one of its ~500 workgroups then re-reads nslab x C x 8 bytes and re-adds them in LDS: 64 us instead of 23 us at 64 x 64 x 320.)
-__global__ __launch_bounds__(256) void k_gn_finalize_parts(unsigned HW, unsigned C, int G, const float *__restrict__ parts, int nslab, unsigned R, int mode,
-                                                           const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float *__restrict__ coef)
+// group moments of batch b into LDS: gs[2 g] = mean_g, gs[2 g + 1] = rstd_g (ends with a barrier).  Thread = (entry e = (group, half) of a
+// slab, slab subset): all of a thread's slab loads are in flight together, the subsets meet through plain LDS stores.  (LDS float atomics
+// instead: 16 ds_add_f32 per thread cost 6.7 us of a 16 us kernel -- the LDS unit serialises them lane by lane.)
+__device__ __forceinline__ void gparts_to_moments(float *gs, float2 *red /* [256] */, unsigned b, unsigned HW, unsigned C, unsigned G,
+                                                  const float *__restrict__ parts, int nslab, unsigned R, int mode, unsigned col_tile, float eps)
 {
-    __shared__ float red[2][4];
-    const unsigned b = blockIdx.x / G, gi = blockIdx.x % G, cpg = C / G, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const unsigned tid = threadIdx.x, cpg = C / G;
+    const unsigned E = 2 * G;                                   // entries per slab (G <= 128: E <= 256)
+    const unsigned nsub = 256 / E, e = tid % E, sub = tid / E;
     const int ns = parts_count(b, HW, R, mode);
-    const unsigned ci = tid % cpg, sub = tid / cpg, nsub = 256 / cpg;   // cpg <= 256
+    const float2 *pb = reinterpret_cast<const float2 *>(parts) + (size_t)b * nslab * E + e;
+    const unsigned g = e >> 1;
+    // half 1 exists only for a group that straddles two column tiles of the producer
+    const bool ok = sub < nsub && (!(e & 1) || (g * cpg) / col_tile != ((g + 1) * cpg - 1) / col_tile);
     float s1 = 0.f, s2 = 0.f;
-    if (sub < nsub) {
-        const float2 *pb = reinterpret_cast<const float2 *>(parts) + ((size_t)b * nslab) * C + gi * cpg + ci;
+    if (ok) {
         int sl = (int)sub;
         for (; sl + 3 * (int)nsub < ns; sl += 4 * (int)nsub) {
-            const float2 v0 = pb[(size_t)sl * C], v1 = pb[(size_t)(sl + nsub) * C], v2 = pb[(size_t)(sl + 2 * nsub) * C], v3 = pb[(size_t)(sl + 3 * nsub) * C];
+            const float2 v0 = pb[(size_t)sl * E], v1 = pb[(size_t)(sl + nsub) * E], v2 = pb[(size_t)(sl + 2 * nsub) * E], v3 = pb[(size_t)(sl + 3 * nsub) * E];
             s1 += (v0.x + v1.x) + (v2.x + v3.x); s2 += (v0.y + v1.y) + (v2.y + v3.y);
         }
-        for (; sl < ns; sl += (int)nsub) { const float2 v = pb[(size_t)sl * C]; s1 += v.x; s2 += v.y; }
+        for (; sl < ns; sl += (int)nsub) { const float2 v = pb[(size_t)sl * E]; s1 += v.x; s2 += v.y; }
     }
-    s1 = wave_sum_f(s1); s2 = wave_sum_f(s2);
-    if (lane == 0) { red[0][wid] = s1; red[1][wid] = s2; }
+    if (sub < nsub) red[sub * E + e] = make_float2(s1, s2);
     __syncthreads();
     const float n = (float)HW * (float)cpg;
-    const float mu = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / n;
-    const float var = fmaxf(((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / n - mu * mu, 0.f);
-    const float rstd = rsqrtf(var + eps);
-    for (unsigned c = gi * cpg + tid; c < (gi + 1) * cpg; c += 256) {
-        const float a = rstd * gamma[c];
-        *reinterpret_cast<float2 *>(coef + ((size_t)b * C + c) * 2) = make_float2(a, beta[c] - mu * a);
+    if (tid < G) {
+        float t1 = 0.f, t2 = 0.f;
+        for (unsigned k = 0; k < nsub; ++k) {
+            const float2 a = red[k * E + 2 * tid], c = red[k * E + 2 * tid + 1];
+            t1 += a.x + c.x; t2 += a.y + c.y;
+        }
+        const float mu = t1 / n;
+        gs[2 * tid] = mu; gs[2 * tid + 1] = rsqrtf(fmaxf(t2 / n - mu * mu, 0.f) + eps);
+    }
+    __syncthreads();
+}
+
+// Apply pass with the statistics prologue.  A thread owns ONE 16-byte channel chunk and walks the pixels of its slab (slab plan of the
+// statistics kernels): its 16 coefficients live in registers -- no coefficient table in the loop (the first version read a [C][2] LDS
+// table per chunk: 64-byte lane stride = 16-way bank conflicts, 43 us against 12 us for the plain apply kernel at 64 x 64 x 320 / 640) --
+// and gamma / beta and the first pixels of x are requested before the partials (nothing of that depends on the statistics).
+template <class T>
+__global__ __launch_bounds__(256) void k_gn_apply_parts(const unsigned short *__restrict__ x, unsigned short *__restrict__ y, unsigned HW,
+                                                        unsigned C, unsigned G, const float *__restrict__ parts, int nslab, unsigned R, int mode,
+                                                        unsigned col_tile, const float *__restrict__ gamma, const float *__restrict__ beta, float eps, int act,
+                                                        int nchb, int pix_per_block)
+{
+    __shared__ float gs[256];                // [G][2], G <= 128
+    __shared__ float2 red[256];
+    const unsigned b = blockIdx.z, tid = threadIdx.x, cpg = C / G;
+    const int lanes = 256 / nchb;
+    const int cch = tid % nchb, pl = tid / nchb;
+    const unsigned c0 = (blockIdx.y * nchb + cch) * 8;
+    const bool live = pl < lanes;
+    const int p0 = blockIdx.x * pix_per_block, p1 = min(p0 + pix_per_block, (int)HW);
+    const unsigned short *xb = x + (size_t)b * HW * C + c0;
+    unsigned short *yb = y + (size_t)b * HW * C + c0;
+    float4 gm[2], bt[2];
+    uint4 pre[4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        gm[k] = live ? *reinterpret_cast<const float4 *>(gamma + c0 + 4 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bt[k] = live ? *reinterpret_cast<const float4 *>(beta + c0 + 4 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int p = p0 + pl + u * lanes;
+        pre[u] = (live && p < p1) ? *reinterpret_cast<const uint4 *>(xb + (size_t)p * C) : make_uint4(0u, 0u, 0u, 0u);
+    }
+    gparts_to_moments(gs, red, b, HW, C, G, parts, nslab, R, mode, col_tile, eps);
+    if (!live) return;
+    float ca[8], cd[8];
+    const float gmv[8] = {gm[0].x, gm[0].y, gm[0].z, gm[0].w, gm[1].x, gm[1].y, gm[1].z, gm[1].w};
+    const float btv[8] = {bt[0].x, bt[0].y, bt[0].z, bt[0].w, bt[1].x, bt[1].y, bt[1].z, bt[1].w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const unsigned g = (c0 + j) / cpg;
+        ca[j] = gs[2 * g + 1] * gmv[j];
+        cd[j] = btv[j] - gs[2 * g] * ca[j];
+    }
+    auto one = [&](int p, const uint4 &raw) __attribute__((always_inline)) {
+        float f[8];
+        unpack8<T>(raw, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = f[j] * ca[j] + cd[j];
+            f[j] = act ? silu(v) : v;
+        }
+        *reinterpret_cast<uint4 *>(yb + (size_t)p * C) = pack8<T>(f);
+    };
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int p = p0 + pl + u * lanes;
+        if (p < p1) one(p, pre[u]);
+    }
+    for (int p = p0 + pl + 4 * lanes; p < p1; p += 4 * lanes) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int pp = p + u * lanes; v[u] = *reinterpret_cast<const uint4 *>(xb + (size_t)(pp < p1 ? pp : p) * C); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int pp = p + u * lanes; if (pp < p1) one(pp, v[u]); }
+    }
+}
+
+// the coefficients alone, [B][C][2] to global (input of the fused transformer head): one workgroup per batch
+__global__ __launch_bounds__(256) void k_gn_coef_parts(unsigned HW, unsigned C, unsigned G, const float *__restrict__ parts, int nslab, unsigned R, int mode,
+                                                       unsigned col_tile, const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                                       float *__restrict__ out)
+{
+    __shared__ float gs[256];
+    __shared__ float2 red[256];
+    const unsigned b = blockIdx.x, cpg = C / G;
+    gparts_to_moments(gs, red, b, HW, C, G, parts, nslab, R, mode, col_tile, eps);
+    for (unsigned c = threadIdx.x; c < C; c += 256) {
+        const unsigned g = c / cpg;
+        const float a = gs[2 * g + 1] * gamma[c];
+        *reinterpret_cast<float2 *>(out + ((size_t)b * C + c) * 2) = make_float2(a, beta[c] - gs[2 * g] * a);
     }
 }
 
@@ -389,7 +479,7 @@ __global__ __launch_bounds__(256) void k_concat_add_stats(const unsigned short *
 template <class T>
 __global__ __launch_bounds__(256) void k_concat_add_parts(const unsigned short *__restrict__ a, int C1, const unsigned short *__restrict__ bsrc,
                                                           const unsigned short *__restrict__ c, int C2, unsigned short *__restrict__ out,
-                                                          int HW, int nchb, int pix_per_block, float *__restrict__ parts)
+                                                          int HW, int nchb, int pix_per_block, int cpg, float *__restrict__ parts)
 {
     extern __shared__ float sp[];   // [lanes][nchb][16]
     const int b = blockIdx.z, C = C1 + C2;
@@ -450,9 +540,18 @@ __global__ __launch_bounds__(256) void k_concat_add_parts(const unsigned short *
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[j] += o[j];
         }
-        float *dst = parts + (((size_t)b * gridDim.x + blockIdx.x) * C + c0) * 2;
+        float *o = sp + (size_t)cch * 16;          // lane 0's own slot: per-channel (sum, sum^2) of this slab for the group pass
 #pragma unroll
-        for (int j = 0; j < 16; j += 4) *reinterpret_cast<float4 *>(dst + j) = make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]);
+        for (int j = 0; j < 16; ++j) o[j] = acc[j];
+    }
+    __syncthreads();
+    // group g of this workgroup's channel slice = cpg consecutive channels (the slice holds whole groups: checked on the host) -> half 0
+    const int gslice = nchb * 8 / cpg, G = C / cpg;
+    if (tid < gslice) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int cc = tid * cpg; cc < (tid + 1) * cpg; ++cc) { s1 += sp[2 * cc]; s2 += sp[2 * cc + 1]; }
+        const int gg = blockIdx.y * gslice + tid;
+        *reinterpret_cast<float2 *>(parts + (((((size_t)b * gridDim.x + blockIdx.x) * G + gg) * 2) * 2)) = make_float2(s1, s2);
     }
 }
 
@@ -814,28 +913,31 @@ int gc_dn_concat_add(int dtype, const void *a, int C1, const void *b, const void
 }
 
 int gc_dn_groupnorm_coef_parts(int64_t B, int64_t HW, int C, int G, const float *gamma, const float *beta, float eps, const float *parts,
-                               int64_t rows_per_slab, int nslab, int slab_mode, float *coef, void *stream)
+                               int64_t rows_per_slab, int nslab, int slab_mode, int col_tile, float *coef, void *stream)
 {
-    GC_REQUIRE(C % G == 0 && C / G <= 256 && parts && gamma && beta && coef && rows_per_slab > 0 && nslab > 0, "groupnorm_coef_parts: bad arguments");
-    hipLaunchKernelGGL(k_gn_finalize_parts, dim3((unsigned)(B * G)), dim3(256), 0, gc::S(stream), (unsigned)HW, (unsigned)C, G, parts, nslab,
-                       (unsigned)rows_per_slab, slab_mode, gamma, beta, eps, coef);
+    GC_REQUIRE(C % G == 0 && G <= 128 && parts && gamma && beta && coef && rows_per_slab > 0 && nslab > 0 && col_tile > 0 && B * HW < (int64_t)1 << 31,
+               "groupnorm_coef_parts: bad arguments");
+    hipLaunchKernelGGL(k_gn_coef_parts, dim3((unsigned)B), dim3(256), 0, gc::S(stream), (unsigned)HW, (unsigned)C, (unsigned)G, parts, nslab,
+                       (unsigned)rows_per_slab, slab_mode, (unsigned)col_tile, gamma, beta, eps, coef);
     return gc::check_launch("gc_dn_groupnorm_coef_parts");
 }
 
+static void concat_parts_plan(int64_t HW, int C, int *nslab, int *ppb, int *ny, int *nchb);
+
 int gc_dn_groupnorm_apply_parts(int dtype, const void *x, void *y, int64_t B, int64_t HW, int C, int G, const float *gamma, const float *beta,
-                                float eps, int act, const float *parts, int64_t rows_per_slab, int nslab, int slab_mode, float *coef_ws, void *stream)
+                                float eps, int act, const float *parts, int64_t rows_per_slab, int nslab, int slab_mode, int col_tile, void *stream)
 {
-    GC_REQUIRE(C % 8 == 0 && coef_ws, "groupnorm_apply_parts: C must be a multiple of 8; coefficient workspace [B][C][2] required");
-    GC_REQUIRE(B * HW * (int64_t)(C / 8) < (int64_t)1 << 31, "groupnorm_apply_parts: tensor too large");
-    const int rc = gc_dn_groupnorm_coef_parts(B, HW, C, G, gamma, beta, eps, parts, rows_per_slab, nslab, slab_mode, coef_ws, stream);
-    if (rc != GC_OK) return rc;
-    const int64_t chunks = B * HW * (C / 8);
-    hipStream_t s = gc::S(stream);
+    GC_REQUIRE(C % 8 == 0 && C % G == 0 && G <= 128 && parts && gamma && beta, "groupnorm_apply_parts: C must be a multiple of 8 and of G; partials required");
+    GC_REQUIRE(HW * (int64_t)C < (int64_t)1 << 31 && B * HW < (int64_t)1 << 31 && B <= 65535 && rows_per_slab > 0 && nslab > 0 && col_tile > 0,
+               "groupnorm_apply_parts: bad sizes");
+    int ns, ppb, ny, nchb;                      // pixel slabs of 16 / 32 pixels x channel slices of <= 256 chunks (the plan of gc_dn_concat_add_parts)
+    concat_parts_plan(HW, C, &ns, &ppb, &ny, &nchb);
+    dim3 grid((unsigned)ns, ny, (unsigned)B);
     DN_DISPATCH(dtype,
-                hipLaunchKernelGGL((k_gn_apply<BF16>), dim3(ew_grid(chunks)), dim3(256), 0, s, (const unsigned short *)x,
-                                   (unsigned short *)y, (unsigned)HW, (unsigned)C, coef_ws, act, (unsigned)chunks),
-                hipLaunchKernelGGL((k_gn_apply<F16>), dim3(ew_grid(chunks)), dim3(256), 0, s, (const unsigned short *)x,
-                                   (unsigned short *)y, (unsigned)HW, (unsigned)C, coef_ws, act, (unsigned)chunks));
+                hipLaunchKernelGGL((k_gn_apply_parts<BF16>), grid, dim3(256), 0, gc::S(stream), (const unsigned short *)x, (unsigned short *)y,
+                                   (unsigned)HW, (unsigned)C, (unsigned)G, parts, nslab, (unsigned)rows_per_slab, slab_mode, (unsigned)col_tile, gamma, beta, eps, act, nchb, ppb),
+                hipLaunchKernelGGL((k_gn_apply_parts<F16>), grid, dim3(256), 0, gc::S(stream), (const unsigned short *)x, (unsigned short *)y,
+                                   (unsigned)HW, (unsigned)C, (unsigned)G, parts, nslab, (unsigned)rows_per_slab, slab_mode, (unsigned)col_tile, gamma, beta, eps, act, nchb, ppb));
     return gc::check_launch("gc_dn_groupnorm_apply_parts");
 }
 
@@ -851,30 +953,35 @@ static void concat_parts_plan(int64_t HW, int C, int *nslab, int *ppb, int *ny, 
     *ppb = p; *nslab = (int)((HW + p - 1) / p);
 }
 
-int gc_dn_concat_parts_layout(int64_t rows_per_batch, int C, int64_t *rows_per_slab, int *nslab)
+int gc_dn_concat_parts_layout(int64_t rows_per_batch, int C, int gn_groups, int64_t *rows_per_slab, int *nslab, int *col_tile)
 {
-    GC_REQUIRE(rows_per_slab && nslab && rows_per_batch > 0 && C % 8 == 0, "concat_parts_layout: bad arguments");
+    GC_REQUIRE(rows_per_slab && nslab && col_tile && rows_per_batch > 0 && C % 8 == 0 && gn_groups >= 1, "concat_parts_layout: bad arguments");
+    *rows_per_slab = 0; *nslab = 0; *col_tile = 0;
     int ns, ppb, ny, nchb;
     concat_parts_plan(rows_per_batch, C, &ns, &ppb, &ny, &nchb);
-    *rows_per_slab = ppb; *nslab = ns;
+    if (C % gn_groups != 0 || (nchb * 8) % (C / gn_groups) != 0 || nchb * 8 / (C / gn_groups) > 256) return GC_OK;     // a channel slice must hold whole groups
+    *rows_per_slab = ppb; *nslab = ns; *col_tile = nchb * 8;
     return GC_OK;
 }
 
 int gc_dn_concat_add_parts(int dtype, const void *a, int C1, const void *b, const void *c, int C2, void *out, int64_t M, int64_t rows_per_batch,
-                           float *parts, void *stream)
+                           int gn_groups, float *parts, void *stream)
 {
+    GC_REQUIRE(gn_groups >= 1 && (C1 + C2) % gn_groups == 0, "concat_parts: gn_groups must divide C1 + C2");
+    const int cpg = (C1 + C2) / gn_groups;
     GC_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && parts && out, "concat_parts: channel counts must be multiples of 8; output and partials buffer required");
     GC_REQUIRE(rows_per_batch > 0 && M % rows_per_batch == 0 && M / rows_per_batch <= 65535, "concat_parts: M must be B * rows_per_batch");
     int nslab, ppb, ny, nchb;
     concat_parts_plan(rows_per_batch, C1 + C2, &nslab, &ppb, &ny, &nchb);
+    GC_REQUIRE((nchb * 8) % cpg == 0 && nchb * 8 / cpg <= 256, "concat_parts: a channel slice must hold whole groups (see gc_dn_concat_parts_layout)");
     const int lanes = 256 / nchb;
     dim3 grid((unsigned)nslab, ny, (unsigned)(M / rows_per_batch));
     const size_t lds = sizeof(float) * 16 * (size_t)lanes * nchb;
     DN_DISPATCH(dtype,
                 hipLaunchKernelGGL((k_concat_add_parts<BF16>), grid, dim3(256), lds, gc::S(stream), (const unsigned short *)a, C1,
-                                   (const unsigned short *)b, (const unsigned short *)c, C2, (unsigned short *)out, (int)rows_per_batch, nchb, ppb, parts),
+                                   (const unsigned short *)b, (const unsigned short *)c, C2, (unsigned short *)out, (int)rows_per_batch, nchb, ppb, cpg, parts),
                 hipLaunchKernelGGL((k_concat_add_parts<F16>), grid, dim3(256), lds, gc::S(stream), (const unsigned short *)a, C1,
-                                   (const unsigned short *)b, (const unsigned short *)c, C2, (unsigned short *)out, (int)rows_per_batch, nchb, ppb, parts));
+                                   (const unsigned short *)b, (const unsigned short *)c, C2, (unsigned short *)out, (int)rows_per_batch, nchb, ppb, cpg, parts));
     return gc::check_launch("gc_dn_concat_add_parts");
 }
 

@@ -161,13 +161,14 @@ _zero_page = {}
 
 
 class ChanParts:
-    """Per-channel partial (sum, sum^2) of a tensor per row slab, left by its PRODUCER (gc_gemm_desc.out_chan_parts / gc_dn_concat_add_parts)
-    for the GroupNorm that follows (groupnorm(..., parts=)): buf fp32 [B, nslab, C, 2]; rows = rows per slab; mode 0: slabs are the
-    producer's row tiles counted over all rows, 1: slabs restart at every batch."""
-    __slots__ = ("buf", "rows", "nslab", "mode")
+    """Partial (sum, sum^2) of a tensor per row slab and GroupNorm group, left by its PRODUCER (gc_gemm_desc.out_chan_parts /
+    gc_dn_concat_add_parts) for the GroupNorm that follows (groupnorm(..., parts=)): buf fp32 [B, nslab, G, 2 halves, 2]; rows = rows per
+    slab; mode 0: slabs are the producer's row tiles counted over all rows, 1: slabs restart at every batch; col_tile = the producer's
+    column tile (half 1 holds the rest of a group that straddles two of them); groups = G."""
+    __slots__ = ("buf", "rows", "nslab", "mode", "col_tile", "groups")
 
-    def __init__(self, buf, rows, nslab, mode):
-        self.buf, self.rows, self.nslab, self.mode = buf, rows, nslab, mode
+    def __init__(self, buf, rows, nslab, mode, col_tile, groups):
+        self.buf, self.rows, self.nslab, self.mode, self.col_tile, self.groups = buf, rows, nslab, mode, col_tile, groups
 
 
 class RowStats:
@@ -179,7 +180,7 @@ class RowStats:
         self.buf, self.slots = None, 0
 
 
-def _run_gemm(d, dev, what, row_stats=None, want_parts=False):
+def _run_gemm(d, dev, what, row_stats=None, want_parts=False, gn_groups=32):
     """-> ChanParts of the output when want_parts and the kernel this problem selects can produce them, else None"""
     lib = L.lib()
     z = _zero_page.get(dev)
@@ -198,11 +199,15 @@ def _run_gemm(d, dev, what, row_stats=None, want_parts=False):
         d.out_row_stats = row_stats.buf.data_ptr()
     parts = None
     if want_parts and d.rows_per_batch >= 256:
-        rows, ns = C.c_int64(0), C.c_int(0)
-        L.check(lib.gc_dn_gemm_chan_parts_layout(C.byref(d), C.byref(rows), C.byref(ns)), "gc_dn_gemm_chan_parts_layout")
+        rows, ns, ct = C.c_int64(0), C.c_int(0), C.c_int(0)
+        d.gn_groups = gn_groups
+        L.check(lib.gc_dn_gemm_chan_parts_layout(C.byref(d), C.byref(rows), C.byref(ns), C.byref(ct)), "gc_dn_gemm_chan_parts_layout")
         if rows.value > 0:
-            parts = ChanParts(torch.empty(d.M // d.rows_per_batch, ns.value, d.N, 2, dtype=torch.float32, device=dev), rows.value, ns.value, 0)
+            parts = ChanParts(torch.empty(d.M // d.rows_per_batch, ns.value, gn_groups, 2, 2, dtype=torch.float32, device=dev), rows.value, ns.value,
+                              0, ct.value, gn_groups)
             d.out_chan_parts = parts.buf.data_ptr()
+        else:
+            d.gn_groups = 0
     L.check(lib.gc_dn_gemm(C.byref(d), _stream()), what)
     return parts
 
@@ -216,7 +221,7 @@ def _stats_args(d, ln, group_stats):
 
 def linear(x, w, bias=None, residual=None, act=0, geglu=False, out_f32=False, scale=1.0, rowvec=None, rows_per_batch=0,
            ld_rowvec=None, out=None, want_out=True, out_t=None, ldt=0, t_batch_stride=0, t_col0=0, out_cols=None,
-           ln=None, row_stats=None, group_stats=None, chan_parts=False):
+           ln=None, row_stats=None, group_stats=None, chan_parts=False, gn_groups=32):
     """x [..., K] (last dim contiguous, rows strided by x.stride(-2)) @ w[N,K]^T with fused epilogue.
     chan_parts=True: returns (out, ChanParts | None) -- the per-channel partial sums of the output for a following GroupNorm (needs rows_per_batch);
     ln=(RowStats of x, colsum [N], eps): LayerNorm folded in (w carries gamma, bias carries W beta);
@@ -252,12 +257,12 @@ def linear(x, w, bias=None, residual=None, act=0, geglu=False, out_f32=False, sc
     if out_t is not None:
         d.out_t = out_t.data_ptr(); d.ldt = ldt; d.t_batch_stride = t_batch_stride; d.t_col0 = t_col0
     _stats_args(d, ln, group_stats)
-    parts = _run_gemm(d, x.device, "gc_dn_gemm", row_stats, want_parts=chan_parts and not BATCH_INVARIANT)
+    parts = _run_gemm(d, x.device, "gc_dn_gemm", row_stats, want_parts=chan_parts and not BATCH_INVARIANT, gn_groups=gn_groups)
     return (out, parts) if chan_parts else out
 
 
 def conv3x3(x, w, bias=None, stride=1, upsample=False, rowvec=None, ld_rowvec=None, residual=None, act=0, scale=1.0,
-            out_f32=False, pad_lo=1, group_stats=None, chan_parts=False):
+            out_f32=False, pad_lo=1, group_stats=None, chan_parts=False, gn_groups=32):
     """x [B,H,W,Cin] NHWC, w [N, 9*Cin] ((tap, cin) order), pad 1.  chan_parts=True: returns (out, ChanParts | None)."""
     _gpu(x, w)
     B, H, W_, Cin = x.shape
@@ -287,7 +292,7 @@ def conv3x3(x, w, bias=None, stride=1, upsample=False, rowvec=None, ld_rowvec=No
     d.out_scale = scale; d.act = act
     d.out = out.data_ptr(); d.ldc = N; d.out_f32 = int(out_f32)
     _stats_args(d, None, group_stats)
-    parts = _run_gemm(d, x.device, "gc_dn_gemm(conv3x3)", want_parts=chan_parts and not BATCH_INVARIANT)
+    parts = _run_gemm(d, x.device, "gc_dn_gemm(conv3x3)", want_parts=chan_parts and not BATCH_INVARIANT, gn_groups=gn_groups)
     return (out, parts) if chan_parts else out
 
 
@@ -295,7 +300,7 @@ _gn_ws = {}
 
 
 def groupnorm(x, gamma, beta, groups, eps, silu, parts=None):
-    """x [B,H,W,C] (or [B,HW,C]).  parts: the ChanParts x's producer left -> finalize + apply (gc_dn_groupnorm_apply_parts): no statistics pass over x."""
+    """x [B,H,W,C] (or [B,HW,C]).  parts: the ChanParts x's producer left -> ONE launch (gc_dn_groupnorm_apply_parts) instead of three."""
     _gpu(x)
     B, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * Cc)
@@ -304,13 +309,10 @@ def groupnorm(x, gamma, beta, groups, eps, silu, parts=None):
         if z is not None:
             return z
     if parts is not None:
+        assert parts.groups == groups
         y = torch.empty_like(x)
-        key = (x.device, B, Cc, stream_handle(), "coef")          # coefficient scratch, per stream
-        ws = _gn_ws.get(key)
-        if ws is None:
-            ws = _gn_ws[key] = torch.empty(B, Cc, 2, dtype=torch.float32, device=x.device)
         L.check(L.lib().gc_dn_groupnorm_apply_parts(_dt(x), _p(x), _p(y), C.c_int64(B), C.c_int64(HW), Cc, groups, _p(gamma), _p(beta), C.c_float(eps),
-                                                    int(silu), _p(parts.buf), C.c_int64(parts.rows), parts.nslab, parts.mode, _p(ws), _stream()),
+                                                    int(silu), _p(parts.buf), C.c_int64(parts.rows), parts.nslab, parts.mode, parts.col_tile, _stream()),
                 "gc_dn_groupnorm_apply_parts")
         return y
     key = (x.device, B, HW, Cc, stream_handle())      # scratch is per stream: two networks may run concurrently
@@ -435,7 +437,7 @@ def layernorm(x, gamma, beta, eps=1e-5):
     return y
 
 
-def concat_add(a, b, c=None, group_stats=None, chan_parts=False):
+def concat_add(a, b, c=None, group_stats=None, chan_parts=False, gn_groups=32):
     """cat([a, b (+ c)], dim=-1) on channels-last tensors [B, ..., C]; group_stats (zeroed fp32 [B, G, 2]) receives the
     per-(batch, GroupNorm group) (sum, sum^2) of the output; chan_parts=True: returns (out, ChanParts | None) instead."""
     _gpu(a, b, c)
@@ -446,10 +448,12 @@ def concat_add(a, b, c=None, group_stats=None, chan_parts=False):
         rpb = M // a.shape[0]
         if rpb < 256 or BATCH_INVARIANT or "gn" in OPTIONS.ablate:
             return concat_add(a, b, c), None
-        rows, ns = C.c_int64(0), C.c_int(0)
-        L.check(L.lib().gc_dn_concat_parts_layout(C.c_int64(rpb), C1 + C2, C.byref(rows), C.byref(ns)), "gc_dn_concat_parts_layout")
-        parts = ChanParts(torch.empty(a.shape[0], ns.value, C1 + C2, 2, dtype=torch.float32, device=a.device), rows.value, ns.value, 1)
-        L.check(L.lib().gc_dn_concat_add_parts(_dt(a), _p(a), C1, _p(b), _p(c), C2, _p(out), C.c_int64(M), C.c_int64(rpb), _p(parts.buf), _stream()),
+        rows, ns, ct = C.c_int64(0), C.c_int(0), C.c_int(0)
+        L.check(L.lib().gc_dn_concat_parts_layout(C.c_int64(rpb), C1 + C2, gn_groups, C.byref(rows), C.byref(ns), C.byref(ct)), "gc_dn_concat_parts_layout")
+        if rows.value == 0:
+            return concat_add(a, b, c), None
+        parts = ChanParts(torch.empty(a.shape[0], ns.value, gn_groups, 2, 2, dtype=torch.float32, device=a.device), rows.value, ns.value, 1, ct.value, gn_groups)
+        L.check(L.lib().gc_dn_concat_add_parts(_dt(a), _p(a), C1, _p(b), _p(c), C2, _p(out), C.c_int64(M), C.c_int64(rpb), gn_groups, _p(parts.buf), _stream()),
                 "gc_dn_concat_add_parts")
         return out, parts
     L.check(L.lib().gc_dn_concat_add(_dt(a), _p(a), C1, _p(b), _p(c), C2, _p(out), C.c_int64(M), C.c_int64(M // a.shape[0]),
@@ -559,7 +563,7 @@ def groupnorm_coef(x, gamma, beta, groups, eps, parts=None):
     if parts is not None and "gn" not in OPTIONS.ablate:
         coef = torch.empty(B, Cc, 2, dtype=torch.float32, device=x.device)
         L.check(L.lib().gc_dn_groupnorm_coef_parts(C.c_int64(B), C.c_int64(HW), Cc, groups, _p(gamma), _p(beta), C.c_float(eps), _p(parts.buf),
-                                                   C.c_int64(parts.rows), parts.nslab, parts.mode, _p(coef), _stream()), "gc_dn_groupnorm_coef_parts")
+                                                   C.c_int64(parts.rows), parts.nslab, parts.mode, parts.col_tile, _p(coef), _stream()), "gc_dn_groupnorm_coef_parts")
         return coef
     key = (x.device, B, HW, Cc, stream_handle())
     ws = _gn_ws.get(key)

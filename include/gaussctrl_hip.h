@@ -285,20 +285,22 @@ typedef struct gc_gemm_desc {
     int a_scale;               /* E8M0 byte of the activation tensor */
     int kernel_variant;        /* 0 = automatic.  Overrides for tests / experiments: bits 0-2 force the 8-wave kernel's m-tiles per wave (2,3,4); */
                                /* 0x10 4-wave kernel only; 0x20 force the 8-wave kernel; 0x40 no k-slices for part-filled conv grids; 0x80 slice 8x8-map convs too */
-    float *out_chan_parts;     /* NULL or [M / rows_per_batch][nslab][N][2]: per-CHANNEL partial (sum, sum of squares) of the stored output per row slab */
-                               /* (layout: gc_dn_gemm_chan_parts_layout), PLAIN stores -- no atomics, no zero-init -> gc_dn_groupnorm_apply_parts /   */
-                               /* gc_dn_groupnorm_coef_parts: the statistics pass of the GroupNorm that follows this conv / linear for free        */
+    float *out_chan_parts;     /* NULL or [M / rows_per_batch][nslab][gn_groups][2][2]: partial (sum, sum of squares) of the stored output per row slab,  */
+                               /* GroupNorm group (N / gn_groups channels) and half (1: rest of a group straddling two column tiles); layout:          */
+                               /* gc_dn_gemm_chan_parts_layout.  PLAIN stores -- no atomics, no zero-init -> gc_dn_groupnorm_apply_parts /              */
+                               /* gc_dn_groupnorm_coef_parts: the statistics pass of the GroupNorm that follows this conv / linear for free           */
     int64_t plan_rows;         /* 0 = plan for M.  > 0 (the rows ONE frame contributes: tokens, or Ho * Wo): kernel family and split-K are planned as if */
                                /* M were plan_rows, so every output row is accumulated in the same order whatever else shares the batch */
                                /* (batch-invariant results: a view's latents do not depend on its chunk-mates or on the rank count) */
 } gc_gemm_desc;
 size_t gc_dn_gemm_workspace_bytes(const gc_gemm_desc *desc);
 int gc_dn_gemm_row_stat_slots(const gc_gemm_desc *desc);   /* column slabs per row this problem writes to out_row_stats (with desc->workspace set) */
-/* Layout of out_chan_parts for this problem (call with desc->workspace set, as for the launch): *rows_per_slab rows per slab (slabs =
- * the kernel's row tiles, counted over all M rows; a tile that straddles two batches contributes a slab to each) and *nslab slab slots per
- * batch.  *rows_per_slab = 0: the kernel this problem selects cannot produce them (GEGLU / transposed / fp32 / fp8 outputs, upsample-fused
- * convs, rows_per_batch < 256 or not a multiple of 32, 4-wave kernel) -- run the stand-alone GroupNorm instead. */
-int gc_dn_gemm_chan_parts_layout(const gc_gemm_desc *desc, int64_t *rows_per_slab, int *nslab);
+/* Layout of out_chan_parts for this problem (call with desc->workspace and desc->gn_groups set, as for the launch): *rows_per_slab rows per
+ * slab (slabs = the kernel's row tiles, counted over all M rows; a tile that straddles two batches contributes a slab to each), *nslab slab
+ * slots per batch, *col_tile = the kernel's column tile (a group that straddles two column tiles has its rest in half 1).
+ * *rows_per_slab = 0: the kernel this problem selects cannot produce them (GEGLU / transposed / fp32 / fp8 outputs, upsample-fused convs,
+ * rows_per_batch < 256 or not a multiple of 32, 4-wave kernel) -- run the stand-alone GroupNorm instead. */
+int gc_dn_gemm_chan_parts_layout(const gc_gemm_desc *desc, int64_t *rows_per_slab, int *nslab, int *col_tile);
 int gc_dn_gemm(const gc_gemm_desc *desc, void *stream);
 
 /* Fused multi-K/V-set attention = CrossViewAttnProcessor core, gaussctrl/utils.py:86-117 (+ compute_attn :25-37). */
@@ -412,22 +414,22 @@ int gc_dn_layernorm(int dtype, const void *x, void *y, int64_t M, int C, const f
 int gc_dn_concat_add(int dtype, const void *a, int C1, const void *b, const void *c, int C2, void *out, int64_t M,
                      int64_t rows_per_batch, float *group_stats, int gn_groups, void *stream);
 
-/* GroupNorm(+SiLU) whose statistics pass was done by the PRODUCER of x: `parts` [B][nslab][C][2] are per-channel partial (sum, sum of
- * squares) per row slab as left by gc_gemm_desc.out_chan_parts (slab_mode 0: slabs = the GEMM's row tiles of rows_per_slab rows counted
- * over all B * HW rows) or gc_dn_concat_add_parts (slab_mode 1: slabs restart at every batch).  Two launches instead of three
- * (gc_dn_groupnorm): a tiny finalize over the partials (coef_ws fp32 [B][C][2], caller-owned scratch) + the apply pass; the read of x for
- * the statistics is gone.  Semantics = torch.nn.GroupNorm of diffusers' ResnetBlock2D / Transformer2DModel reached from
+/* GroupNorm(+SiLU) whose statistics pass was done by the PRODUCER of x: `parts` [B][nslab][G][2][2] are partial (sum, sum of squares)
+ * per row slab, group and half as left by gc_gemm_desc.out_chan_parts (slab_mode 0: slabs = the GEMM's row tiles of rows_per_slab rows
+ * counted over all B * HW rows) or gc_dn_concat_add_parts (slab_mode 1: slabs restart at every batch); col_tile from the same layout
+ * query.  ONE launch instead of three (gc_dn_groupnorm): the few KB of partials, the moments and the coefficients are formed in the apply
+ * kernel's prologue.  Semantics = torch.nn.GroupNorm of diffusers' ResnetBlock2D / Transformer2DModel reached from
  * /root/reference/gaussctrl/gc_pipeline.py:142-145,209-219. */
 int gc_dn_groupnorm_apply_parts(int dtype, const void *x, void *y, int64_t B, int64_t HW, int C, int G, const float *gamma, const float *beta,
-                                float eps, int act, const float *parts, int64_t rows_per_slab, int nslab, int slab_mode, float *coef_ws, void *stream);
+                                float eps, int act, const float *parts, int64_t rows_per_slab, int nslab, int slab_mode, int col_tile, void *stream);
 /* the coefficients alone: coef [B][C][2], y = x * coef[.][c][0] + coef[.][c][1] (input of gc_dn_transformer_head) */
 int gc_dn_groupnorm_coef_parts(int64_t B, int64_t HW, int C, int G, const float *gamma, const float *beta, float eps, const float *parts,
-                               int64_t rows_per_slab, int nslab, int slab_mode, float *coef, void *stream);
-/* gc_dn_concat_add that also leaves the per-channel partials of its output: parts [M / rows_per_batch][nslab][C1 + C2][2], slab_mode 1,
- * layout from gc_dn_concat_parts_layout(rows_per_batch, C1 + C2, ...) */
-int gc_dn_concat_parts_layout(int64_t rows_per_batch, int C, int64_t *rows_per_slab, int *nslab);
+                               int64_t rows_per_slab, int nslab, int slab_mode, int col_tile, float *coef, void *stream);
+/* gc_dn_concat_add that also leaves the group partials of its output: parts [M / rows_per_batch][nslab][gn_groups][2][2], slab_mode 1,
+ * layout from gc_dn_concat_parts_layout (*rows_per_slab = 0: channel slices would cut groups -- use gc_dn_concat_add) */
+int gc_dn_concat_parts_layout(int64_t rows_per_batch, int C, int gn_groups, int64_t *rows_per_slab, int *nslab, int *col_tile);
 int gc_dn_concat_add_parts(int dtype, const void *a, int C1, const void *b, const void *c, int C2, void *out, int64_t M, int64_t rows_per_batch,
-                           float *parts, void *stream);
+                           int gn_groups, float *parts, void *stream);
 /* out = act(a*sa + b*sb) over n elements (b may be NULL). */
 int gc_dn_axpby(int dtype, const void *a, float sa, const void *b, float sb, int act, void *out, int64_t n, void *stream);
 /* float32 -> dtype with optional SiLU (time-embedding vectors). */

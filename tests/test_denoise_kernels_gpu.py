@@ -118,14 +118,19 @@ def test_groupnorm(dt, B, HW, C, G):
     _close(ops.groupnorm(x, gamma, beta, G, 1e-5, True), F.silu(ref), dt, extra=2.0)
 
 
-def _parts_sums(parts, b, HW):
-    """add up the slabs of batch b the way gc_dn_groupnorm_apply_parts does -> [C, 2]"""
+def _parts_sums(parts, b, HW, cpg):
+    """add up the slabs / halves of batch b the way gc_dn_groupnorm_apply_parts does -> [G, 2]"""
     if parts.mode == 1:
         ns = (HW + parts.rows - 1) // parts.rows
     else:
         ns = ((b + 1) * HW - 1) // parts.rows - (b * HW) // parts.rows + 1
     assert ns <= parts.nslab
-    return parts.buf[b, :ns].double().sum(0)
+    p = parts.buf[b, :ns].double()                      # [ns, G, 2 halves, 2]
+    tot = p[:, :, 0].sum(0)
+    for g in range(parts.groups):                       # half 1 is defined only for a group that straddles two column tiles
+        if (g * cpg) // parts.col_tile != ((g + 1) * cpg - 1) // parts.col_tile:
+            tot[g] += p[:, g, 1].sum(0)
+    return tot
 
 
 @pytest.mark.parametrize("dt", DTS)
@@ -165,11 +170,13 @@ def test_groupnorm_from_producer_partials(dt, kind, B, H, Cin, Cout):
     Bo, Co = out.shape[0], out.shape[-1]
     HW = out.numel() // (Bo * Co)
     o64 = out.double().reshape(Bo, HW, Co)
+    cpg = Co // G
     for bi in range(Bo):
-        got = _parts_sums(parts, bi, HW)
-        want = torch.stack([o64[bi].sum(0), (o64[bi] ** 2).sum(0)], -1)
-        within(f"{kind}: channel partial sums vs fp64 (rel to sum |x| resp. sum x^2)",
-               ((got - want).abs() / torch.stack([o64[bi].abs().sum(0), (o64[bi] ** 2).sum(0)], -1).clamp_min(1e-6)).max().item(), 2e-6)
+        got = _parts_sums(parts, bi, HW, cpg)
+        og = o64[bi].reshape(HW, G, cpg)
+        want = torch.stack([og.sum((0, 2)), (og ** 2).sum((0, 2))], -1)
+        within(f"{kind}: group partial sums vs fp64 (rel to sum |x| resp. sum x^2)",
+               ((got - want).abs() / torch.stack([og.abs().sum((0, 2)), (og ** 2).sum((0, 2))], -1).clamp_min(1e-6)).max().item(), 2e-6)
     gamma = torch.randn(Co, device=DEV); beta = torch.randn(Co, device=DEV)
     ref = F.group_norm(o64.transpose(1, 2), G, gamma.double(), beta.double(), 1e-5).transpose(1, 2).reshape(out.shape)
     for silu in (False, True):
