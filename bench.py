@@ -53,7 +53,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "fp8"])     # fp8: e4m3 resnet convs on the block-scaled MFMA, bf16 elsewhere
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="edit", choices=["edit", "raster"])
-    ap.add_argument("--ref-mode", default="rotate", choices=["rotate", "owner0", "replicate"])    # N > 1: who computes the reference bank
+    ap.add_argument("--ref-mode", default="rotate", choices=["rotate", "owner0", "replicate", "allgather"])    # N > 1: who computes the reference bank
+    # (allgather: the reference trajectory sharded by sample, K / V^T all-gathered per attention layer; N in {2, 4, 8})
     ap.add_argument("--inflight", type=int, default=2)         # chunks in flight on independent HIP stream pairs (1: strictly one after the other)
     ap.add_argument("--no-secondary", action="store_true")     # skip the short f16 secondary measurement (default workload, N = 1)
     ap.add_argument("--mask", action="store_true")   # BASELINE configs[3]: edits composited through a (synthetic elliptical) mask, gc_pipeline.py:226-234
@@ -282,6 +283,9 @@ class Bench:
         """the reference bank of `scene` as a trajectory that advance_bank() moves: local (N = 1 / replicate) or a RefBankStream"""
         if self.ref_mode in ("local", "replicate"):
             return self.pipe.begin_ref_bank(*self.ref_inputs())
+        if self.ref_mode == "allgather":
+            from gaussctrl_amd.dist import RefShard
+            return self.pipe.begin_ref_bank_sharded(*self.ref_inputs(), RefShard(self.world, self.rank, group=self.bank_group))
         from gaussctrl_amd.dist import RefBankStream
         st = RefBankStream(self.pipe, self.owner_of(scene), self.world, self.rank, self.dev, self.nsteps, group=self.bank_group,
                            layers=self.bank_layers)
@@ -552,10 +556,11 @@ def main():
             ref_copies = world if args.ref_mode == "replicate" and world > 1 else 1
             flop = views_done * (nsteps * 2 * per_sample + VAE_DECODE_GFLOP * 1e9) + scenes * ref_copies * nsteps * 8 * per_sample
             mfma_util = flop / dt_s / (world * PEAK_TFLOPS[args.dtype] * 1e12)
-            par = (f"views of one scene sharded x{world}" + (" (load balanced: the bank owner edits ~4 views fewer)" if world > 1 and args.ref_mode != "replicate" else " (v % N)") +
+            par = (f"views of one scene sharded x{world}" + (" (load balanced: the bank owner edits ~4 views fewer)" if world > 1 and args.ref_mode in ("rotate", "owner0") else " (v % N)") +
                    "; reference bank: " +
                    ({"rotate": "owner rotates per scene, per-DDIM-step async RCCL broadcast", "owner0": "rank 0 owns, per-DDIM-step async RCCL broadcast",
-                     "replicate": "replicated on every rank (no collective)"}[args.ref_mode] if world > 1 else "local") +
+                     "replicate": "replicated on every rank (no collective)",
+                     "allgather": "trajectory sharded by sample, per-layer RCCL all-gather of K / V^T"}[args.ref_mode] if world > 1 else "local") +
                    f"; flat async gradient all-reduce; {B0_inflight} chunk(s) in flight on independent stream pairs; ControlNet || UNet encoder on 2 HIP streams")
         else:
             flop, mfma_util = None, None

@@ -9,11 +9,14 @@ Collectives:
     (236 / 472 / 944 MB at 1 / 2 / 4 M Gaussians) instead of a per-tensor DDP bucket walk -- xGMI rings are
     per-link bound, so few large messages;
   * all-gather of the edited images at the end of edit_images (3 MB per view) so every rank trains on all views;
-  * the reference K/V bank is REPLICATED by default (every rank runs the 4-view reference trajectory itself: no
-    data-path collective, +4/V_local compute -- SURVEY 8e calls this the validation mode); `broadcast_ref_bank` is the
-    opt-in alternative: the owner rank computes the trajectory once and broadcasts each DDIM step's K / V^T as ONE flat
-    buffer per step (20 messages of ~0.5 GB per scene instead of 920 small ones: ring collectives over xGMI are per-link
-    bound), issued step by step so that a caller can overlap step i's transfer with step i+1's compute.
+  * the reference K/V bank, three ways: (a) `RefShard` + DenoisePipeline.begin_ref_bank_sharded -- the reference trajectory itself is
+    sharded by sample and every cross-view attention layer ALL-GATHERS K / V^T (north_star's collective in its literal form; nobody
+    carries extra work; `bench.py --ref-mode allgather`, GaussCtrlPipelineConfig.ref_bank_allgather); (b) `RefBankStream` -- an owner
+    rank (rotating per scene in bench.py, the default there: `--ref-mode rotate`) computes the trajectory and posts each DDIM step's
+    K / V^T as ONE flat async broadcast (20 messages of ~0.5 GB per scene: ring collectives over xGMI are per-link bound) that rides
+    under the other ranks' denoise kernels, views load-balanced around the owner (`shard_views_balanced`); (c) replicated (every rank
+    runs the 4-view trajectory itself: no data-path collective -- the plugin's default, ref_bank_owner = -1, and the A/B
+    `--ref-mode replicate`).
 These helpers are device-agnostic so the N>1 logic is covered by world_size-2 gloo tests on CPU."""
 from __future__ import annotations
 
@@ -149,6 +152,63 @@ def broadcast_ref_bank(bank, src: int, world_size: int, rank: int, device=None, 
     if rank != src:
         bank.mode = "use"
     return bank
+
+
+class RefShard:
+    """Sharding of the reference trajectory itself (SURVEY.md 8e / north_star: "RCCL all-gather of reference-view K/V over xGMI").
+    The trajectory's network batch is 2 CFG halves x 4 reference frames = 8 samples, sample s = half * 4 + frame; rank r runs the samples
+    s % world == r (world in {2, 4, 8}: world 2 -> both halves of frames {r, r + 2}; 4 -> both halves of frame r; 8 -> one sample).
+    Every cross-view attention layer needs K / V^T of all four references of a half and the edit chunks later need all eight: one
+    all-gather per layer (K and V^T packed into one message) gives both.  When a rank holds a single half (world 8) the CFG
+    combination needs the partner half's eps: one small all-gather per DDIM step.  Compared with an owner rank + broadcast
+    (RefBankStream) nobody carries ~4 views' worth of extra work, so views shard plainly as v % world."""
+
+    def __init__(self, world_size: int, rank: int, group=None):
+        assert world_size in (2, 4, 8), "the 8 reference samples shard over 2, 4 or 8 ranks"
+        self.world, self.rank, self.group = world_size, rank, group
+        self.samples = [s for s in range(8) if s % world_size == rank]
+        self.frames = sorted({s % 4 for s in self.samples})
+        self.halves = sorted({s // 4 for s in self.samples})
+        self.half_base = 4 * self.halves[0]
+        self.per_rank = len(self.samples)
+        self._host_sync = None
+
+    def _sync_if_needed(self, t):
+        if self._host_sync is None:
+            import torch.distributed as dist
+            self._host_sync = dist.get_backend(self.group) != "nccl"     # c10d's NCCL work orders itself after the current stream
+        if self._host_sync and t.is_cuda:
+            torch.cuda.current_stream().synchronize()                    # gloo reads / writes the buffers from the host side
+
+    def _all_gather(self, flat):
+        import torch.distributed as dist
+        out = torch.empty(self.world * flat.numel(), dtype=flat.dtype, device=flat.device)
+        self._sync_if_needed(flat)
+        dist.all_gather_into_tensor(out, flat, group=self.group)
+        self._sync_if_needed(flat)
+        return out.view(self.world, -1)
+
+    def gather_kv(self, k, vt):
+        """k [S_loc, L, C] (a column slice of the Q | K buffer), vt [S_loc, C, Lp] of this rank's samples -> (K [8, L, C] with the row
+        stride the attention kernel reads the live K with, V^T [8, C, Lp]) in sample order."""
+        S, L, C = k.shape
+        Lp = vt.shape[-1]
+        ld = k.stride(1)
+        nk = S * L * C
+        g = self._all_gather(torch.cat([k.reshape(-1) if k.is_contiguous() else k.contiguous().reshape(-1), vt.reshape(-1)]))
+        # rank r's slot j is sample j * world + r: [world, S] -> [S, world] = sample order
+        kf = g[:, :nk].view(self.world, S, L, C).transpose(0, 1).reshape(8, L, C)
+        vf = g[:, nk:].view(self.world, S, C, Lp).transpose(0, 1).reshape(8, C, Lp).contiguous()
+        buf = torch.empty(8, L, ld, dtype=k.dtype, device=k.device)
+        kr = buf[..., ld - C:]
+        kr.copy_(kf)
+        return kr, vf
+
+    def gather_eps_pairs(self, eps):
+        """eps [S_loc, h, w, c] of this rank's single-half samples -> [2 * S_loc, h, w, c] = [unconditional ; conditional] of the same frames"""
+        g = self._all_gather(eps.reshape(-1)).view((self.world, self.per_rank) + tuple(eps.shape[1:])).transpose(0, 1).reshape((8,) + tuple(eps.shape[1:]))
+        idx = [f for f in self.frames] + [4 + f for f in self.frames]
+        return g[idx].contiguous()
 
 
 MAX_INFLIGHT = 3        # async reference-bank broadcasts in flight (owner: packed copies kept; others: receive buffers posted)

@@ -63,6 +63,8 @@ class GaussCtrlPipelineConfig(_PipelineConfigBase):
     cache_reference_kv: bool = True
     ref_bank_owner: int = -1           # world_size > 1: rank that computes the reference trajectory and broadcasts its K / V^T step
                                        # by step (-1: every rank computes it itself -- no data-path collective)
+    ref_bank_allgather: bool = False   # world_size in {2, 4, 8}: shard the reference trajectory itself by sample; every cross-view attention
+                                       # layer all-gathers K / V^T (dist.RefShard) -- no owner, no extra work on any rank; wins over ref_bank_owner
     inflight_chunks: int = 2           # chunks of edit_images in flight on independent HIP stream pairs (consecutive chunks only share the
                                        # read-only reference bank; 1 = strictly one after the other, as the reference runs them)
     round_like_reference: bool = False  # True: round the rendered rgb / depth to fp16 before inversion, disparity and the mask composite,
@@ -202,6 +204,9 @@ class GaussCtrlPipeline(_PipelineBase):
         td = self.datamanager.train_data
         cn, cp = self._encode(self.negative_prompts), self._encode(self.positive_prompt)
         owner = self.config.ref_bank_owner if (self.world_size > 1 and self.config.cache_reference_kv) else -1
+        gather = bool(self.config.ref_bank_allgather) and self.config.cache_reference_kv and self.world_size in (2, 4, 8)
+        if gather:
+            owner = -1
         need_refs = owner < 0 or self.local_rank == owner or not self.config.cache_reference_kv
         if need_refs:
             self.render_reverse_refs()        # views are sharded: the 4 reference views may live on other ranks (cheap to redo here)
@@ -211,7 +216,12 @@ class GaussCtrlPipeline(_PipelineBase):
             ref_disp = torch.stack([self.depth2disparity_torch(td[i]["depth_image"]) for i in self.ref_indices])
         bank = None
         if self.config.cache_reference_kv:
-            if owner >= 0:
+            if gather:
+                # the reference trajectory sharded by sample, K / V^T all-gathered per attention layer (north_star's collective)
+                from .dist import RefShard
+                tr = self.pipe.begin_ref_bank_sharded(ref_z0, ref_disp, cn, cp, RefShard(self.world_size, self.local_rank))
+                bank = self.pipe.advance_ref_bank(tr, None)
+            elif owner >= 0:
                 # one owner rank runs the 4-view reference trajectory; each DDIM step's K / V^T is broadcast (one flat RCCL message
                 # per step) while the owner already computes the next step (SURVEY.md 8e collective 1)
                 from .dist import broadcast_ref_bank_pipelined

@@ -202,7 +202,7 @@ def _run_gemm(d, dev, what, row_stats=None, want_parts=False, gn_groups=32):
         rows, ns, ct = C.c_int64(0), C.c_int(0), C.c_int(0)
         d.gn_groups = gn_groups
         L.check(lib.gc_dn_gemm_chan_parts_layout(C.byref(d), C.byref(rows), C.byref(ns), C.byref(ct)), "gc_dn_gemm_chan_parts_layout")
-        if rows.value > 0:
+        if 0 < rows.value and ns.value <= 64:        # (more slabs -- the VAE's 256 x 256 / 512 x 512 maps -- would make the apply prologue the long pole)
             parts = ChanParts(torch.empty(d.M // d.rows_per_batch, ns.value, gn_groups, 2, 2, dtype=torch.float32, device=dev), rows.value, ns.value,
                               0, ct.value, gn_groups)
             d.out_chan_parts = parts.buf.data_ptr()

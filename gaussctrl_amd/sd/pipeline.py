@@ -103,9 +103,10 @@ class DenoisePipeline:
 
     # ---------------------------------------------------------------------------------- core loop
     def _begin(self, latents, disparity, ctx, cfg: bool, mode: str, coeff_unet: float, coeff_cn: float,
-               guidance: float, inverse: bool, steps: int | None, bank: RefBank | None, fph: int) -> dict:
-        """State of one denoise trajectory (advanced by _advance): latents fp32 [f,4,h,w]; disparity fp32 [f,3,H,W]."""
-        rep = 2 if cfg else 1
+               guidance: float, inverse: bool, steps: int | None, bank: RefBank | None, fph: int, rep: int | None = None) -> dict:
+        """State of one denoise trajectory (advanced by _advance): latents fp32 [f,4,h,w]; disparity fp32 [f,3,H,W].
+        rep: copies of the frames in the network batch (default 2 with CFG; 1 on a rank that holds ONE CFG half of a sharded trajectory)."""
+        rep = (2 if cfg else 1) if rep is None else rep
         lat = latents.permute(0, 2, 3, 1).contiguous().float()            # master copy fp32 [f,h,w,4]
         xin = to_nhwc8(latents, self.dtype)
         xin = torch.cat([xin] * rep, 0).contiguous()                        # cat([latents]*2)
@@ -127,8 +128,9 @@ class DenoisePipeline:
             i = st["i"]; t = ts[i]
             if bank is not None:
                 bank.step = i
-            a_cn = AttnCtx(st["mode"], st["cc"], st["fph"], self.text_kv, bank, "controlnet")
-            a_un = AttnCtx(st["mode"], st["cu"], st["fph"], self.text_kv, bank, "unet")
+            tkv = st.get("text_kv", self.text_kv)          # (a sharded trajectory on ONE CFG half keeps its own one-row text K / V^T cache)
+            a_cn = AttnCtx(st["mode"], st["cc"], st["fph"], tkv, bank, "controlnet")
+            a_un = AttnCtx(st["mode"], st["cu"], st["fph"], tkv, bank, "unet")
             if self.two_streams:
                 # The ControlNet and the UNet encoder + mid block only share their input: run them on two HIP streams so that
                 # the part-filled grids of the 16x16 / 8x8 layers and every kernel's fill / epilogue phase overlap with the
@@ -148,6 +150,8 @@ class DenoisePipeline:
                 down, mid = self.controlnet.forward(xin, t, ctx, cemb, a_cn, self.cn_scale)
                 eps = self.unet.forward(xin, t, ctx, down, mid, a_un)
             a_from, a_to = self.sched.alphas(t, self.n, st["inverse"])
+            if st.get("shard") is not None and st["rep"] == 1:
+                eps = st["shard"].gather_eps_pairs(eps)         # this rank holds one CFG half: the partner half's eps of the same frames
             ops.cfg_ddim_step(eps, lat, xin, st["g"], st["cfg"], a_from, a_to, st["rep"])
             st["i"] = i + 1
             if st.get("on_step") is not None:          # parity tests read the latents after every DDIM step
@@ -190,9 +194,31 @@ class DenoisePipeline:
         return self._begin(ref_latents, ref_disparity, ctx, True, "xview", 0.6, 0.0, self.guidance, False, steps, bank,
                            ref_latents.shape[0])
 
+    def begin_ref_bank_sharded(self, ref_latents, ref_disparity, ctx_neg, ctx_pos, shard, steps=None) -> dict:
+        """The reference trajectory SHARDED over the ranks (north_star: "RCCL all-gather of reference-view K/V"): of the 2 CFG halves x 4
+        reference frames, this rank runs the samples `shard` (dist.RefShard) assigns to it; every cross-view attention layer all-gathers
+        K / V^T, so each rank ends with the complete bank and nobody carries the reference work alone.  ref_latents / ref_disparity hold
+        all 4 frames (cheap to have everywhere); advance with advance_ref_bank.  Same result as begin_ref_bank (bit-identical in
+        batch-invariant mode: every kernel then accumulates per frame)."""
+        ctx = torch.cat([ctx_neg, ctx_pos], 0).to(self.dtype).contiguous()
+        bank = RefBank()
+        bank.mode = "record"
+        bank.shard = shard
+        fr = shard.frames
+        tr = self._begin(ref_latents[fr], ref_disparity[fr], ctx[shard.halves[0]:shard.halves[-1] + 1].contiguous(), True, "xview", 0.6, 0.0,
+                         self.guidance, False, steps, bank, len(fr), rep=len(shard.halves))
+        tr["shard"] = shard
+        if len(shard.halves) == 2:
+            tr["ctx"] = self._ctx(ctx_neg, ctx_pos)         # (resets the shared text K / V^T cache if it belongs to another prompt pair)
+            tr["text_kv"] = self.text_kv
+        else:
+            tr["text_kv"] = {}                              # one CFG half: a one-row text cache of its own
+        return tr
+
     def advance_ref_bank(self, tr: dict, nsteps: int | None = None):
         if self._advance(tr, nsteps):
             tr["bank"].mode = "use"
+            tr["bank"].shard = None
             return tr["bank"]
         return None
 

@@ -76,6 +76,8 @@ class RefBank:
         self.store = {}
         self.mode = "off"
         self.step = 0
+        self.shard = None           # mode 'record' on a SHARDED reference trajectory (dist.RefShard): this rank's forward holds only its
+                                    # share of the 2 x 4 reference samples; every layer all-gathers K / V^T (the collective of north_star)
 
     def key(self, layer):
         return (self.step, layer)
@@ -235,6 +237,13 @@ class SDNet:
         a = actx.coeff
         sets = ([(-1, a)] if a != 0.0 else []) + [(r, (1.0 - a) / 4.0) for r in range(4)]    # utils.py:95-102,117
         bank = actx.bank
+        if bank is not None and bank.mode == "record" and bank.shard is not None:
+            # sharded reference trajectory: K / V^T of ALL 2 x 4 reference samples by one all-gather per layer; the local queries attend to
+            # the four references of their own CFG half out of the gathered bank (which is, at the same time, the finished bank entry)
+            kr, vtr = bank.shard.gather_kv(k, vt)
+            bank.store[bank.key((actx.net, p))] = (kr, vtr)
+            h0 = bank.shard.half_base                    # first reference row of the half the local batch starts with
+            return ops.attention(q, k, vt, heads, sets, actx.f, Lk=L, kref=kr[h0:], vtref=vtr[h0:], ref_fph=4, q_prescaled=self.qpre)
         if bank is not None and bank.mode == "record":
             bank.store[bank.key((actx.net, p))] = (k, vt)            # the batch IS the reference batch [2*4]
         if bank is not None and bank.mode == "use":

@@ -134,3 +134,38 @@ def test_gloo_world2_collectives():
     mp.spawn(_worker, args=(world, 29000 + os.getpid() % 2000, ret), nprocs=world, join=True)
     assert ret[0][0] == [0, 2, 4, 6] and ret[1][0] == [1, 3, 5]
     assert all(ret[r][1] and ret[r][2] for r in range(world))
+
+
+def _shard_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gaussctrl_amd.dist import RefShard
+        sh = RefShard(world, rank)
+        g = torch.Generator().manual_seed(9)
+        L, C, Lp = 24, 16, 24
+        qk = torch.randn(8, L, 2 * C, generator=g).to(torch.bfloat16)          # the full reference batch, sample s = half * 4 + frame
+        vt = torch.randn(8, C, Lp, generator=g).to(torch.bfloat16)
+        eps = torch.randn(8, 4, 4, 8, generator=g)
+        mine = sh.samples
+        ok = mine == [s for s in range(8) if s % world == rank] and sh.frames == sorted({s % 4 for s in mine})
+        ok = ok and sh.half_base == 4 * (mine[0] // 4) and len(sh.halves) == (1 if world == 8 else 2)
+        kr, vr = sh.gather_kv(qk[mine][..., C:], vt[mine])                      # K is a column slice of the Q | K buffer, as in the network
+        ok = ok and torch.equal(kr, qk[..., C:]) and torch.equal(vr, vt) and kr.stride(1) == 2 * C and kr.shape == (8, L, C)
+        if len(sh.halves) == 1:
+            pair = sh.gather_eps_pairs(eps[mine])
+            f = sh.frames
+            ok = ok and torch.equal(pair, torch.cat([eps[f], eps[[4 + x for x in f]]]))
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_reference_trajectory_shards_allgather_layout(world):
+    """dist.RefShard (north_star's per-layer all-gather of the reference K / V^T): sample -> rank assignment, the gathered bank in
+    sample order with the Q | K row stride, and the CFG partner exchange when a rank holds a single half (world 8)."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_shard_worker, args=(world, 29650 + world + os.getpid() % 200, ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world)), dict(ret)

@@ -6,6 +6,7 @@ import os
 
 import numpy as np
 import pytest
+from _margins import within
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -14,7 +15,7 @@ pytestmark = pytest.mark.gpu
 V, H, W, N = 6, 128, 128, 20000
 
 
-def _build(world, rank, owner):
+def _build(world, rank, owner, gather=False):
     from gaussctrl_amd import synthetic as syn
     from gaussctrl_amd.gc_model import GaussCtrlModel, GaussCtrlModelConfig
     from gaussctrl_amd.gc_pipeline import GaussCtrlPipeline, GaussCtrlPipelineConfig, SimpleDataManager
@@ -24,7 +25,7 @@ def _build(world, rank, owner):
     cams = Cameras(syn.make_cameras(V, seed=1), 140.0, 140.0, 64.0, 64.0, W, H)
     model = GaussCtrlModel(GaussCtrlModelConfig(background_color="black"), params=P, device=dev)
     cfg = GaussCtrlPipelineConfig(edit_prompt="a polar bear", reverse_prompt="a bear", chunk_size=2, num_inference_steps=3, dtype="f16",
-                                  synthetic_weights=True, ref_bank_owner=owner)
+                                  synthetic_weights=True, ref_bank_owner=owner, ref_bank_allgather=gather)
     pipe = GaussCtrlPipeline(cfg, dev, world_size=world, local_rank=rank, datamanager=SimpleDataManager(cams, seed=3), model=model)
     return pipe, model
 
@@ -41,23 +42,27 @@ def _run(pipe, model):
     return imgs, losses, model.means.detach().cpu()
 
 
-def _worker(rank, world, port, owner, ret):
+def _worker(rank, world, port, owner, ret, gather=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from gaussctrl_amd.sd import ops as sdops
     sdops.configure(sdops.options_from_env())          # the spawned rank takes GC_BATCH_INVARIANT from the parent test
     try:
-        pipe, model = _build(world, rank, owner)
+        pipe, model = _build(world, rank, owner, gather)
         imgs, losses, means = _run(pipe, model)
         ret[rank] = (imgs.numpy(), losses, means.numpy())
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("owner,invariant", [(-1, False), (0, False), (0, True)])
+@pytest.mark.parametrize("owner,invariant", [(-1, False), (0, False), (0, True), ("allgather", False), ("allgather", True)])
 def test_two_ranks_one_gpu_match_single_rank(owner, invariant, monkeypatch):
     """invariant: batch-invariant kernel planning (sd.ops.BATCH_INVARIANT; the spawned ranks read GC_BATCH_INVARIANT) -- the edited images
-    of the 2-rank run are then BIT-identical to the single-rank run, although the chunks hold other views."""
+    of the 2-rank run are then BIT-identical to the single-rank run, although the chunks hold other views.
+    owner "allgather": the reference trajectory itself is sharded by sample (rank r runs both CFG halves of frames {r, r + 2}) and every
+    cross-view attention layer all-gathers K / V^T (dist.RefShard) -- bit-identical to the single-rank bank in invariant mode too."""
+    gather = owner == "allgather"
+    owner = -1 if gather else owner
     from gaussctrl_amd.sd import ops as sdops
     monkeypatch.setenv("GC_BATCH_INVARIANT", "1" if invariant else "0")
     monkeypatch.setattr(sdops, "BATCH_INVARIANT", invariant)
@@ -67,7 +72,7 @@ def test_two_ranks_one_gpu_match_single_rank(owner, invariant, monkeypatch):
     torch.cuda.empty_cache()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, 29500 + os.getpid() % 400 + (7 if owner >= 0 else 0), owner, ret), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, 29500 + os.getpid() % 400 + (7 if owner >= 0 else 0) + (13 if gather else 0), owner, ret, gather), nprocs=2, join=True)
     for r in range(2):
         imgs, losses, means = ret[r]
         # every rank ends with ALL edited views (all-gather); f16 kernels with float atomics in the GroupNorm statistics: not bit-equal
@@ -78,7 +83,11 @@ def test_two_ranks_one_gpu_match_single_rank(owner, invariant, monkeypatch):
         d = np.abs(imgs - ref_imgs.numpy())
         if invariant:
             assert np.array_equal(imgs, ref_imgs.numpy()), (d.mean(), d.max())
-        assert d.mean() < 5e-3 and d.max() < 0.1, (d.mean(), d.max())
+        # (allgather: the BANK itself is computed with another batch composition -- 4 samples per rank instead of 8 -- so every view also
+        # sees the reference frames' accumulation-order noise through the cross-view terms: twice the bars; the invariant variant of the
+        # same run is bit-identical, which is the actual check of the sharded trajectory)
+        within("2-rank vs 1-rank edited images: mean |diff|", d.mean(), 1e-2 if gather else 5e-3, strict=True)
+        within("2-rank vs 1-rank edited images: max |diff|", d.max(), 0.2 if gather else 0.1, strict=True)
         # same views, averaged gradients of identical renders = the single-rank gradients: same losses / parameters up to atomics noise
         assert np.allclose(losses, ref_losses, rtol=2e-2, atol=1e-3), (losses, ref_losses)
         assert np.abs(means - ref_means.numpy()).max() < 1e-3
