@@ -988,19 +988,123 @@ __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g
         }
         return;
     }
+    if constexpr (LEAN) {
+        // ---- lean epilogue.  EVERY operand load is issued first, branch-free (rows / columns past the edge re-read a valid element,
+        // absent operands read the zero page), then the tile is computed and stored.  The generic epilogue loads bias / row-vector /
+        // residual under per-lane branches inside the m loop: at every control-flow join hipcc falls back to s_waitcnt vmcnt(0), and on
+        // gfx9 that counter also holds the STORES in flight -- MT x NTW serialised store round trips per wave (seen in the ISA).
+        const unsigned char *zp = (const unsigned char *)g.zeros;
+        const bool has_b = g.bias != nullptr, has_rv = g.rowvec != nullptr, has_res = g.residual != nullptr;
+        const float *biasp = has_b ? g.bias : reinterpret_cast<const float *>(zp);
+        const float *rvp = has_rv ? g.rowvec : reinterpret_cast<const float *>(zp);
+        const unsigned char *resp = has_res ? (const unsigned char *)g.residual : zp;
+        // the row vector is per batch: a tile holds rows of at most two batches (rows_per_batch >= BM, checked by the launcher)
+        const int64_t bA = m_base / g.rows_per_batch, b_last = (g.M - 1) / g.rows_per_batch;
+        const int64_t bB = bA + 1 < b_last ? bA + 1 : b_last;
+        const int64_t m_rv = (bA + 1) * g.rows_per_batch;                       // first row of batch bB
+        float4 bia[NTW], rvA[NTW], rvB[NTW];
+        uint2 rs[MT][NTW];
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int64_t n = n_lane + nt * 16, nc = n < g.N ? n : g.N - 4;
+            bia[nt] = *reinterpret_cast<const float4 *>(biasp + (has_b ? nc : 0));
+            rvA[nt] = *reinterpret_cast<const float4 *>(rvp + (has_rv ? bA * g.ld_rowvec + nc : 0));
+            rvB[nt] = *reinterpret_cast<const float4 *>(rvp + (has_rv ? bB * g.ld_rowvec + nc : 0));
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int64_t m = m_base + wm * (16 * MT) + mt * 16 + fr, mc = m < g.M ? m : g.M - 1;
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int64_t n = n_lane + nt * 16, nc = n < g.N ? n : g.N - 4;
+                rs[mt][nt] = *reinterpret_cast<const uint2 *>(resp + (has_res ? (mc * g.ldr + nc) * 2 : 0));
+            }
+        }
+        uint2 pks[CS ? MT : 1][CS ? NTW : 1];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int64_t m = m_base + wm * (16 * MT) + mt * 16 + fr;
+            const bool second = m >= m_rv;
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int64_t n = n_lane + nt * 16;
+                const float4 rv = second ? rvB[nt] : rvA[nt];
+                float v[4] = {acc[nt][mt][0] + bia[nt].x + rv.x, acc[nt][mt][1] + bia[nt].y + rv.y,
+                              acc[nt][mt][2] + bia[nt].z + rv.z, acc[nt][mt][3] + bia[nt].w + rv.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= g.out_scale;
+                v[0] += T::to_f((unsigned short)(rs[mt][nt].x & 0xffff)); v[1] += T::to_f((unsigned short)(rs[mt][nt].x >> 16));
+                v[2] += T::to_f((unsigned short)(rs[mt][nt].y & 0xffff)); v[3] += T::to_f((unsigned short)(rs[mt][nt].y >> 16));
+                const uint2 pk = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
+                const bool ok = m < g.M && n < g.N;
+                if (ok) *reinterpret_cast<uint2 *>((unsigned char *)g.out + (m * g.ldc + n) * 2) = pk;
+                if constexpr (CS) pks[mt][nt] = ok ? pk : make_uint2(0u, 0u);      // statistics of the values as STORED
+            }
+        }
+        if constexpr (CS) {
+            // Statistics pass, ONE copy of the code (the first version flushed at every batch boundary inside the unrolled m loop: MT + 1
+            // copies of 40 DPP reductions, +3 000 instructions and +5.5 us per launch of pure instruction fetch): pass p sums the rows of batch
+            // slot p -- slot 0 = the batch of the tile's first row, slot 1 = the next one, present only in a tile that straddles a batch
+            // boundary (a 16-row m-tile never does: rows_per_batch % 16 == 0; BM <= rows_per_batch: at most one boundary).
+            const int64_t m_split = (m_base / g.rows_per_batch + 1) * g.rows_per_batch;          // first row of the next batch
+            const int64_t m_end = m_base + BM < g.M ? m_base + BM : g.M;
+            const int npass = m_split < m_end ? 2 : 1;
+    #pragma unroll 1
+            for (int pass = 0; pass < npass; ++pass) {
+                float cs[NTW][4], cq[NTW][4];
+    #pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) { cs[nt][r] = 0.f; cq[nt][r] = 0.f; }
+    #pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int64_t m_tile = m_base + wm * (16 * MT) + mt * 16;             // wave-uniform
+                    const float wgt = ((m_tile >= m_split ? 1 : 0) == pass) ? 1.f : 0.f;
+    #pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) {
+                        const uint2 pk = pks[mt][nt];
+                        const float t0 = wgt * T::to_f((unsigned short)(pk.x & 0xffff)), t1 = wgt * T::to_f((unsigned short)(pk.x >> 16));
+                        const float t2 = wgt * T::to_f((unsigned short)(pk.y & 0xffff)), t3 = wgt * T::to_f((unsigned short)(pk.y >> 16));
+                        cs[nt][0] += t0; cq[nt][0] += t0 * t0; cs[nt][1] += t1; cq[nt][1] += t1 * t1;
+                        cs[nt][2] += t2; cq[nt][2] += t2 * t2; cs[nt][3] += t3; cq[nt][3] += t3 * t3;
+                    }
+                }
+                float *tb = ctab + (pass * BN + wn * (16 * NTW) + fc * 4) * 2;
+    #pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float sa = row16_sum(cs[nt][r]), sb = row16_sum(cq[nt][r]);
+                        if (fr == 0) {
+                            __hip_atomic_fetch_add(tb + (nt * 16 + r) * 2, sa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_add(tb + (nt * 16 + r) * 2 + 1, sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the LDS adds; NOT the output stores still in flight
+            __builtin_amdgcn_s_barrier();
+            const int64_t b0 = m_base / g.rows_per_batch;
+            const int cpg = g.gn_cpg, G = (int)(g.N / cpg);
+            const int n_hi = (int)(n_base + BN < g.N ? n_base + BN : g.N);
+            const int g_first = (int)n_base / cpg, ng = (n_hi - 1) / cpg - g_first + 1;        // groups that overlap this column tile (<= BN / cpg + 2)
+            for (int i = tid; i < 2 * ng; i += 512) {
+                const int slot = i >= ng ? 1 : 0, gg = g_first + i - slot * ng;
+                if (slot == 1 && !(m_split < m_end)) continue;
+                const int c_lo = gg * cpg > (int)n_base ? gg * cpg : (int)n_base, c_hi = (gg + 1) * cpg < n_hi ? (gg + 1) * cpg : n_hi;
+                float s1 = 0.f, s2 = 0.f;
+                for (int c = c_lo; c < c_hi; ++c) { const float2 t = *reinterpret_cast<const float2 *>(ctab + (slot * BN + c - (int)n_base) * 2); s1 += t.x; s2 += t.y; }
+                const int64_t b = b0 + slot;
+                const int64_t slab = mblk - (b * g.rows_per_batch) / BM;       // tiles are counted over all M rows
+                const int half = gg * cpg < (int)n_base ? 1 : 0;
+                *reinterpret_cast<float2 *>(g.chan_parts + ((((b * g.cp_nslab + slab) * G + gg) * 2 + half) * 2)) = make_float2(s1, s2);
+            }
+        }
+    } else {
     float4 bia[NTW];
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         const int64_t n = n_lane + nt * 16;
         bia[nt] = (g.bias && n < g.N) ? *reinterpret_cast<const float4 *>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    // CS: the stored values of this lane (2-byte pairs; zero where nothing is stored) are kept for the statistics pass after the stores
-    uint2 pks[CS ? MT : 1][CS ? NTW : 1];
-    if constexpr (CS) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) pks[mt][nt] = make_uint2(0u, 0u);
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -1059,66 +1163,8 @@ __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[(on - g.t_col0 + r) * g.ldt] = T::from_f(v[r]);
             }
-            if constexpr (CS) pks[mt][nt] = pk;      // statistics of the values as STORED (rounded to the activation type)
         }
     }
-    if constexpr (CS) {
-        // Statistics pass, ONE copy of the code (the first version flushed at every batch boundary inside the unrolled m loop: MT + 1
-        // copies of 40 DPP reductions, +3 000 instructions and +5.5 us per launch of pure instruction fetch): pass p sums the rows of batch
-        // slot p -- slot 0 = the batch of the tile's first row, slot 1 = the next one, present only in a tile that straddles a batch
-        // boundary (a 16-row m-tile never does: rows_per_batch % 16 == 0; BM <= rows_per_batch: at most one boundary).
-        const int64_t m_split = (m_base / g.rows_per_batch + 1) * g.rows_per_batch;          // first row of the next batch
-        const int64_t m_end = m_base + BM < g.M ? m_base + BM : g.M;
-        const int npass = m_split < m_end ? 2 : 1;
-#pragma unroll 1
-        for (int pass = 0; pass < npass; ++pass) {
-            float cs[NTW][4], cq[NTW][4];
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { cs[nt][r] = 0.f; cq[nt][r] = 0.f; }
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int64_t m_tile = m_base + wm * (16 * MT) + mt * 16;             // wave-uniform
-                const float wgt = ((m_tile >= m_split ? 1 : 0) == pass) ? 1.f : 0.f;
-#pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) {
-                    const uint2 pk = pks[mt][nt];
-                    const float t0 = wgt * T::to_f((unsigned short)(pk.x & 0xffff)), t1 = wgt * T::to_f((unsigned short)(pk.x >> 16));
-                    const float t2 = wgt * T::to_f((unsigned short)(pk.y & 0xffff)), t3 = wgt * T::to_f((unsigned short)(pk.y >> 16));
-                    cs[nt][0] += t0; cq[nt][0] += t0 * t0; cs[nt][1] += t1; cq[nt][1] += t1 * t1;
-                    cs[nt][2] += t2; cq[nt][2] += t2 * t2; cs[nt][3] += t3; cq[nt][3] += t3 * t3;
-                }
-            }
-            float *tb = ctab + (pass * BN + wn * (16 * NTW) + fc * 4) * 2;
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float sa = row16_sum(cs[nt][r]), sb = row16_sum(cq[nt][r]);
-                    if (fr == 0) {
-                        __hip_atomic_fetch_add(tb + (nt * 16 + r) * 2, sa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(tb + (nt * 16 + r) * 2 + 1, sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the LDS adds; NOT the output stores still in flight
-        __builtin_amdgcn_s_barrier();
-        const int64_t b0 = m_base / g.rows_per_batch;
-        const int cpg = g.gn_cpg, G = (int)(g.N / cpg);
-        const int n_hi = (int)(n_base + BN < g.N ? n_base + BN : g.N);
-        const int g_first = (int)n_base / cpg, ng = (n_hi - 1) / cpg - g_first + 1;        // groups that overlap this column tile (<= BN / cpg + 2)
-        for (int i = tid; i < 2 * ng; i += 512) {
-            const int slot = i >= ng ? 1 : 0, gg = g_first + i - slot * ng;
-            if (slot == 1 && !(m_split < m_end)) continue;
-            const int c_lo = gg * cpg > (int)n_base ? gg * cpg : (int)n_base, c_hi = (gg + 1) * cpg < n_hi ? (gg + 1) * cpg : n_hi;
-            float s1 = 0.f, s2 = 0.f;
-            for (int c = c_lo; c < c_hi; ++c) { const float2 t = *reinterpret_cast<const float2 *>(ctab + (slot * BN + c - (int)n_base) * 2); s1 += t.x; s2 += t.y; }
-            const int64_t b = b0 + slot;
-            const int64_t slab = mblk - (b * g.rows_per_batch) / BM;       // tiles are counted over all M rows
-            const int half = gg * cpg < (int)n_base ? 1 : 0;
-            *reinterpret_cast<float2 *>(g.chan_parts + ((((b * g.cp_nslab + slab) * G + gg) * 2 + half) * 2)) = make_float2(s1, s2);
-        }
     }
 }
 
@@ -1799,7 +1845,11 @@ void launch8(const GemmArgs &g, dim3 grid, hipStream_t s)
 }
 
 // lean epilogue (no GEGLU / activation / fp32 / transposed output): fast conv, upsample-fused conv, K % 64 == 0 linear
-inline bool lean_of(const GemmArgs &g, int mode) { return !g.geglu && g.act == 0 && !g.out_f32 && !g.out_t && g.out && mode != 1 && (mode != 0 || g.K % 64 == 0); }
+inline bool lean_of(const GemmArgs &g, int mode)
+{
+    return !g.geglu && g.act == 0 && !g.out_f32 && !g.out_t && g.out && mode != 1 && (mode != 0 || g.K % 64 == 0) && g.N >= 4 &&
+           (!g.rowvec || g.rows_per_batch >= 256);
+}
 template <class T, int NTW, int MT>
 void dispatch8lean_m(const GemmArgs &g, int mode, dim3 grid, hipStream_t s)
 {

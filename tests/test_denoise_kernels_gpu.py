@@ -165,6 +165,8 @@ def test_groupnorm_from_producer_partials(dt, kind, B, H, Cin, Cout):
         a = (_rand((B, H, H, Cin), dt, 1.0, 1).float() + 2.0).to(dt); bb = _rand((B, H, H, Cout), dt, 1.0, 2); cc = _rand((B, H, H, Cout), dt, 1.0, 3)
         out, parts = ops.concat_add(a, bb, cc, chan_parts=True)
         plain = ops.concat_add(a, bb, cc)
+    if parts is None and ops.KERNEL_VARIANT["gemm"]:
+        pytest.skip("a forced kernel variant (tests/test_gemm_variants_gpu.py) without the statistics epilogue")
     assert parts is not None, "this shape must take the producer-statistics path"
     assert torch.equal(out, plain)                          # the statistics epilogue does not change what is stored
     Bo, Co = out.shape[0], out.shape[-1]
