@@ -521,7 +521,10 @@ def main():
             roof = raster_roofline(args, B, g, stats, H * W)
         else:
             rr = raster_roofline(args, B, g, stats, H * W)          # the rasterizer half of the same run: chain roofline at this N
-            roof_raster = {"bound": "hbm", "unit": "GB/s", "peak": 8000.0, "achieved": rr["chain"]["GBps"], "frac": rr["chain"]["frac"],
+            # headline fraction = priced on the (tile, Gaussian) pairs the kernels really move (tight boxes); `frac_reference_lists` prices
+            # the same time against gsplat's longer lists (what the reference would have to move)
+            roof_raster = {"bound": "hbm", "unit": "GB/s", "peak": 8000.0, "achieved": round(rr["chain"]["frac_processed_pairs"] * 8000.0, 1),
+                           "frac": rr["chain"]["frac_processed_pairs"], "frac_reference_lists": rr["chain"]["frac"],
                            "kernel_us_per_view": rr["chain"]["kernel_us_per_view"], "algorithmic_MB_per_view": rr["chain"]["algorithmic_MB_per_view"],
                            "traffic_ratio": rr["chain"].get("traffic_ratio"), "N": rr["chain"]["N"], "M_mean": rr["chain"]["M_mean"],
                            "M_processed_mean": rr["chain"]["M_processed_mean"], "frac_processed_pairs": rr["chain"]["frac_processed_pairs"],
