@@ -229,6 +229,7 @@ class GaussCtrlPipeline(_PipelineBase):
                                                     self._dev, self.num_inference_steps)
             else:
                 bank = self.pipe.build_ref_bank(ref_z0, ref_disp, cn, cp)
+        self._last_bank = bank                   # (kept for inspection: tests hash it)
         views = self._my_views()
         # consecutive chunks only share the (read-only) bank: run them on alternating streams so that one chunk's part-filled grids and
         # fill / drain phases are covered by the other's kernels (bench.py --inflight: +3 % views/s at chunk_size 3)
