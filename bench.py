@@ -499,7 +499,7 @@ def main():
         # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r02_attn_traffic.json, scripts/
         # pmc_kernel_traffic.py: FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes on the UNet's 5-set launch at chunk_size 3)
         traffic = None
-        for tname in ("r03_attn_traffic.json", "r02_attn_traffic.json"):
+        for tname in ("r04_attn_traffic.json", "r02_attn_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if kind.startswith(("k_attn4", "k_attn5")) and c == 3 and os.path.exists(tpath) and traffic is None:
                 for kn, v in json.load(open(tpath))["kernels"].items():
