@@ -241,9 +241,7 @@ class GaussCtrlPipeline(_PipelineBase):
         if ready is not None:
             # the chunk streams are ordered after `main` only: everything they share must be complete there first.  With a bank
             # received by broadcast nothing has touched the pipeline's lazily filled caches yet (text K / V^T, time-embedding rows).
-            import os as _os
-            if _os.environ.get("GC_TEST_NOWARM", "0") == "0":
-                self.pipe.warm_caches(cn, cp)
+            self.pipe.warm_caches(cn, cp)
             ready.record(main)
         for ci, s in enumerate(range(0, len(views), self.chunk_size)):
             chunk = views[s:s + self.chunk_size]
