@@ -330,11 +330,13 @@ template <> struct Pages<F16> {
 // loads with vmcnt(0) before every ds_read; ordering is by explicit vmcnt + s_barrier.
 __device__ __forceinline__ void glds16_v(const void *gsrc, unsigned lds_dst, unsigned long long mask)     // 64-bit address per lane
 {
+    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);        // wave-uniform by construction; the "s" constraint needs the compiler to know it
     asm volatile("s_mov_b32 m0, %1\n\ts_mov_b64 exec, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\ts_mov_b64 exec, -1"
                  :: "v"(gsrc), "s"(lds_dst), "s"(mask) : "memory");
 }
 __device__ __forceinline__ void glds16_s(const void *sbase, unsigned voff, unsigned lds_dst, unsigned long long mask)   // uniform base + lane offset
 {
+    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
     asm volatile("s_mov_b32 m0, %2\n\ts_mov_b64 exec, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, -1"
                  :: "v"(voff), "s"(sbase), "s"(lds_dst), "s"(mask) : "memory");
 }

@@ -16,10 +16,15 @@ views = [int(v) for v in os.environ.get("GC_STRESS_VIEWS", "1,3,5").split(",")]
 FIELDS = ("xys", "depths", "radii", "num_tiles_hit", "gaussian_ids_sorted", "tile_bins", "final_index")
 ref, bad = None, 0
 KEEP = {}
+QREF = {n: getattr(model, n).detach().clone() for n in ("quats", "scales", "features_rest")} if os.environ.get("GC_STRESS_ECHO", "1") == "1" else None
 cams = pipe.datamanager.cameras
 for it in range(iters):
     cur = {}
     for i in views:
+        if QREF is not None:                      # does a plain torch copy kernel see the parameters as they are?
+            for name, r in QREF.items():
+                if not torch.equal(getattr(model, name).detach().clone(), r):
+                    print(f"   torch clone of {name} differs from its first copy (iteration {it}, before view {i})", flush=True)
         o = model.get_outputs_for_camera(cams[i:i + 1] if hasattr(cams, "__getitem__") else cams[i])
         a = model._aux
         cur[i] = {f: h(getattr(a, f)) for f in FIELDS}

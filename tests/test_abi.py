@@ -59,3 +59,16 @@ def test_no_oracle_import_in_product():
             if fn.endswith(".py"):
                 src = open(os.path.join(dp, fn)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dp, fn)
+
+
+def test_library_has_no_packed_fp32_arithmetic(built):
+    """DESIGN.md 7.0 (round 4): v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 return wrong results in lanes 48..63 on the MI355X boxes of this
+    pool whenever a wavefront of ANOTHER process issues MFMAs on the same SIMD (profiles/r04_packed_fp32_fault.txt; found through the
+    two-ranks-on-one-GPU test).  The library is built with the SLP and loop vectorizers off, which is where every one of them came from;
+    this holds the disassembly of the shipped code objects at zero."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("packed_fp32_audit", os.path.join(ROOT, "scripts", "packed_fp32_audit.py"))
+    audit = importlib.util.module_from_spec(spec); spec.loader.exec_module(audit)
+    found, functions = audit.audit(built)
+    assert functions > 300, functions            # every translation unit's code object was found
+    assert not found, found
