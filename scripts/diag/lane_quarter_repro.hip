@@ -3,6 +3,8 @@
 //   MODE 0: five early loads, no LDS                       MODE 1: + the cooperative float4 staging of features_rest through LDS (as the product)
 //   MODE 2: staging first, the five loads after it          MODE 3: as 1, plus transcendental work (exp / sqrt / divide) before the echo
 //   MODE 4: as 0 but with the 46 KB LDS allocation only (never touched)
+//   MODE 5: loads + 64 dependent PACKED fp32 FMAs (v_pk_fma_f32, inline asm) per lane     MODE 6: the same arithmetic as 128 scalar v_fma_f32
+//   (5 and 6 give the same bits; only 5 deviates beside another process's MFMA kernels: profiles/r04_packed_fp32_fault.txt)
 // hipcc --offload-arch=gfx950 -O3 -shared -fPIC scripts/diag/lane_quarter_repro.hip -o scripts/diag/lane_quarter_repro.so
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -55,6 +57,31 @@ __global__ __launch_bounds__(256) void k_echo(int64_t N, const float *__restrict
     o[10] = opl; o[11] = d0; o[12] = d1; o[13] = d2; o[14] = rs; o[15] = extra;
 }
 
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+template <bool PACKED>
+__global__ __launch_bounds__(256) void k_fma(int64_t N, const float *__restrict__ quats, float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float4 q = *reinterpret_cast<const float4 *>(quats + 4 * i);
+    float2v acc = {q.x, q.y}, a = {0.75f + 0.01f * q.z, 0.5f - 0.01f * q.w}, b = {q.w * 0.125f, q.z * 0.25f};
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+        if (PACKED) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
+        else {
+            float x = acc.x, y = acc.y;
+            asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(a.x), "v"(b.x));
+            asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(y) : "v"(a.y), "v"(b.y));
+            acc.x = x; acc.y = y;
+        }
+    }
+    float *o = out + i * 16;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) o[k] = 0.f;
+    o[6] = q.x; o[7] = q.y; o[8] = q.z; o[9] = q.w; o[14] = acc.x; o[15] = acc.y;
+}
+
 extern "C" int diag_echo(int mode, int64_t N, const float *means, const float *ls, const float *quats, const float *opl, const float *dc,
                          const float *rest, float *out, void *stream)
 {
@@ -66,6 +93,8 @@ extern "C" int diag_echo(int mode, int64_t N, const float *means, const float *l
     case 2: hipLaunchKernelGGL(k_echo<2>, g, b, 0, s, N, means, ls, quats, opl, dc, rest, out); break;
     case 3: hipLaunchKernelGGL(k_echo<3>, g, b, 0, s, N, means, ls, quats, opl, dc, rest, out); break;
     case 4: hipLaunchKernelGGL(k_echo<4>, g, b, 0, s, N, means, ls, quats, opl, dc, rest, out); break;
+    case 5: hipLaunchKernelGGL(k_fma<true>, g, b, 0, s, N, quats, out); break;
+    case 6: hipLaunchKernelGGL(k_fma<false>, g, b, 0, s, N, quats, out); break;
     default: return 1;
     }
     return hipGetLastError() == hipSuccess ? 0 : 2;
