@@ -52,7 +52,8 @@ def parse():
     ap.add_argument("--denoise-steps", type=int, default=20)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "fp8"])     # fp8: e4m3 resnet convs on the block-scaled MFMA, bf16 elsewhere
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="edit", choices=["edit", "raster"])
+    ap.add_argument("--workload", default="edit", choices=["edit", "raster", "full"])   # full: SURVEY.md 8d's optional whole-pipeline number (N = 1)
+    ap.add_argument("--train-iters", type=int, default=500)     # --workload full: Adam iterations after the edit (gc_trainer.py:186-201)
     ap.add_argument("--ref-mode", default="rotate", choices=["rotate", "owner0", "replicate", "allgather"])    # N > 1: who computes the reference bank
     # (allgather: the reference trajectory sharded by sample, K / V^T all-gathered per attention layer; N in {2, 4, 8})
     ap.add_argument("--inflight", type=int, default=2)         # chunks in flight on independent HIP stream pairs (1: strictly one after the other)
@@ -427,8 +428,72 @@ class Bench:
         return dn, rs
 
 
+def run_full_pipeline(args):
+    """SURVEY.md 8d, the optional whole-pipeline number: ONE scene through the product classes exactly as the reference's trainer drives them
+    (/root/reference/gaussctrl/gc_trainer.py:186-201): render_reverse (eval render + VAE encode + DDIM inversion of all V views), edit_images
+    (reference trajectory + chunks of `chunk_size`, decode), then `--train-iters` iterations of train_iteration (one random edited view per
+    iteration: render fwd + L1/SSIM + backward + fused Adam).  BASELINE configs[1] sizes; synthetic SD1.5-shaped weights; N = 1 only.
+    value = wall seconds for the scene (lower is better); the three phases are reported beside it."""
+    import time
+    import torch
+    from gaussctrl_amd import synthetic as syn
+    from gaussctrl_amd.gc_config import build_optimizers
+    from gaussctrl_amd.gc_model import GaussCtrlModel, GaussCtrlModelConfig
+    from gaussctrl_amd.gc_pipeline import GaussCtrlPipeline, GaussCtrlPipelineConfig, SimpleDataManager
+    from gaussctrl_amd.ns_compat import Cameras
+    dev = "cuda:0"
+    V = args.views or 40
+    K = syn.BEAR_INTRINSICS
+    cams = Cameras(syn.make_cameras(V, seed=1), K["fx"], K["fy"], K["cx"], K["cy"], 512, 512)
+
+    def scene():
+        model = GaussCtrlModel(GaussCtrlModelConfig(background_color="black"), params=syn.make_gaussians(args.gaussians, seed=0), device=dev)
+        cfg = GaussCtrlPipelineConfig(edit_prompt="a polar bear", reverse_prompt="a bear", chunk_size=args.chunk_size,
+                                      num_inference_steps=args.denoise_steps, dtype="f16" if args.dtype == "f16" else "bf16",
+                                      synthetic_weights=True, inflight_chunks=args.inflight)
+        return GaussCtrlPipeline(cfg, dev, datamanager=SimpleDataManager(cams, seed=3), model=model), model
+
+    def run(pipe, model, iters):
+        import random
+        random.seed(11)
+        t = [time.perf_counter()]
+        pipe.render_reverse(); torch.cuda.synchronize(); t.append(time.perf_counter())
+        pipe.edit_images(); torch.cuda.synchronize(); t.append(time.perf_counter())
+        opts = build_optimizers(model)
+        for s in range(iters):
+            pipe.train_iteration(opts, 30000 + s)
+        torch.cuda.synchronize(); t.append(time.perf_counter())
+        return [b - a for a, b in zip(t, t[1:])]
+
+    pipe, model = scene()
+    for _ in range(max(0, args.warmup)):                   # untimed: one short pass warms the allocator and every kernel's first launch
+        run(pipe, model, 20)
+    for td in pipe.datamanager.train_data:
+        for k in ("z_0_image", "unedited_image", "depth_image", "image"):
+            td.pop(k, None)
+    del pipe, model
+    torch.cuda.empty_cache()
+    pipe, model = scene()
+    torch.cuda.synchronize()
+    inv, edit, train = run(pipe, model, args.train_iters)
+    total = inv + edit + train
+    print(json.dumps({
+        "metric": "full GaussCtrl pipeline, seconds per scene (DDIM inversion + edit + Adam iterations)", "value": round(total, 3), "unit": "s",
+        "n_gpus": 1, "steps": 1, "warmup": args.warmup, "ms_per_step": round(total * 1e3, 1), "higher_is_better": False, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"full pipeline: {V} views 512x512, {args.gaussians} Gaussians, chunk {args.chunk_size}, {args.denoise_steps} DDIM steps, "
+                               f"{args.train_iters} Adam iterations (BASELINE configs[1] sizes), product classes GaussCtrlPipeline.render_reverse / edit_images / train_iteration",
+                   "weights": "synthetic SD1.5-shaped (no checkpoints on the build machines)"},
+        "phases_s": {"render_reverse (render + VAE encode + inversion)": round(inv, 3), "edit_images": round(edit, 3),
+                     f"train_iteration x {args.train_iters}": round(train, 3)},
+        "edited_views_per_s_edit_phase": round(V / edit, 3), "train_iterations_per_s": round(args.train_iters / train, 1)}), flush=True)
+
+
 def main():
     args = parse()
+    if args.workload == "full":
+        assert args.gpus == 1, "--workload full is a single-GPU measurement"
+        return run_full_pipeline(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
