@@ -35,6 +35,7 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
     constexpr int PD = NST - 1, GRP = 2;                                   // DMA instructions per wave per tile: one K, one V^T
     constexpr float BIG = 30000.f;
     constexpr int XL = NST * (KBYTES + VBYTES);                            // byte offset of the denominator exchange area (2 KB)
+    constexpr int XS = XL + 2048, MAXSETS = 5;                             // byte offset of the per-set key SAMPLE tiles (8 KB each)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *sK = smem, *sV = smem + NST * KBYTES;
     float *xl = reinterpret_cast<float *>(smem + XL);
@@ -48,10 +49,9 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
     block_coords(a, 2, qblk, h, b);
     const int q_wave0 = qblk * 256 + (wid >> 1) * 64;
     const int ntiles = a.Lk >> 6;
-    const int nsteps = a.nsets * ntiles;
 
     // ---- LDS image, written once: zeros, column D of every key row = 1, the ones row of V^T
-    for (int i = tid; i < (XL + 2048) / 16; i += NT) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < (XS + MAXSETS * KBYTES) / 16; i += NT) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     for (int i = tid; i < NST * 64; i += NT) {
         const int st = i >> 6, row = i & 63;
@@ -83,12 +83,18 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
     unsigned abl_sink = 0;
 
     // ---- LDS-DMA plan of this lane (k_attn4's, 8 waves: one K and one V^T instruction per wave and tile)
-    int k_off, v_off;
+    int k_off, v_off, ks_off;
     unsigned long long k_msk, v_msk;
     {
         const int p = wid * 64 + lane, row = p >> 3, lc = (p & 7) ^ swz4(row);
         k_msk = __ballot(lc * 8 < D);
         k_off = (row * (int)a.ldk + lc * 8) * 2;
+        // The exponent offset of a K/V set is the row maximum over a SAMPLE of 64 of its keys (round 4; before: its first 32 keys).  Sample
+        // row j is key j * (Lk / 64) + ((8 j + (j >> 3)) mod (Lk / 64)): on a 64-wide token map one key in every 8 x 8 block of the map, so a
+        // query whose large logits sit anywhere in the image has a sample near them -- in f16 P = exp2(s - offset) must stay below 2^16, and
+        // the first keys (the top-left corner of the image) say little about a query at the bottom (profiles/r04_attn5_f16_sample.txt).
+        const int kj = row * ntiles + ((8 * row + (row >> 3)) % ntiles);
+        ks_off = (kj * (int)a.ldk + lc * 8) * 2;
     }
     {
         const int p = VSH * wid + lane, row = p >> 3, lc = (p & 7) ^ swz4(row);
@@ -167,6 +173,7 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
     for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
 
     const unsigned char *rk = sK, *rv = sV;
+    const unsigned char *samp = smem + XS;           // sample tile of the current set
     f32x16 S0, S1;                       // S'^T of the wave's key block for query block 0 / 1 (single-buffered: see the schedule below)
     uint4 pf[QB][2], kf[KS], vf[2][DB];
     // exp unit w of k-step t: registers 8 t + 2 w, + 1 of S -> one packed word of the P fragment (2 v_exp_f32 + 1 v_cvt_pk)
@@ -203,24 +210,26 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
         wait_vmcnt<(PD - 2) * GRP>();
         if (!(ABL && (abl & 4))) __builtin_amdgcn_s_barrier();
         if (!(ABL && (abl & 8))) issue_kv(std::integral_constant<int, SLOT < 0 ? -1 : (SLOT + PD) % NST>{});
-        const unsigned char *kb_ = SLOT < 0 ? rk : sK + SLOT * KBYTES, *vb_ = SLOT < 0 ? rv : sV + SLOT * VBYTES;
+        const unsigned char *vb_ = SLOT < 0 ? rv : sV + SLOT * VBYTES;
         if (SLOT < 0) {
             rk = rk + KBYTES == sK + NST * KBYTES ? sK : rk + KBYTES;
             rv = rv + VBYTES == sV + NST * VBYTES ? sV : rv + VBYTES;
         }
         if (first) {
-            // first tile of a K/V set: the row maximum over its FIRST key block becomes the set's offset -- evaluated by both waves of
-            // a pair on the same data, so they agree bit for bit without an exchange
+            // first tile of a K/V set: the row maximum over the set's SAMPLE tile (64 keys spread over the whole set, DMA'd in the prologue)
+            // becomes the set's offset -- evaluated by both waves of a pair on the same data, so they agree bit for bit without an exchange
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
                 if (hg == HS) qf[qb][KSS].x = pack2<T>(0.f, -BIG);
-                f32x16 m0 = zero16;
+                float t = -BIG;
+#pragma unroll 1
+                for (int hb = 0; hb < 2; ++hb) {               // the sample tile's two 32-key blocks, one accumulator (rolled: the kernel is register-tight)
+                    f32x16 m0 = zero16;
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) m0 = T::mfma32(*reinterpret_cast<const uint4 *>(kb_ + k0o[ks]), qf[qb][ks], m0);
-                float t = fmaxf(fmaxf(m0[0], m0[1]), m0[2]);
+                    for (int ks = 0; ks < KS; ++ks) m0 = T::mfma32(*reinterpret_cast<const uint4 *>(samp + k0o[ks] + hb * 4096), qf[qb][ks], m0);
 #pragma unroll
-                for (int r = 3; r + 1 < 16; r += 2) t = fmaxf(fmaxf(t, m0[r]), m0[r + 1]);
-                t = fmaxf(t, m0[15]);
+                    for (int r = 0; r + 1 < 16; r += 2) t = fmaxf(fmaxf(t, m0[r]), m0[r + 1]);
+                }
                 const unsigned x = __float_as_uint(t);
                 const auto r1 = __builtin_amdgcn_permlane32_swap(x, x, false, false);
                 t = fmaxf(__uint_as_float(r1[0]), __uint_as_float(r1[1]));
@@ -308,8 +317,11 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
         }
     };
 
-    // ---- prologue: PD tiles in flight
+    // ---- prologue: the sample tiles of every set (they land first: loads complete in order), then PD tiles in flight
     __syncthreads();
+#pragma unroll
+    for (int s = 0; s < MAXSETS; ++s)
+        if (s < a.nsets) glds16_s(tab(kb_tab, s), (unsigned)ks_off, ldsK + XS + s * KBYTES + wid * 1024, k_msk);
     static_for<0, PD>([&](auto j_) __attribute__((always_inline)) { issue_kv(std::integral_constant<int, decltype(j_)::value>{}); });
     ck.dst = ldsK + wid * 1024 + PD * KBYTES; cv.dst = ldsV + wid * (VSH * 16) + PD * VBYTES;      // (dynamic form: next slot)
     wait_vmcnt<(PD - 1) * GRP>();
@@ -320,6 +332,7 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
 #pragma unroll
         for (int db = 0; db < DB; ++db) vf[t][db] = make_uint4(0, 0, 0, 0);
     for (int s = 0; s < a.nsets; ++s) {
+        samp = smem + XS + s * KBYTES;
 #pragma unroll
         for (int r = 0; r < 16; ++r) S1[r] = -BIG;                  // exp2 -> 0: the pipeline starts with P1 = 0
         pf[1][0] = make_uint4(0, 0, 0, 0);
@@ -368,7 +381,7 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
 template <class T, bool PRE, int NST, bool ABL = false>
 void launch_attn5_(const AttnArgs &a, int B, hipStream_t s)
 {
-    constexpr size_t ring = (size_t)NST * (64 * 128 + 2 * 32 * 128) + 2048, xchg = (size_t)8 * 20 * 64 * 4;
+    constexpr size_t ring = (size_t)NST * (64 * 128 + 2 * 32 * 128) + 2048 + 5 * (64 * 128), xchg = (size_t)8 * 20 * 64 * 4;   // ring + exchange + 5 sample tiles
     constexpr size_t safe = SafeLds<40>::KBYTES + SafeLds<40>::VBYTES;
     constexpr size_t lds = ring > xchg ? (ring > safe ? ring : safe) : (xchg > safe ? xchg : safe);
     static gc::AttrOnce once;

@@ -4,7 +4,10 @@
 //   MODE 2: staging first, the five loads after it          MODE 3: as 1, plus transcendental work (exp / sqrt / divide) before the echo
 //   MODE 4: as 0 but with the 46 KB LDS allocation only (never touched)
 //   MODE 5: loads + 64 dependent PACKED fp32 FMAs (v_pk_fma_f32, inline asm) per lane     MODE 6: the same arithmetic as 128 scalar v_fma_f32
-//   (5 and 6 give the same bits; only 5 deviates beside another process's MFMA kernels: profiles/r04_packed_fp32_fault.txt)
+//   MODE 7: quaternion -> rotation -> covariance arithmetic in plain C (this file is built with hipcc's default vectorizers: packed fp32)
+//   MODE 8..12: inline-asm chains of the packed forms the projection kernel contained: 8 v_pk_mul_f32 + v_pk_add_f32, 9 v_pk_fma_f32 with
+//   op_sel_hi:[0,1,1], 10 v_pk_mul_f32 with an SGPR-pair operand, 11 v_pk_mov_b32 op_sel:[1,0], 12 eight INDEPENDENT v_pk_fma_f32 accumulators,
+//   13 scalar VALU ops and packed ops feeding each other back to back, 14 packed ops with neg modifiers
 // hipcc --offload-arch=gfx950 -O3 -shared -fPIC scripts/diag/lane_quarter_repro.hip -o scripts/diag/lane_quarter_repro.so
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -82,6 +85,72 @@ __global__ __launch_bounds__(256) void k_fma(int64_t N, const float *__restrict_
     o[6] = q.x; o[7] = q.y; o[8] = q.z; o[9] = q.w; o[14] = acc.x; o[15] = acc.y;
 }
 
+__global__ __launch_bounds__(256) void k_cov(int64_t N, const float *__restrict__ log_scales, const float *__restrict__ quats, float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float4 q = *reinterpret_cast<const float4 *>(quats + 4 * i);
+    const float s0 = log_scales[3 * i] * 0.25f + 1.f, s1 = log_scales[3 * i + 1] * 0.25f + 1.f, s2 = log_scales[3 * i + 2] * 0.25f + 1.f;
+    const float w = q.x, x = q.y, y = q.z, z = q.w;
+    float R[9] = {1.f - 2.f * (y * y + z * z), 2.f * (x * y - w * z), 2.f * (x * z + w * y),
+                  2.f * (x * y + w * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - w * x),
+                  2.f * (x * z - w * y), 2.f * (y * z + w * x), 1.f - 2.f * (x * x + y * y)};
+    float M[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { M[3 * r] = R[3 * r] * s0; M[3 * r + 1] = R[3 * r + 1] * s1; M[3 * r + 2] = R[3 * r + 2] * s2; }
+    float *o = out + i * 16;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) o[k] = 0.f;
+    o[0] = (M[0] * M[0] + M[1] * M[1]) + M[2] * M[2]; o[1] = (M[0] * M[3] + M[1] * M[4]) + M[2] * M[5];
+    o[2] = (M[0] * M[6] + M[1] * M[7]) + M[2] * M[8]; o[3] = (M[3] * M[3] + M[4] * M[4]) + M[5] * M[5];
+    o[4] = (M[3] * M[6] + M[4] * M[7]) + M[5] * M[8]; o[5] = (M[6] * M[6] + M[7] * M[7]) + M[8] * M[8];
+    o[6] = q.x; o[7] = q.y; o[8] = q.z; o[9] = q.w;
+}
+
+template <int FORM>
+__global__ __launch_bounds__(256) void k_pk(int64_t N, const float *__restrict__ quats, float *__restrict__ out, float2v sv)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float4 q = *reinterpret_cast<const float4 *>(quats + 4 * i);
+    float2v acc = {q.x, q.y}, a = {1.f + 0.001f * q.z, 1.f - 0.001f * q.w}, b = {q.w * 0.125f, q.z * 0.25f};
+    float2v acc8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc8[k] = acc + (float)k;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+        if (FORM == 8) { asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(acc) : "v"(a)); asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(acc) : "v"(b)); }
+        if (FORM == 9) asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(a), "v"(b));
+        if (FORM == 10) { asm volatile("v_pk_mul_f32 %0, %1, %0" : "+v"(acc) : "s"(sv)); asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(acc) : "v"(b)); }
+        if (FORM == 11) { asm volatile("v_pk_mov_b32 %0, %0, %1 op_sel:[1,0]" : "+v"(acc) : "v"(b)); asm volatile("v_pk_mov_b32 %0, %1, %0 op_sel:[1,0]" : "+v"(b) : "v"(a)); }
+        if (FORM == 12) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(acc8[j]) : "v"(a), "v"(b));
+        }
+        if (FORM == 13) {       // scalar VALU results feed a packed op and the packed result feeds scalar ops, back to back
+            float x = acc.x, y = acc.y;
+            asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x) : "v"(a.x));
+            asm volatile("v_mul_f32 %0, %0, %1" : "+v"(y) : "v"(a.y));
+            acc.x = x; acc.y = y;
+            asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(acc) : "v"(b));
+            x = acc.x; y = acc.y;
+            asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(a.y), "v"(b.y));
+            asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(y) : "v"(a.x), "v"(b.x));
+            acc.x = x; acc.y = y;
+            asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(acc) : "v"(a));
+        }
+        if (FORM == 14) { asm volatile("v_pk_mul_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(acc) : "v"(a)); asm volatile("v_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(acc) : "v"(b)); }
+    }
+    if (FORM == 12) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { acc.x += acc8[j].x; acc.y += acc8[j].y; }
+    }
+    float *o = out + i * 16;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) o[k] = 0.f;
+    o[6] = q.x; o[7] = q.y; o[8] = q.z; o[9] = q.w; o[12] = b.x; o[13] = b.y; o[14] = acc.x; o[15] = acc.y;
+}
+
 extern "C" int diag_echo(int mode, int64_t N, const float *means, const float *ls, const float *quats, const float *opl, const float *dc,
                          const float *rest, float *out, void *stream)
 {
@@ -95,6 +164,14 @@ extern "C" int diag_echo(int mode, int64_t N, const float *means, const float *l
     case 4: hipLaunchKernelGGL(k_echo<4>, g, b, 0, s, N, means, ls, quats, opl, dc, rest, out); break;
     case 5: hipLaunchKernelGGL(k_fma<true>, g, b, 0, s, N, quats, out); break;
     case 6: hipLaunchKernelGGL(k_fma<false>, g, b, 0, s, N, quats, out); break;
+    case 7: hipLaunchKernelGGL(k_cov, g, b, 0, s, N, ls, quats, out); break;
+    case 8: hipLaunchKernelGGL(k_pk<8>, g, b, 0, s, N, quats, out, float2v{1.0009765625f, 0.9990234375f}); break;
+    case 9: hipLaunchKernelGGL(k_pk<9>, g, b, 0, s, N, quats, out, float2v{1.f, 1.f}); break;
+    case 10: hipLaunchKernelGGL(k_pk<10>, g, b, 0, s, N, quats, out, float2v{1.0009765625f, 0.9990234375f}); break;
+    case 11: hipLaunchKernelGGL(k_pk<11>, g, b, 0, s, N, quats, out, float2v{1.f, 1.f}); break;
+    case 12: hipLaunchKernelGGL(k_pk<12>, g, b, 0, s, N, quats, out, float2v{1.f, 1.f}); break;
+    case 13: hipLaunchKernelGGL(k_pk<13>, g, b, 0, s, N, quats, out, float2v{1.f, 1.f}); break;
+    case 14: hipLaunchKernelGGL(k_pk<14>, g, b, 0, s, N, quats, out, float2v{1.f, 1.f}); break;
     default: return 1;
     }
     return hipGetLastError() == hipSuccess ? 0 : 2;

@@ -17,7 +17,7 @@ if sys.argv[1] == "load":
     print(f"load: {n} matmuls", flush=True)
 else:
     mode, secs = int(sys.argv[2]), float(sys.argv[3])
-    lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "lane_quarter_repro.so"))
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "lane_quarter_repro_scalar.so" if os.environ.get("LQ_LIB") == "scalar" else "lane_quarter_repro.so"))   # _scalar: the same file built with -fno-slp-vectorize -fno-vectorize
     N = 20000
     g = torch.Generator(device=dev); g.manual_seed(0)
     mk = lambda *s: torch.randn(*s, device=dev, generator=g)
@@ -33,6 +33,8 @@ else:
 
     ref = call()
     torch.cuda.synchronize()
+    if len(sys.argv) > 4:                       # the reference is taken BEFORE the disturbing process starts: wait for it
+        time.sleep(float(sys.argv[4]))
     want = torch.cat([means, ls, quats, opl[:, None], dc], 1)
     if mode < 5:
         assert torch.equal(ref[:, :14], want), "the first call is not a copy of its inputs"
