@@ -35,7 +35,8 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
     constexpr int PD = NST - 1, GRP = 2;                                   // DMA instructions per wave per tile: one K, one V^T
     constexpr float BIG = 30000.f;
     constexpr int XL = NST * (KBYTES + VBYTES);                            // byte offset of the denominator exchange area (2 KB)
-    constexpr int XS = XL + 2048, MAXSETS = 5;                             // byte offset of the per-set key SAMPLE tiles (8 KB each)
+    constexpr int XS = XL + 2048, NSAMP = 2;                               // byte offset of the key SAMPLE tiles (8 KB each; sets s and s + 1: ping-pong)
+    constexpr bool SAMPLED = std::is_same<T, F16>::value;                  // bf16's 8-bit exponent needs no careful offset: it keeps the first key block
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *sK = smem, *sV = smem + NST * KBYTES;
     float *xl = reinterpret_cast<float *>(smem + XL);
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
     const int ntiles = a.Lk >> 6;
 
     // ---- LDS image, written once: zeros, column D of every key row = 1, the ones row of V^T
-    for (int i = tid; i < (XS + MAXSETS * KBYTES) / 16; i += NT) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < (XS + (SAMPLED ? NSAMP * KBYTES + 16 : 0)) / 16; i += NT) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     for (int i = tid; i < NST * 64; i += NT) {
         const int st = i >> 6, row = i & 63;
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
     unsigned abl_sink = 0;
 
     // ---- LDS-DMA plan of this lane (k_attn4's, 8 waves: one K and one V^T instruction per wave and tile)
-    int k_off, v_off, ks_off;
+    int k_off, v_off;
     unsigned long long k_msk, v_msk;
     {
         const int p = wid * 64 + lane, row = p >> 3, lc = (p & 7) ^ swz4(row);
@@ -93,8 +94,6 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
         // row j is key j * (Lk / 64) + ((8 j + (j >> 3)) mod (Lk / 64)): on a 64-wide token map one key in every 8 x 8 block of the map, so a
         // query whose large logits sit anywhere in the image has a sample near them -- in f16 P = exp2(s - offset) must stay below 2^16, and
         // the first keys (the top-left corner of the image) say little about a query at the bottom (profiles/r04_attn5_f16_sample.txt).
-        const int kj = row * ntiles + ((8 * row + (row >> 3)) % ntiles);
-        ks_off = (kj * (int)a.ldk + lc * 8) * 2;
     }
     {
         const int p = VSH * wid + lane, row = p >> 3, lc = (p & 7) ^ swz4(row);
@@ -122,6 +121,15 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
     auto tab = [&](unsigned long long t, int s) __attribute__((always_inline)) -> const unsigned char * {
         const unsigned lo = __builtin_amdgcn_readlane((unsigned)t, s), hi = __builtin_amdgcn_readlane((unsigned)(t >> 32), s);
         return (const unsigned char *)(((unsigned long long)hi << 32) | lo);
+    };
+    // (recomputed where it is used -- twice per set at most -- instead of held in a register through the tile loop)
+    auto sample_off = [&]() __attribute__((always_inline)) -> unsigned {
+        const int p = wid * 64 + lane, row = p >> 3, lc = (p & 7) ^ swz4(row);
+        const int kj = row * ntiles + ((8 * row + (row >> 3)) % ntiles);
+        return (unsigned)((kj * (int)a.ldk + lc * 8) * 2);
+    };
+    auto issue_sample = [&](int s) __attribute__((always_inline)) {       // the sample tile of set s -> slot s & 1
+        glds16_s(tab(kb_tab, s), sample_off(), ldsK + XS + (s & 1) * KBYTES + wid * 1024, k_msk);
     };
     struct Cur { const unsigned char *p; int tile, s; unsigned dst; };
     Cur ck, cv;
@@ -167,7 +175,8 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) otot1[qb][r] = 0.f;
     }
-    int bad = 0;
+    int bad = 0, bail = 0;
+    volatile unsigned *ovf = reinterpret_cast<volatile unsigned *>(smem + XS + NSAMP * KBYTES);      // f16: "a partial denominator overflowed" flag of the workgroup
     f32x16 zero16;
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
@@ -210,23 +219,25 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
         wait_vmcnt<(PD - 2) * GRP>();
         if (!(ABL && (abl & 4))) __builtin_amdgcn_s_barrier();
         if (!(ABL && (abl & 8))) issue_kv(std::integral_constant<int, SLOT < 0 ? -1 : (SLOT + PD) % NST>{});
-        const unsigned char *vb_ = SLOT < 0 ? rv : sV + SLOT * VBYTES;
+        const unsigned char *kb_ = SLOT < 0 ? rk : sK + SLOT * KBYTES, *vb_ = SLOT < 0 ? rv : sV + SLOT * VBYTES;
+        (void)kb_;
         if (SLOT < 0) {
             rk = rk + KBYTES == sK + NST * KBYTES ? sK : rk + KBYTES;
             rv = rv + VBYTES == sV + NST * VBYTES ? sV : rv + VBYTES;
         }
         if (first) {
-            // first tile of a K/V set: the row maximum over the set's SAMPLE tile (64 keys spread over the whole set, DMA'd in the prologue)
-            // becomes the set's offset -- evaluated by both waves of a pair on the same data, so they agree bit for bit without an exchange
+            // first tile of a K/V set: the row maximum over the set's SAMPLE tile (f16: 64 keys spread over the whole set, DMA'd in the
+            // prologue; bf16: the set's first 32 keys) becomes the set's offset -- evaluated by both waves of a pair on the same data, so they agree bit for bit without an exchange
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
                 if (hg == HS) qf[qb][KSS].x = pack2<T>(0.f, -BIG);
                 float t = -BIG;
+                const unsigned char *src = SAMPLED ? samp : kb_;
 #pragma unroll 1
-                for (int hb = 0; hb < 2; ++hb) {               // the sample tile's two 32-key blocks, one accumulator (rolled: the kernel is register-tight)
+                for (int hb = 0; hb < (SAMPLED ? 2 : 1); ++hb) {   // f16: the sample tile's two 32-key blocks, one accumulator (rolled: the kernel is register-tight)
                     f32x16 m0 = zero16;
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) m0 = T::mfma32(*reinterpret_cast<const uint4 *>(samp + k0o[ks] + hb * 4096), qf[qb][ks], m0);
+                    for (int ks = 0; ks < KS; ++ks) m0 = T::mfma32(*reinterpret_cast<const uint4 *>(src + k0o[ks] + hb * 4096), qf[qb][ks], m0);
 #pragma unroll
                     for (int r = 0; r + 1 < 16; r += 2) t = fmaxf(fmaxf(t, m0[r]), m0[r + 1]);
                 }
@@ -298,7 +309,17 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb)
             if (hg == hg_l) xl[(wid * QB + qb) * 32 + qi] = os[qb][db_l][r_l];
+        if (SAMPLED && !ABL) {          // f16: an overflowed partial denominator (inf / NaN) is known before the exchange -- flag it through the same barrier
+            bool ov = false;
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) ov |= hg == hg_l && !(os[qb][db_l][r_l] < 1e37f);
+            if (__ballot(ov) != 0ull && lane == 0) *ovf = 1u;
+        }
         __syncthreads();
+        if (SAMPLED && !ABL) bail = (int)*ovf;
+        // the sample tile of set s + 2 replaces set s's (read at the set's first tile, long ago); it has a whole set to land.  One more load
+        // in the in-order queue only makes the counted waits of the next tiles wait for older loads, never for fewer.
+        if (SAMPLED && s + 2 < a.nsets) issue_sample(s + 2);
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             const float l = xl[(wid * QB + qb) * 32 + qi] + xl[((wid ^ 1) * QB + qb) * 32 + qi];
@@ -319,9 +340,10 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
 
     // ---- prologue: the sample tiles of every set (they land first: loads complete in order), then PD tiles in flight
     __syncthreads();
-#pragma unroll
-    for (int s = 0; s < MAXSETS; ++s)
-        if (s < a.nsets) glds16_s(tab(kb_tab, s), (unsigned)ks_off, ldsK + XS + s * KBYTES + wid * 1024, k_msk);
+    if (SAMPLED) {
+        issue_sample(0);
+        if (a.nsets > 1) issue_sample(1);
+    }
     static_for<0, PD>([&](auto j_) __attribute__((always_inline)) { issue_kv(std::integral_constant<int, decltype(j_)::value>{}); });
     ck.dst = ldsK + wid * 1024 + PD * KBYTES; cv.dst = ldsV + wid * (VSH * 16) + PD * VBYTES;      // (dynamic form: next slot)
     wait_vmcnt<(PD - 1) * GRP>();
@@ -332,7 +354,7 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
 #pragma unroll
         for (int db = 0; db < DB; ++db) vf[t][db] = make_uint4(0, 0, 0, 0);
     for (int s = 0; s < a.nsets; ++s) {
-        samp = smem + XS + s * KBYTES;
+        samp = smem + XS + (s & 1) * KBYTES;
 #pragma unroll
         for (int r = 0; r < 16; ++r) S1[r] = -BIG;                  // exp2 -> 0: the pipeline starts with P1 = 0
         pf[1][0] = make_uint4(0, 0, 0, 0);
@@ -347,11 +369,13 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
             for (int t = 0; t < ntiles; ++t) tile_step(t == 0, std::integral_constant<int, -1>{});
         }
         fold(s);
+        if (SAMPLED && !ABL && bail) break;      // f16: leave for the safe body as soon as a set has overflowed instead of finishing the other sets first
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     if (ABL && abl_sink == 0x12345u) bad = 1;
-    if (__syncthreads_or(ABL ? (bad & 2) : bad)) {      // some row left the exponent range of its first-block offset: safe recomputation
+    if (bail || __syncthreads_or(ABL ? (bad & 2) : bad)) {      // some row left the exponent range of its set's offset: safe recomputation
+        __syncthreads();                                        // (every wave is past its last LDS read; the DMA was drained above)
         attn_safe_body<T, D, 2, NW>(a, qblk, h, b, smem, smem + SafeLds<D>::KBYTES);
         return;
     }
@@ -381,7 +405,7 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
 template <class T, bool PRE, int NST, bool ABL = false>
 void launch_attn5_(const AttnArgs &a, int B, hipStream_t s)
 {
-    constexpr size_t ring = (size_t)NST * (64 * 128 + 2 * 32 * 128) + 2048 + 5 * (64 * 128), xchg = (size_t)8 * 20 * 64 * 4;   // ring + exchange + 5 sample tiles
+    constexpr size_t ring = (size_t)NST * (64 * 128 + 2 * 32 * 128) + 2048 + 2 * (64 * 128) + 16, xchg = (size_t)8 * 20 * 64 * 4;   // ring + exchange + 2 sample tiles + flag
     constexpr size_t safe = SafeLds<40>::KBYTES + SafeLds<40>::VBYTES;
     constexpr size_t lds = ring > xchg ? (ring > safe ? ring : safe) : (xchg > safe ? xchg : safe);
     static gc::AttrOnce once;
