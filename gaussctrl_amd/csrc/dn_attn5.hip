@@ -24,7 +24,7 @@ __device__ unsigned g_attn5_dbg = 0;
 // scales both partial O^T), the partial weighted sums once at the end of the kernel.
 // ABL: instrumented instantiation for timing ablations (results wrong by construction): a.abl bit 0 no v_exp, 1 no exp units at
 // all, 2 no s_barrier, 3 no LDS-DMA, 4 no LDS fragment reads
-template <class T, bool PRE, int NST = 4, bool ABL = false>
+template <class T, bool PRE, int NST = 4, bool ABL = false, bool PV16 = !ABL>
 __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
 {
     constexpr int D = 40, NW = 8, KS = 3, DB = 2, QB = 2;
@@ -164,16 +164,33 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
 #pragma unroll
         for (int t = 0; t < 2; ++t) vfo[t] = qi * 128 + (((2 * (2 * kh + t) + hg) ^ swz4(qi)) << 4);
     }
+    // PV16 (round 4): O^T rows 32..47 (channels 32..39 and the ones row; 48..63 are padding) come from 16x16x32 MFMAs -- two per query block
+    // and 32 keys (16 passes) instead of two 32x32x16 (32 passes): -14 % MFMA passes per tile.  Their A operand is V^T rows 32 + (lane & 15) with
+    // the 8 keys of chunk c(g) = {0, 2, 1, 3}[g = lane >> 4] of the wave's key block (ONE ds_read_b128 per tile); their B operand is made from
+    // the two P fragments of the 32x32x16 form by v_permlane16_swap: swap(P(t=0), P(t=1)) = (queries 0..15, queries 16..31) x the four
+    // 8-key chunks in exactly that order.
+    int vfo16;
+    {
+        const int r16 = lane & 15, g = lane >> 4, c = ((g & 1) << 1) | (g >> 1);
+        vfo16 = (32 + r16) * 128 + (((4 * kh + c) ^ swz4(r16)) << 4);
+    }
 
     // O^T rows 40..63 are never stored: of row block 1 only rows 32..39 (registers 0..3) are carried across K/V sets
-    f32x16 os[QB][DB], otot0[QB];
-    f32x4 otot1[QB];
+    f32x16 os[QB][PV16 ? 1 : DB], otot0[QB];
+    f32x4 otot1[QB][PV16 ? 2 : 1];                   // PV16: per 16-query half (16x16 accumulator layout: lane (query & 15, rows 4 (lane >> 4) + r))
+    f32x4 o1[QB][2];                                 // PV16: O^T rows 32..47 of the current set, per 16-query half
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { otot0[qb][r] = 0.f; os[qb][0][r] = 0.f; os[qb][1][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) {
+            otot0[qb][r] = 0.f; os[qb][0][r] = 0.f;
+            if constexpr (!PV16) os[qb][DB - 1][r] = 0.f;
+        }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) otot1[qb][r] = 0.f;
+        for (int r = 0; r < 4; ++r) {
+            otot1[qb][0][r] = 0.f; o1[qb][0][r] = 0.f; o1[qb][1][r] = 0.f;
+            if constexpr (PV16) otot1[qb][1][r] = 0.f;
+        }
     }
     int bad = 0, bail = 0;
     volatile unsigned *ovf = reinterpret_cast<volatile unsigned *>(smem + XS + NSAMP * KBYTES);      // f16: "a partial denominator overflowed" flag of the workgroup
@@ -184,7 +201,7 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
     const unsigned char *rk = sK, *rv = sV;
     const unsigned char *samp = smem + XS;           // sample tile of the current set
     f32x16 S0, S1;                       // S'^T of the wave's key block for query block 0 / 1 (single-buffered: see the schedule below)
-    uint4 pf[QB][2], kf[KS], vf[2][DB];
+    uint4 pf[QB][2], kf[KS], vf[2][PV16 ? 1 : DB], vf16 = make_uint4(0, 0, 0, 0);
     // exp unit w of k-step t: registers 8 t + 2 w, + 1 of S -> one packed word of the P fragment (2 v_exp_f32 + 1 v_cvt_pk)
     auto unit = [&](const f32x16 &S, uint4 &p, int w, int t) __attribute__((always_inline)) {
         const int r0 = 8 * t + 2 * w;
@@ -197,6 +214,12 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
         else if (w == 1) p.y = v;
         else if (w == 2) p.z = v;
         else p.w = v;
+    };
+    // PV16: the two 16x16x32 B operands (queries 0..15 / 16..31 x 32 keys) from the 32x32x16 P fragments of the two 16-key k-steps
+    auto p16 = [&](const uint4 &p0, const uint4 &p1, uint4 &qa, uint4 &qb_) __attribute__((always_inline)) {
+        const auto x = __builtin_amdgcn_permlane16_swap(p0.x, p1.x, false, false), y = __builtin_amdgcn_permlane16_swap(p0.y, p1.y, false, false);
+        const auto z = __builtin_amdgcn_permlane16_swap(p0.z, p1.z, false, false), w = __builtin_amdgcn_permlane16_swap(p0.w, p1.w, false, false);
+        qa = make_uint4(x[0], y[0], z[0], w[0]); qb_ = make_uint4(x[1], y[1], z[1], w[1]);
     };
     // Software pipeline of one tile, in issue order (MFMA groups and the exp units that run in their shadow):
     //   A  wait + barrier (tiles i and i+1 landed, tile i-1's slot free), DMA of tile i+PD
@@ -258,22 +281,42 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
         S0 = T::mfma32(kf[2], qf[0][2], S0);
         unit(S1, pf[1][1], 2, 1); unit(S1, pf[1][1], 3, 1);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PV16) {
+            uint4 qa, qc;
+            os[1][0] = T::mfma32(vf[0][0], pf[1][0], os[1][0]);      // D
+            p16(pf[1][0], pf[1][1], qa, qc);
+            __builtin_amdgcn_sched_barrier(0);
+            os[1][0] = T::mfma32(vf[1][0], pf[1][1], os[1][0]);
+            unit(S0, pf[0][0], 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            o1[1][0] = T::mfma(vf16, qa, o1[1][0]);
+            unit(S0, pf[0][0], 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            o1[1][1] = T::mfma(vf16, qc, o1[1][1]);
+            unit(S0, pf[0][0], 2, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(ABL && (abl & 16))) {     // E
+                vf[0][0] = *reinterpret_cast<const uint4 *>(vb_ + vfo[0]); vf[1][0] = *reinterpret_cast<const uint4 *>(vb_ + vfo[1]);
+                vf16 = *reinterpret_cast<const uint4 *>(vb_ + vfo16);
+            }
+        } else {
         os[1][0] = T::mfma32(vf[0][0], pf[1][0], os[1][0]);      // D
         __builtin_amdgcn_sched_barrier(0);
-        os[1][1] = T::mfma32(vf[0][1], pf[1][0], os[1][1]);
+        os[1][DB - 1] = T::mfma32(vf[0][DB - 1], pf[1][0], os[1][DB - 1]);
         unit(S0, pf[0][0], 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         os[1][0] = T::mfma32(vf[1][0], pf[1][1], os[1][0]);
         unit(S0, pf[0][0], 1, 0);
         __builtin_amdgcn_sched_barrier(0);
-        os[1][1] = T::mfma32(vf[1][1], pf[1][1], os[1][1]);
+        os[1][DB - 1] = T::mfma32(vf[1][DB - 1], pf[1][1], os[1][DB - 1]);
         unit(S0, pf[0][0], 2, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (!(ABL && (abl & 16))) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)     // E
 #pragma unroll
-                for (int db = 0; db < DB; ++db) vf[t][db] = *reinterpret_cast<const uint4 *>(vb_ + vfo[t] + db * 4096);
+                for (int db = 0; db < (PV16 ? 1 : DB); ++db) vf[t][db] = *reinterpret_cast<const uint4 *>(vb_ + vfo[t] + db * 4096);
+        }
         }
         S1 = T::mfma32(kf[0], qf[1][0], zero16);        // F
         unit(S0, pf[0][0], 3, 0); unit(S0, pf[0][1], 0, 1);
@@ -285,34 +328,67 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
         unit(S0, pf[0][1], 3, 1);
         __builtin_amdgcn_sched_barrier(0);
         rd_kf(SLOT < 0 ? rk : sK + ((SLOT + 1) % NST) * KBYTES);      // tile i+1 (landed: the barrier above waited for it)
+        if constexpr (PV16) {
+            uint4 qa, qc;
+            os[0][0] = T::mfma32(vf[0][0], pf[0][0], os[0][0]);      // G
+            p16(pf[0][0], pf[0][1], qa, qc);
+            __builtin_amdgcn_sched_barrier(0);
+            os[0][0] = T::mfma32(vf[1][0], pf[0][1], os[0][0]);
+            unit(S1, pf[1][0], 0, 0); unit(S1, pf[1][0], 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            o1[0][0] = T::mfma(vf16, qa, o1[0][0]);
+            unit(S1, pf[1][0], 2, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            o1[0][1] = T::mfma(vf16, qc, o1[0][1]);
+            unit(S1, pf[1][0], 3, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
         os[0][0] = T::mfma32(vf[0][0], pf[0][0], os[0][0]);      // G
         __builtin_amdgcn_sched_barrier(0);
-        os[0][1] = T::mfma32(vf[0][1], pf[0][0], os[0][1]);
+        os[0][DB - 1] = T::mfma32(vf[0][DB - 1], pf[0][0], os[0][DB - 1]);
         unit(S1, pf[1][0], 0, 0); unit(S1, pf[1][0], 1, 0);
         __builtin_amdgcn_sched_barrier(0);
         os[0][0] = T::mfma32(vf[1][0], pf[0][1], os[0][0]);
         unit(S1, pf[1][0], 2, 0);
         __builtin_amdgcn_sched_barrier(0);
-        os[0][1] = T::mfma32(vf[1][1], pf[0][1], os[0][1]);
+        os[0][DB - 1] = T::mfma32(vf[1][DB - 1], pf[0][1], os[0][DB - 1]);
         unit(S1, pf[1][0], 3, 0);
         __builtin_amdgcn_sched_barrier(0);
+        }
     };
     // end of a K/V set: finish the pipeline (B and D of the last tile), then O_total += w / (l_a + l_b) * O_set; a wave's partial
     // denominator is row D of its O^T (the ones row of V^T)
     auto fold = [&](int s) __attribute__((always_inline)) {
         unit(S1, pf[1][1], 0, 1); unit(S1, pf[1][1], 1, 1); unit(S1, pf[1][1], 2, 1); unit(S1, pf[1][1], 3, 1);
-        os[1][0] = T::mfma32(vf[0][0], pf[1][0], os[1][0]);
-        os[1][1] = T::mfma32(vf[0][1], pf[1][0], os[1][1]);
-        os[1][0] = T::mfma32(vf[1][0], pf[1][1], os[1][0]);
-        os[1][1] = T::mfma32(vf[1][1], pf[1][1], os[1][1]);
         constexpr int db_l = D / 32, dl = D % 32, r_l = (dl >> 3) * 4 + (dl & 3), hg_l = (dl >> 2) & 1;
+        static_assert(!PV16 || (db_l == 1 && dl == 8), "PV16: the ones row is row 8 of the 16-row block (D = 40)");
+        const bool lden = PV16 ? (lane >> 4) == 2 : hg == hg_l;       // lanes that hold partial denominators (PV16: rows 8..11 of the 16x16 tiles)
+        if constexpr (PV16) {
+            uint4 qa, qc;
+            os[1][0] = T::mfma32(vf[0][0], pf[1][0], os[1][0]);
+            p16(pf[1][0], pf[1][1], qa, qc);
+            os[1][0] = T::mfma32(vf[1][0], pf[1][1], os[1][0]);
+            o1[1][0] = T::mfma(vf16, qa, o1[1][0]);
+            o1[1][1] = T::mfma(vf16, qc, o1[1][1]);
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb)
-            if (hg == hg_l) xl[(wid * QB + qb) * 32 + qi] = os[qb][db_l][r_l];
+            for (int qb = 0; qb < QB; ++qb)
+                if (lden) { xl[(wid * QB + qb) * 32 + (lane & 15)] = o1[qb][0][0]; xl[(wid * QB + qb) * 32 + 16 + (lane & 15)] = o1[qb][1][0]; }
+        } else {
+            os[1][0] = T::mfma32(vf[0][0], pf[1][0], os[1][0]);
+            os[1][DB - 1] = T::mfma32(vf[0][DB - 1], pf[1][0], os[1][DB - 1]);
+            os[1][0] = T::mfma32(vf[1][0], pf[1][1], os[1][0]);
+            os[1][DB - 1] = T::mfma32(vf[1][DB - 1], pf[1][1], os[1][DB - 1]);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+                if (lden) xl[(wid * QB + qb) * 32 + qi] = os[qb][DB - 1][r_l];
+        }
         if (SAMPLED && !ABL) {          // f16: an overflowed partial denominator (inf / NaN) is known before the exchange -- flag it through the same barrier
             bool ov = false;
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb) ov |= hg == hg_l && !(os[qb][db_l][r_l] < 1e37f);
+            for (int qb = 0; qb < QB; ++qb) {
+                if constexpr (PV16) ov |= lden && !(o1[qb][0][0] < 1e37f && o1[qb][1][0] < 1e37f);
+                else ov |= lden && !(os[qb][DB - 1][r_l] < 1e37f);
+            }
             if (__ballot(ov) != 0ull && lane == 0) *ovf = 1u;
         }
         __syncthreads();
@@ -331,10 +407,24 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
             const float inv = a.set_w[s] / l;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { otot0[qb][r] += os[qb][0][r] * inv; os[qb][0][r] = 0.f; }
+            if constexpr (PV16) {
+                // the 16x16 tiles: lane (query & 15) of half hh holds query 16 hh + (lane & 15) -- this lane's own query qi when hh == (qi >> 4), else qi ^ 16
+                const float l2 = xl[(wid * QB + qb) * 32 + (qi ^ 16)] + xl[((wid ^ 1) * QB + qb) * 32 + (qi ^ 16)];
+                bad |= !(l2 > 0.f && l2 < 1e37f);
+                const float inv2 = a.set_w[s] / l2;
+                const bool up = (qi >> 4) & 1;
+                const float i0 = up ? inv2 : inv, i1 = up ? inv : inv2;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) otot1[qb][r] += os[qb][1][r] * inv;
+                for (int r = 0; r < 4; ++r) {
+                    otot1[qb][0][r] += o1[qb][0][r] * i0; otot1[qb][1][r] += o1[qb][1][r] * i1;
+                    o1[qb][0][r] = 0.f; o1[qb][1][r] = 0.f;
+                }
+            } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) os[qb][1][r] = 0.f;
+                for (int r = 0; r < 4; ++r) otot1[qb][0][r] += os[qb][DB - 1][r] * inv;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) os[qb][DB - 1][r] = 0.f;
+            }
         }
     };
 
@@ -352,7 +442,7 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int db = 0; db < DB; ++db) vf[t][db] = make_uint4(0, 0, 0, 0);
+        for (int db = 0; db < (PV16 ? 1 : DB); ++db) vf[t][db] = make_uint4(0, 0, 0, 0);
     for (int s = 0; s < a.nsets; ++s) {
         samp = smem + XS + (s & 1) * KBYTES;
 #pragma unroll
@@ -380,32 +470,49 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
         return;
     }
     // ---- combine the two key halves: wave kh hands its partial of query block 1 - kh to its partner and stores block kh
-    float *xo = reinterpret_cast<float *>(smem) + (size_t)wid * (20 * 64);
+    constexpr int XR = PV16 ? 24 : 20;               // exchanged registers per lane
+    float *xo = reinterpret_cast<float *>(smem) + (size_t)wid * (XR * 64);
 #pragma unroll
     for (int r = 0; r < 16; ++r) xo[r * 64 + lane] = kh ? otot0[0][r] : otot0[1][r];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) xo[(16 + r) * 64 + lane] = kh ? otot1[0][r] : otot1[1][r];
+    for (int hh = 0; hh < (PV16 ? 2 : 1); ++hh)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xo[(16 + 4 * hh + r) * 64 + lane] = kh ? otot1[0][hh][r] : otot1[1][hh][r];
     __syncthreads();
-    const float *xp = reinterpret_cast<const float *>(smem) + (size_t)(wid ^ 1) * (20 * 64);
+    const float *xp = reinterpret_cast<const float *>(smem) + (size_t)(wid ^ 1) * (XR * 64);
     const int q = q_wave0 + 32 * kh + qi;
     unsigned short *orow = a.O + (int64_t)b * a.o_bs + (int64_t)q * a.ldo + h * D;
     {
-        float o[20];
+        float o[XR];
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r] = (kh ? otot0[1][r] : otot0[0][r]) + xp[r * 64 + lane];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[16 + r] = (kh ? otot1[1][r] : otot1[0][r]) + xp[(16 + r) * 64 + lane];
+        for (int hh = 0; hh < (PV16 ? 2 : 1); ++hh)
 #pragma unroll
-        for (int rq = 0; rq < 5; ++rq)      // channels 8 rq + 4 hg .. + 4 (rq = 4: rows 32..39 of row block 1)
+            for (int r = 0; r < 4; ++r) o[16 + 4 * hh + r] = (kh ? otot1[1][hh][r] : otot1[0][hh][r]) + xp[(16 + 4 * hh + r) * 64 + lane];
+#pragma unroll
+        for (int rq = 0; rq < (PV16 ? 4 : 5); ++rq)      // channels 8 rq + 4 hg .. + 4 (not PV16: rq = 4 = rows 32..39 of row block 1)
             *reinterpret_cast<uint2 *>(orow + 8 * rq + 4 * hg) =
                 make_uint2(pack2<T>(o[4 * rq], o[4 * rq + 1]), pack2<T>(o[4 * rq + 2], o[4 * rq + 3]));
+        if constexpr (PV16) {
+            // channels 32..39 from the 16x16 tiles: lanes 0..31 hold rows 4 (lane >> 4) + r of query 16 hh + (lane & 15) of the block
+            if (hg == 0) {
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int q16 = q_wave0 + 32 * kh + 16 * hh + (lane & 15);
+                    unsigned short *orow16 = a.O + (int64_t)b * a.o_bs + (int64_t)q16 * a.ldo + h * D;
+                    *reinterpret_cast<uint2 *>(orow16 + 32 + 4 * (lane >> 4)) =
+                        make_uint2(pack2<T>(o[16 + 4 * hh], o[16 + 4 * hh + 1]), pack2<T>(o[16 + 4 * hh + 2], o[16 + 4 * hh + 3]));
+                }
+            }
+        }
     }
 }
 
 template <class T, bool PRE, int NST, bool ABL = false>
 void launch_attn5_(const AttnArgs &a, int B, hipStream_t s)
 {
-    constexpr size_t ring = (size_t)NST * (64 * 128 + 2 * 32 * 128) + 2048 + 2 * (64 * 128) + 16, xchg = (size_t)8 * 20 * 64 * 4;   // ring + exchange + 2 sample tiles + flag
+    constexpr size_t ring = (size_t)NST * (64 * 128 + 2 * 32 * 128) + 2048 + 2 * (64 * 128) + 16, xchg = (size_t)8 * 24 * 64 * 4;   // ring + exchange + 2 sample tiles + flag
     constexpr size_t safe = SafeLds<40>::KBYTES + SafeLds<40>::VBYTES;
     constexpr size_t lds = ring > xchg ? (ring > safe ? ring : safe) : (xchg > safe ? xchg : safe);
     static gc::AttrOnce once;
