@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--chunk-size", type=int, default=3)
     ap.add_argument("--denoise-steps", type=int, default=20)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "fp8"])     # fp8: e4m3 resnet convs on the block-scaled MFMA, bf16 elsewhere
+    ap.add_argument("--fp8-linears", type=int, default=0)     # with --dtype fp8: bit mask of the transformer linears that also run on e4m3 (weights.add_fp8_linears)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="edit", choices=["edit", "raster", "full"])   # full: SURVEY.md 8d's optional whole-pipeline number (N = 1)
     ap.add_argument("--train-iters", type=int, default=500)     # --workload full: Adam iterations after the edit (gc_trainer.py:186-201)
@@ -217,8 +218,10 @@ class Bench:
             uw = prepare(usd, dt, dev, heads=8, fold_ln=fold_ln)
             cw = prepare(csd, dt, dev, heads=8, fold_ln=fold_ln)
             if dtype_name == "fp8":
-                from gaussctrl_amd.sd.weights import add_fp8_convs
+                from gaussctrl_amd.sd.weights import add_fp8_convs, add_fp8_linears
                 add_fp8_convs(uw, usd, dev); add_fp8_convs(cw, csd, dev)
+                if args.fp8_linears and not fold_ln:      # C = 640 / 1280 transformer linears on e4m3 (bit 0 feed-forward, 1 attn2.to_q, 2 Q | K | V)
+                    add_fp8_linears(uw, args.fp8_linears); add_fp8_linears(cw, args.fp8_linears)
             del usd, csd
             vw = prepare_vae_weights(arch.random_state_dict(arch.vae_decoder_shapes(), 300, dev), dt, dev)
             self.pipe = DenoisePipeline(uw, cw, vw, self.nsteps, 5.0)
@@ -564,16 +567,18 @@ def main():
         # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r02_attn_traffic.json, scripts/
         # pmc_kernel_traffic.py: FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes on the UNet's 5-set launch at chunk_size 3)
         traffic = None
+        traffic_src = None
         for tname in ("r04_attn_traffic.json", "r02_attn_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if kind.startswith(("k_attn4", "k_attn5")) and c == 3 and os.path.exists(tpath) and traffic is None:
                 for kn, v in json.load(open(tpath))["kernels"].items():
                     if kind[:7] in kn and "traffic_MB_per_dispatch" in v:
                         traffic = int(round(v["traffic_MB_per_dispatch"] * 1e6))
+                        traffic_src = f"profiles/{tname}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this kernel (not measured in this run)"
         roof = {"bound": "mfma", "kernel": kind + (" (multi-K/V-set flash attention, dn_attn.hip)" if kind.startswith("k_attn") else
                                                     " (k_gemm / k_gemm8 MFMA GEMM and implicit 3x3 conv, variant picked per grid, dn_gemm.hip)"),
                 "achieved": round(ach, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": traffic,
+                "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": traffic, "traffic_source": traffic_src,
                 "launches": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
                 "algorithmic_gflop_per_launch": round(d["flop"] / d["launches"] / 1e9, 3),
                 "other": {k: {"launches": v["launches"], "ms": round(v["ms"], 2),

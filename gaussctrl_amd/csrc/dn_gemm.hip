@@ -176,6 +176,11 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
     g.out_row_stats = d->out_row_stats; g.out_group_stats = d->out_group_stats; g.gn_groups = d->gn_groups;
     g.gn_cpg = d->gn_groups > 0 ? (int)(d->N / d->gn_groups) : 1;
     g.w_scale = (const unsigned char *)d->w_scale; g.a_scale = d->a_scale;
+    g.out_fp8 = d->out_fp8; g.out_qscale = d->out_fp8 > 0 ? exp2f((float)(127 - d->out_fp8)) : 1.f;
+    GC_REQUIRE(d->out_fp8 >= 0 && d->out_fp8 < 255, "out_fp8 must be 0 (off) or an E8M0 byte 1 .. 254");
+    GC_REQUIRE(!d->out_fp8 || (d->fp8 && d->mode == 0 && d->out && !d->out_f32 && !d->out_t && !d->out_chan_parts && !d->ln_row_stats && !d->out_row_stats &&
+                               !d->out_group_stats && d->ldc % 4 == 0),
+               "out_fp8: an fp8 linear with a plain output (no fp32 / transposed output, no statistics, no LayerNorm fold), ldc % 4 == 0");
     g.dbg = (d->kernel_variant >> 8) & 0xff;
     GC_REQUIRE((d->ln_row_stats == nullptr) == (d->ln_colsum == nullptr), "ln_row_stats and ln_colsum must be given together");
     GC_REQUIRE(!d->ln_row_stats || d->mode == 0, "LayerNorm folding applies to linear GEMMs");
@@ -210,11 +215,12 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
     g.zeros = d->zeros;
     if (d->fp8) {      // OCP e4m3 operands on the block-scaled MFMA (k_gemm8q): A / W are bytes, K counts fp8 elements
         GC_REQUIRE(d->zeros && d->w_scale, "fp8: zeros page and per-row weight scales are required");
-        GC_REQUIRE(d->K % 128 == 0 && !d->geglu && !d->out_t, "fp8: K % 128 == 0, no GEGLU / transposed output");
+        GC_REQUIRE(d->K % 128 == 0, "fp8: K % 128 == 0");
+        GC_REQUIRE(!(d->geglu || d->out_t) || (d->mode == 0 && !fuse_of(g)), "fp8: GEGLU / transposed output on linears with the plain epilogue only");
         GC_REQUIRE(d->mode == 0 || (d->Cin % 128 == 0 && !d->upsample), "fp8 conv: Cin (padded) % 128 == 0, no fused upsample");
         GC_REQUIRE(d->mode == 1 || d->lda % 16 == 0, "fp8 linear: lda % 16 == 0");
         GC_REQUIRE((int64_t)d->N * d->K < ((int64_t)1 << 31) && (d->mode == 1 ? (int64_t)d->B * d->Hi * d->Wi * d->Cin : d->M * d->lda) < ((int64_t)1 << 31), "fp8: 32-bit offsets");
-        const int ntw = (d->N % 160 == 0 && d->N % 128 != 0) ? 5 : 4;
+        const int ntw = (d->N % 160 == 0 && d->N % 128 != 0 && !d->geglu) ? 5 : 4;      // (GEGLU pairs n-tiles inside a wave: even count)
         // the e4m3 fragments are 8 registers each (32 k per lane): only the variants that stay under 256 VGPRs without spilling are
         // instantiated -- (NTW 5, MT 2), (NTW 4, MT 2 | 3); a spill reload is a VM load that stalls behind the LDS-DMA queue
         int mt = force_mt ? force_mt : choose_mt(d->M, d->N, ntw, true);

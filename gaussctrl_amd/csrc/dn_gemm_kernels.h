@@ -52,6 +52,8 @@ struct GemmArgs {
     int gn_groups, gn_cpg;              // a few float atomics into the zero-initialised buffer     -> gc_dn_groupnorm_apply
     const unsigned char *w_scale;       // fp8 path: E8M0 scale byte per weight row [N] (weights stored as e4m3 * 2^(127 - byte))
     int a_scale;                        // fp8 path: E8M0 scale byte of the whole activation tensor
+    int out_fp8; float out_qscale;      // fp8 path, plain epilogue: store e4m3 BYTES of v * out_qscale (= 2^(127 - out_fp8)) at out[m * ldc + n]: the
+                                        // e4m3 activation operand of the next fp8 GEMM (GEGLU hidden -> FF down projection)
     int dbg;                            // experiment switches (kernel_variant bits 8..): 1 no global group atomics, 2 no LDS atomics, 4 no DPP
     // partial GroupNorm-group sums of the stored output, the statistics pass of the GroupNorm that follows (k_gemm8 CS = true,
     // k_splitk_epilogue_cs): chan_parts[b][slab][group][half] = (sum, sum^2) over the rows of batch b inside the slab-th row tile (cp_rows
@@ -1647,7 +1649,13 @@ __global__ __launch_bounds__(512, 1) void k_gemm8q(const GemmArgs g)
                 v[2] += T::to_f((unsigned short)(rs[nt].y & 0xffff)); v[3] += T::to_f((unsigned short)(rs[nt].y >> 16));
             }
             const bool to_t = g.out_t && on >= g.t_col0;
-            if (g.out && !(to_t && g.t_col0 > 0)) {
+            if (g.out_fp8) {   // e4m3 bytes, saturated like gc_dn_groupnorm_apply_fp8 (4 columns = one 32-bit store)
+                const float q0 = fminf(fmaxf(v[0] * g.out_qscale, -448.f), 448.f), q1 = fminf(fmaxf(v[1] * g.out_qscale, -448.f), 448.f);
+                const float q2 = fminf(fmaxf(v[2] * g.out_qscale, -448.f), 448.f), q3 = fminf(fmaxf(v[3] * g.out_qscale, -448.f), 448.f);
+                int w8 = 0;
+                w8 = __builtin_amdgcn_cvt_pk_fp8_f32(q0, q1, w8, false); w8 = __builtin_amdgcn_cvt_pk_fp8_f32(q2, q3, w8, true);
+                *reinterpret_cast<int *>((unsigned char *)g.out + m * g.ldc + on) = w8;
+            } else if (g.out && !(to_t && g.t_col0 > 0)) {
                 if (g.out_f32)
                     *reinterpret_cast<float4 *>((float *)g.out + m * g.ldc + on) = make_float4(v[0], v[1], v[2], v[3]);
                 else

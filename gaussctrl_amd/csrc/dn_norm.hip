@@ -598,6 +598,53 @@ __global__ __launch_bounds__(256) void k_layernorm(const unsigned short *__restr
     }
 }
 
+// LayerNorm with an OCP fp8 (e4m3) output: same wave-per-row two-pass kernel, 8 bytes stored per 16-byte input chunk; stored value =
+// y * qscale (power of two: the tensor-wide E8M0 activation scale of the fp8 GEMM that consumes it), saturated to +-448.
+template <class T>
+__global__ __launch_bounds__(256) void k_layernorm_fp8(const unsigned short *__restrict__ x, unsigned char *__restrict__ y8,
+                                                       int64_t M, int C, const float *__restrict__ gamma,
+                                                       const float *__restrict__ beta, float eps, float qscale)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nch = C / 8;
+    float f[4][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+            unpack8<T>(*reinterpret_cast<const uint4 *>(x + row * C + ch * 8), f[i]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += f[i][j];
+        }
+    }
+    const float mean = wave_sum_f(s) / (float)C;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (lane + 64 * i < nch) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = f[i][j] - mean; v += d * d; }
+        }
+    const float rstd = rsqrtf(wave_sum_f(v) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                o[j] = fminf(fmaxf(((f[i][j] - mean) * rstd * gamma[ch * 8 + j] + beta[ch * 8 + j]) * qscale, -448.f), 448.f);
+            int w0 = 0, w1 = 0;
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(o[0], o[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(o[2], o[3], w0, true);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(o[4], o[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(o[6], o[7], w1, true);
+            *reinterpret_cast<uint2 *>(y8 + row * C + ch * 8) = make_uint2((unsigned)w0, (unsigned)w1);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ elementwise
 // out[M, C1+C2] = [a[M,C1] | b[M,C2] (+ c[M,C2])]   (skip concat of the up blocks, with the ControlNet
 // residual add of `down_block_res_samples` folded in)
@@ -881,6 +928,19 @@ int gc_dn_layernorm(int dtype, const void *x, void *y, int64_t M, int C, const f
                 hipLaunchKernelGGL((k_layernorm<BF16>), grid, dim3(256), 0, gc::S(stream), (const unsigned short *)x, (unsigned short *)y, M, C, gamma, beta, eps),
                 hipLaunchKernelGGL((k_layernorm<F16>), grid, dim3(256), 0, gc::S(stream), (const unsigned short *)x, (unsigned short *)y, M, C, gamma, beta, eps));
     return gc::check_launch("gc_dn_layernorm");
+}
+
+int gc_dn_layernorm_fp8(int dtype, const void *x, void *y8, int64_t M, int C, const float *gamma, const float *beta,
+                        float eps, int a_scale, void *stream)
+{
+    GC_REQUIRE(C % 16 == 0 && C <= 2048, "layernorm_fp8: C must be a multiple of 16 and <= 2048");
+    GC_REQUIRE(a_scale > 0 && a_scale < 255 && M > 0 && x && y8 && gamma && beta, "layernorm_fp8: bad scale / null argument");
+    const float qscale = exp2f((float)(127 - a_scale));
+    dim3 grid((unsigned)((M + 3) / 4));
+    DN_DISPATCH(dtype,
+                hipLaunchKernelGGL((k_layernorm_fp8<BF16>), grid, dim3(256), 0, gc::S(stream), (const unsigned short *)x, (unsigned char *)y8, M, C, gamma, beta, eps, qscale),
+                hipLaunchKernelGGL((k_layernorm_fp8<F16>), grid, dim3(256), 0, gc::S(stream), (const unsigned short *)x, (unsigned char *)y8, M, C, gamma, beta, eps, qscale));
+    return gc::check_launch("gc_dn_layernorm_fp8");
 }
 
 int gc_dn_concat_add(int dtype, const void *a, int C1, const void *b, const void *c, int C2, void *out, int64_t M, int64_t rows_per_batch,

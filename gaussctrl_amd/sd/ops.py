@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
                 ("ln_row_stats", C.c_void_p), ("ln_row_stat_slots", C.c_int), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float),
                 ("out_row_stats", C.c_void_p), ("out_group_stats", C.c_void_p), ("gn_groups", C.c_int),
                 ("fp8", C.c_int), ("w_scale", C.c_void_p), ("a_scale", C.c_int),
-                ("kernel_variant", C.c_int), ("out_chan_parts", C.c_void_p), ("plan_rows", C.c_int64)]
+                ("kernel_variant", C.c_int), ("out_chan_parts", C.c_void_p), ("plan_rows", C.c_int64), ("out_fp8", C.c_int)]
 
 
 class AttnDesc(C.Structure):
@@ -402,13 +402,16 @@ def conv3x3_fp8(x8, w8, w_scale, out_dtype, bias=None, stride=1, rowvec=None, ld
 
 
 def linear_fp8(x8, w8, w_scale, out_dtype, bias=None, residual=None, act=0, scale=1.0, a_scale=127, rows_per_batch=0, row_stats=None,
-               group_stats=None, ln=None):
-    """x8 [..., K] e4m3 bytes @ w8[N, K]^T (K % 128 == 0) on the block-scaled MFMA, output `out_dtype`."""
+               group_stats=None, ln=None, geglu=False, out_fp8=0, out_t=None, ldt=0, t_batch_stride=0, t_col0=0, out_cols=None):
+    """x8 [..., K] e4m3 bytes @ w8[N, K]^T (K % 128 == 0) on the block-scaled MFMA, output `out_dtype` -- or, with out_fp8 = an E8M0 byte,
+    e4m3 bytes of value * 2^(127 - out_fp8) (uint8 tensor: the operand of the next fp8 linear).  geglu: rows of w8 / bias permuted by
+    weights.geglu_permute, output [..., N / 2]; out_t / ldt / t_batch_stride / t_col0 / out_cols: the fused Q | K | V^T layout of `linear`."""
     _gpu(x8, w8, w_scale)
     K = x8.shape[-1]
     M = x8.numel() // K
     N = w8.shape[0]
-    out = torch.empty(x8.shape[:-1] + (N,), dtype=out_dtype, device=x8.device)
+    No = N // 2 if geglu else (N if out_cols is None else out_cols)
+    out = torch.empty(x8.shape[:-1] + (No,), dtype=torch.uint8 if out_fp8 else out_dtype, device=x8.device)
     d = GemmDesc()
     d.dtype = DT[out_dtype]; d.mode = 0; d.M, d.N, d.K = M, N, K
     d.A = x8.data_ptr(); d.lda = x8.stride(-2) if x8.dim() > 1 else K; d.W = w8.data_ptr()
@@ -416,12 +419,24 @@ def linear_fp8(x8, w8, w_scale, out_dtype, bias=None, residual=None, act=0, scal
     d.rows_per_batch = rows_per_batch
     if residual is not None:
         d.residual = residual.data_ptr(); d.ldr = residual.stride(-2)
-    d.out_scale = scale; d.act = act
-    d.out = out.data_ptr(); d.ldc = N
+    d.out_scale = scale; d.act = act; d.geglu = int(geglu)
+    d.out = out.data_ptr(); d.ldc = out.stride(-2) if out.dim() > 1 else No; d.out_fp8 = int(out_fp8)
+    if out_t is not None:
+        d.out_t = out_t.data_ptr(); d.ldt = ldt; d.t_batch_stride = t_batch_stride; d.t_col0 = t_col0
     d.fp8 = 1; d.w_scale = w_scale.data_ptr(); d.a_scale = int(a_scale)
     _stats_args(d, ln, group_stats)
     _run_gemm(d, x8.device, "gc_dn_gemm(linear fp8)", row_stats)
     return out
+
+
+def layernorm_fp8(x, gamma, beta, eps=1e-5, a_scale=127):
+    """LayerNorm with an e4m3 output [.., C] (uint8) for linear_fp8; a_scale = E8M0 byte of the tensor-wide scale (stored = y * 2^(127 - a_scale))."""
+    _gpu(x)
+    Cc = x.shape[-1]
+    y = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    L.check(L.lib().gc_dn_layernorm_fp8(_dt(x), _p(x), _p(y), C.c_int64(x.numel() // Cc), Cc, _p(gamma), _p(beta),
+                                        C.c_float(eps), int(a_scale), _stream()), "gc_dn_layernorm_fp8")
+    return y
 
 
 def layernorm(x, gamma, beta, eps=1e-5):

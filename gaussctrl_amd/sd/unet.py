@@ -113,6 +113,11 @@ class SDNet:
                                                                     # measured neutral (7.02 vs 6.97 views/s) and it gives up the shifted sums
         self.fp8 = bool(weights.get("_fp8_convs", False))           # resnet 3x3 convs on e4m3 operands (weights.add_fp8_convs)
         self.fp8_a_scale = 127                                      # E8M0 byte of the conv inputs (GroupNorm + SiLU outputs are O(1): 2^0)
+        # transformer-block linears of the C = 640 / 1280 levels on e4m3 operands (weights.add_fp8_linears): the three LayerNorms write e4m3,
+        # the GEGLU epilogue writes the FF hidden as e4m3; E8M0 bytes of the two activation kinds (LayerNorm outputs, GEGLU hidden): 2^0
+        self.fp8_lin = int(weights.get("_fp8_linears", 0))          # bit 0: feed-forward, bit 1: attn2.to_q, bit 2: Q | K | V
+        self.fp8_ln_scale = 127
+        self.fp8_ff_scale = 127
         # level-0 transformer blocks: everything after the self-attention in ONE launch (ops.transformer_tail, csrc/dn_ttail.hip): 148 us
         # against 225 us for the nine per-op launches at 6 x 4096 tokens, +4.3 % views/s end to end.  ops.KernelOptions.fused_tail.
         self.fused_tail = ops.OPTIONS.fused_tail
@@ -216,16 +221,22 @@ class SDNet:
             return ops.conv3x3(h, w[p + ".conv2.weight"], w[p + ".conv2.bias"], residual=sc, chan_parts=True)
         return ops.conv3x3(h, w[p + ".conv2.weight"], w[p + ".conv2.bias"], residual=sc, group_stats=os_), os_
 
-    def _self_attention(self, p, n, actx: AttnCtx, ln=None):
-        """n: LayerNorm-ed tokens, or the raw tokens with ln = (row sums, colsum, eps) when norm1 is folded into the Q|K|V GEMM"""
+    def _self_attention(self, p, n, actx: AttnCtx, ln=None, dt=None):
+        """n: LayerNorm-ed tokens, or the raw tokens with ln = (row sums, colsum, eps) when norm1 is folded into the Q|K|V GEMM, or (dt given)
+        the e4m3 bytes of the LayerNorm-ed tokens for the fp8 projection (weights.add_fp8_linears)"""
         w = self.w
         heads = self.cfg["heads"]
         B, L, Cc = n.shape
         Lp = (L + 7) // 8 * 8
-        vt = torch.zeros(B, Cc, Lp, dtype=n.dtype, device=n.device) if Lp != L else torch.empty(B, Cc, Lp, dtype=n.dtype, device=n.device)
+        adt = dt or n.dtype
+        vt = torch.zeros(B, Cc, Lp, dtype=adt, device=n.device) if Lp != L else torch.empty(B, Cc, Lp, dtype=adt, device=n.device)
         # one GEMM for Q | K | V: columns [0,2C) -> qk [B,L,2C], columns [2C,3C) -> V^T [B,C,Lp]
-        qk = ops.linear(n, w[p + ".to_qkv.weight"], w.get(p + ".to_qkv.bias") if ln is not None else None, rows_per_batch=L, out_t=vt,
-                        ldt=Lp, t_batch_stride=Cc * Lp, t_col0=2 * Cc, out_cols=2 * Cc, ln=ln)
+        if dt is not None:
+            qk = ops.linear_fp8(n, w[p + ".to_qkv.w8"], w[p + ".to_qkv.w8_scale"], dt, rows_per_batch=L, out_t=vt, ldt=Lp, t_batch_stride=Cc * Lp,
+                                t_col0=2 * Cc, out_cols=2 * Cc, a_scale=self.fp8_ln_scale)
+        else:
+            qk = ops.linear(n, w[p + ".to_qkv.weight"], w.get(p + ".to_qkv.bias") if ln is not None else None, rows_per_batch=L, out_t=vt,
+                            ldt=Lp, t_batch_stride=Cc * Lp, t_col0=2 * Cc, out_cols=2 * Cc, ln=ln)
         return self._attend(p, qk[..., :Cc], qk[..., Cc:], vt, actx)
 
     def _attend(self, p, q, k, vt, actx: AttnCtx):
@@ -289,6 +300,9 @@ class SDNet:
         # direct caller with one ctx row per frame -- takes the per-op path)
         tail = self.tail_eligible(p, ctx) and (H * W_) % 128 == 0 and B % ctx.shape[0] == 0
         hfr = False
+        # (C = 640 / 1280 blocks: weights.add_fp8_linears; k_gemm8q has no k-slices, so the few-row problems -- the 8 x 8 maps, where the 5120 -> 1280
+        # down projection is 30 tiles of 40 k-steps -- stay on the split-K bf16 kernels, as the small-map convolutions do)
+        q8 = self.fp8_lin if (not fold and not tail and (t + ".ff.net.0.proj.w8") in w and B * H * W_ >= 1024) else 0
         if self.fused_head and (p + ".head.w") in w and not fold and (xs is None or isinstance(xs, ops.ChanParts)) and (H * W_) % 128 == 0:
             x3 = x.view(B, H * W_, Cc)
             coef = ops.groupnorm_coef(x3, w[p + ".norm.weight"], w[p + ".norm.bias"], self.cfg["groups"], 1e-6, parts=xs)
@@ -301,6 +315,9 @@ class SDNet:
             h = ops.linear(h.view(B, H * W_, Cc), w[p + ".proj_in.weight"], w[p + ".proj_in.bias"], row_stats=rs)
             if fold:
                 o = self._self_attention(t + ".attn1", h, actx, ln=(rs, w[t + ".attn1.to_qkv.colsum"], 1e-5))
+            elif q8 & 4:
+                o = self._self_attention(t + ".attn1", ops.layernorm_fp8(h, w[t + ".norm1.weight"], w[t + ".norm1.bias"], a_scale=self.fp8_ln_scale),
+                                         actx, dt=h.dtype)
             else:
                 o = self._self_attention(t + ".attn1", ops.layernorm(h, w[t + ".norm1.weight"], w[t + ".norm1.bias"]), actx)
         if tail:
@@ -312,6 +329,9 @@ class SDNet:
         h = ops.linear(o, w[t + ".attn1.to_out.0.weight"], w[t + ".attn1.to_out.0.bias"], residual=h, row_stats=rs)
         if fold:
             q = ops.linear(h, w[t + ".attn2.to_q.weight"], w[t + ".attn2.to_q.bias"], ln=(rs, w[t + ".attn2.to_q.colsum"], 1e-5))
+        elif q8 & 2:
+            q = ops.linear_fp8(ops.layernorm_fp8(h, w[t + ".norm2.weight"], w[t + ".norm2.bias"], a_scale=self.fp8_ln_scale),
+                               w[t + ".attn2.to_q.w8"], w[t + ".attn2.to_q.w8_scale"], h.dtype, a_scale=self.fp8_ln_scale)
         else:
             q = ops.linear(ops.layernorm(h, w[t + ".norm2.weight"], w[t + ".norm2.bias"]), w[t + ".attn2.to_q.weight"])
         k, vt, Lt = self._text_kv(t + ".attn2", ctx, actx)
@@ -322,10 +342,18 @@ class SDNet:
         if fold:
             ff = ops.linear(h, w[t + ".ff.net.0.proj.weight"], w[t + ".ff.net.0.proj.bias"], geglu=True,
                             ln=(rs, w[t + ".ff.net.0.proj.colsum"], 1e-5))
+        elif q8 & 1:      # LayerNorm -> e4m3, GEGLU projection on the block-scaled MFMA writing the hidden as e4m3, down projection on it
+            ff = ops.linear_fp8(ops.layernorm_fp8(h, w[t + ".norm3.weight"], w[t + ".norm3.bias"], a_scale=self.fp8_ln_scale),
+                                w[t + ".ff.net.0.proj.w8"], w[t + ".ff.net.0.proj.w8_scale"], h.dtype, w[t + ".ff.net.0.proj.bias"], geglu=True,
+                                a_scale=self.fp8_ln_scale, out_fp8=self.fp8_ff_scale)
         else:
             ff = ops.linear(ops.layernorm(h, w[t + ".norm3.weight"], w[t + ".norm3.bias"]), w[t + ".ff.net.0.proj.weight"],
                             w[t + ".ff.net.0.proj.bias"], geglu=True)
-        h = ops.linear(ff, w[t + ".ff.net.2.weight"], w[t + ".ff.net.2.bias"], residual=h)
+        if q8 & 1:
+            h = ops.linear_fp8(ff, w[t + ".ff.net.2.w8"], w[t + ".ff.net.2.w8_scale"], h.dtype, w[t + ".ff.net.2.bias"], residual=h,
+                               a_scale=self.fp8_ff_scale)
+        else:
+            h = ops.linear(ff, w[t + ".ff.net.2.weight"], w[t + ".ff.net.2.bias"], residual=h)
         os_ = self._cs(B, Cc, H * W_)
         if self.gn_parts and os_ is None:
             out, os_ = ops.linear(h, w[p + ".proj_out.weight"], w[p + ".proj_out.bias"], residual=x.view(B, H * W_, Cc), rows_per_batch=H * W_,

@@ -249,3 +249,19 @@ def add_fp8_convs(out: dict, sd: dict, device) -> dict:
             out[k[:-len("weight")] + "w8"], out[k[:-len("weight")] + "w8_scale"] = q, sc
     out["_fp8_convs"] = True
     return out
+
+
+def add_fp8_linears(out: dict, which: int = 7) -> dict:
+    """fp8 copies of the transformer-block linears whose input a LayerNorm or the GEGLU epilogue can write as e4m3 (levels with
+    C % 128 == 0, i.e. the C = 640 / 1280 blocks; the C = 320 blocks run in the row-resident head / tail kernels): the fused Q | K | V
+    projection, attn2.to_q, the GEGLU projection and the FF down projection -- ~85 % of a block's linear FLOPs.  Quantised from the PREPARED
+    tensors of `out` (softmax scale folded into Q, GEGLU rows permuted), per output row (quantize_rows_e4m3).  Not with folded LayerNorms."""
+    assert not out.get("_ln_folded"), "fp8 linears take their input from the LayerNorm kernel: prepare(fold_ln=False)"
+    for k in list(out.keys()):
+        if k.endswith(".attn1.to_qkv.weight") and out[k].shape[1] % 128 == 0:
+            t = k[:-len("attn1.to_qkv.weight")]
+            for name in ("attn1.to_qkv", "attn2.to_q", "ff.net.0.proj", "ff.net.2"):
+                q, sc = quantize_rows_e4m3(out[t + name + ".weight"].float())
+                out[t + name + ".w8"], out[t + name + ".w8_scale"] = q, sc
+    out["_fp8_linears"] = int(which)        # bit 0: feed-forward, bit 1: attn2.to_q, bit 2: Q | K | V (SDNet.fp8_lin)
+    return out

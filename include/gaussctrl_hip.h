@@ -292,6 +292,9 @@ typedef struct gc_gemm_desc {
     int64_t plan_rows;         /* 0 = plan for M.  > 0 (the rows ONE frame contributes: tokens, or Ho * Wo): kernel family and split-K are planned as if */
                                /* M were plan_rows, so every output row is accumulated in the same order whatever else shares the batch */
                                /* (batch-invariant results: a view's latents do not depend on its chunk-mates or on the rank count) */
+    int out_fp8;               /* fp8 linears only: 0 = output in `dtype`; else an E8M0 byte: `out` receives e4m3 BYTES [M][ldc] of value * 2^(127 - out_fp8), */
+                               /* saturated to +-448 -- the activation operand of a following fp8 GEMM with a_scale = out_fp8 (GEGLU hidden ->    */
+                               /* FF down projection: the feed-forward of /root/reference/gaussctrl/utils.py:121-131's blocks stays in e4m3)       */
 } gc_gemm_desc;
 size_t gc_dn_gemm_workspace_bytes(const gc_gemm_desc *desc);
 int gc_dn_gemm_row_stat_slots(const gc_gemm_desc *desc);   /* column slabs per row this problem writes to out_row_stats (with desc->workspace set) */
@@ -409,6 +412,10 @@ int gc_dn_group_stats(int dtype, const void *x, int64_t B, int64_t HW, int C, in
 /* LayerNorm over C on [M][C]. */
 int gc_dn_layernorm(int dtype, const void *x, void *y, int64_t M, int C, const float *gamma, const float *beta,
                     float eps, void *stream);
+/* LayerNorm over C on [M][C] with an OCP fp8 (e4m3) output y8[M][C] (bytes; C % 16 == 0): stored = y * 2^(127 - a_scale), saturated to
+ * +-448 -- the activation operand of the fp8 linears that consume a LayerNorm (Q | K | V, attn2.to_q, the GEGLU projection). */
+int gc_dn_layernorm_fp8(int dtype, const void *x, void *y8, int64_t M, int C, const float *gamma, const float *beta,
+                        float eps, int a_scale, void *stream);
 /* out[M][C1+C2] = [a | b (+ c)] : skip concat of the up blocks with the ControlNet residual add folded in.
  * group_stats (optional, caller-zeroed [M / rows_per_batch][gn_groups][2]): per (batch, GroupNorm group) (sum, sum of squares) of `out`. */
 int gc_dn_concat_add(int dtype, const void *a, int C1, const void *b, const void *c, int C2, void *out, int64_t M,

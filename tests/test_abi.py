@@ -72,3 +72,42 @@ def test_library_has_no_packed_fp32_arithmetic(built):
     found, functions = audit.audit(built)
     assert functions > 300, functions            # every translation unit's code object was found
     assert not found, found
+
+
+def test_descriptor_structs_match_the_header(tmp_path):
+    """the ctypes mirrors of gc_gemm_desc / gc_attn_desc (gaussctrl_amd/sd/ops.py) have the size and the last-field offset the C compiler
+    gives the header's structs: a field added on one side only would shift every later argument silently."""
+    import subprocess
+    from gaussctrl_amd.sd import ops
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "gaussctrl_hip.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu\\n", sizeof(gc_gemm_desc), offsetof(gc_gemm_desc, out_fp8), sizeof(gc_attn_desc),'
+                   ' offsetof(gc_attn_desc, workspace_bytes)); return 0; }\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert got == [ctypes.sizeof(ops.GemmDesc), ops.GemmDesc.out_fp8.offset, ctypes.sizeof(ops.AttnDesc), ops.AttnDesc.workspace_bytes.offset]
+
+
+def test_fp8_linear_copies_of_transformer_weights():
+    """weights.add_fp8_linears (host side, CPU): e4m3 copies exist for the C % 128 == 0 blocks only, dequantise to within one e4m3 step of
+    the prepared 2-byte weights (row scale = power of two, row maximum in the top binade), and keep the GEGLU row permutation."""
+    import torch
+    from gaussctrl_amd.sd.weights import add_fp8_linears
+    g = torch.Generator().manual_seed(0)
+    out = {}
+    for name, C in (("a.transformer_blocks.0.", 640), ("b.transformer_blocks.0.", 320)):
+        for lin, (n, k) in (("attn1.to_qkv", (3 * C, C)), ("attn2.to_q", (C, C)), ("ff.net.0.proj", (8 * C, C)), ("ff.net.2", (C, 4 * C))):
+            out[name + lin + ".weight"] = (torch.randn(n, k, generator=g) * k ** -0.5 * torch.exp2(torch.randint(-6, 6, (n, 1), generator=g).float())).to(torch.bfloat16)
+    add_fp8_linears(out, 5)
+    assert out["_fp8_linears"] == 5
+    assert not any(k.startswith("b.") and k.endswith(".w8") for k in out)
+    for lin in ("attn1.to_qkv", "attn2.to_q", "ff.net.0.proj", "ff.net.2"):
+        w = out["a.transformer_blocks.0." + lin + ".weight"].double()
+        q, sc = out["a.transformer_blocks.0." + lin + ".w8"], out["a.transformer_blocks.0." + lin + ".w8_scale"]
+        assert q.dtype == torch.uint8 and q.shape == w.shape and sc.shape == (w.shape[0],)
+        deq = q.view(torch.float8_e4m3fn).double() * torch.exp2(sc.double() - 127)[:, None]
+        amax = w.abs().amax(1, keepdim=True)
+        assert bool(((deq - w).abs() <= 0.0626 * w.abs() + amax * 2.0 ** -9).all())          # half an e4m3 step (normal), subnormal floor
+        stored_max = q.view(torch.float8_e4m3fn).float().abs().amax(1)
+        assert bool((stored_max >= 224).all()) and bool((stored_max <= 448).all())

@@ -449,6 +449,83 @@ def test_linear_fp8(dt, M, N, K):
     _close(got, ref + r.double().cpu(), dt)
 
 
+def _e4m3_bytes_match(y8, want_real, a_scale, max_frac):
+    """y8 (uint8, e4m3 of value * 2^(127 - a_scale)) equals the e4m3 rounding of `want_real` (fp64): a share < max_frac of the bytes may sit
+    ONE e4m3 step away (the kernel's fp32 arithmetic lands on the other side of a rounding boundary), none further."""
+    q = 2.0 ** (a_scale - 127)
+    got = y8.view(torch.float8_e4m3fn).double().cpu() * q
+    want = (want_real.cpu() / q).clamp(-448, 448).float().to(torch.float8_e4m3fn).double() * q
+    diff = (got - want).abs()
+    within("share of e4m3 bytes that differ from the rounded fp64 result", float((diff > 0).double().mean()), max_frac)
+    assert bool((diff <= torch.maximum(0.126 * want.abs(), torch.tensor(2.0 ** -9 * q).double()) + 1e-12).all()), float(diff.max())
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("M,C", [(1024, 640), (384, 1280), (1001, 1280), (64, 320)])
+def test_layernorm_fp8(dt, M, C):
+    """LayerNorm with an e4m3 output (gc_dn_layernorm_fp8): the e4m3 rounding of the fp64 LayerNorm of the same input."""
+    from gaussctrl_amd.sd import ops
+    x = (_rand((M, C), dt, 1.0, 1).float() * 1.7 + 0.4).to(dt)
+    gamma = torch.randn(C, device=DEV) * 0.5 + 1.0; beta = torch.randn(C, device=DEV) * 0.3
+    ref = F.layer_norm(x.double(), (C,), gamma.double(), beta.double(), 1e-5)
+    for a_scale in (127, 125):
+        y8 = ops.layernorm_fp8(x, gamma, beta, 1e-5, a_scale)
+        assert y8.shape == x.shape and y8.dtype == torch.uint8
+        _e4m3_bytes_match(y8, ref, a_scale, 2e-3)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("M,N,K", [(1024, 5120, 640), (384, 10240, 1280), (1000, 2560, 640), (6144, 5120, 640)])
+def test_linear_fp8_geglu_and_e4m3_output(dt, M, N, K):
+    """the GEGLU projection on e4m3 operands (k_gemm8q, rows permuted by weights.geglu_permute): 2-byte output vs fp64 of the same operands,
+    and the e4m3 output (gc_gemm_desc.out_fp8) vs the e4m3 rounding of that fp64 result; then the FF down projection consumes the bytes."""
+    from gaussctrl_amd.sd import ops
+    from gaussctrl_amd.sd.weights import quantize_rows_e4m3, geglu_permute
+    g = torch.Generator().manual_seed(4)
+    x8 = (torch.randn(M, K, generator=g) * 1.5).to(torch.float8_e4m3fn).view(torch.uint8)
+    w32 = torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g) * 0.5
+    w8, wsc = quantize_rows_e4m3(w32)
+    full = _deq(x8) @ _deq(w8, wsc).T + b.double()
+    ref = full[:, :N // 2] * F.gelu(full[:, N // 2:])
+    wp, bp = geglu_permute(w8, b)
+    scp, _ = geglu_permute(wsc, None)
+    got = ops.linear_fp8(x8.to(DEV), wp.to(DEV), scp.to(DEV), dt, bp.to(DEV), geglu=True)
+    assert got.shape == (M, N // 2)
+    _close(got, ref, dt, extra=2.0)
+    for osc in (127, 126):
+        y8 = ops.linear_fp8(x8.to(DEV), wp.to(DEV), scp.to(DEV), dt, bp.to(DEV), geglu=True, out_fp8=osc)
+        assert y8.dtype == torch.uint8 and y8.shape == (M, N // 2)
+        _e4m3_bytes_match(y8, ref, osc, 5e-3)
+        # the down projection on those bytes (a_scale = the producer's out_fp8)
+        w2, w2sc = quantize_rows_e4m3(torch.randn(K, N // 2, generator=g) * (N // 2) ** -0.5)
+        r = _rand((M, K), dt, 1.0, 5)
+        ref2 = (_deq(y8.cpu()) * 2.0 ** (osc - 127)) @ _deq(w2, w2sc).T + r.double().cpu()
+        _close(ops.linear_fp8(y8, w2.to(DEV), w2sc.to(DEV), dt, residual=r, a_scale=osc), ref2, dt)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("B,L,C", [(2, 1024, 640), (3, 256, 1280), (2, 64, 1280), (1, 100, 640)])
+def test_linear_fp8_qkv_transposed_v(dt, B, L, C):
+    """the fused Q | K | V projection on e4m3 operands: columns [0, 2C) -> qk [B, L, 2C], columns [2C, 3C) -> V^T [B, C, Lp] (the layout of
+    ops.linear(out_t=...) the attention kernels read)."""
+    from gaussctrl_amd.sd import ops
+    from gaussctrl_amd.sd.weights import quantize_rows_e4m3
+    g = torch.Generator().manual_seed(6)
+    x8 = (torch.randn(B, L, C, generator=g) * 1.5).to(torch.float8_e4m3fn).view(torch.uint8)
+    w8, wsc = quantize_rows_e4m3(torch.randn(3 * C, C, generator=g) * C ** -0.5)
+    ref = _deq(x8) @ _deq(w8, wsc).T
+    Lp = (L + 7) // 8 * 8
+    vt = torch.zeros(B, C, Lp, dtype=dt, device=DEV)
+    qk = ops.linear_fp8(x8.to(DEV), w8.to(DEV), wsc.to(DEV), dt, rows_per_batch=L, out_t=vt, ldt=Lp, t_batch_stride=C * Lp, t_col0=2 * C,
+                        out_cols=2 * C)
+    assert qk.shape == (B, L, 2 * C)
+    _close(qk, ref[..., :2 * C], dt)
+    _close(vt[..., :L].transpose(1, 2), ref[..., 2 * C:], dt)
+    if Lp != L:
+        assert float(vt[..., L:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("B,HW,C", [(2, 256, 320), (3, 64, 1280), (6, 4096, 320), (2, 1024, 960)])
 def test_groupnorm_apply_fp8(dt, B, HW, C):
