@@ -50,8 +50,8 @@ def parse():
     ap.add_argument("--views", type=int, default=None)     # default: 40 (edit, BASELINE configs[1]) / 256 cameras (raster, configs[4])
     ap.add_argument("--chunk-size", type=int, default=3)
     ap.add_argument("--denoise-steps", type=int, default=20)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "fp8"])     # fp8: e4m3 resnet convs on the block-scaled MFMA, bf16 elsewhere
-    ap.add_argument("--fp8-linears", type=int, default=0)     # with --dtype fp8: bit mask of the transformer linears that also run on e4m3 (weights.add_fp8_linears)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "fp8"])     # fp8: e4m3 resnet convs + C = 640 / 1280 transformer linears on the block-scaled MFMA, bf16 elsewhere
+    ap.add_argument("--fp8-linears", type=int, default=7)     # with --dtype fp8: bit mask of the C = 640 / 1280 transformer linears that also run on e4m3 (weights.add_fp8_linears; 0: convolutions only)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="edit", choices=["edit", "raster", "full"])   # full: SURVEY.md 8d's optional whole-pipeline number (N = 1)
     ap.add_argument("--train-iters", type=int, default=500)     # --workload full: Adam iterations after the edit (gc_trainer.py:186-201)

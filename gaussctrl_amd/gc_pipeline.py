@@ -60,6 +60,9 @@ class GaussCtrlPipelineConfig(_PipelineConfigBase):
     # --- additions of this implementation
     controlnet_ckpt: str = "lllyasviel/sd-controlnet-depth"      # hard-coded in the reference (:100)
     dtype: str = "f16"                 # the reference runs fp16 (:101); "bf16" is the throughput default of bench.py
+    fp8: int = 0                       # BASELINE configs[3] "fp8 MFMA UNet path" (with dtype "bf16" / "f16" for everything else): 1 = resnet 3x3
+                                       # convolutions on OCP e4m3 operands (block-scaled MFMA), 2 = also the transformer linears of the C = 640 /
+                                       # 1280 levels (LayerNorm and GEGLU write e4m3); latents within 6e-2 relative L2 of the fp32 oracle
     cache_reference_kv: bool = True
     ref_bank_owner: int = -1           # world_size > 1: rank that computes the reference trajectory and broadcasts its K / V^T step
                                        # by step (-1: every rank computes it itself -- no data-path collective)
@@ -135,8 +138,16 @@ class GaussCtrlPipeline(_PipelineBase):
             sdops.configure(options=config.kernel_options)
         if config.batch_invariant:
             sdops.configure(batch_invariant=True)
-        self.pipe = DenoisePipeline(prepare(get("unet", arch.unet_shapes(), 100), self.dtype, dev, heads=8),
-                                    prepare(get("controlnet", arch.controlnet_shapes(), 200), self.dtype, dev, heads=8),
+        def prepared(name, shapes, seed):
+            sd = get(name, shapes, seed)
+            out = prepare(sd, self.dtype, dev, heads=8)
+            if config.fp8 >= 1:
+                from .sd.weights import add_fp8_convs, add_fp8_linears
+                add_fp8_convs(out, sd, dev)
+                if config.fp8 >= 2:
+                    add_fp8_linears(out)
+            return out
+        self.pipe = DenoisePipeline(prepared("unet", arch.unet_shapes(), 100), prepared("controlnet", arch.controlnet_shapes(), 200),
                                     prepare_vae_weights(get("vae_decoder", arch.vae_decoder_shapes(), 300), self.dtype, dev),
                                     self.num_inference_steps, self.guidance_scale, self.controlnet_conditioning_scale)
         self.vae_encoder = VAEEncoder(prepare_vae_encoder_weights(get("vae_encoder", arch.vae_encoder_shapes(), 400), self.dtype, dev))

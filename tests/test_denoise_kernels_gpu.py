@@ -492,7 +492,14 @@ def test_linear_fp8_geglu_and_e4m3_output(dt, M, N, K):
     scp, _ = geglu_permute(wsc, None)
     got = ops.linear_fp8(x8.to(DEV), wp.to(DEV), scp.to(DEV), dt, bp.to(DEV), geglu=True)
     assert got.shape == (M, N // 2)
-    _close(got, ref, dt, extra=2.0)
+    # GEGLU multiplies two accumulators: the accumulation noise `_close` grants ONE accumulator (5 % of a rounding of the largest value; the
+    # block-scaled MFMA uses 0.64 of it on a plain fp8 linear in f16, test_linear_fp8) reaches the output times |gelu(gate)| + |x| |gelu'(gate)|
+    hid, gate = full[:, :N // 2], full[:, N // 2:]
+    tol = EPS[dt] * 2.0
+    acc = tol * float(full.abs().max()) * 0.05
+    slack = acc * (float(F.gelu(gate).abs().max()) + 1.13 * float(hid.abs().max())) + 1e-6
+    err = (got.double().cpu() - ref).abs()
+    within("GEGLU output: (err - one rounding) / propagated accumulation slack", ((err - tol * ref.abs()) / slack).clamp_min(0).max().item(), 1.0)
     for osc in (127, 126):
         y8 = ops.linear_fp8(x8.to(DEV), wp.to(DEV), scp.to(DEV), dt, bp.to(DEV), geglu=True, out_fp8=osc)
         assert y8.dtype == torch.uint8 and y8.shape == (M, N // 2)
@@ -500,8 +507,15 @@ def test_linear_fp8_geglu_and_e4m3_output(dt, M, N, K):
         # the down projection on those bytes (a_scale = the producer's out_fp8)
         w2, w2sc = quantize_rows_e4m3(torch.randn(K, N // 2, generator=g) * (N // 2) ** -0.5)
         r = _rand((M, K), dt, 1.0, 5)
-        ref2 = (_deq(y8.cpu()) * 2.0 ** (osc - 127)) @ _deq(w2, w2sc).T + r.double().cpu()
-        _close(ops.linear_fp8(y8, w2.to(DEV), w2sc.to(DEV), dt, residual=r, a_scale=osc), ref2, dt)
+        a2, wd2 = _deq(y8.cpu()) * 2.0 ** (osc - 127), _deq(w2, w2sc)
+        ref2 = a2 @ wd2.T + r.double().cpu()
+        got2 = ops.linear_fp8(y8, w2.to(DEV), w2sc.to(DEV), dt, residual=r, a_scale=osc).double().cpu()
+        # the GEGLU hidden is heavy-tailed (a few values of 30 .. 50 among many below 1) and K = 4C is long: what the block-scaled MFMA loses while
+        # it aligns 128 products per instruction scales with sum_k |a_k w_k|, not with the output -- bound it there: one output rounding +
+        # 2^-14 of the magnitude sum (measured 2^-17.3 .. 2^-15.6 on MI355X; an ideal fp32 accumulation would sit near sqrt(K) 2^-24 ~ 2^-18)
+        mag = a2.abs() @ wd2.abs().T + r.double().cpu().abs()
+        within("fp8 down projection: (err - one rounding) / (2^-14 sum |a w|)",
+               (((got2 - ref2).abs() - EPS[dt] * ref2.abs()).clamp_min(0) / (2.0 ** -14 * mag)).max().item(), 1.0)
 
 
 @pytest.mark.parametrize("dt", DTS)

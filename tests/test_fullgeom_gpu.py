@@ -299,8 +299,8 @@ def test_edit_f7_h64_fp8_convs_and_linears(nets, which):
     """configs[3] "fp8 MFMA UNet path", widened: besides the resnet convolutions, the transformer linears of the C = 640 / 1280 levels run on
     e4m3 operands (weights.add_fp8_linears; which = 1: GEGLU projection + FF down projection with the hidden kept in e4m3; 7: also the fused
     Q | K | V and attn2.to_q, their inputs written as e4m3 by the LayerNorm kernel), all 20 DDIM steps at the benchmarked geometry against the
-    fp32 oracle fixture.  Own bar of the e4m3 path (3 mantissa bits on both operands of ~60 % of the network's MACs): relative L2 of the
-    latents <= 1e-1 at every step (the convolutions alone: <= 6e-2, test_edit_f7_h64_fp8_convs)."""
+    fp32 oracle fixture.  Own bar of the e4m3 path, the one of the convolutions alone (test_edit_f7_h64_fp8_convs): relative L2 of the latents
+    <= 6e-2 at every step -- measured 2.67e-2 for both masks against 2.7e-2 without the linears: their e4m3 noise does not show."""
     from oracle import sd15_torch as sd
     from gaussctrl_amd.sd.pipeline import DenoisePipeline
     from gaussctrl_amd.sd.weights import add_fp8_convs, add_fp8_linears
@@ -322,4 +322,4 @@ def test_edit_f7_h64_fp8_convs_and_linears(nets, which):
                     on_step=lambda i, l: trace.append(l.permute(0, 3, 1, 2).float().cpu()))
     cur = _curve(trace, ref)
     print(f"\nedit f=7 h=64 fp8 convs + linears (mask {which}): rel L2 per step:\n  " + " ".join(f"{e:.2e}" for e in cur))
-    within("max(cur)", max(cur), 1e-1)
+    within("max(cur)", max(cur), 6e-2)
