@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--chunk-size", type=int, default=3)
     ap.add_argument("--denoise-steps", type=int, default=20)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "fp8"])     # fp8: e4m3 resnet convs + C = 640 / 1280 transformer linears on the block-scaled MFMA, bf16 elsewhere
+    ap.add_argument("--fp8-min-hw", type=int, default=256)   # with --dtype fp8: smallest map (pixels) whose resnet convs run on e4m3 (256: 16 x 16 maps, k-sliced; 1024: round-3 behaviour)
     ap.add_argument("--fp8-linears", type=int, default=7)     # with --dtype fp8: bit mask of the C = 640 / 1280 transformer linears that also run on e4m3 (weights.add_fp8_linears; 0: convolutions only)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="edit", choices=["edit", "raster", "full"])   # full: SURVEY.md 8d's optional whole-pipeline number (N = 1)
@@ -220,6 +221,7 @@ class Bench:
             if dtype_name == "fp8":
                 from gaussctrl_amd.sd.weights import add_fp8_convs, add_fp8_linears
                 add_fp8_convs(uw, usd, dev); add_fp8_convs(cw, csd, dev)
+                uw["_fp8_min_hw"] = cw["_fp8_min_hw"] = args.fp8_min_hw
                 if args.fp8_linears and not fold_ln:      # C = 640 / 1280 transformer linears on e4m3 (bit 0 feed-forward, 1 attn2.to_q, 2 Q | K | V)
                     add_fp8_linears(uw, args.fp8_linears); add_fp8_linears(cw, args.fp8_linears)
             del usd, csd

@@ -47,11 +47,45 @@ void plan(const gc_gemm_desc *d, int *ntw, int *splits, int *tps)
     *splits = (nk + *tps - 1) / *tps;
 }
 
+
+// fp8 (k_gemm8q) problems: column tile, m-tiles per wave and k-slices.  Long-K plain problems on part-filled grids (3x3 convs on 16 x 16
+// maps, the FF down projection on few rows) are cut into k-slices of >= 8 k-tiles (1 024 elements) so that ~256 workgroups run; the
+// split-K reduce kernels of the 2-byte path finish them (and leave the GroupNorm partials).  assume_ws: size query before the caller
+// has a workspace.
+struct SelQ { int ntw, mt, splits, tps; };
+void select_fp8(const gc_gemm_desc *d, SelQ *o, bool assume_ws)
+{
+    const int force_mt = d->kernel_variant & 7;
+    o->ntw = (d->N % 160 == 0 && d->N % 128 != 0 && !d->geglu) ? 5 : 4;      // (GEGLU pairs n-tiles inside a wave: even count)
+    // the e4m3 fragments are 8 registers each (32 k per lane): only the variants that stay under 256 VGPRs without spilling are
+    // instantiated -- (NTW 5, MT 2), (NTW 4, MT 2 | 3); a spill reload is a VM load that stalls behind the LDS-DMA queue
+    int mt = force_mt ? force_mt : choose_mt(d->M, d->N, o->ntw, true);
+    if (o->ntw == 5) mt = 2; else if (mt > 3) mt = 3;
+    if (mt < 2) mt = 2;
+    const int nkq = (int)(d->K / 128);
+    o->splits = 1; o->tps = nkq;
+    const bool plain = !d->geglu && !d->out_t && !d->out_fp8 && !d->out_f32 && d->out && !d->ln_row_stats && !d->out_row_stats && !d->out_group_stats && d->act == 0;
+    const int64_t nbn = (d->N + 32 * o->ntw - 1) / (32 * o->ntw), tiles = ((d->M + 127) / 128) * nbn;
+    if (plain && !force_mt && !(d->kernel_variant & 0x40) && tiles <= 128 && nkq >= 16) {
+        int s = (int)std::min<int64_t>(tiles < 96 ? (256 + tiles - 1) / tiles : 256 / tiles, nkq / 8);
+        if (s > 16) s = 16;
+        if (s >= 2 && (assume_ws || (d->workspace && d->workspace_bytes >= sizeof(float) * (size_t)s * (size_t)d->M * (size_t)d->N))) {
+            mt = 2; o->tps = (nkq + s - 1) / s; o->splits = (nkq + o->tps - 1) / o->tps;
+        }
+    }
+    o->mt = mt;
+}
 }  // namespace
 
 extern "C" size_t gc_dn_gemm_workspace_bytes(const gc_gemm_desc *d)
 {
-    if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->fp8) return 0;
+    if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+    if (d->fp8) {
+        if (d->K % 128 != 0) return 0;
+        SelQ q;
+        select_fp8(d, &q, true);
+        return q.splits > 1 ? sizeof(float) * (size_t)q.splits * (size_t)d->M * (size_t)d->N : 0;
+    }
     int ntw, splits, tps;
     plan(d, &ntw, &splits, &tps);
     return splits > 1 ? sizeof(float) * (size_t)splits * (size_t)d->M * (size_t)d->N : 0;
@@ -127,7 +161,14 @@ void chan_parts_layout(const gc_gemm_desc *d, const Sel &sel, int64_t *rows, int
 {
     *rows = 0; *nslab = 0; *col_tile = 0;
     const int64_t rpb = d->rows_per_batch;
-    if (d->fp8 || d->geglu || d->act != 0 || d->out_t || !d->out || d->out_f32 || d->ln_row_stats || d->out_row_stats || d->out_group_stats) return;
+    if (d->fp8) {                    // k_gemm8q: only the k-sliced problems (their reduce kernel is the 2-byte path's)
+        SelQ q;
+        select_fp8(d, &q, false);
+        if (q.splits < 2 || d->K % 128 != 0 || rpb < 256 || rpb % 32 != 0 || d->M % rpb != 0 || d->gn_groups < 1 || d->N % d->gn_groups != 0 || d->N / d->gn_groups > 64) return;
+        *rows = CS_RB; *nslab = (int)(rpb / CS_RB); *col_tile = 64;
+        return;
+    }
+    if (d->geglu || d->act != 0 || d->out_t || !d->out || d->out_f32 || d->ln_row_stats || d->out_row_stats || d->out_group_stats) return;
     if (rpb < 256 || rpb % 32 != 0 || d->M % rpb != 0) return;
     if (d->gn_groups < 1 || d->N % d->gn_groups != 0) return;
     const int64_t cpg = d->N / d->gn_groups;
@@ -220,15 +261,16 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
         GC_REQUIRE(d->mode == 0 || (d->Cin % 128 == 0 && !d->upsample), "fp8 conv: Cin (padded) % 128 == 0, no fused upsample");
         GC_REQUIRE(d->mode == 1 || d->lda % 16 == 0, "fp8 linear: lda % 16 == 0");
         GC_REQUIRE((int64_t)d->N * d->K < ((int64_t)1 << 31) && (d->mode == 1 ? (int64_t)d->B * d->Hi * d->Wi * d->Cin : d->M * d->lda) < ((int64_t)1 << 31), "fp8: 32-bit offsets");
-        const int ntw = (d->N % 160 == 0 && d->N % 128 != 0 && !d->geglu) ? 5 : 4;      // (GEGLU pairs n-tiles inside a wave: even count)
-        // the e4m3 fragments are 8 registers each (32 k per lane): only the variants that stay under 256 VGPRs without spilling are
-        // instantiated -- (NTW 5, MT 2), (NTW 4, MT 2 | 3); a spill reload is a VM load that stalls behind the LDS-DMA queue
-        int mt = force_mt ? force_mt : choose_mt(d->M, d->N, ntw, true);
-        if (ntw == 5) mt = 2; else if (mt > 3) mt = 3;
-        g.splits = 1; g.tiles_per_split = (int)(d->K / 128); g.ws = nullptr;
+        SelQ q;
+        select_fp8(d, &q, false);
+        const int ntw = q.ntw, mt = q.mt;
+        g.splits = q.splits; g.tiles_per_split = q.tps; g.ws = q.splits > 1 ? (float *)d->workspace : nullptr;
+        GC_REQUIRE(!d->out_chan_parts || q.splits > 1, "fp8: channel partials come from the k-sliced problems only (gc_dn_gemm_chan_parts_layout)");
+        if (d->out_chan_parts) { g.cp_nslab = (int)(g.rows_per_batch / CS_RB); g.cp_rows = CS_RB; }
         const int64_t nbn_q = (d->N + 32 * ntw - 1) / (32 * ntw), nbm_q = (d->M + 64 * mt - 1) / (64 * mt);
-        const dim3 gq((unsigned)(nbm_q * nbn_q), 1u);
+        const dim3 gq((unsigned)(nbm_q * nbn_q), (unsigned)q.splits);
         dn_gemm_launch_fp8(g, d->dtype, d->mode == 1 ? 2 : 3, ntw, mt, gq, s);
+        if (q.splits > 1) { if (g.chan_parts) dn_gemm_launch_splitk_epilogue_cs(g, d->dtype, s); else dn_gemm_launch_splitk_epilogue(g, d->dtype, s); }
         return gc::check_launch("gc_dn_gemm(fp8)");
     }
     g.splits = sel.splits; g.tiles_per_split = sel.tps; g.ws = (float *)d->workspace;

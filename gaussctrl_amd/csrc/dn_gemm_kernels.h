@@ -1407,7 +1407,11 @@ __global__ __launch_bounds__(512, 1) void k_gemm8q(const GemmArgs g)
     const int64_t bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
     const int64_t mblk = bid / nbn, nblk = bid % nbn;
     const int64_t m_base = mblk * BM, n_base = nblk * BN;
-    const int nk = (int)(g.K / BKB);
+    // k-slices (long-K problems on part-filled grids: the 16 x 16-map convolutions): slice blockIdx.y covers k-tiles [k0, k0 + nk) and leaves an
+    // fp32 partial slab for the split-K reduce kernels, exactly as k_gemm8 does
+    const int nk_all = (int)(g.K / BKB);
+    const int k0 = g.splits > 1 ? (int)blockIdx.y * g.tiles_per_split : 0;
+    const int nk = g.splits > 1 ? (nk_all - k0 < g.tiles_per_split ? nk_all - k0 : g.tiles_per_split) : nk_all;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
     float *srow = reinterpret_cast<float *>(smem + NS * STAGE);
     if constexpr (FUSE) {
@@ -1448,11 +1452,11 @@ __global__ __launch_bounds__(512, 1) void k_gemm8q(const GemmArgs g)
         w_off[i] = (int)(n < g.N ? n : g.N - 1) * (int)g.K + (ls ^ ((row >> 1) & 7)) * 16;
     }
     const unsigned char *Ab = (const unsigned char *)g.A, *Wb = (const unsigned char *)g.W, *Zp = (const unsigned char *)g.zeros;
-    int ld_tap = 0, ld_ci = 0;
+    int ld_tap = MODE == 2 ? (k0 * BKB) / g.Cin : 0, ld_ci = MODE == 2 ? (k0 * BKB) % g.Cin : 0;
     struct TileSrc { int kb, tap, tap_off; unsigned sbase; };
     auto issue_begin = [&](int kt, int stage) __attribute__((always_inline)) -> TileSrc {
         TileSrc t;
-        t.kb = kt * BKB; t.tap = 0; t.tap_off = 0;
+        t.kb = (k0 + kt) * BKB; t.tap = 0; t.tap_off = 0;
         if (MODE == 2) {
             t.tap = ld_tap;
             const int dy = ld_tap / 3, dx = ld_tap - dy * 3;

@@ -268,12 +268,14 @@ __device__ __forceinline__ void gparts_to_moments(float *gs, float2 *red /* [256
 // statistics kernels): its 16 coefficients live in registers -- no coefficient table in the loop (the first version read a [C][2] LDS
 // table per chunk: 64-byte lane stride = 16-way bank conflicts, 43 us against 12 us for the plain apply kernel at 64 x 64 x 320 / 640) --
 // and gamma / beta and the first pixels of x are requested before the partials (nothing of that depends on the statistics).
-template <class T>
+template <class T, bool Q8 = false>
 __global__ __launch_bounds__(256) void k_gn_apply_parts(const unsigned short *__restrict__ x, unsigned short *__restrict__ y, unsigned HW,
                                                         unsigned C, unsigned G, const float *__restrict__ parts, int nslab, unsigned R, int mode,
                                                         unsigned col_tile, const float *__restrict__ gamma, const float *__restrict__ beta, float eps, int act,
-                                                        int nchb, int pix_per_block)
+                                                        int nchb, int pix_per_block, unsigned Cp = 0, float qscale = 1.f)
 {
+    // Q8: e4m3 output y8[b][p][Cp] bytes (Cp = C rounded up to 128, padding channels written as zero by the thread of the last chunk),
+    // stored = value * qscale saturated to +-448: the input of an fp8 convolution / linear (k_gn_apply_stats_fp8 with the producer's partials)
     __shared__ float gs[256];                // [G][2], G <= 128
     __shared__ float2 red[256];
     const unsigned b = blockIdx.z, tid = threadIdx.x, cpg = C / G;
@@ -315,7 +317,19 @@ __global__ __launch_bounds__(256) void k_gn_apply_parts(const unsigned short *__
             float v = f[j] * ca[j] + cd[j];
             f[j] = act ? silu(v) : v;
         }
-        *reinterpret_cast<uint4 *>(yb + (size_t)p * C) = pack8<T>(f);
+        if constexpr (Q8) {
+            unsigned char *o8 = reinterpret_cast<unsigned char *>(y) + ((size_t)b * HW + p) * Cp + c0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = fminf(fmaxf(f[j] * qscale, -448.f), 448.f);
+            int w0 = 0, w1 = 0;
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
+            *reinterpret_cast<uint2 *>(o8) = make_uint2((unsigned)w0, (unsigned)w1);
+            if (c0 + 8 == C)
+                for (unsigned c = C; c < Cp; c += 8) *reinterpret_cast<uint2 *>(o8 + (c - c0)) = make_uint2(0u, 0u);
+        } else {
+            *reinterpret_cast<uint4 *>(yb + (size_t)p * C) = pack8<T>(f);
+        }
     };
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -999,6 +1013,28 @@ int gc_dn_groupnorm_apply_parts(int dtype, const void *x, void *y, int64_t B, in
                 hipLaunchKernelGGL((k_gn_apply_parts<F16>), grid, dim3(256), 0, gc::S(stream), (const unsigned short *)x, (unsigned short *)y,
                                    (unsigned)HW, (unsigned)C, (unsigned)G, parts, nslab, (unsigned)rows_per_slab, slab_mode, (unsigned)col_tile, gamma, beta, eps, act, nchb, ppb));
     return gc::check_launch("gc_dn_groupnorm_apply_parts");
+}
+
+int gc_dn_groupnorm_apply_parts_fp8(int dtype, const void *x, void *y8, int64_t B, int64_t HW, int C, int C_padded, int G, const float *gamma,
+                                    const float *beta, float eps, int act, const float *parts, int64_t rows_per_slab, int nslab, int slab_mode,
+                                    int col_tile, int a_scale, void *stream)
+{
+    GC_REQUIRE(C % 8 == 0 && C % G == 0 && G <= 128 && parts && gamma && beta, "groupnorm_apply_parts_fp8: C must be a multiple of 8 and of G; partials required");
+    GC_REQUIRE(C_padded >= C && C_padded % 128 == 0 && a_scale > 0 && a_scale < 255, "groupnorm_apply_parts_fp8: padded channel count % 128 == 0; E8M0 scale byte");
+    GC_REQUIRE(HW * (int64_t)C_padded < (int64_t)1 << 31 && B * HW < (int64_t)1 << 31 && B <= 65535 && rows_per_slab > 0 && nslab > 0 && col_tile > 0,
+               "groupnorm_apply_parts_fp8: bad sizes");
+    int ns, ppb, ny, nchb;
+    concat_parts_plan(HW, C, &ns, &ppb, &ny, &nchb);
+    dim3 grid((unsigned)ns, ny, (unsigned)B);
+    const float qscale = exp2f((float)(127 - a_scale));
+    DN_DISPATCH(dtype,
+                hipLaunchKernelGGL((k_gn_apply_parts<BF16, true>), grid, dim3(256), 0, gc::S(stream), (const unsigned short *)x, (unsigned short *)y8,
+                                   (unsigned)HW, (unsigned)C, (unsigned)G, parts, nslab, (unsigned)rows_per_slab, slab_mode, (unsigned)col_tile, gamma, beta, eps, act, nchb, ppb,
+                                   (unsigned)C_padded, qscale),
+                hipLaunchKernelGGL((k_gn_apply_parts<F16, true>), grid, dim3(256), 0, gc::S(stream), (const unsigned short *)x, (unsigned short *)y8,
+                                   (unsigned)HW, (unsigned)C, (unsigned)G, parts, nslab, (unsigned)rows_per_slab, slab_mode, (unsigned)col_tile, gamma, beta, eps, act, nchb, ppb,
+                                   (unsigned)C_padded, qscale));
+    return gc::check_launch("gc_dn_groupnorm_apply_parts_fp8");
 }
 
 static void concat_parts_plan(int64_t HW, int C, int *nslab, int *ppb, int *ny, int *nchb)

@@ -363,6 +363,21 @@ def group_stats(x, gs):
     return gs
 
 
+def groupnorm_apply_parts_fp8(x, parts, gamma, beta, groups, eps, silu, a_scale=127):
+    """GroupNorm(+SiLU) -> e4m3 [B,H,W,pad128(C)] in ONE launch from the ChanParts x's producer left (gc_dn_groupnorm_apply_parts_fp8)."""
+    _gpu(x)
+    Cc = x.shape[-1]
+    B = x.shape[0]
+    HW = x.numel() // (B * Cc)
+    Cp = pad128(Cc)
+    assert parts.groups == groups
+    y = torch.empty(x.shape[:-1] + (Cp,), dtype=torch.uint8, device=x.device)
+    L.check(L.lib().gc_dn_groupnorm_apply_parts_fp8(_dt(x), _p(x), _p(y), C.c_int64(B), C.c_int64(HW), Cc, Cp, groups, _p(gamma), _p(beta), C.c_float(eps),
+                                                    int(silu), _p(parts.buf), C.c_int64(parts.rows), parts.nslab, parts.mode, parts.col_tile, int(a_scale),
+                                                    _stream()), "gc_dn_groupnorm_apply_parts_fp8")
+    return y
+
+
 def groupnorm_fp8(x, gamma, beta, groups, eps, silu, a_scale=127):
     """Stand-alone GroupNorm(+SiLU) -> e4m3: one statistics launch (gc_dn_group_stats) + the quantising apply."""
     _gpu(x)
@@ -374,7 +389,7 @@ def groupnorm_fp8(x, gamma, beta, groups, eps, silu, a_scale=127):
 
 
 def conv3x3_fp8(x8, w8, w_scale, out_dtype, bias=None, stride=1, rowvec=None, ld_rowvec=None, residual=None, act=0, scale=1.0, a_scale=127,
-                group_stats=None):
+                group_stats=None, chan_parts=False, gn_groups=32):
     """3x3 conv (pad 1) on e4m3 operands with the block-scaled MFMA: x8 [B,H,W,Cp] uint8 (Cp % 128 == 0), w8 [N, 9*Cp] uint8 ((tap, cin)
     order), w_scale [N] uint8 E8M0 per output channel; output in `out_dtype` (bf16 / f16) with the usual fused epilogue."""
     _gpu(x8, w8, w_scale)
@@ -397,8 +412,9 @@ def conv3x3_fp8(x8, w8, w_scale, out_dtype, bias=None, stride=1, rowvec=None, ld
     d.out = out.data_ptr(); d.ldc = N; d.out_f32 = 0
     d.fp8 = 1; d.w_scale = w_scale.data_ptr(); d.a_scale = int(a_scale)
     _stats_args(d, None, group_stats)
-    _run_gemm(d, x8.device, "gc_dn_gemm(conv3x3 fp8)")
-    return out
+    # chan_parts=True: returns (out, ChanParts | None) -- the k-sliced problems (16 x 16 maps) leave the GroupNorm partials of their output
+    parts = _run_gemm(d, x8.device, "gc_dn_gemm(conv3x3 fp8)", want_parts=chan_parts and not BATCH_INVARIANT, gn_groups=gn_groups)
+    return (out, parts) if chan_parts else out
 
 
 def linear_fp8(x8, w8, w_scale, out_dtype, bias=None, residual=None, act=0, scale=1.0, a_scale=127, rows_per_batch=0, row_stats=None,

@@ -113,6 +113,7 @@ class SDNet:
                                                                     # measured neutral (7.02 vs 6.97 views/s) and it gives up the shifted sums
         self.fp8 = bool(weights.get("_fp8_convs", False))           # resnet 3x3 convs on e4m3 operands (weights.add_fp8_convs)
         self.fp8_a_scale = 127                                      # E8M0 byte of the conv inputs (GroupNorm + SiLU outputs are O(1): 2^0)
+        self.fp8_min_hw = int(weights.get("_fp8_min_hw", 256))      # smallest map whose resnet convs run on e4m3 (16 x 16: k-sliced k_gemm8q)
         # transformer-block linears of the C = 640 / 1280 levels on e4m3 operands (weights.add_fp8_linears): the three LayerNorms write e4m3,
         # the GEGLU epilogue writes the FF hidden as e4m3; E8M0 bytes of the two activation kinds (LayerNorm outputs, GEGLU hidden): 2^0
         self.fp8_lin = int(weights.get("_fp8_linears", 0))          # bit 0: feed-forward, bit 1: attn2.to_q, bit 2: Q | K | V
@@ -150,8 +151,8 @@ class SDNet:
         else the stand-alone statistics pass + a quantising apply"""
         w = self.w
         g = self.cfg["groups"]
-        if isinstance(xs, ops.ChanParts):
-            xs = None                        # (the e4m3 apply kernel takes per-group sums only)
+        if isinstance(xs, ops.ChanParts):    # the producer left its partial sums: one launch
+            return ops.groupnorm_apply_parts_fp8(x, xs, w[p + ".weight"], w[p + ".bias"], g, eps, True, self.fp8_a_scale)
         if xs is not None:
             return ops.groupnorm_apply_fp8(x, xs, w[p + ".weight"], w[p + ".bias"], g, eps, True, self.fp8_a_scale)
         return ops.groupnorm_fp8(x, w[p + ".weight"], w[p + ".bias"], g, eps, True, self.fp8_a_scale)
@@ -197,11 +198,15 @@ class SDNet:
         cout = w[p + ".conv1.weight"].shape[0]
         hs = self._cs(B, cout, HW)
         g = self.cfg["groups"]
-        q8 = self.fp8 and (p + ".conv1.w8") in w and HW >= 1024      # 16x16 / 8x8 maps: few tiles, long K -> the split-K bf16 kernels
+        q8 = self.fp8 and (p + ".conv1.w8") in w and HW >= self.fp8_min_hw      # 8x8 maps: few tiles, long K -> the split-K bf16 kernels
         if q8:        # fp8 path: the GroupNorm writes e4m3, the conv runs on the block-scaled MFMA
             h8 = self.gn_fp8(x, xs, p + ".norm1", eps)
-            h = ops.conv3x3_fp8(h8, w[p + ".conv1.w8"], w[p + ".conv1.w8_scale"], x.dtype, w[p + ".conv1.bias"], rowvec=rv, ld_rowvec=0,
-                                a_scale=self.fp8_a_scale, group_stats=hs)
+            if self.gn_parts and hs is None:       # (the k-sliced 16 x 16-map problems leave the partials of their output; others return None)
+                h, hs = ops.conv3x3_fp8(h8, w[p + ".conv1.w8"], w[p + ".conv1.w8_scale"], x.dtype, w[p + ".conv1.bias"], rowvec=rv, ld_rowvec=0,
+                                        a_scale=self.fp8_a_scale, chan_parts=True)
+            else:
+                h = ops.conv3x3_fp8(h8, w[p + ".conv1.w8"], w[p + ".conv1.w8_scale"], x.dtype, w[p + ".conv1.bias"], rowvec=rv, ld_rowvec=0,
+                                    a_scale=self.fp8_a_scale, group_stats=hs)
         else:
             h = self.gn(x, xs, p + ".norm1", eps, True)
             if self.gn_parts and hs is None:
@@ -214,6 +219,9 @@ class SDNet:
         os_ = self._cs(B, cout, HW)
         if q8:
             h8 = self.gn_fp8(h, hs, p + ".norm2", eps)
+            if self.gn_parts and os_ is None:
+                return ops.conv3x3_fp8(h8, w[p + ".conv2.w8"], w[p + ".conv2.w8_scale"], x.dtype, w[p + ".conv2.bias"], residual=sc,
+                                       a_scale=self.fp8_a_scale, chan_parts=True)
             return ops.conv3x3_fp8(h8, w[p + ".conv2.w8"], w[p + ".conv2.w8_scale"], x.dtype, w[p + ".conv2.bias"], residual=sc,
                                    a_scale=self.fp8_a_scale, group_stats=os_), os_
         h = self.gn(h, hs, p + ".norm2", eps, True)

@@ -429,6 +429,12 @@ int gc_dn_concat_add(int dtype, const void *a, int C1, const void *b, const void
  * /root/reference/gaussctrl/gc_pipeline.py:142-145,209-219. */
 int gc_dn_groupnorm_apply_parts(int dtype, const void *x, void *y, int64_t B, int64_t HW, int C, int G, const float *gamma, const float *beta,
                                 float eps, int act, const float *parts, int64_t rows_per_slab, int nslab, int slab_mode, int col_tile, void *stream);
+/* The same with an OCP fp8 (e4m3) output y8[B][HW][C_padded] (bytes, C_padded % 128 == 0, padding channels zero; stored = value *
+ * 2^(127 - a_scale), saturated to +-448): GroupNorm(+SiLU) in ONE launch as the input of an fp8 convolution (gc_dn_groupnorm_apply_fp8
+ * with the producer's partials instead of a statistics pass). */
+int gc_dn_groupnorm_apply_parts_fp8(int dtype, const void *x, void *y8, int64_t B, int64_t HW, int C, int C_padded, int G, const float *gamma,
+                                    const float *beta, float eps, int act, const float *parts, int64_t rows_per_slab, int nslab, int slab_mode,
+                                    int col_tile, int a_scale, void *stream);
 /* the coefficients alone: coef [B][C][2], y = x * coef[.][c][0] + coef[.][c][1] (input of gc_dn_transformer_head) */
 int gc_dn_groupnorm_coef_parts(int64_t B, int64_t HW, int C, int G, const float *gamma, const float *beta, float eps, const float *parts,
                                int64_t rows_per_slab, int nslab, int slab_mode, int col_tile, float *coef, void *stream);

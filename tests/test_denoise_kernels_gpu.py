@@ -541,6 +541,75 @@ def test_linear_fp8_qkv_transposed_v(dt, B, L, C):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("kind,B,H,Cin,Cout", [("linear", 6, 64, 320, 320), ("linear", 2, 32, 640, 640), ("conv", 6, 16, 1280, 1280), ("concat", 6, 64, 320, 640),
+                                               ("concat", 2, 32, 640, 640)])
+def test_groupnorm_apply_parts_fp8(dt, kind, B, H, Cin, Cout):
+    """GroupNorm + SiLU -> e4m3 in ONE launch from the partial sums the producer of the tensor left (gc_dn_groupnorm_apply_parts_fp8): the
+    e4m3 rounding of the fp64 GroupNorm of the stored tensor; channel counts that pad to 128 (320 -> 384, 960 -> 1024) have zero padding."""
+    from gaussctrl_amd.sd import ops
+    from gaussctrl_amd.sd.weights import conv3x3_weight
+    if kind == "linear":
+        x = _rand((B, H * H, Cin), dt, 1.0, 1); w = _rand((Cout, Cin), dt, Cin ** -0.5, 2); b = torch.randn(Cout, device=DEV) + 0.7
+        out, parts = ops.linear(x, w, b, rows_per_batch=H * H, chan_parts=True)
+    elif kind == "conv":
+        x = _rand((B, H, H, Cin), dt, 1.0, 1); w = _rand((Cout, Cin, 3, 3), dt, (9 * Cin) ** -0.5, 2); b = torch.randn(Cout, device=DEV) + 0.7
+        out, parts = ops.conv3x3(x, conv3x3_weight(w, dt), b, chan_parts=True)
+    else:
+        a = (_rand((B, H, H, Cin), dt, 1.0, 1).float() + 1.0).to(dt); bb = _rand((B, H, H, Cout), dt, 1.0, 2)
+        out, parts = ops.concat_add(a, bb, None, chan_parts=True)
+    if parts is None and ops.KERNEL_VARIANT["gemm"]:
+        pytest.skip("a forced kernel variant without the statistics epilogue")
+    assert parts is not None
+    Co = out.shape[-1]
+    o64 = out.double().reshape(B, -1, Co)
+    gamma = torch.randn(Co, device=DEV) * 0.5 + 1.0; beta = torch.randn(Co, device=DEV) * 0.5
+    ref = F.silu(F.group_norm(o64.transpose(1, 2), 32, gamma.double(), beta.double(), 1e-5).transpose(1, 2))
+    for a_scale in (127, 126):
+        y8 = ops.groupnorm_apply_parts_fp8(out, parts, gamma, beta, 32, 1e-5, True, a_scale)
+        Cp = ops.pad128(Co)
+        assert y8.shape == out.shape[:-1] + (Cp,) and (Cp == Co or int(y8[..., Co:].max()) == 0)
+        _e4m3_bytes_match(y8.reshape(B, -1, Cp)[..., :Co], ref, a_scale, 2e-3)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("B,H,Cin,Cout", [(6, 16, 1280, 1280), (6, 16, 2560, 1280), (3, 16, 640, 1280), (14, 16, 1280, 1280), (6, 16, 1920, 1280)])
+def test_conv3x3_fp8_k_sliced_with_partials(dt, B, H, Cin, Cout):
+    """the 16 x 16-map resnet convolutions on e4m3 operands: k_gemm8q in k-slices + the split-K reduce kernel of the 2-byte path, which also
+    leaves the GroupNorm partials of the output -- output vs fp64 of the same operands, partials vs the stored output, and the one-launch
+    e4m3 GroupNorm that follows."""
+    from gaussctrl_amd.sd import ops
+    from gaussctrl_amd.sd.weights import conv3x3_weight_fp8
+    g = torch.Generator().manual_seed(7)
+    x8 = (torch.randn(B, H, H, Cin, generator=g) * 1.5).to(torch.float8_e4m3fn).view(torch.uint8)
+    w32 = torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5
+    w8, wsc = conv3x3_weight_fp8(w32)
+    b = torch.randn(Cout, generator=g) + 0.5
+    rv = torch.randn(1, Cout, generator=g).to(DEV)
+    res = _rand((B, H, H, Cout), dt, 1.0, 3)
+    wr = _deq(w8, wsc).reshape(-1, 3, 3, Cin)[:Cout].permute(0, 3, 1, 2)
+    ref = F.conv2d(_deq(x8).permute(0, 3, 1, 2), wr, b.double(), padding=1).permute(0, 2, 3, 1) + rv.double().cpu() + res.double().cpu()
+    out, parts = ops.conv3x3_fp8(x8.to(DEV), w8.to(DEV), wsc.to(DEV), dt, b.to(DEV), rowvec=rv, ld_rowvec=0, residual=res, chan_parts=True)
+    _close(out, ref, dt)
+    plain = ops.conv3x3_fp8(x8.to(DEV), w8.to(DEV), wsc.to(DEV), dt, b.to(DEV), rowvec=rv, ld_rowvec=0, residual=res)
+    assert torch.equal(out, plain)
+    if B * H * H <= 128 * 12:
+        assert parts is not None, "a part-filled grid with a long K must take the k-sliced path"
+    if parts is not None:
+        G, cpg = 32, Cout // 32
+        o64 = out.double().reshape(B, H * H, Cout)
+        for bi in range(B):
+            got = _parts_sums(parts, bi, H * H, cpg)
+            og = o64[bi].reshape(H * H, G, cpg)
+            want = torch.stack([og.sum((0, 2)), (og ** 2).sum((0, 2))], -1)
+            within("fp8 conv: group partial sums vs fp64 (rel to sum |x| resp. sum x^2)",
+                   ((got - want).abs() / torch.stack([og.abs().sum((0, 2)), (og ** 2).sum((0, 2))], -1).clamp_min(1e-6)).max().item(), 2e-6)
+        gamma = torch.randn(Cout, device=DEV) * 0.5 + 1.0; beta = torch.randn(Cout, device=DEV) * 0.5
+        refn = F.silu(F.group_norm(o64.transpose(1, 2), 32, gamma.double(), beta.double(), 1e-5).transpose(1, 2))
+        y8 = ops.groupnorm_apply_parts_fp8(out, parts, gamma, beta, 32, 1e-5, True, 127)
+        _e4m3_bytes_match(y8.reshape(B, H * H, -1)[..., :Cout], refn, 127, 2e-3)
+
+
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("B,HW,C", [(2, 256, 320), (3, 64, 1280), (6, 4096, 320), (2, 1024, 960)])
 def test_groupnorm_apply_fp8(dt, B, HW, C):
     """GroupNorm + SiLU with e4m3 output: equals the e4m3 rounding of the fp32 result (ties / 1-ulp-of-fp8 differences allowed on < 1e-3

@@ -323,3 +323,12 @@ def test_edit_f7_h64_fp8_convs_and_linears(nets, which):
     cur = _curve(trace, ref)
     print(f"\nedit f=7 h=64 fp8 convs + linears (mask {which}): rel L2 per step:\n  " + " ".join(f"{e:.2e}" for e in cur))
     within("max(cur)", max(cur), 6e-2)
+    # the product path at the benchmark's grids: reference bank + a 3-view chunk (CFG batch 6 -- there the 16 x 16-map convolutions are part-
+    # filled grids and run as k-sliced k_gemm8q + the split-K reduce kernel that leaves the GroupNorm partials; B = 14 above does not slice)
+    bank = pipe.build_ref_bank(lat[:4].to(DEV), disp[:4].to(DEV), cn.to(DEV), cp.to(DEV))
+    trace_c = []
+    pipe.edit_chunk_cached(lat[4:].to(DEV), disp[4:].to(DEV), cn.to(DEV), cp.to(DEV), bank,
+                           on_step=lambda i, l: trace_c.append(l.permute(0, 3, 1, 2).float().cpu()))
+    cur_c = [_rel(t, torch.tensor(ref[i][4:])) for i, t in enumerate(trace_c)]
+    print(f"cached-reference path, chunk frames vs oracle:\n  " + " ".join(f"{e:.2e}" for e in cur_c))
+    within("max(cur_c)", max(cur_c), 6e-2)
