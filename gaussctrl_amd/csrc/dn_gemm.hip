@@ -164,8 +164,21 @@ void chan_parts_layout(const gc_gemm_desc *d, const Sel &sel, int64_t *rows, int
     if (d->fp8) {                    // k_gemm8q: only the k-sliced problems (their reduce kernel is the 2-byte path's)
         SelQ q;
         select_fp8(d, &q, false);
-        if (q.splits < 2 || d->K % 128 != 0 || rpb < 256 || rpb % 32 != 0 || d->M % rpb != 0 || d->gn_groups < 1 || d->N % d->gn_groups != 0 || d->N / d->gn_groups > 64) return;
-        *rows = CS_RB; *nslab = (int)(rpb / CS_RB); *col_tile = 64;
+        if (d->K % 128 != 0 || rpb < 256 || rpb % 32 != 0 || d->M % rpb != 0 || d->gn_groups < 1 || d->N % d->gn_groups != 0) return;
+        const int64_t cpg = d->N / d->gn_groups;
+        if (q.splits > 1) {          // the reduce-epilogue kernel produces them (64-column blocks)
+            if (cpg > 64) return;
+            *rows = CS_RB; *nslab = (int)(rpb / CS_RB); *col_tile = 64;
+            return;
+        }
+        // unsliced fast convs: k_gemm8q's own channel-partial epilogue (lean: bias / row vector / scale / residual / 2-byte store)
+        const bool lean = d->mode == 1 && !d->upsample && !d->geglu && !d->out_t && !d->out_fp8 && !d->out_f32 && d->out && d->act == 0 &&
+                          !d->ln_row_stats && !d->out_row_stats && !d->out_group_stats;
+        const int64_t bm = 64 * q.mt;
+        if (!lean || bm > rpb || cpg > 32 * q.ntw) return;
+        *rows = bm;
+        *nslab = (int)(rpb % bm == 0 ? rpb / bm : (rpb + bm - 1) / bm + 1);
+        *col_tile = 32 * q.ntw;
         return;
     }
     if (d->geglu || d->act != 0 || d->out_t || !d->out || d->out_f32 || d->ln_row_stats || d->out_row_stats || d->out_group_stats) return;
@@ -265,8 +278,7 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
         select_fp8(d, &q, false);
         const int ntw = q.ntw, mt = q.mt;
         g.splits = q.splits; g.tiles_per_split = q.tps; g.ws = q.splits > 1 ? (float *)d->workspace : nullptr;
-        GC_REQUIRE(!d->out_chan_parts || q.splits > 1, "fp8: channel partials come from the k-sliced problems only (gc_dn_gemm_chan_parts_layout)");
-        if (d->out_chan_parts) { g.cp_nslab = (int)(g.rows_per_batch / CS_RB); g.cp_rows = CS_RB; }
+        GC_REQUIRE(!d->out_chan_parts || q.splits > 1 || (d->mode == 1 && !fuse_of(g)), "fp8: channel partials come from k-sliced problems and fast convs");
         const int64_t nbn_q = (d->N + 32 * ntw - 1) / (32 * ntw), nbm_q = (d->M + 64 * mt - 1) / (64 * mt);
         const dim3 gq((unsigned)(nbm_q * nbn_q), (unsigned)q.splits);
         dn_gemm_launch_fp8(g, d->dtype, d->mode == 1 ? 2 : 3, ntw, mt, gq, s);

@@ -1391,7 +1391,7 @@ void launch8p(const GemmArgs &g, int nwg, hipStream_t s)
 // the MFMAs of tile kt.  Output / epilogue (bf16 or f16, all fusions) = wave_epilogue.
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 
-template <class T, int MODE, int NTW, int MT, bool FUSE>
+template <class T, int MODE, int NTW, int MT, bool FUSE, bool CS = false>
 __global__ __launch_bounds__(512, 1) void k_gemm8q(const GemmArgs g)
 {
     static_assert(MODE == 2 || MODE == 3, "fp8 path: fast conv (2) and aligned linear (3)");
@@ -1416,6 +1416,11 @@ __global__ __launch_bounds__(512, 1) void k_gemm8q(const GemmArgs g)
     float *srow = reinterpret_cast<float *>(smem + NS * STAGE);
     if constexpr (FUSE) {
         if (g.row_stats) row_stats_prologue<BM>(g, m_base, srow);
+    }
+    static_assert(!(FUSE && CS), "one statistics epilogue at a time");
+    float *ctab = reinterpret_cast<float *>(smem + NS * STAGE);          // CS: [2 batch slots][BN][2] channel sums of this tile, behind the ring
+    if constexpr (CS) {      // zeroed here: the k loop's barriers order it before the epilogue's LDS adds
+        for (int i = tid; i < 4 * BN; i += 512) ctab[i] = 0.f;
     }
     const int lr = lane >> 3, ls = lane & 7;
     // ---- per-lane DMA plan (bytes)
@@ -1599,6 +1604,119 @@ __global__ __launch_bounds__(512, 1) void k_gemm8q(const GemmArgs g)
                 if (n < g.N)
                     *reinterpret_cast<float4 *>(g.ws + ((int64_t)blockIdx.y * g.M + m) * g.N + n) =
                         make_float4(acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]);
+            }
+        }
+        return;
+    }
+    if constexpr (CS) {
+        // ---- lean epilogue + channel partials (the CS epilogue of k_gemm8, same arithmetic and layout).  EVERY operand load is issued first, branch-free (rows / columns past the edge re-read a valid element,
+        // absent operands read the zero page), then the tile is computed and stored.  The generic epilogue loads bias / row-vector /
+        // residual under per-lane branches inside the m loop: at every control-flow join hipcc falls back to s_waitcnt vmcnt(0), and on
+        // gfx9 that counter also holds the STORES in flight -- MT x NTW serialised store round trips per wave (seen in the ISA).
+        const unsigned char *zp = (const unsigned char *)g.zeros;
+        const bool has_b = g.bias != nullptr, has_rv = g.rowvec != nullptr, has_res = g.residual != nullptr;
+        const float *biasp = has_b ? g.bias : reinterpret_cast<const float *>(zp);
+        const float *rvp = has_rv ? g.rowvec : reinterpret_cast<const float *>(zp);
+        const unsigned char *resp = has_res ? (const unsigned char *)g.residual : zp;
+        // the row vector is per batch: a tile holds rows of at most two batches (rows_per_batch >= BM, checked by the launcher)
+        const int64_t bA = m_base / g.rows_per_batch, b_last = (g.M - 1) / g.rows_per_batch;
+        const int64_t bB = bA + 1 < b_last ? bA + 1 : b_last;
+        const int64_t m_rv = (bA + 1) * g.rows_per_batch;                       // first row of batch bB
+        float4 bia[NTW], rvA[NTW], rvB[NTW];
+        uint2 rs[MT][NTW];
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int64_t n = n_lane + nt * 16, nc = n < g.N ? n : g.N - 4;
+            bia[nt] = *reinterpret_cast<const float4 *>(biasp + (has_b ? nc : 0));
+            rvA[nt] = *reinterpret_cast<const float4 *>(rvp + (has_rv ? bA * g.ld_rowvec + nc : 0));
+            rvB[nt] = *reinterpret_cast<const float4 *>(rvp + (has_rv ? bB * g.ld_rowvec + nc : 0));
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int64_t m = m_base + wm * (16 * MT) + mt * 16 + fr, mc = m < g.M ? m : g.M - 1;
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int64_t n = n_lane + nt * 16, nc = n < g.N ? n : g.N - 4;
+                rs[mt][nt] = *reinterpret_cast<const uint2 *>(resp + (has_res ? (mc * g.ldr + nc) * 2 : 0));
+            }
+        }
+        uint2 pks[MT][NTW];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int64_t m = m_base + wm * (16 * MT) + mt * 16 + fr;
+            const bool second = m >= m_rv;
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int64_t n = n_lane + nt * 16;
+                const float4 rv = second ? rvB[nt] : rvA[nt];
+                float v[4] = {acc[nt][mt][0] + bia[nt].x + rv.x, acc[nt][mt][1] + bia[nt].y + rv.y,
+                              acc[nt][mt][2] + bia[nt].z + rv.z, acc[nt][mt][3] + bia[nt].w + rv.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= g.out_scale;
+                v[0] += T::to_f((unsigned short)(rs[mt][nt].x & 0xffff)); v[1] += T::to_f((unsigned short)(rs[mt][nt].x >> 16));
+                v[2] += T::to_f((unsigned short)(rs[mt][nt].y & 0xffff)); v[3] += T::to_f((unsigned short)(rs[mt][nt].y >> 16));
+                const uint2 pk = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
+                const bool ok = m < g.M && n < g.N;
+                if (ok) *reinterpret_cast<uint2 *>((unsigned char *)g.out + (m * g.ldc + n) * 2) = pk;
+                pks[mt][nt] = ok ? pk : make_uint2(0u, 0u);      // statistics of the values as STORED
+            }
+        }
+        {
+            // Statistics pass, ONE copy of the code (the first version flushed at every batch boundary inside the unrolled m loop: MT + 1
+            // copies of 40 DPP reductions, +3 000 instructions and +5.5 us per launch of pure instruction fetch): pass p sums the rows of batch
+            // slot p -- slot 0 = the batch of the tile's first row, slot 1 = the next one, present only in a tile that straddles a batch
+            // boundary (a 16-row m-tile never does: rows_per_batch % 16 == 0; BM <= rows_per_batch: at most one boundary).
+            const int64_t m_split = (m_base / g.rows_per_batch + 1) * g.rows_per_batch;          // first row of the next batch
+            const int64_t m_end = m_base + BM < g.M ? m_base + BM : g.M;
+            const int npass = m_split < m_end ? 2 : 1;
+    #pragma unroll 1
+            for (int pass = 0; pass < npass; ++pass) {
+                float cs[NTW][4], cq[NTW][4];
+    #pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) { cs[nt][r] = 0.f; cq[nt][r] = 0.f; }
+    #pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int64_t m_tile = m_base + wm * (16 * MT) + mt * 16;             // wave-uniform
+                    const float wgt = ((m_tile >= m_split ? 1 : 0) == pass) ? 1.f : 0.f;
+    #pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) {
+                        const uint2 pk = pks[mt][nt];
+                        const float t0 = wgt * T::to_f((unsigned short)(pk.x & 0xffff)), t1 = wgt * T::to_f((unsigned short)(pk.x >> 16));
+                        const float t2 = wgt * T::to_f((unsigned short)(pk.y & 0xffff)), t3 = wgt * T::to_f((unsigned short)(pk.y >> 16));
+                        cs[nt][0] += t0; cq[nt][0] += t0 * t0; cs[nt][1] += t1; cq[nt][1] += t1 * t1;
+                        cs[nt][2] += t2; cq[nt][2] += t2 * t2; cs[nt][3] += t3; cq[nt][3] += t3 * t3;
+                    }
+                }
+                float *tb = ctab + (pass * BN + wn * (16 * NTW) + fc * 4) * 2;
+    #pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float sa = row16_sum(cs[nt][r]), sb = row16_sum(cq[nt][r]);
+                        if (fr == 0) {
+                            __hip_atomic_fetch_add(tb + (nt * 16 + r) * 2, sa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_add(tb + (nt * 16 + r) * 2 + 1, sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the LDS adds; NOT the output stores still in flight
+            __builtin_amdgcn_s_barrier();
+            const int64_t b0 = m_base / g.rows_per_batch;
+            const int cpg = g.gn_cpg, G = (int)(g.N / cpg);
+            const int n_hi = (int)(n_base + BN < g.N ? n_base + BN : g.N);
+            const int g_first = (int)n_base / cpg, ng = (n_hi - 1) / cpg - g_first + 1;        // groups that overlap this column tile (<= BN / cpg + 2)
+            for (int i = tid; i < 2 * ng; i += 512) {
+                const int slot = i >= ng ? 1 : 0, gg = g_first + i - slot * ng;
+                if (slot == 1 && !(m_split < m_end)) continue;
+                const int c_lo = gg * cpg > (int)n_base ? gg * cpg : (int)n_base, c_hi = (gg + 1) * cpg < n_hi ? (gg + 1) * cpg : n_hi;
+                float s1 = 0.f, s2 = 0.f;
+                for (int c = c_lo; c < c_hi; ++c) { const float2 t = *reinterpret_cast<const float2 *>(ctab + (slot * BN + c - (int)n_base) * 2); s1 += t.x; s2 += t.y; }
+                const int64_t b = b0 + slot;
+                const int64_t slab = mblk - (b * g.rows_per_batch) / BM;       // tiles are counted over all M rows
+                const int half = gg * cpg < (int)n_base ? 1 : 0;
+                *reinterpret_cast<float2 *>(g.chan_parts + ((((b * g.cp_nslab + slab) * G + gg) * 2 + half) * 2)) = make_float2(s1, s2);
             }
         }
         return;
