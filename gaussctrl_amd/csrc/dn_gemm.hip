@@ -65,7 +65,9 @@ void select_fp8(const gc_gemm_desc *d, SelQ *o, bool assume_ws)
     const int nkq = (int)(d->K / 128);
     o->splits = 1; o->tps = nkq;
     const bool plain = !d->geglu && !d->out_t && !d->out_fp8 && !d->out_f32 && d->out && !d->ln_row_stats && !d->out_row_stats && !d->out_group_stats && d->act == 0;
-    const int64_t nbn = (d->N + 32 * o->ntw - 1) / (32 * o->ntw), tiles = ((d->M + 127) / 128) * nbn;
+    // (plan_rows: the k-slices -- the accumulation order of every output row -- follow the rows ONE frame contributes, as in the 2-byte path)
+    const int64_t Msel = d->plan_rows > 0 ? d->plan_rows : d->M;
+    const int64_t nbn = (d->N + 32 * o->ntw - 1) / (32 * o->ntw), tiles = ((Msel + 127) / 128) * nbn;
     if (plain && !force_mt && !(d->kernel_variant & 0x40) && tiles <= 128 && nkq >= 16) {
         int s = (int)std::min<int64_t>(tiles < 96 ? (256 + tiles - 1) / tiles : 256 / tiles, nkq / 8);
         if (s > 16) s = 16;

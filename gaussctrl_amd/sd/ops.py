@@ -406,6 +406,8 @@ def conv3x3_fp8(x8, w8, w_scale, out_dtype, bias=None, stride=1, rowvec=None, ld
     if rowvec is not None:
         d.rowvec = rowvec.data_ptr(); d.ld_rowvec = rowvec.stride(0) if ld_rowvec is None else ld_rowvec
     d.rows_per_batch = Ho * Wo
+    if BATCH_INVARIANT:
+        d.plan_rows = Ho * Wo
     if residual is not None:
         d.residual = residual.data_ptr(); d.ldr = N
     d.out_scale = scale; d.act = act
@@ -433,6 +435,8 @@ def linear_fp8(x8, w8, w_scale, out_dtype, bias=None, residual=None, act=0, scal
     d.A = x8.data_ptr(); d.lda = x8.stride(-2) if x8.dim() > 1 else K; d.W = w8.data_ptr()
     d.bias = None if bias is None else bias.data_ptr()
     d.rows_per_batch = rows_per_batch
+    if BATCH_INVARIANT and x8.dim() >= 3:
+        d.plan_rows = M // x8.shape[0]                # the rows one frame contributes
     if residual is not None:
         d.residual = residual.data_ptr(); d.ldr = residual.stride(-2)
     d.out_scale = scale; d.act = act; d.geglu = int(geglu)

@@ -280,11 +280,14 @@ typedef struct gc_gemm_desc {
     int gn_groups;             /* float atomics (caller zero-fills) -> gc_dn_groupnorm_apply; needs rows_per_batch % 16 == 0, gn_groups <= 32 */
     /* fp8 path (BASELINE configs[3]): A and W hold OCP e4m3 bytes (K, lda, Cin count fp8 elements; K % 128 == 0, conv: Cin % 128 == 0), */
     /* multiplied on the block-scaled MFMA; real value = stored * 2^(scale byte - 127) (E8M0): one byte per weight row, one for all of A. */
+    /* Linears take the GEGLU / transposed-V epilogues of the 2-byte path; long-K problems on part-filled grids (16 x 16-map convs) run in  */
+    /* k-slices when `workspace` holds gc_dn_gemm_workspace_bytes(desc) bytes; out_chan_parts: fast convs and the k-sliced problems.         */
     int fp8;
     const void *w_scale;       /* [N] E8M0 bytes */
     int a_scale;               /* E8M0 byte of the activation tensor */
     int kernel_variant;        /* 0 = automatic.  Overrides for tests / experiments: bits 0-2 force the 8-wave kernel's m-tiles per wave (2,3,4); */
-                               /* 0x10 4-wave kernel only; 0x20 force the 8-wave kernel; 0x40 no k-slices for part-filled conv grids; 0x80 slice 8x8-map convs too */
+                               /* 0x10 4-wave kernel only; 0x20 force the 8-wave kernel; 0x40 no k-slices for part-filled conv grids; 0x80 slice 8x8-map convs too. */
+                               /* fp8 problems (k_gemm8q) honour bits 0-2 (a forced tile height also disables their k-slices) and 0x40 */
     float *out_chan_parts;     /* NULL or [M / rows_per_batch][nslab][gn_groups][2][2]: partial (sum, sum of squares) of the stored output per row slab,  */
                                /* GroupNorm group (N / gn_groups channels) and half (1: rest of a group straddling two column tiles); layout:          */
                                /* gc_dn_gemm_chan_parts_layout.  PLAIN stores -- no atomics, no zero-init -> gc_dn_groupnorm_apply_parts /              */
