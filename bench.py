@@ -221,7 +221,6 @@ class Bench:
             if dtype_name == "fp8":
                 from gaussctrl_amd.sd.weights import add_fp8_convs, add_fp8_linears
                 add_fp8_convs(uw, usd, dev); add_fp8_convs(cw, csd, dev)
-                uw["_fp8_min_hw"] = cw["_fp8_min_hw"] = args.fp8_min_hw
                 if args.fp8_linears and not fold_ln:      # C = 640 / 1280 transformer linears on e4m3 (bit 0 feed-forward, 1 attn2.to_q, 2 Q | K | V)
                     add_fp8_linears(uw, args.fp8_linears); add_fp8_linears(cw, args.fp8_linears)
             del usd, csd
@@ -528,7 +527,7 @@ def main():
         dist = None
 
     from gaussctrl_amd.sd import ops as sdops
-    sdops.configure(sdops.options_from_env())       # experiment switches (GC_FUSED_TAIL=0, GC_ATTN_V=4, GC_ABLATE=gn, ...): default = product
+    sdops.configure(sdops.options_from_env(), fp8_min_hw=args.fp8_min_hw)       # experiment switches (GC_FUSED_TAIL=0, GC_ATTN_V=4, GC_ABLATE=gn, ...): default = product
     if args.views is None:
         args.views = 40 if args.workload == "edit" else 256
     c, V, nsteps = args.chunk_size, args.views, args.denoise_steps

@@ -61,6 +61,8 @@ class KernelOptions:
     two_streams: bool = True         # ControlNet || UNet encoder on two HIP streams inside a denoise step
     gn_parts: bool = True            # GroupNorm statistics from the producer's epilogue (per-channel partials, plain stores): the
                                      # stand-alone statistics + finalize launches disappear (1 launch per GroupNorm instead of 3)
+    fp8_min_hw: int = 256            # fp8 path (weights.add_fp8_convs): smallest map, in pixels, whose resnet convolutions run on e4m3 -- 16 x 16 maps
+                                     # run k-sliced; the 8 x 8 maps measure slower in e4m3 than on the split-K bf16 kernels
     ablate: frozenset = frozenset()  # TIMING ablations (results wrong by construction; scripts/ablate_classes.sh): op classes whose
                                      # launches are skipped -- {"gn", "ln", "attn", "linear", "conv", "head", "tail"}
 

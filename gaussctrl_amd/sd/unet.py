@@ -113,7 +113,7 @@ class SDNet:
                                                                     # measured neutral (7.02 vs 6.97 views/s) and it gives up the shifted sums
         self.fp8 = bool(weights.get("_fp8_convs", False))           # resnet 3x3 convs on e4m3 operands (weights.add_fp8_convs)
         self.fp8_a_scale = 127                                      # E8M0 byte of the conv inputs (GroupNorm + SiLU outputs are O(1): 2^0)
-        self.fp8_min_hw = int(weights.get("_fp8_min_hw", 256))      # smallest map whose resnet convs run on e4m3 (16 x 16: k-sliced k_gemm8q)
+        self.fp8_min_hw = ops.OPTIONS.fp8_min_hw                    # smallest map whose resnet convs run on e4m3 (16 x 16: k-sliced k_gemm8q)
         # transformer-block linears of the C = 640 / 1280 levels on e4m3 operands (weights.add_fp8_linears): the three LayerNorms write e4m3,
         # the GEGLU epilogue writes the FF hidden as e4m3; E8M0 bytes of the two activation kinds (LayerNorm outputs, GEGLU hidden): 2^0
         self.fp8_lin = int(weights.get("_fp8_linears", 0))          # bit 0: feed-forward, bit 1: attn2.to_q, bit 2: Q | K | V
