@@ -111,3 +111,51 @@ def test_fp8_linear_copies_of_transformer_weights():
         assert bool(((deq - w).abs() <= 0.0626 * w.abs() + amax * 2.0 ** -9).all())          # half an e4m3 step (normal), subnormal floor
         stored_max = q.view(torch.float8_e4m3fn).float().abs().amax(1)
         assert bool((stored_max >= 224).all()) and bool((stored_max <= 448).all())
+
+
+def test_fp8_gemm_planning_queries(built):
+    """host-side planning of the fp8 GEMM (no GPU needed: gc_dn_gemm_workspace_bytes / gc_dn_gemm_chan_parts_layout are pure functions of
+    the descriptor): the 16 x 16-map convolutions at the benchmark's batch are k-sliced and leave their GroupNorm partials through the
+    reduce kernel (32-row slabs, 64-column blocks); full grids are not sliced and leave them through k_gemm8q's own epilogue (row-tile
+    slabs); GEGLU / e4m3-output / statistics problems are never sliced; with plan_rows (batch-invariant mode) the slice count depends on the
+    rows ONE frame contributes, not on the batch."""
+    from gaussctrl_amd.sd.ops import GemmDesc
+    lib = ctypes.CDLL(built)
+    lib.gc_dn_gemm_workspace_bytes.restype = ctypes.c_size_t
+
+    def conv(B, hw, cin, cout, **kw):
+        d = GemmDesc()
+        d.dtype = 0; d.mode = 1; d.M, d.N, d.K = B * hw * hw, cout, 9 * cin
+        d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.stride, d.pad_lo = B, hw, hw, cin, hw, hw, 1, 1
+        d.rows_per_batch = hw * hw; d.fp8 = 1; d.a_scale = 127; d.out = 1; d.ldc = cout; d.lda = cin
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return d
+
+    def splits(d):
+        return lib.gc_dn_gemm_workspace_bytes(ctypes.byref(d)) // (4 * d.M * d.N)
+
+    def layout(d, with_ws=True):
+        if with_ws:
+            d.workspace = 1; d.workspace_bytes = lib.gc_dn_gemm_workspace_bytes(ctypes.byref(d))
+        d.gn_groups = 32
+        rows, ns, ct = ctypes.c_int64(0), ctypes.c_int(0), ctypes.c_int(0)
+        assert lib.gc_dn_gemm_chan_parts_layout(ctypes.byref(d), ctypes.byref(rows), ctypes.byref(ns), ctypes.byref(ct)) == 0
+        return rows.value, ns.value, ct.value
+
+    assert splits(conv(6, 16, 1280, 1280)) == 2                 # 120 tiles of 90 k-steps -> 240 workgroups
+    assert splits(conv(3, 16, 1280, 1280)) == 5                 # 60 tiles -> 300 workgroups of 18 k-steps
+    assert splits(conv(6, 16, 2560, 1280)) == 2
+    assert splits(conv(14, 16, 1280, 1280)) == 0                # 280 tiles: a full grid
+    assert splits(conv(6, 32, 640, 640)) == 0 and splits(conv(6, 64, 384, 320)) == 0
+    assert splits(conv(6, 16, 1280, 1280, geglu=1)) == 0 and splits(conv(6, 16, 1280, 1280, out_fp8=127)) == 0
+    assert splits(conv(6, 16, 1280, 1280, out_group_stats=1)) == 0
+    assert splits(conv(6, 16, 1280, 1280, kernel_variant=2)) == 0          # a forced tile height does not slice
+    assert layout(conv(6, 16, 1280, 1280)) == (32, 8, 64)       # reduce kernel: 32-row slabs, 64-column blocks
+    assert layout(conv(6, 16, 1280, 1280), with_ws=False) == (128, 2, 128)   # no workspace -> unsliced, k_gemm8q's own partial epilogue
+    assert layout(conv(14, 16, 1280, 1280)) == (192, 3, 128)    # MT 3 tiles of 192 rows straddle the 256-row batches
+    assert layout(conv(6, 64, 384, 320)) == (128, 32, 160)      # N = 320 (Cin 320 padded to 384): 160-column tiles
+    assert layout(conv(6, 8, 1280, 1280))[0] == 0               # 8 x 8 maps: fewer than 256 rows per batch -> no partials
+    # batch-invariant planning: the same slices whatever shares the batch
+    a, b = conv(6, 16, 1280, 1280, plan_rows=256), conv(14, 16, 1280, 1280, plan_rows=256)
+    assert splits(a) == splits(b) == 10
