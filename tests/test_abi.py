@@ -159,3 +159,43 @@ def test_fp8_gemm_planning_queries(built):
     # batch-invariant planning: the same slices whatever shares the batch
     a, b = conv(6, 16, 1280, 1280, plan_rows=256), conv(14, 16, 1280, 1280, plan_rows=256)
     assert splits(a) == splits(b) == 10
+
+
+def test_gemm_planning_matches_the_documented_design(built):
+    """the 2-byte GEMM's host-side planning at the benchmark's shapes (CFG batch 6), as DESIGN.md 3.2 / 7.0 states it: 64 x 64 maps at C = 320 on
+    192-row x 160-column tiles; 32 x 32 maps on 128 x 128 tiles; the long-K part-filled grids in k-slices whose reduce kernel leaves the GroupNorm
+    partials in 32-row slabs; the 8 x 8 maps in 15 slices ("128 x 128 x 15 slices") without partials (fewer than 256 rows per batch); GEGLU
+    never sliced.  Pure functions of the descriptor: no GPU needed."""
+    from gaussctrl_amd.sd.ops import GemmDesc
+    lib = ctypes.CDLL(built)
+    lib.gc_dn_gemm_workspace_bytes.restype = ctypes.c_size_t
+
+    def conv(B, hw, cin, cout):
+        d = GemmDesc()
+        d.dtype = 0; d.mode = 1; d.M, d.N, d.K = B * hw * hw, cout, 9 * cin
+        d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.stride, d.pad_lo = B, hw, hw, cin, hw, hw, 1, 1
+        d.rows_per_batch = hw * hw; d.out = 1; d.ldc = cout; d.lda = cin; d.zeros = 1
+        return d
+
+    def lin(M, N, K, rpb=0, geglu=0):
+        d = GemmDesc()
+        d.dtype = 0; d.mode = 0; d.M, d.N, d.K = M, N, K
+        d.lda = K; d.out = 1; d.ldc = N; d.zeros = 1; d.rows_per_batch = rpb; d.geglu = geglu
+        return d
+
+    def plan(d):
+        ws = lib.gc_dn_gemm_workspace_bytes(ctypes.byref(d))
+        d.workspace = 1; d.workspace_bytes = ws; d.gn_groups = 32
+        rows, ns, ct = ctypes.c_int64(0), ctypes.c_int(0), ctypes.c_int(0)
+        assert lib.gc_dn_gemm_chan_parts_layout(ctypes.byref(d), ctypes.byref(rows), ctypes.byref(ns), ctypes.byref(ct)) == 0
+        return ws // (4 * d.M * d.N), (rows.value, ns.value, ct.value)
+
+    assert plan(conv(6, 64, 320, 320)) == (0, (192, 23, 160))
+    assert plan(conv(6, 32, 640, 640)) == (0, (128, 8, 128))
+    assert plan(conv(6, 16, 1280, 1280)) == (4, (32, 8, 64))
+    assert plan(conv(6, 16, 2560, 1280)) == (4, (32, 8, 64))
+    assert plan(conv(6, 8, 1280, 1280)) == (15, (0, 0, 0))
+    assert plan(lin(6144, 640, 640, 1024)) == (0, (128, 8, 128))              # proj_out of a 32 x 32 block
+    assert plan(lin(1536, 1280, 5120, 256)) == (4, (32, 8, 64))               # FF down projection, 16 x 16 block
+    assert plan(lin(384, 1280, 5120, 64))[0] == 10                            # ... 8 x 8 block
+    assert plan(lin(6144, 5120, 640, geglu=1)) == (0, (0, 0, 0))
