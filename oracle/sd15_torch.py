@@ -25,6 +25,32 @@ import math
 import torch
 import torch.nn.functional as F
 
+# --------------------------------------------------------------------------------------- e4m3 emulation (BASELINE configs[3])
+# Restatement of the ARITHMETIC of the product's fp8 path (gaussctrl_amd/sd/unet.py with weights.add_fp8_convs / add_fp8_linears; DESIGN.md
+# 3.3) on top of this fp32 oracle: the same tensors are rounded to OCP e4m3 at the same sites -- resnet conv1 / conv2 inputs (GroupNorm + SiLU
+# outputs, tensor-wide scale 2^0, saturation at +-448) on maps of >= min_hw pixels; in the transformer blocks with C % 128 == 0 and >=
+# min_rows token rows the LayerNorm outputs that feed Q | K | V (bit 2), attn2.to_q (bit 1) and the GEGLU projection (bit 0) and the GEGLU
+# hidden that feeds the down projection; weights per OUTPUT ROW with a power-of-two scale that puts the row maximum in e4m3's top binade --
+# and multiplied exactly (fp32 here; the block-scaled MFMA accumulates in fp32).  It answers one question: how far from the fp32 oracle
+# SHOULD latents computed with these roundings be?  (tests/golden/make_fullgeom_golden.py edit7_e4m3; the product's measured distance is compared
+# with it in DESIGN.md 3.3.)  FP8_EMU = None: off (every other use of this file).
+FP8_EMU = None          # or {"min_hw": 256, "min_rows": 1024, "linears": 7, "cache": {}}
+
+
+def _q8(x):
+    return x.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(x.dtype)
+
+
+def _q8_rows(w, key):
+    """weight [N, ...] -> its e4m3 rounding with one power-of-two scale per output row (gaussctrl_amd/sd/weights.py::quantize_rows_e4m3)"""
+    c = FP8_EMU["cache"]
+    if key not in c:
+        w2 = w.reshape(w.shape[0], -1).float()
+        e = torch.floor(torch.log2(448.0 / w2.abs().amax(dim=1).clamp_min(1e-30))).clamp(-100, 100)
+        sc = torch.exp2(e)[:, None]
+        c[key] = ((w2 * sc).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float() / sc).reshape(w.shape).to(w.dtype)
+    return c[key]
+
 SD15 = dict(block_out_channels=(320, 640, 1280, 1280), layers_per_block=2, heads=8, cross_dim=768,
             in_channels=4, out_channels=4, groups=32, attn_levels=(True, True, True, False),
             cond_channels=(16, 32, 96, 256), text_len=77)
@@ -204,13 +230,20 @@ def cross_view_attention(q, k, v, heads, self_attn_coeff, unet_chunk_size=2, num
     return self_attn_coeff * out_self + (1 - self_attn_coeff) * (acc / num_refs)
 
 
-def attention_layer(w, p, x, ctx, heads, mode, coeff):
+def attention_layer(w, p, x, ctx, heads, mode, coeff, q8=0):
     """One CrossViewAttnProcessor.__call__ (utils.py:44-133) for a [B,L,C] input; mode in {"plain","xview"}.
     Text cross-attention (ctx given) is ordinary attention in both modes (utils.py:111-117)."""
-    q = x @ w[p + ".to_q.weight"].T
-    src = x if ctx is None else ctx
-    k = src @ w[p + ".to_k.weight"].T
-    v = src @ w[p + ".to_v.weight"].T
+    wq, wk, wv = w[p + ".to_q.weight"], w[p + ".to_k.weight"], w[p + ".to_v.weight"]
+    xq = x
+    if q8 & (4 if ctx is None else 2):       # e4m3 emulation: the LayerNorm output and the projection weights it meets
+        xq = _q8(x)
+        wq = _q8_rows(wq, (id(w), p + ".to_q"))
+        if ctx is None:
+            wk, wv = _q8_rows(wk, (id(w), p + ".to_k")), _q8_rows(wv, (id(w), p + ".to_v"))
+    q = xq @ wq.T
+    src = xq if ctx is None else ctx
+    k = src @ wk.T
+    v = src @ wv.T
     if ctx is None and mode == "xview":
         o = cross_view_attention(q, k, v, heads, coeff)
     else:
@@ -236,11 +269,18 @@ def _conv(w, p, x, stride=1, pad=None):
     return F.conv2d(x, w[p + ".weight"], w[p + ".bias"], stride=stride, padding=(k // 2 if pad is None else pad))
 
 
+def _conv8(w, p, x):
+    """3x3 conv of the e4m3-rounded input with the row-wise e4m3-rounded weights (e4m3 emulation of a resnet convolution)"""
+    return F.conv2d(_q8(x), _q8_rows(w[p + ".weight"], (id(w), p)), w[p + ".bias"], padding=1)
+
+
 def resnet(w, p, x, temb, groups, eps=1e-5):
-    h = _conv(w, p + ".conv1", F.silu(_gn(w, p + ".norm1", x, groups, eps)))
+    q8 = FP8_EMU is not None and x.shape[2] * x.shape[3] >= FP8_EMU["min_hw"]
+    conv = _conv8 if q8 else _conv
+    h = conv(w, p + ".conv1", F.silu(_gn(w, p + ".norm1", x, groups, eps)))
     if temb is not None:
         h = h + (F.silu(temb) @ w[p + ".time_emb_proj.weight"].T + w[p + ".time_emb_proj.bias"])[:, :, None, None]
-    h = _conv(w, p + ".conv2", F.silu(_gn(w, p + ".norm2", h, groups, eps)))
+    h = conv(w, p + ".conv2", F.silu(_gn(w, p + ".norm2", h, groups, eps)))
     if (p + ".conv_shortcut.weight") in w:
         x = _conv(w, p + ".conv_shortcut", x)
     return x + h
@@ -253,12 +293,17 @@ def transformer(w, p, x, ctx, cfg, mode, coeff):
     h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
     t = p + ".transformer_blocks.0"
     ln = lambda n, z: F.layer_norm(z, (C,), w[f"{t}.{n}.weight"], w[f"{t}.{n}.bias"], 1e-5)
-    h = attention_layer(w, t + ".attn1", ln("norm1", h), None, cfg["heads"], mode, coeff) + h
-    h = attention_layer(w, t + ".attn2", ln("norm2", h), ctx, cfg["heads"], mode, coeff) + h
+    q8 = FP8_EMU["linears"] if (FP8_EMU is not None and C % 128 == 0 and B * H * W >= FP8_EMU["min_rows"]) else 0
+    h = attention_layer(w, t + ".attn1", ln("norm1", h), None, cfg["heads"], mode, coeff, q8) + h
+    h = attention_layer(w, t + ".attn2", ln("norm2", h), ctx, cfg["heads"], mode, coeff, q8) + h
     n3 = ln("norm3", h)
-    pr = n3 @ w[t + ".ff.net.0.proj.weight"].T + w[t + ".ff.net.0.proj.bias"]
+    w1, w2 = w[t + ".ff.net.0.proj.weight"], w[t + ".ff.net.2.weight"]
+    if q8 & 1:                               # e4m3 emulation: LayerNorm output, both FF weights, and the GEGLU hidden between them
+        n3, w1, w2 = _q8(n3), _q8_rows(w1, (id(w), t + ".ff1")), _q8_rows(w2, (id(w), t + ".ff2"))
+    pr = n3 @ w1.T + w[t + ".ff.net.0.proj.bias"]
     hid, gate = pr.chunk(2, dim=-1)
-    h = (hid * F.gelu(gate)) @ w[t + ".ff.net.2.weight"].T + w[t + ".ff.net.2.bias"] + h
+    gg = hid * F.gelu(gate)
+    h = (_q8(gg) if q8 & 1 else gg) @ w2.T + w[t + ".ff.net.2.bias"] + h
     h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
     return _conv(w, p + ".proj_out", h) + res
 

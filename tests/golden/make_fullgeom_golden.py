@@ -19,7 +19,7 @@ steps, the 8 chunk frames decoded by the VAE and composited through the syntheti
 (gc_pipeline.py:209-234).  Stored: latents after steps 1, 2, 5, 10, 20 and the composited images on a stride-4 pixel lattice
 (full-resolution decode parity has its own fixture, fullgeom_vae_h64.npz).
 
-usage: python tests/golden/make_fullgeom_golden.py [edit7|vae|invert|edit12|config4|vaeenc ...]
+usage: python tests/golden/make_fullgeom_golden.py [edit7|vae|invert|edit12|config4|vaeenc|edit7_e4m3 ...]
 """
 import os
 import sys
@@ -138,6 +138,27 @@ def config4(h, seed, name):
     print(f"{name}: {time.time() - t0:.0f}s", flush=True)
 
 
+def edit_e4m3(f, h, steps, seed, name, ref_name):
+    """The same trajectory with the ARITHMETIC of the product's fp8 path restated on the oracle (sd.FP8_EMU: e4m3 roundings at the sites
+    gaussctrl_amd/sd/unet.py quantises -- resnet conv inputs on maps >= 16 x 16, LayerNorm outputs / GEGLU hidden / weights of the C = 640 /
+    1280 transformer linears), first `steps` DDIM steps: what distance from the fp32 trajectory e4m3 operands by themselves produce."""
+    uw, cw = weights()
+    lat, disp, cn, cp = inputs(f, h, seed)
+    trace = []
+    t0 = time.time()
+    sd.FP8_EMU = {"min_hw": 256, "min_rows": 1024, "linears": 7, "cache": {}}
+    try:
+        with torch.no_grad():
+            sd.denoise_chunk(uw, cw, lat, bf16r(disp), bf16r(cn), bf16r(cp), 5.0, steps, sd.SD15, 20, trace=trace)
+    finally:
+        sd.FP8_EMU = None
+    ref = np.load(os.path.join(HERE, ref_name))["lat_steps"]
+    rel = [float((t - torch.tensor(ref[i])).norm() / torch.tensor(ref[i]).norm()) for i, t in enumerate(trace)]
+    np.savez_compressed(os.path.join(HERE, name), lat_steps=torch.stack(trace).numpy().astype(np.float32), rel_vs_fp32=np.array(rel),
+                        meta=np.array([f, h, steps, seed, SEED_UNET, SEED_CN], np.int64))
+    print(f"{name}: {time.time() - t0:.0f}s; relative L2 of the e4m3-emulating oracle vs the fp32 oracle per step: " + " ".join(f"{e:.3e}" for e in rel), flush=True)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(int(os.environ.get("GC_GOLDEN_THREADS", "7")))
     sd.ATTN_IMPL = "sdpa"
@@ -147,6 +168,8 @@ if __name__ == "__main__":
             vae(64, 1, "fullgeom_vae_h64.npz")
         elif w == "edit7":       # BASELINE configs[1]: chunk_size 3 -> f = 7, CFG batch 14, all 20 steps
             edit(7, 64, 20, 2, "fullgeom_edit_f7_h64.npz")
+        elif w == "edit7_e4m3":  # the fp8 path's arithmetic restated on the oracle, first 6 steps of the edit7 trajectory
+            edit_e4m3(7, 64, int(os.environ.get("GC_E4M3_STEPS", "6")), 2, "fullgeom_edit_f7_h64_e4m3.npz", "fullgeom_edit_f7_h64.npz")
         elif w == "invert":      # render_reverse's inversion, 3 views batched, all 20 steps
             invert(3, 64, 20, 5, "fullgeom_invert_f3_h64.npz")
         elif w == "edit12":      # BASELINE configs[3]: chunk_size 8 -> f = 12, CFG batch 24 (2 of 20 steps)

@@ -323,6 +323,17 @@ def test_edit_f7_h64_fp8_convs_and_linears(nets, which):
     cur = _curve(trace, ref)
     print(f"\nedit f=7 h=64 fp8 convs + linears (mask {which}): rel L2 per step:\n  " + " ".join(f"{e:.2e}" for e in cur))
     within("max(cur)", max(cur), 6e-2)
+    if which == 7:
+        # ... and against the oracle that restates the fp8 path's ARITHMETIC (oracle/sd15_torch.py FP8_EMU: e4m3 roundings at the same sites;
+        # tests/golden/make_fullgeom_golden.py edit7_e4m3, first 6 steps).  That oracle sits 2.08e-2 .. 2.66e-2 from the fp32 one -- the product's
+        # 2.12e-2 .. 2.72e-2 is what e4m3 operands cost, not kernel error.  The two round the same tensors, but a value near an e4m3 boundary
+        # rounds either way under a bf16-sized perturbation, so they are not expected to coincide; the bar here is the one the triangle
+        # inequality guarantees (distance to fp32 of each < 3e-2); the recorded value is what a later round can tighten.
+        emu = np.load(os.path.join(GOLD, "fullgeom_edit_f7_h64_e4m3.npz"))
+        cur_e = [_rel(trace[i], torch.tensor(emu["lat_steps"][i])) for i in range(emu["lat_steps"].shape[0])]
+        print("vs the e4m3-emulating oracle (its own distance to fp32: " + " ".join(f"{e:.2e}" for e in emu["rel_vs_fp32"]) + "):\n  " +
+              " ".join(f"{e:.2e}" for e in cur_e))
+        within("max(cur_e)", max(cur_e), 6e-2)
     # the product path at the benchmark's grids: reference bank + a 3-view chunk (CFG batch 6 -- there the 16 x 16-map convolutions are part-
     # filled grids and run as k-sliced k_gemm8q + the split-K reduce kernel that leaves the GroupNorm partials; B = 14 above does not slice)
     bank = pipe.build_ref_bank(lat[:4].to(DEV), disp[:4].to(DEV), cn.to(DEV), cp.to(DEV))

@@ -117,3 +117,36 @@ def test_layernorm_fold_algebra():
     n = pr.shape[1] // 2
     idx = torch.arange(n).reshape(n // 16, 16); perm = torch.cat([idx, idx + n], 1).reshape(-1)
     assert float((fold(t + "ff.net.0.proj") - pr[:, perm]).abs().max()) < 5e-6
+
+
+def test_e4m3_emulation_hooks():
+    """sd.FP8_EMU (the arithmetic of the product's fp8 path restated on the oracle): inert when no site qualifies (bit-identical to the fp32
+    oracle), every site class moves the result when on, the weight rounding is the product's (row maximum in e4m3's top binade, at most half
+    an e4m3 step per element), and the whole-network distance at a tiny geometry is of e4m3's order (3 mantissa bits), not a blow-up."""
+    cfg = sd.TINY
+    torch.manual_seed(0)
+    uw, cw = sd.make_unet_weights(cfg, 1), sd.make_controlnet_weights(cfg, 2)
+    f, h = 5, 8
+    lat = torch.randn(f, 4, h, h); disp = torch.rand(f, 3, 8 * h, 8 * h)
+    cn, cp = torch.randn(1, cfg["text_len"], cfg["cross_dim"]), torch.randn(1, cfg["text_len"], cfg["cross_dim"])
+    run = lambda: sd.denoise_chunk(uw, cw, lat, disp, cn, cp, 5.0, 2, cfg, 20)
+    plain = run()
+    outs = {}
+    try:
+        sd.FP8_EMU = {"min_hw": 1 << 30, "min_rows": 1 << 30, "linears": 7, "cache": {}}
+        assert torch.equal(run(), plain)
+        for name, emu in (("convs", dict(min_hw=4, min_rows=1 << 30, linears=0)), ("ff", dict(min_hw=1 << 30, min_rows=1, linears=1)),
+                          ("to_q", dict(min_hw=1 << 30, min_rows=1, linears=2)), ("qkv", dict(min_hw=1 << 30, min_rows=1, linears=4)),
+                          ("all", dict(min_hw=4, min_rows=1, linears=7))):
+            sd.FP8_EMU = dict(emu, cache={})
+            outs[name] = float((run() - plain).norm() / plain.norm())
+        w = torch.randn(64, 3, 3, 3) * torch.exp2(torch.randint(-8, 8, (64, 1, 1, 1)).float())
+        sd.FP8_EMU = {"cache": {}}
+        q = sd._q8_rows(w, "w")
+    finally:
+        sd.FP8_EMU = None
+    assert all(v > 1e-5 for v in outs.values()), outs                    # every site class is live (TINY has C = 128 levels)
+    assert 1e-3 < outs["all"] < 1e-1, outs
+    amax = w.abs().amax(dim=(1, 2, 3), keepdim=True)
+    assert bool(((q - w).abs() <= 0.0626 * w.abs() + amax * 2.0 ** -9).all())
+    assert torch.equal(run(), plain)                                     # and off again
