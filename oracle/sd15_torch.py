@@ -41,6 +41,20 @@ def _q8(x):
     return x.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(x.dtype)
 
 
+# --------------------------------------------------------------------------------------- 2-byte activation emulation
+# ACT_ROUND = torch.bfloat16 / torch.float16: every tensor the product STORES in its activation type between kernels is rounded to that type
+# here (conv / linear outputs after their fused bias / time-embedding / residual epilogue, GroupNorm and LayerNorm outputs, Q / K / V,
+# attention outputs, the GEGLU hidden, the ControlNet residual sums, the 2-byte network input); weights are whatever the caller passes (the
+# fixtures round them to bf16), arithmetic inside an op stays fp32 as on the MFMA.  Like FP8_EMU it answers "what does the storage type cost by
+# itself" -- the derivation of the bf16 / f16 parity bars.  Not modelled: the softmax probabilities rounded for the P V MFMA, and
+# the level-0 blocks' row-resident kernels, which keep MORE in fp32 registers than this does.  None: off.
+ACT_ROUND = None
+
+
+def _r(x):
+    return x if ACT_ROUND is None else x.to(ACT_ROUND).to(torch.float32)
+
+
 def _q8_rows(w, key):
     """weight [N, ...] -> its e4m3 rounding with one power-of-two scale per output row (gaussctrl_amd/sd/weights.py::quantize_rows_e4m3)"""
     c = FP8_EMU["cache"]
@@ -240,15 +254,15 @@ def attention_layer(w, p, x, ctx, heads, mode, coeff, q8=0):
         wq = _q8_rows(wq, (id(w), p + ".to_q"))
         if ctx is None:
             wk, wv = _q8_rows(wk, (id(w), p + ".to_k")), _q8_rows(wv, (id(w), p + ".to_v"))
-    q = xq @ wq.T
+    q = _r(xq @ wq.T)
     src = xq if ctx is None else ctx
-    k = src @ wk.T
-    v = src @ wv.T
+    k = _r(src @ wk.T)
+    v = _r(src @ wv.T)
     if ctx is None and mode == "xview":
         o = cross_view_attention(q, k, v, heads, coeff)
     else:
         o = plain_attention(q, k, v, heads)
-    return o @ w[p + ".to_out.0.weight"].T + w[p + ".to_out.0.bias"]
+    return _r(o) @ w[p + ".to_out.0.weight"].T + w[p + ".to_out.0.bias"]        # (the caller adds the residual, then rounds)
 
 
 # =========================================================================================== blocks
@@ -277,35 +291,35 @@ def _conv8(w, p, x):
 def resnet(w, p, x, temb, groups, eps=1e-5):
     q8 = FP8_EMU is not None and x.shape[2] * x.shape[3] >= FP8_EMU["min_hw"]
     conv = _conv8 if q8 else _conv
-    h = conv(w, p + ".conv1", F.silu(_gn(w, p + ".norm1", x, groups, eps)))
+    h = conv(w, p + ".conv1", _r(F.silu(_gn(w, p + ".norm1", x, groups, eps))))
     if temb is not None:
         h = h + (F.silu(temb) @ w[p + ".time_emb_proj.weight"].T + w[p + ".time_emb_proj.bias"])[:, :, None, None]
-    h = conv(w, p + ".conv2", F.silu(_gn(w, p + ".norm2", h, groups, eps)))
+    h = conv(w, p + ".conv2", _r(F.silu(_gn(w, p + ".norm2", _r(h), groups, eps))))
     if (p + ".conv_shortcut.weight") in w:
-        x = _conv(w, p + ".conv_shortcut", x)
-    return x + h
+        x = _r(_conv(w, p + ".conv_shortcut", x))
+    return _r(x + h)
 
 
 def transformer(w, p, x, ctx, cfg, mode, coeff):
     B, C, H, W = x.shape
     res = x
-    h = _conv(w, p + ".proj_in", _gn(w, p + ".norm", x, cfg["groups"], 1e-6))
+    h = _r(_conv(w, p + ".proj_in", _r(_gn(w, p + ".norm", x, cfg["groups"], 1e-6))))
     h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
     t = p + ".transformer_blocks.0"
-    ln = lambda n, z: F.layer_norm(z, (C,), w[f"{t}.{n}.weight"], w[f"{t}.{n}.bias"], 1e-5)
+    ln = lambda n, z: _r(F.layer_norm(z, (C,), w[f"{t}.{n}.weight"], w[f"{t}.{n}.bias"], 1e-5))
     q8 = FP8_EMU["linears"] if (FP8_EMU is not None and C % 128 == 0 and B * H * W >= FP8_EMU["min_rows"]) else 0
-    h = attention_layer(w, t + ".attn1", ln("norm1", h), None, cfg["heads"], mode, coeff, q8) + h
-    h = attention_layer(w, t + ".attn2", ln("norm2", h), ctx, cfg["heads"], mode, coeff, q8) + h
+    h = _r(attention_layer(w, t + ".attn1", ln("norm1", h), None, cfg["heads"], mode, coeff, q8) + h)
+    h = _r(attention_layer(w, t + ".attn2", ln("norm2", h), ctx, cfg["heads"], mode, coeff, q8) + h)
     n3 = ln("norm3", h)
     w1, w2 = w[t + ".ff.net.0.proj.weight"], w[t + ".ff.net.2.weight"]
     if q8 & 1:                               # e4m3 emulation: LayerNorm output, both FF weights, and the GEGLU hidden between them
         n3, w1, w2 = _q8(n3), _q8_rows(w1, (id(w), t + ".ff1")), _q8_rows(w2, (id(w), t + ".ff2"))
     pr = n3 @ w1.T + w[t + ".ff.net.0.proj.bias"]
     hid, gate = pr.chunk(2, dim=-1)
-    gg = hid * F.gelu(gate)
-    h = (_q8(gg) if q8 & 1 else gg) @ w2.T + w[t + ".ff.net.2.bias"] + h
+    gg = _r(hid * F.gelu(gate))
+    h = _r((_q8(gg) if q8 & 1 else gg) @ w2.T + w[t + ".ff.net.2.bias"] + h)
     h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
-    return _conv(w, p + ".proj_out", h) + res
+    return _r(_conv(w, p + ".proj_out", h) + res)
 
 
 def _time_embed(w, t, B, cfg):
@@ -325,7 +339,7 @@ def _encoder(w, x, temb, ctx, cfg, mode, coeff):
                 x = transformer(w, f"down_blocks.{i}.attentions.{j}", x, ctx, cfg, mode, coeff)
             skips.append(x)
         if i < len(boc) - 1:
-            x = _conv(w, f"down_blocks.{i}.downsamplers.0.conv", x, stride=2, pad=1)
+            x = _r(_conv(w, f"down_blocks.{i}.downsamplers.0.conv", x, stride=2, pad=1))
             skips.append(x)
     x = resnet(w, "mid_block.resnets.0", x, temb, cfg["groups"])
     x = transformer(w, "mid_block.attentions.0", x, ctx, cfg, mode, coeff)
@@ -336,28 +350,27 @@ def _encoder(w, x, temb, ctx, cfg, mode, coeff):
 def controlnet_forward(w, sample, t, ctx, cond, cfg=SD15, conditioning_scale=1.0, mode="xview", coeff=0.0):
     """ControlNetModel.forward -> (12 down residuals, mid residual).  coeff=0: gc_pipeline.py:166-168."""
     temb = _time_embed(w, t, sample.shape[0], cfg)
-    x = _conv(w, "conv_in", sample)
-    c = F.silu(_conv(w, "controlnet_cond_embedding.conv_in", cond))
+    c = _r(F.silu(_conv(w, "controlnet_cond_embedding.conv_in", cond)))
     nblk = 2 * (len(cfg["cond_channels"]) - 1)
     for k in range(nblk):
-        c = F.silu(_conv(w, f"controlnet_cond_embedding.blocks.{k}", c, stride=2 if k % 2 == 1 else 1, pad=1))
-    c = _conv(w, "controlnet_cond_embedding.conv_out", c)
-    x = x + c
+        c = _r(F.silu(_conv(w, f"controlnet_cond_embedding.blocks.{k}", c, stride=2 if k % 2 == 1 else 1, pad=1)))
+    c = _r(_conv(w, "controlnet_cond_embedding.conv_out", c))
+    x = _r(_conv(w, "conv_in", _r(sample)) + c)
     x, skips = _encoder(w, x, temb, ctx, cfg, mode, coeff)
-    down = [_conv(w, f"controlnet_down_blocks.{n}", s) * conditioning_scale for n, s in enumerate(skips)]
-    mid = _conv(w, "controlnet_mid_block", x) * conditioning_scale
+    down = [_r(_conv(w, f"controlnet_down_blocks.{n}", s) * conditioning_scale) for n, s in enumerate(skips)]
+    mid = _r(_conv(w, "controlnet_mid_block", x) * conditioning_scale)
     return down, mid
 
 
 def unet_forward(w, sample, t, ctx, down_res=None, mid_res=None, cfg=SD15, mode="xview", coeff=0.6):
     """UNet2DConditionModel.forward with ControlNet residuals.  coeff=0.6: gc_pipeline.py:163-165."""
     temb = _time_embed(w, t, sample.shape[0], cfg)
-    x = _conv(w, "conv_in", sample)
+    x = _r(_conv(w, "conv_in", _r(sample)))
     x, skips = _encoder(w, x, temb, ctx, cfg, mode, coeff)
     if down_res is not None:
-        skips = [s + r for s, r in zip(skips, down_res)]
+        skips = [_r(s + r) for s, r in zip(skips, down_res)]
     if mid_res is not None:
-        x = x + mid_res
+        x = _r(x + mid_res)
     boc = cfg["block_out_channels"]
     rev_attn = list(reversed(cfg["attn_levels"]))
     for i in range(len(boc)):
@@ -368,8 +381,8 @@ def unet_forward(w, sample, t, ctx, down_res=None, mid_res=None, cfg=SD15, mode=
                 x = transformer(w, f"up_blocks.{i}.attentions.{j}", x, ctx, cfg, mode, coeff)
         if i < len(boc) - 1:
             x = F.interpolate(x, scale_factor=2.0, mode="nearest")
-            x = _conv(w, f"up_blocks.{i}.upsamplers.0.conv", x)
-    x = F.silu(_gn(w, "conv_norm_out", x, cfg["groups"], 1e-5))
+            x = _r(_conv(w, f"up_blocks.{i}.upsamplers.0.conv", x))
+    x = _r(F.silu(_gn(w, "conv_norm_out", x, cfg["groups"], 1e-5)))
     return _conv(w, "conv_out", x)
 
 

@@ -19,7 +19,7 @@ steps, the 8 chunk frames decoded by the VAE and composited through the syntheti
 (gc_pipeline.py:209-234).  Stored: latents after steps 1, 2, 5, 10, 20 and the composited images on a stride-4 pixel lattice
 (full-resolution decode parity has its own fixture, fullgeom_vae_h64.npz).
 
-usage: python tests/golden/make_fullgeom_golden.py [edit7|vae|invert|edit12|config4|vaeenc|edit7_e4m3 ...]
+usage: python tests/golden/make_fullgeom_golden.py [edit7|vae|invert|edit12|config4|vaeenc|edit7_e4m3|edit7_actround ...]
 """
 import os
 import sys
@@ -159,6 +159,28 @@ def edit_e4m3(f, h, steps, seed, name, ref_name):
     print(f"{name}: {time.time() - t0:.0f}s; relative L2 of the e4m3-emulating oracle vs the fp32 oracle per step: " + " ".join(f"{e:.3e}" for e in rel), flush=True)
 
 
+def edit_actround(f, h, steps, seed, name, ref_name):
+    """What the 2-byte STORAGE of activations costs by itself: the same trajectory with sd.ACT_ROUND = bfloat16 / float16 (every tensor the
+    product stores between kernels rounded to that type, arithmetic fp32), first `steps` DDIM steps, relative L2 vs the fp32 trajectory.
+    The derivation of the parity bars of tests/test_fullgeom_gpu.py.  Stores the curves only."""
+    uw, cw = weights()
+    lat, disp, cn, cp = inputs(f, h, seed)
+    ref = np.load(os.path.join(HERE, ref_name))["lat_steps"]
+    out = {}
+    for dname, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+        trace = []
+        t0 = time.time()
+        sd.ACT_ROUND = dt
+        try:
+            with torch.no_grad():
+                sd.denoise_chunk(uw, cw, lat, bf16r(disp), bf16r(cn), bf16r(cp), 5.0, steps, sd.SD15, 20, trace=trace)
+        finally:
+            sd.ACT_ROUND = None
+        out[dname] = np.array([float((t - torch.tensor(ref[i])).norm() / torch.tensor(ref[i]).norm()) for i, t in enumerate(trace)])
+        print(f"{name} [{dname} activations]: {time.time() - t0:.0f}s; relative L2 vs the fp32 oracle per step: " + " ".join(f"{e:.3e}" for e in out[dname]), flush=True)
+    np.savez_compressed(os.path.join(HERE, name), rel_bf16=out["bf16"], rel_f16=out["f16"], meta=np.array([f, h, steps, seed, SEED_UNET, SEED_CN], np.int64))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(int(os.environ.get("GC_GOLDEN_THREADS", "7")))
     sd.ATTN_IMPL = "sdpa"
@@ -170,6 +192,8 @@ if __name__ == "__main__":
             edit(7, 64, 20, 2, "fullgeom_edit_f7_h64.npz")
         elif w == "edit7_e4m3":  # the fp8 path's arithmetic restated on the oracle, first 6 steps of the edit7 trajectory
             edit_e4m3(7, 64, int(os.environ.get("GC_E4M3_STEPS", "6")), 2, "fullgeom_edit_f7_h64_e4m3.npz", "fullgeom_edit_f7_h64.npz")
+        elif w == "edit7_actround":  # the oracle with bf16 / f16 activation storage, first 6 steps of the edit7 trajectory
+            edit_actround(7, 64, int(os.environ.get("GC_E4M3_STEPS", "6")), 2, "fullgeom_edit_f7_h64_actround.npz", "fullgeom_edit_f7_h64.npz")
         elif w == "invert":      # render_reverse's inversion, 3 views batched, all 20 steps
             invert(3, 64, 20, 5, "fullgeom_invert_f3_h64.npz")
         elif w == "edit12":      # BASELINE configs[3]: chunk_size 8 -> f = 12, CFG batch 24 (2 of 20 steps)

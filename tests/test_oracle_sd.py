@@ -150,3 +150,27 @@ def test_e4m3_emulation_hooks():
     amax = w.abs().amax(dim=(1, 2, 3), keepdim=True)
     assert bool(((q - w).abs() <= 0.0626 * w.abs() + amax * 2.0 ** -9).all())
     assert torch.equal(run(), plain)                                     # and off again
+
+
+def test_activation_storage_emulation():
+    """sd.ACT_ROUND (every tensor the product stores between kernels rounded to bf16 / f16, arithmetic fp32): off = the fp32 oracle bit for
+    bit; on, the latents move by the storage type's order -- and bf16 costs ~8x f16 (3 fewer mantissa bits), the ratio the parity bars of
+    tests/test_fullgeom_gpu.py assume (1e-3 for f16 = north_star's, 8e-3 for bf16)."""
+    cfg = sd.TINY
+    torch.manual_seed(0)
+    uw, cw = sd.make_unet_weights(cfg, 1), sd.make_controlnet_weights(cfg, 2)
+    f, h = 5, 8
+    lat = torch.randn(f, 4, h, h); disp = torch.rand(f, 3, 8 * h, 8 * h)
+    cn, cp = torch.randn(1, cfg["text_len"], cfg["cross_dim"]), torch.randn(1, cfg["text_len"], cfg["cross_dim"])
+    run = lambda: sd.denoise_chunk(uw, cw, lat, disp, cn, cp, 5.0, 3, cfg, 20)
+    plain = run()
+    d = {}
+    try:
+        for dt in (torch.bfloat16, torch.float16):
+            sd.ACT_ROUND = dt
+            d[dt] = float((run() - plain).norm() / plain.norm())
+    finally:
+        sd.ACT_ROUND = None
+    assert torch.equal(run(), plain)
+    assert 1e-3 < d[torch.bfloat16] < 2e-2 and 1e-4 < d[torch.float16] < 2.5e-3, d
+    assert 5.0 < d[torch.bfloat16] / d[torch.float16] < 12.0, d
