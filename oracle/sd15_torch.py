@@ -262,7 +262,10 @@ def attention_layer(w, p, x, ctx, heads, mode, coeff, q8=0):
         o = cross_view_attention(q, k, v, heads, coeff)
     else:
         o = plain_attention(q, k, v, heads)
-    return _r(o) @ w[p + ".to_out.0.weight"].T + w[p + ".to_out.0.bias"]        # (the caller adds the residual, then rounds)
+    wo = w[p + ".to_out.0.weight"]
+    if q8 & 8:                               # (design study, not a product site: the attention output and the out-projection in e4m3)
+        o, wo = _q8(o), _q8_rows(wo, (id(w), p + ".to_out"))
+    return _r(o) @ wo.T + w[p + ".to_out.0.bias"]        # (the caller adds the residual, then rounds)
 
 
 # =========================================================================================== blocks
@@ -307,7 +310,7 @@ def transformer(w, p, x, ctx, cfg, mode, coeff):
     h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
     t = p + ".transformer_blocks.0"
     ln = lambda n, z: _r(F.layer_norm(z, (C,), w[f"{t}.{n}.weight"], w[f"{t}.{n}.bias"], 1e-5))
-    q8 = FP8_EMU["linears"] if (FP8_EMU is not None and C % 128 == 0 and B * H * W >= FP8_EMU["min_rows"]) else 0
+    q8 = FP8_EMU["linears"] if (FP8_EMU is not None and (C % 128 == 0 or FP8_EMU.get("any_c")) and B * H * W >= FP8_EMU["min_rows"]) else 0
     h = _r(attention_layer(w, t + ".attn1", ln("norm1", h), None, cfg["heads"], mode, coeff, q8) + h)
     h = _r(attention_layer(w, t + ".attn2", ln("norm2", h), ctx, cfg["heads"], mode, coeff, q8) + h)
     n3 = ln("norm3", h)

@@ -192,6 +192,21 @@ if __name__ == "__main__":
             edit(7, 64, 20, 2, "fullgeom_edit_f7_h64.npz")
         elif w == "edit7_e4m3":  # the fp8 path's arithmetic restated on the oracle, first 6 steps of the edit7 trajectory
             edit_e4m3(7, 64, int(os.environ.get("GC_E4M3_STEPS", "6")), 2, "fullgeom_edit_f7_h64_e4m3.npz", "fullgeom_edit_f7_h64.npz")
+        elif w == "edit7_e4m3_study":  # design study (prints only): e4m3 at MORE sites than the product has -- every map size, every channel count
+            # (the C = 320 blocks too), attention outputs + out-projections -- how far would a wider fp8 path sit from fp32?
+            uw, cw = weights()
+            lat, disp, cn, cp = inputs(7, 64, 2)
+            ref = np.load(os.path.join(HERE, "fullgeom_edit_f7_h64.npz"))["lat_steps"]
+            for label, emu in (("convs on every map + linears at every C (bits 0-2)", dict(min_hw=1, min_rows=1, linears=7, any_c=True)),
+                               ("... + attention outputs / out-projections (bit 3)", dict(min_hw=1, min_rows=1, linears=15, any_c=True))):
+                trace = []
+                sd.FP8_EMU = dict(emu, cache={})
+                try:
+                    with torch.no_grad():
+                        sd.denoise_chunk(uw, cw, lat, bf16r(disp), bf16r(cn), bf16r(cp), 5.0, int(os.environ.get("GC_E4M3_STEPS", "3")), sd.SD15, 20, trace=trace)
+                finally:
+                    sd.FP8_EMU = None
+                print(label + ": " + " ".join(f"{float((t - torch.tensor(ref[i])).norm() / torch.tensor(ref[i]).norm()):.3e}" for i, t in enumerate(trace)), flush=True)
         elif w == "edit7_actround":  # the oracle with bf16 / f16 activation storage, first 6 steps of the edit7 trajectory
             edit_actround(7, 64, int(os.environ.get("GC_E4M3_STEPS", "6")), 2, "fullgeom_edit_f7_h64_actround.npz", "fullgeom_edit_f7_h64.npz")
         elif w == "invert":      # render_reverse's inversion, 3 views batched, all 20 steps
