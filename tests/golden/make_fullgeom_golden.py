@@ -19,7 +19,7 @@ steps, the 8 chunk frames decoded by the VAE and composited through the syntheti
 (gc_pipeline.py:209-234).  Stored: latents after steps 1, 2, 5, 10, 20 and the composited images on a stride-4 pixel lattice
 (full-resolution decode parity has its own fixture, fullgeom_vae_h64.npz).
 
-usage: python tests/golden/make_fullgeom_golden.py [edit7|vae|invert|edit12|config4|vaeenc|edit7_e4m3|edit7_actround ...]
+usage: python tests/golden/make_fullgeom_golden.py [edit7|vae|invert|edit12|config4|vaeenc|edit7_e4m3|edit7_actround|invert_actround ...]
 """
 import os
 import sys
@@ -85,6 +85,33 @@ def invert(f, h, steps, seed, name):
     np.savez_compressed(os.path.join(HERE, name), lat_steps=torch.stack(trace).numpy(),
                         meta=np.array([f, h, steps, seed, SEED_UNET, SEED_CN], np.int64))
     print(f"{name}: {time.time() - t0:.0f}s", flush=True)
+
+
+def invert_actround(f, h, steps, seed, name, ref_name):
+    """the inversion trajectory with bf16 / f16 activation storage restated on the oracle (sd.ACT_ROUND), all `steps` steps: curves only"""
+    uw, cw = weights()
+    lat, disp, cn, cp = inputs(f, h, seed)
+    ref = np.load(os.path.join(HERE, ref_name))["lat_steps"]
+    sch = sd.DDIM()
+    ctx = bf16r(cp).expand(f, -1, -1)
+    out = {}
+    for dname, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+        x = lat.clone()
+        rel = []
+        t0 = time.time()
+        sd.ACT_ROUND = dt
+        try:
+            with torch.no_grad():
+                for i, t in enumerate(sch.timesteps(20, inverse=True)[:steps]):
+                    down, mid = sd.controlnet_forward(cw, x, t, ctx, bf16r(disp), sd.SD15, 1.0, "plain", 0.0)
+                    eps = sd.unet_forward(uw, x, t, ctx, down, mid, sd.SD15, "plain", 0.0)
+                    x = sch.inverse_step(eps, t, x, 20)
+                    rel.append(float((x - torch.tensor(ref[i])).norm() / torch.tensor(ref[i]).norm()))
+        finally:
+            sd.ACT_ROUND = None
+        out[dname] = np.array(rel)
+        print(f"{name} [{dname} activations]: {time.time() - t0:.0f}s; relative L2 vs the fp32 oracle per step: " + " ".join(f"{e:.3e}" for e in rel), flush=True)
+    np.savez_compressed(os.path.join(HERE, name), rel_bf16=out["bf16"], rel_f16=out["f16"], meta=np.array([f, h, steps, seed, SEED_UNET, SEED_CN], np.int64))
 
 
 def vae(h, seed, name):
@@ -207,6 +234,8 @@ if __name__ == "__main__":
                 finally:
                     sd.FP8_EMU = None
                 print(label + ": " + " ".join(f"{float((t - torch.tensor(ref[i])).norm() / torch.tensor(ref[i]).norm()):.3e}" for i, t in enumerate(trace)), flush=True)
+        elif w == "invert_actround":  # the inversion trajectory with bf16 / f16 activation storage, all 20 steps
+            invert_actround(3, 64, 20, 5, "fullgeom_invert_f3_h64_actround.npz", "fullgeom_invert_f3_h64.npz")
         elif w == "edit7_actround":  # the oracle with bf16 / f16 activation storage, first 6 steps of the edit7 trajectory
             edit_actround(7, 64, int(os.environ.get("GC_E4M3_STEPS", "6")), 2, "fullgeom_edit_f7_h64_actround.npz", "fullgeom_edit_f7_h64.npz")
         elif w == "invert":      # render_reverse's inversion, 3 views batched, all 20 steps
