@@ -392,17 +392,17 @@ def unet_forward(w, sample, t, ctx, down_res=None, mid_res=None, cfg=SD15, mode=
 def vae_decode(w, z, cfg=VAE_SD):
     """AutoencoderKL.decode(z) (z already divided by 0.18215 by the caller) -> image in [-1,1]."""
     g = cfg["groups"]
-    x = _conv(w, "post_quant_conv", z)
-    x = _conv(w, "decoder.conv_in", x)
+    x = _r(_conv(w, "post_quant_conv", _r(z)))              # (_r: ACT_ROUND emulation of the product's 2-byte storage, identity when off)
+    x = _r(_conv(w, "decoder.conv_in", x))
     x = resnet(w, "decoder.mid_block.resnets.0", x, None, g, 1e-6)
     a = "decoder.mid_block.attentions.0"
     B, C, H, W = x.shape
-    h = _gn(w, a + ".group_norm", x, g, 1e-6).reshape(B, C, H * W).transpose(1, 2)
-    q = h @ w[a + ".to_q.weight"].T + w[a + ".to_q.bias"]
-    k = h @ w[a + ".to_k.weight"].T + w[a + ".to_k.bias"]
-    v = h @ w[a + ".to_v.weight"].T + w[a + ".to_v.bias"]
-    o = plain_attention(q, k, v, 1) @ w[a + ".to_out.0.weight"].T + w[a + ".to_out.0.bias"]
-    x = x + o.transpose(1, 2).reshape(B, C, H, W)
+    h = _r(_gn(w, a + ".group_norm", x, g, 1e-6)).reshape(B, C, H * W).transpose(1, 2)
+    q = _r(h @ w[a + ".to_q.weight"].T + w[a + ".to_q.bias"])
+    k = _r(h @ w[a + ".to_k.weight"].T + w[a + ".to_k.bias"])
+    v = _r(h @ w[a + ".to_v.weight"].T + w[a + ".to_v.bias"])
+    o = _r(plain_attention(q, k, v, 1)) @ w[a + ".to_out.0.weight"].T + w[a + ".to_out.0.bias"]
+    x = _r(x + o.transpose(1, 2).reshape(B, C, H, W))
     x = resnet(w, "decoder.mid_block.resnets.1", x, None, g, 1e-6)
     n = len(cfg["block_out_channels"])
     for i in range(n):
@@ -410,8 +410,8 @@ def vae_decode(w, z, cfg=VAE_SD):
             x = resnet(w, f"decoder.up_blocks.{i}.resnets.{j}", x, None, g, 1e-6)
         if i < n - 1:
             x = F.interpolate(x, scale_factor=2.0, mode="nearest")
-            x = _conv(w, f"decoder.up_blocks.{i}.upsamplers.0.conv", x)
-    x = F.silu(_gn(w, "decoder.conv_norm_out", x, g, 1e-6))
+            x = _r(_conv(w, f"decoder.up_blocks.{i}.upsamplers.0.conv", x))
+    x = _r(F.silu(_gn(w, "decoder.conv_norm_out", x, g, 1e-6)))
     return _conv(w, "decoder.conv_out", x)
 
 
