@@ -17,6 +17,11 @@ PARITY UNPINNED for everything except the attention processor: diffusers and the
 weights are unavailable, so architecture semantics follow the published configs from memory
 ([recall] in SURVEY.md) with seeded random weights of the exact shapes.  State-dict keys follow the
 diffusers naming so real checkpoints can be dropped in.
+
+Two emulation switches (both None = off = the plain fp32 oracle, bit for bit) restate the PRODUCT's roundings on top of this arithmetic,
+to tell what a storage / operand type costs by itself: ACT_ROUND (bf16 / f16 storage of every tensor the product keeps between kernels) and
+FP8_EMU (OCP e4m3 operands at the sites of the product's fp8 path).  tests/golden/make_fullgeom_golden.py edit7_actround / invert_actround /
+edit7_e4m3 ran them at the benchmark geometry; DESIGN.md 2 sets the results beside the product's measured distances.
 """
 from __future__ import annotations
 
