@@ -159,6 +159,7 @@ class GaussCtrlPipeline(_PipelineBase):
             self.weights_source["text_encoder"] = "synthetic(hash of the prompt)"
         self.text_encoder = text_encoder                           # CLIP text tower: outside the hot path
         self.mask_fn = mask_fn                                     # LangSAM stand-in: image[H,W,3] -> mask[H,W] (out of scope)
+        self.bank_hook = None                                      # optional callable(RefBank | None), called once inside edit_images (tests)
         print("[gaussctrl_amd] diffusion weights: " + ", ".join(f"{k} <- {v}" for k, v in sorted(self.weights_source.items())))
 
     if not HAVE_NERFSTUDIO:
@@ -240,7 +241,8 @@ class GaussCtrlPipeline(_PipelineBase):
                                                     self._dev, self.num_inference_steps)
             else:
                 bank = self.pipe.build_ref_bank(ref_z0, ref_disp, cn, cp)
-        self._last_bank = bank                   # (kept for inspection: tests hash it)
+        if self.bank_hook is not None:            # inspection only (tests hash the bank here); the bank itself is NOT retained: 10-15 GB of
+            self.bank_hook(bank)                  # K / V^T that would otherwise stay pinned through the whole training phase
         views = self._my_views()
         # consecutive chunks only share the (read-only) bank: run them on alternating streams so that one chunk's part-filled grids and
         # fill / drain phases are covered by the other's kernels (bench.py --inflight: +3 % views/s at chunk_size 3)

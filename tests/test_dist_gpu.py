@@ -45,9 +45,9 @@ def _run(pipe, model):
     td = pipe.datamanager.train_data
     tr = {"z0": {i: _h(t["z_0_image"]) for i, t in enumerate(td) if "z_0_image" in t},
           "depth": {i: _h(t["depth_image"]) for i, t in enumerate(td) if "depth_image" in t}}
-    pipe.edit_images()
-    bank = getattr(pipe, "_last_bank", None)
-    if bank is not None:
+    def hash_bank(bank):                      # called inside edit_images: the pipeline does not keep the bank alive afterwards
+        if bank is None:
+            return
         import hashlib
         hh = hashlib.md5()
         for key in sorted(bank.store, key=str):
@@ -55,6 +55,10 @@ def _run(pipe, model):
             hh.update(k.detach().float().cpu().contiguous().numpy().tobytes()); hh.update(vt.detach().float().cpu().contiguous().numpy().tobytes())
         tr["bank"] = hh.hexdigest()[:8]
         tr["bank_step0"] = {str(key[1]): _h(bank.store[key][0]) for key in sorted(bank.store, key=str) if key[0] == 0}
+    pipe.bank_hook = hash_bank
+    pipe.edit_images()
+    pipe.bank_hook = None
+    assert not hasattr(pipe, "_last_bank")
     tr["z0_refs"] = {i: _h(td[i]["z_0_image"]) for i in pipe.ref_indices if "z_0_image" in td[i]}
     tr["depth_refs"] = {i: _h(td[i]["depth_image"]) for i in pipe.ref_indices if "depth_image" in td[i]}
     tr["rgb_refs"] = {i: _h(td[i]["unedited_image"]) for i in pipe.ref_indices if "unedited_image" in td[i]}
