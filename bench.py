@@ -48,7 +48,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--gaussians", type=int, default=1_000_000)
     ap.add_argument("--views", type=int, default=None)     # default: 40 (edit, BASELINE configs[1]) / 256 cameras (raster, configs[4])
-    ap.add_argument("--chunk-size", type=int, default=3)
+    ap.add_argument("--chunk-size", type=int, default=None)   # views per step: 3 (edit, BASELINE configs[1]) / 8 (raster-only: one batched launch set per 8 cameras)
+    ap.add_argument("--no-view-batch", action="store_true")   # render the views of a step one camera at a time (the round-4 path) instead of gsplat_ops.render_views
     ap.add_argument("--denoise-steps", type=int, default=20)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "fp8"])     # fp8: e4m3 resnet convs + C = 640 / 1280 transformer linears on the block-scaled MFMA, bf16 elsewhere
     ap.add_argument("--fp8-min-hw", type=int, default=256)   # with --dtype fp8: smallest map (pixels) whose resnet convs run on e4m3 (256: 16 x 16 maps, k-sliced; 1024: round-3 behaviour)
@@ -190,9 +191,10 @@ class Bench:
         from gaussctrl_amd.sd.pipeline import DenoisePipeline
         from gaussctrl_amd.sd.vae import prepare_vae_weights
         from gaussctrl_amd.sd.weights import prepare
-        from gaussctrl_amd.train_ops import l1_ssim_loss
+        from gaussctrl_amd.train_ops import l1_ssim_loss, l1_ssim_loss_views
         self.args, self.rank, self.world, self.dev, self.dist, self.bank_group = args, rank, world, dev, dist, bank_group
-        self.gops, self.sdops, self.l1_ssim_loss = gops, sdops, l1_ssim_loss
+        self.gops, self.sdops, self.l1_ssim_loss, self.l1_ssim_loss_views = gops, sdops, l1_ssim_loss, l1_ssim_loss_views
+        self.view_batch = not args.no_view_batch          # the views of a step through ONE set of launches (gsplat_ops.render_views)
         self.dtype_name = dtype_name
         self.dt = dt = torch.float16 if dtype_name == "f16" else torch.bfloat16
         self.edit = args.workload == "edit"
@@ -284,8 +286,12 @@ class Bench:
             aux.m_cap = self.state["cap"]          # device-side intersection count + capacity: no host round trip in the frame
         return aux
 
-    def note_m(self, aux):
-        if isinstance(aux.M, tuple):
+    def note_m(self, aux, sized_on_host=False):
+        if isinstance(aux.M, tuple) and sized_on_host:      # a view batch that read its counts back to size the lists (first frames)
+            cnts = [int(v) for v in aux.M[0].cpu().reshape(-1)]
+            self.stats["M"] += cnts
+            self.state["cap"] = max(self.state["cap"] or 0, int(max(cnts) * 1.3) + 1024)
+        elif isinstance(aux.M, tuple):
             self.stats["dev"].append(aux.M)        # (count, overflow) device tensors: read after the timed region
         else:
             self.stats["M"].append(aux.M)
@@ -298,6 +304,17 @@ class Bench:
                                                       self.cams[i], self.bg, True, 3, aux)
         self.note_m(aux)
         return rgb, depth, aux
+
+    def render_eval_views(self, views):
+        """the eval renders of a step's views as ONE batched launch set -> [(rgb, depth, aux)] per view"""
+        if not self.view_batch or len(views) < 2:
+            return [self.render_eval(i) for i in views]
+        p, aux = self.params, self.new_aux()
+        with torch.no_grad():
+            rgb, alpha, depth = self.gops.render_views(p["means"], p["scales"], p["quats"], p["opacities"], p["features_dc"], p["features_rest"],
+                                                       [self.cams[i] for i in views], self.bg, True, 3, aux)
+        self.note_m(aux, sized_on_host=aux.m_cap is None)
+        return [(rgb[k], depth[k], aux) for k in range(len(views))]
 
     def disparity_of(self, depth):            # gc_pipeline.py:258-266 as one HIP kernel pair -> [H,W,8] control image (3 channels used)
         return self.sdops.depth_to_disparity(depth, self.dt)
@@ -362,7 +379,7 @@ class Bench:
                 done = self.advance_bank(st["next"], quota)          # owner: compute + post sends; others: post receives (they arrive under (b))
             if self.bank_ready is not None:
                 cur.wait_event(self.bank_ready)       # (no-op on the stream that recorded it)
-            evals = [self.render_eval(i) for i in views]                                                    # (a)
+            evals = self.render_eval_views(views)                                                           # (a)
             if views:
                 disp = torch.stack([self.disparity_of(e[1]) for e in evals])
                 lat = self.pipe.edit_chunk_cached(self.z0[views], disp, self.ctx_neg, self.ctx_pos, st["bank"])   # (b)
@@ -380,7 +397,24 @@ class Bench:
             ev[1].record()
         fg = self.grads[s % len(self.grads)]            # (same index -> same stream when chunks are in flight on several streams)
         fg.wait()                                 # the all-reduce posted two chunks ago (N > 1) has finished before its buffer is rewritten
-        for jj, i in enumerate(views):                                                                      # (d)
+        if self.view_batch and len(views) >= 2:                                                             # (d), batched: one launch set
+            aux = self.new_aux()
+            aux.grad_into, aux.grad_accumulate = fg.views, False
+            rgb, alpha, _ = self.gops.render_views(p["means"], p["scales"], p["quats"], p["opacities"], p["features_dc"], p["features_rest"],
+                                                   [self.cams[i] for i in views], torch.rand(len(views), 3, device=self.dev), False, 3, aux)
+            if edited[0] is not None:
+                target = edited.permute(0, 2, 3, 1).contiguous() if torch.is_tensor(edited) else torch.stack([e.permute(1, 2, 0) for e in edited]).contiguous()
+                if self.args.mask:
+                    target = torch.stack([self.sdops.mask_composite(target[jj], evals[jj][0].contiguous(), self.edit_mask) for jj in range(len(views))])
+            else:
+                target = self.raster_target.expand(len(views), -1, -1, -1)
+            self.l1_ssim_loss_views(rgb, target, 0.2).sum().backward()      # the chunk's gradient SUM, formed inside the projection backward
+            self.note_m(aux, sized_on_host=aux.m_cap is None)
+            st["renders_done"] += len(views)
+            views_iter = []
+        else:
+            views_iter = list(enumerate(views))
+        for jj, i in views_iter:                                                                            # (d), one camera at a time
             aux = self.new_aux()
             aux.grad_into, aux.grad_accumulate = fg.views, jj > 0      # the batch's gradient sum is formed inside the backward kernel
             rgb, alpha, _ = self.gops.render_view(p["means"], p["scales"], p["quats"], p["opacities"], p["features_dc"], p["features_rest"],
@@ -441,8 +475,8 @@ class Bench:
             self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
             dt_s = float(tt.item())
         if self.stats["dev"]:                      # sync-free frames: counts / overflow flags are read only now
-            cnts = torch.stack([a for a, _ in self.stats["dev"]]).flatten().cpu()
-            ovfs = torch.stack([b for _, b in self.stats["dev"]]).flatten().cpu()
+            cnts = torch.cat([a.reshape(-1) for a, _ in self.stats["dev"]]).cpu()
+            ovfs = torch.cat([b.reshape(-1) for _, b in self.stats["dev"]]).cpu()
             assert int(ovfs.max()) == 0, "intersection capacity exceeded in a sync-free frame: raise the capacity margin"
             self.stats["M"] += [int(v) for v in cnts]
             self.stats["dev"] = []
@@ -472,6 +506,7 @@ def run_full_pipeline(args):
     from gaussctrl_amd.ns_compat import Cameras
     dev = "cuda:0"
     V = args.views or 40
+    args.chunk_size = args.chunk_size or 3
     K = syn.BEAR_INTRINSICS
     cams = Cameras(syn.make_cameras(V, seed=1), K["fx"], K["fy"], K["cx"], K["cy"], 512, 512)
 
@@ -555,6 +590,8 @@ def main():
     sdops.configure(sdops.options_from_env(), fp8_min_hw=args.fp8_min_hw)       # experiment switches (GC_FUSED_TAIL=0, GC_ATTN_V=4, GC_ABLATE=gn, ...): default = product
     if args.views is None:
         args.views = 40 if args.workload == "edit" else 256
+    if args.chunk_size is None:
+        args.chunk_size = 3 if args.workload == "edit" else 8
     c, V, nsteps = args.chunk_size, args.views, args.denoise_steps
     H = W = 512
     B = Bench(args, args.dtype, rank, world, dev, dist, bank_group)
@@ -801,6 +838,7 @@ def raster_roofline(args, B, g, stats, HW):
     real = L.lib()
     timer = LibTimer(real)
     n_dev = len(stats["dev"])
+    r_before = B.state["renders_done"]
     L._lib = timer
     try:
         if args.workload == "raster":
@@ -814,8 +852,8 @@ def raster_roofline(args, B, g, stats, HW):
         torch.cuda.synchronize()
     finally:
         L._lib = real
-    Ms = [int(a.item()) for a, _ in stats["dev"][n_dev:]] or stats["M"][-8:]        # pairs the instrumented views really binned (tight boxes)
-    nviews = max(1, sum(1 for n, _, _ in timer.rec if n.startswith("gc_rasterize_bwd")))
+    Ms = [int(v) for a, _ in stats["dev"][n_dev:] for v in a.reshape(-1).cpu()] or stats["M"][-8:]        # pairs the instrumented views really binned (tight boxes)
+    nviews = max(1, B.state["renders_done"] - r_before)            # training renders of the instrumented step (a batched call covers several)
     M_proc = float(np.mean(Ms))
     # The SURVEY 8d byte formula counts the intersections of the reference's lists (gsplat's 3-sigma boxes): that M is measured here on
     # the same cameras with the tight boxes switched off (untimed); `frac` prices the chain against it, `frac_processed_pairs` against
@@ -833,9 +871,17 @@ def raster_roofline(args, B, g, stats, HW):
     N = args.gaussians
     per = {}
     alias = {"gc_rasterize_bwd_clamped": "gc_rasterize_bwd", "gc_raster_finalize_into": "gc_raster_finalize",          # same kernels, round-3 entry points
-             "gc_project_sh_fwd_boxes": "gc_project_sh_fwd", "gc_raster_bin_tiles_boxes": "gc_raster_bin_tiles_dev"}
+             "gc_project_sh_fwd_boxes": "gc_project_sh_fwd", "gc_raster_bin_tiles_boxes": "gc_raster_bin_tiles_dev",
+             # round 5: the batched-views entry points (one call covers every view of the step: per-view time = call time / views)
+             "gc_project_sh_fwd_views": "gc_project_sh_fwd", "gc_raster_depth_order_views": "gc_raster_depth_order",
+             "gc_raster_bin_tiles_views": "gc_raster_bin_tiles_dev", "gc_rasterize_fwd_views": "gc_rasterize_fwd",
+             "gc_rasterize_bwd_views": "gc_rasterize_bwd", "gc_project_sh_bwd_views": "gc_project_sh_bwd",
+             "gc_l1_ssim_fwd_bwd_views": "gc_l1_ssim_fwd_bwd"}
+    tot_stage = {}
     for name, s, e in timer.rec:
-        per.setdefault(alias.get(name, name), []).append(s.elapsed_time(e) * 1e-3)
+        k = alias.get(name, name)
+        tot_stage[k] = tot_stage.get(k, 0.0) + s.elapsed_time(e) * 1e-3
+    per = {k: [v / nviews] for k, v in tot_stage.items()}            # seconds per training view and stage
     traffic = None
     for tname in ("r03_raster_traffic.json", "r02_raster_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", tname)
@@ -863,6 +909,7 @@ def raster_roofline(args, B, g, stats, HW):
             "avg_launch_us": d["avg_us"], "algorithmic_bytes_per_launch": d["algorithmic_MB"] * 1e6,
             "chain": {"algorithmic_MB_per_view": round(tot_b / 1e6, 1), "kernel_us_per_view": round(tot_s * 1e6, 1),
                       "GBps": round(tot_b / tot_s / 1e9, 1), "frac": round(tot_b / tot_s / 8e12, 4), "views_in_sample": nviews,
+                      "views_per_launch_set": (min(args.chunk_size, nviews) if B.view_batch else 1),
                       "N": N, "M_mean": int(M), "M_processed_mean": int(M_proc),
                       "frac_processed_pairs": round((tot_b - 124.0 * (M - M_proc)) / tot_s / 8e12, 4),
                       "traffic_ratio": traffic_ratio, "formula": "N*660 + M*124 + HW*44 bytes per view (SURVEY.md 8d with the SH record no longer re-read in the backward); M = intersections of gsplat's boxes (the reference's lists), M_processed = pairs binned on the tight boxes"},

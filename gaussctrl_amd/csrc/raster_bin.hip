@@ -51,16 +51,21 @@ __device__ __forceinline__ int block_incl_scan(int v, int *total)
     return s + off;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_local(int64_t N, const int32_t *__restrict__ in,
-                                                             int32_t *__restrict__ out, int32_t *__restrict__ block_sums)
+// The three scan kernels take the view (camera) index from blockIdx.y (round 5: batched views): in / order / out are [C][N], the block
+// sums of view c live `ws` words after those of view c - 1, count[c].  order != NULL: the input is gathered through it (in[order[i]]) --
+// the tile counts in depth order without a materialised gather pass.
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_local(int64_t N, const int32_t *__restrict__ in, const int32_t *__restrict__ order,
+                                                             int32_t *__restrict__ out, int32_t *__restrict__ block_sums, int64_t ws)
 {
+    in += blockIdx.y * N; out += blockIdx.y * N; block_sums += blockIdx.y * ws;
+    if (order) order += blockIdx.y * N;
     const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
     int v[SCAN_ITEMS];
     int run = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         int64_t i = base + k;
-        int x = i < N ? in[i] : 0;
+        int x = i < N ? (order ? in[order[i]] : in[i]) : 0;
         run += x;
         v[k] = run;
     }
@@ -75,10 +80,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_local(int64_t N, const in
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
-// single workgroup: exclusive scan of the block sums in place; writes the grand total.
+// single workgroup per view: exclusive scan of the block sums in place; writes the grand total.
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_sums(int nblocks, int32_t *__restrict__ block_sums,
-                                                            int32_t *__restrict__ count)
+                                                            int32_t *__restrict__ count, int64_t ws)
 {
+    block_sums += blockIdx.y * ws; count += blockIdx.y;
     int carry = 0;
     for (int base = 0; base < nblocks; base += SCAN_THREADS) {
         int i = base + threadIdx.x;
@@ -92,8 +98,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_sums(int nblocks, int32_t
 }
 
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_add(int64_t N, int32_t *__restrict__ out,
-                                                           const int32_t *__restrict__ block_sums)
+                                                           const int32_t *__restrict__ block_sums, int64_t ws)
 {
+    out += blockIdx.y * N; block_sums += blockIdx.y * ws;
     const int add = block_sums[blockIdx.x];
     const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK;
 #pragma unroll
@@ -173,18 +180,27 @@ extern "C" {
 
 size_t gc_raster_scan_workspace_bytes(int64_t N) { return sizeof(int32_t) * (size_t)(gc::cdiv(N > 0 ? N : 1, SCAN_CHUNK) + 1); }
 
+int gc_raster_scan_tiles_views(int64_t N, int C, const int32_t *num_tiles_hit, const int32_t *order, int32_t *cum_tiles_hit, int32_t *count_dev,
+                               void *workspace, size_t workspace_bytes, int64_t ws_view_stride, void *stream)
+{
+    GC_REQUIRE(N >= 0 && C >= 1 && count_dev && ws_view_stride % 4 == 0, "bad arguments");
+    if (N == 0) return hipMemsetAsync(count_dev, 0, 4 * (size_t)C, gc::S(stream)) == hipSuccess ? GC_OK : GC_ELAUNCH;
+    if (workspace_bytes < gc_raster_scan_workspace_bytes(N)) { gc::set_error("gc_raster_scan_tiles_views: workspace too small"); return GC_ENOSPC; }
+    GC_REQUIRE(C == 1 || (size_t)ws_view_stride >= gc_raster_scan_workspace_bytes(N), "per-view scan scratch regions overlap");
+    int nb = (int)gc::cdiv(N, SCAN_CHUNK);
+    int32_t *sums = (int32_t *)workspace;
+    const int64_t ws = ws_view_stride / 4;
+    hipLaunchKernelGGL(k_scan_local, dim3(nb, C), dim3(SCAN_THREADS), 0, gc::S(stream), N, num_tiles_hit, order, cum_tiles_hit, sums, ws);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1, C), dim3(SCAN_THREADS), 0, gc::S(stream), nb, sums, count_dev, ws);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb, C), dim3(SCAN_THREADS), 0, gc::S(stream), N, cum_tiles_hit, sums, ws);
+    return gc::check_launch("gc_raster_scan_tiles_views");
+}
+
 int gc_raster_scan_tiles(int64_t N, const int32_t *num_tiles_hit, int32_t *cum_tiles_hit, int32_t *count_dev,
                          void *workspace, size_t workspace_bytes, void *stream)
 {
     GC_REQUIRE(N >= 0 && count_dev, "bad arguments");
-    if (N == 0) return hipMemsetAsync(count_dev, 0, 4, gc::S(stream)) == hipSuccess ? GC_OK : GC_ELAUNCH;
-    if (workspace_bytes < gc_raster_scan_workspace_bytes(N)) { gc::set_error("gc_raster_scan_tiles: workspace too small"); return GC_ENOSPC; }
-    int nb = (int)gc::cdiv(N, SCAN_CHUNK);
-    int32_t *sums = (int32_t *)workspace;
-    hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(SCAN_THREADS), 0, gc::S(stream), N, num_tiles_hit, cum_tiles_hit, sums);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, gc::S(stream), nb, sums, count_dev);
-    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_THREADS), 0, gc::S(stream), N, cum_tiles_hit, sums);
-    return gc::check_launch("gc_raster_scan_tiles");
+    return gc_raster_scan_tiles_views(N, 1, num_tiles_hit, nullptr, cum_tiles_hit, count_dev, workspace, workspace_bytes, 0, stream);
 }
 
 int gc_raster_read_count(const int32_t *count_dev, int32_t *count_host, void *stream)

@@ -23,6 +23,16 @@ constexpr float ALPHA_CAP = 0.999f;
 constexpr float ALPHA_MIN = 1.f / 255.f;
 constexpr float T_STOP = 1e-4f;
 
+// Batched views (round 5: gc_rasterize_fwd_views / gc_rasterize_bwd_views): blockIdx.z = view (camera); per-view arrays are [C][...] with
+// the strides below (elements).  A single-view launch has gridDim.z == 1: every offset is 0.
+struct CV {
+    int64_t n;       // per-Gaussian arrays of a view: xys / 2, conics / 3, colors / 3, extra, v_* ([C][N])
+    int64_t n_op;    // opacities: N when per view, 0 when one array serves every view (sigmoid(opacity) does not depend on the camera)
+    int64_t m;       // gaussian_ids_sorted ([C][M_cap])
+    int tiles;       // tile_bins ([C][T][2])
+    int bg;          // background: 3 when per view, 0 when shared
+};
+
 struct SplatA { float x, y, opac, cxx; };
 struct SplatB { float cxy, cyy, r, g; };
 struct SplatC { float b, e; };
@@ -76,8 +86,15 @@ __global__ __launch_bounds__(BLOCK) void k_rasterize_fwd(int H, int W, int tiles
                                                          const float *__restrict__ colors, const float *__restrict__ opacities,
                                                          const float *__restrict__ extra, const float *__restrict__ background,
                                                          float *__restrict__ out_img, float *__restrict__ out_extra,
-                                                         float *__restrict__ final_Ts, int32_t *__restrict__ final_index)
+                                                         float *__restrict__ final_Ts, int32_t *__restrict__ final_index, CV cv)
 {
+    {
+        const int64_t v = blockIdx.z, hw = (int64_t)H * W;
+        ids_sorted += v * cv.m; tile_bins += v * 2 * cv.tiles; xys += v * 2 * cv.n; conics += v * 3 * cv.n; colors += v * 3 * cv.n;
+        opacities += v * cv.n_op; background += v * cv.bg;
+        if (HAS_EXTRA) { extra += v * cv.n; out_extra += v * hw; }
+        out_img += v * 3 * hw; final_Ts += v * hw; final_index += v * hw;
+    }
     __shared__ SplatA sA[BLOCK];
     __shared__ SplatB sB[BLOCK];
     __shared__ SplatC sC[BLOCK];
@@ -201,8 +218,17 @@ __global__ __launch_bounds__(BLOCK) void k_rasterize_bwd(int H, int W, int tiles
                                                          const float *__restrict__ v_out, const float *__restrict__ v_out_alpha,
                                                          const float *__restrict__ pre_clamp,
                                                          float *__restrict__ v_xy, float *__restrict__ v_conic,
-                                                         float *__restrict__ v_colors, float *__restrict__ v_opacity)
+                                                         float *__restrict__ v_colors, float *__restrict__ v_opacity, CV cv)
 {
+    {
+        const int64_t v = blockIdx.z, hw = (int64_t)H * W;
+        ids_sorted += v * cv.m; tile_bins += v * 2 * cv.tiles; xys += v * 2 * cv.n; conics += v * 3 * cv.n; colors += v * 3 * cv.n;
+        opacities += v * cv.n_op; background += v * cv.bg;
+        final_Ts += v * hw; final_index += v * hw; v_out += v * 3 * hw;
+        if (v_out_alpha) v_out_alpha += v * hw;
+        if (pre_clamp) pre_clamp += v * 3 * hw;
+        v_xy += v * 2 * cv.n; v_conic += v * 3 * cv.n; v_colors += v * 3 * cv.n; v_opacity += v * cv.n;
+    }
     __shared__ SplatA sA[BLOCK];
     __shared__ SplatB sB[BLOCK];
     __shared__ float sBlue[BLOCK];
@@ -337,36 +363,64 @@ __global__ __launch_bounds__(BLOCK) void k_rasterize_bwd(int H, int W, int tiles
 
 extern "C" {
 
+static int rasterize_fwd_impl(const char *what, int C, int64_t N, int64_t M_cap, int shared_opacities, int shared_background, int img_h, int img_w,
+                              int tiles_x, int tiles_y, const int32_t *gaussian_ids_sorted,
+                              const int32_t *tile_bins, const float *xys, const float *conics, const float *colors,
+                              const float *opacities, const float *extra, const float *background, float *out_img,
+                              float *out_extra, float *final_Ts, int32_t *final_index, void *stream)
+{
+    if (!(img_h > 0 && img_w > 0 && tiles_x == (img_w + TILE - 1) / TILE && tiles_y == (img_h + TILE - 1) / TILE)) {
+        gc::set_error("%s: tile bounds do not match the image size", what); return GC_EINVAL;
+    }
+    if ((extra == nullptr) != (out_extra == nullptr)) { gc::set_error("%s: extra and out_extra must be given together", what); return GC_EINVAL; }
+    CV cv; cv.n = N; cv.n_op = shared_opacities ? 0 : N; cv.m = M_cap; cv.tiles = tiles_x * tiles_y; cv.bg = shared_background ? 0 : 3;
+    dim3 grid(tiles_x, tiles_y, C), block(BLOCK);
+    if (extra)
+        hipLaunchKernelGGL(k_rasterize_fwd<true>, grid, block, 0, gc::S(stream), img_h, img_w, tiles_x, gaussian_ids_sorted,
+                           tile_bins, xys, conics, colors, opacities, extra, background, out_img, out_extra, final_Ts, final_index, cv);
+    else
+        hipLaunchKernelGGL(k_rasterize_fwd<false>, grid, block, 0, gc::S(stream), img_h, img_w, tiles_x, gaussian_ids_sorted,
+                           tile_bins, xys, conics, colors, opacities, extra, background, out_img, out_extra, final_Ts, final_index, cv);
+    return gc::check_launch(what);
+}
+
 int gc_rasterize_fwd(int img_h, int img_w, int tiles_x, int tiles_y, const int32_t *gaussian_ids_sorted,
                      const int32_t *tile_bins, const float *xys, const float *conics, const float *colors,
                      const float *opacities, const float *extra, const float *background, float *out_img,
                      float *out_extra, float *final_Ts, int32_t *final_index, void *stream)
 {
-    GC_REQUIRE(img_h > 0 && img_w > 0 && tiles_x == (img_w + TILE - 1) / TILE && tiles_y == (img_h + TILE - 1) / TILE,
-               "tile bounds do not match the image size");
-    GC_REQUIRE((extra == nullptr) == (out_extra == nullptr), "extra and out_extra must be given together");
-    dim3 grid(tiles_x, tiles_y), block(BLOCK);
-    if (extra)
-        hipLaunchKernelGGL(k_rasterize_fwd<true>, grid, block, 0, gc::S(stream), img_h, img_w, tiles_x, gaussian_ids_sorted,
-                           tile_bins, xys, conics, colors, opacities, extra, background, out_img, out_extra, final_Ts, final_index);
-    else
-        hipLaunchKernelGGL(k_rasterize_fwd<false>, grid, block, 0, gc::S(stream), img_h, img_w, tiles_x, gaussian_ids_sorted,
-                           tile_bins, xys, conics, colors, opacities, extra, background, out_img, out_extra, final_Ts, final_index);
-    return gc::check_launch("gc_rasterize_fwd");
+    return rasterize_fwd_impl("gc_rasterize_fwd", 1, 0, 0, 1, 1, img_h, img_w, tiles_x, tiles_y, gaussian_ids_sorted, tile_bins, xys, conics, colors,
+                              opacities, extra, background, out_img, out_extra, final_Ts, final_index, stream);
 }
 
-static int rasterize_bwd_impl(const char *what, int img_h, int img_w, int tiles_x, int tiles_y, const int32_t *gaussian_ids_sorted,
+/* C views in one launch (grid.z = view): gaussian_ids_sorted [C][M_cap], tile_bins [C][T][2], xys / conics / colors / extra [C][N][..],
+ * opacities [N] (shared_opacities = 1) or [C][N], background [3] (shared_background = 1) or [C][3]; outputs [C][H][W][..]. */
+int gc_rasterize_fwd_views(int C, int64_t N, int64_t M_cap, int shared_opacities, int shared_background, int img_h, int img_w, int tiles_x,
+                           int tiles_y, const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys, const float *conics,
+                           const float *colors, const float *opacities, const float *extra, const float *background, float *out_img,
+                           float *out_extra, float *final_Ts, int32_t *final_index, void *stream)
+{
+    GC_REQUIRE(C >= 1 && C <= 65535 && N >= 0 && M_cap >= 0, "bad arguments");
+    return rasterize_fwd_impl("gc_rasterize_fwd_views", C, N, M_cap, shared_opacities, shared_background, img_h, img_w, tiles_x, tiles_y,
+                              gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities, extra, background, out_img, out_extra, final_Ts,
+                              final_index, stream);
+}
+
+static int rasterize_bwd_impl(const char *what, int C, int64_t N, int64_t M_cap, int shared_opacities, int shared_background, int img_h, int img_w,
+                              int tiles_x, int tiles_y, const int32_t *gaussian_ids_sorted,
                               const int32_t *tile_bins, const float *xys, const float *conics, const float *colors,
                               const float *opacities, const float *background, const float *final_Ts, const int32_t *final_index,
                               const float *v_out, const float *v_out_alpha, const float *pre_clamp, float *v_xy, float *v_conic,
                               float *v_colors, float *v_opacity, void *stream)
 {
-    GC_REQUIRE(img_h > 0 && img_w > 0 && tiles_x == (img_w + TILE - 1) / TILE && tiles_y == (img_h + TILE - 1) / TILE,
-               "tile bounds do not match the image size");
-    dim3 grid(tiles_x, tiles_y), block(BLOCK);
+    if (!(img_h > 0 && img_w > 0 && tiles_x == (img_w + TILE - 1) / TILE && tiles_y == (img_h + TILE - 1) / TILE)) {
+        gc::set_error("%s: tile bounds do not match the image size", what); return GC_EINVAL;
+    }
+    CV cv; cv.n = N; cv.n_op = shared_opacities ? 0 : N; cv.m = M_cap; cv.tiles = tiles_x * tiles_y; cv.bg = shared_background ? 0 : 3;
+    dim3 grid(tiles_x, tiles_y, C), block(BLOCK);
     hipLaunchKernelGGL(k_rasterize_bwd, grid, block, 0, gc::S(stream), img_h, img_w, tiles_x, gaussian_ids_sorted, tile_bins,
                        xys, conics, colors, opacities, background, final_Ts, final_index, v_out, v_out_alpha, pre_clamp, v_xy, v_conic,
-                       v_colors, v_opacity);
+                       v_colors, v_opacity, cv);
     return gc::check_launch(what);
 }
 
@@ -376,9 +430,8 @@ int gc_rasterize_bwd(int img_h, int img_w, int tiles_x, int tiles_y, int64_t N, 
                      const float *v_out, const float *v_out_alpha, float *v_xy, float *v_conic, float *v_colors,
                      float *v_opacity, void *stream)
 {
-    (void)N;
-    return rasterize_bwd_impl("gc_rasterize_bwd", img_h, img_w, tiles_x, tiles_y, gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities,
-                              background, final_Ts, final_index, v_out, v_out_alpha, nullptr, v_xy, v_conic, v_colors, v_opacity, stream);
+    return rasterize_bwd_impl("gc_rasterize_bwd", 1, N, 0, 1, 1, img_h, img_w, tiles_x, tiles_y, gaussian_ids_sorted, tile_bins, xys, conics, colors,
+                              opacities, background, final_Ts, final_index, v_out, v_out_alpha, nullptr, v_xy, v_conic, v_colors, v_opacity, stream);
 }
 
 /* the same with the backward of get_outputs' rgb clamp folded into the pixel load: v_out is masked where pre_clamp > 1 */
@@ -388,10 +441,24 @@ int gc_rasterize_bwd_clamped(int img_h, int img_w, int tiles_x, int tiles_y, int
                              const float *v_out, const float *v_out_alpha, const float *pre_clamp, float *v_xy, float *v_conic,
                              float *v_colors, float *v_opacity, void *stream)
 {
-    (void)N;
     GC_REQUIRE(pre_clamp, "pre_clamp image required (gc_rasterize_bwd is the form without the clamp)");
-    return rasterize_bwd_impl("gc_rasterize_bwd_clamped", img_h, img_w, tiles_x, tiles_y, gaussian_ids_sorted, tile_bins, xys, conics, colors,
-                              opacities, background, final_Ts, final_index, v_out, v_out_alpha, pre_clamp, v_xy, v_conic, v_colors, v_opacity, stream);
+    return rasterize_bwd_impl("gc_rasterize_bwd_clamped", 1, N, 0, 1, 1, img_h, img_w, tiles_x, tiles_y, gaussian_ids_sorted, tile_bins, xys, conics,
+                              colors, opacities, background, final_Ts, final_index, v_out, v_out_alpha, pre_clamp, v_xy, v_conic, v_colors, v_opacity,
+                              stream);
+}
+
+/* C views in one launch: v_out [C][H][W][3], v_out_alpha [C][H][W] or NULL, pre_clamp [C][H][W][3] or NULL (clamp backward folded in);
+ * v_xy [C][N][2], v_conic [C][N][3], v_colors [C][N][3], v_opacity [C][N] must be ZERO on entry (the kernel adds into them). */
+int gc_rasterize_bwd_views(int C, int64_t N, int64_t M_cap, int shared_opacities, int shared_background, int img_h, int img_w, int tiles_x,
+                           int tiles_y, const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys, const float *conics,
+                           const float *colors, const float *opacities, const float *background, const float *final_Ts,
+                           const int32_t *final_index, const float *v_out, const float *v_out_alpha, const float *pre_clamp, float *v_xy,
+                           float *v_conic, float *v_colors, float *v_opacity, void *stream)
+{
+    GC_REQUIRE(C >= 1 && C <= 65535 && N >= 0 && M_cap >= 0, "bad arguments");
+    return rasterize_bwd_impl("gc_rasterize_bwd_views", C, N, M_cap, shared_opacities, shared_background, img_h, img_w, tiles_x, tiles_y,
+                              gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities, background, final_Ts, final_index, v_out, v_out_alpha,
+                              pre_clamp, v_xy, v_conic, v_colors, v_opacity, stream);
 }
 
 }  // extern "C"

@@ -536,6 +536,209 @@ __global__ __launch_bounds__(256) void k_project_sh_bwd(int64_t N, Cam cam, int 
     }
 }
 
+// ---------------------------------------------------------------- kernels: C views per launch (round 5)
+// The 236-byte parameter record of a Gaussian does not depend on the camera: a launch over C views reads it ONCE (the SH block staged
+// through LDS once) and projects / shades it for every view of the batch, instead of C launches that each stream the whole record again --
+// 236 + C * 60 bytes per Gaussian instead of C * 296.  Same device functions, same operation order as the single-view kernel: every output
+// of view c is bit-identical to what gc_project_sh_fwd[_boxes] writes for that camera.  Per-view outputs are [C][N][..]; `opac` (sigmoid of
+// the opacity logit, camera independent) is written once, [N]; depth_pairs (optional) are the depth-order sort's input pairs.
+constexpr int MAXV = 8;
+struct CamBatch { Cam cam[MAXV]; int C; };
+
+template <int K>
+__global__ __launch_bounds__(256) void k_project_sh_fwd_views(int64_t N, CamBatch cb, int n_use,
+                                                              const float *__restrict__ means, const float *__restrict__ log_scales,
+                                                              const float *__restrict__ quats, const float *__restrict__ op_logit,
+                                                              const float *__restrict__ f_dc, const float *__restrict__ f_rest,
+                                                              float *__restrict__ xys, float *__restrict__ depths,
+                                                              int32_t *__restrict__ radii, float *__restrict__ conics,
+                                                              int32_t *__restrict__ tiles_hit, float *__restrict__ rgbs,
+                                                              float *__restrict__ opac, uint32_t *__restrict__ tile_box,
+                                                              uint2 *__restrict__ depth_pairs)
+{
+    constexpr int R = (K - 1) * 3;
+    __shared__ __attribute__((aligned(16))) float srest[R > 0 ? 256 * R : 4];
+    const int tid = threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.x * 256;
+    const int64_t i = i0 + tid;
+    const int64_t ic = i < N ? i : N - 1;
+    const float p0 = means[3 * ic], p1 = means[3 * ic + 1], p2 = means[3 * ic + 2];
+    const float l0 = log_scales[3 * ic], l1 = log_scales[3 * ic + 1], l2 = log_scales[3 * ic + 2];
+    float4 q = *reinterpret_cast<const float4 *>(quats + 4 * ic);
+    const float opl = op_logit[ic];
+    const float d0 = f_dc[3 * ic], d1 = f_dc[3 * ic + 1], d2 = f_dc[3 * ic + 2];
+    if (R > 0 && n_use > 0) {
+        const int64_t cnt = ((N - i0 < 256 ? N - i0 : 256)) * R;
+        const float *src = f_rest + i0 * R;
+        for (int64_t j = tid; j < cnt / 4; j += 256) reinterpret_cast<float4 *>(srest)[j] = reinterpret_cast<const float4 *>(src)[j];
+        for (int64_t j = (cnt / 4) * 4 + tid; j < cnt; j += 256) srest[j] = src[j];
+        __syncthreads();
+    }
+    if (i >= N) return;
+    const float s0 = expf(l0), s1 = expf(l1), s2 = expf(l2);
+    const float qn = sqrtf(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w);
+    q.x = q.x / qn; q.y = q.y / qn; q.z = q.z / qn; q.w = q.w / qn;
+    const float op = sigmoidf(opl);
+    opac[i] = op;
+    const float *r = srest + tid * R;
+    for (int v = 0; v < cb.C; ++v) {
+        const Cam &cam = cb.cam[v];
+        const int64_t o = (int64_t)v * N + i;
+        Proj pr;
+        const bool ok = project_one(cam, p0, p1, p2, s0, s1, s2, q.x, q.y, q.z, q.w, pr);
+        xys[2 * o] = pr.xy[0]; xys[2 * o + 1] = pr.xy[1];
+        if (tile_box) {
+            uint32_t box = 0;
+            if (ok) box = tight_tile_box(cam, pr, op);
+            tile_box[o] = box;
+            pr.tiles_hit = (int)(((box >> 8) & 255u) - (box & 255u)) * (int)((box >> 24) - ((box >> 16) & 255u));
+        }
+        depths[o] = pr.depth; radii[o] = pr.radius; tiles_hit[o] = pr.tiles_hit;
+        conics[3 * o] = pr.conic[0]; conics[3 * o + 1] = pr.conic[1]; conics[3 * o + 2] = pr.conic[2];
+        if (depth_pairs) depth_pairs[o] = make_uint2(pr.radius > 0 ? __float_as_uint(pr.depth) : 0xFFFFFFFFu, (uint32_t)i);
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+        if (ok) {
+            if (n_use < 0) {
+                c0 = sigmoidf(d0); c1 = sigmoidf(d1); c2 = sigmoidf(d2);
+            } else {
+                float dx = p0 - cam.ox, dy = p1 - cam.oy, dz = p2 - cam.oz;
+                float dn = sqrtf((dx * dx + dy * dy) + dz * dz);
+                dx = dx / dn; dy = dy / dn; dz = dz / dn;
+                float B[16];
+                sh_basis(n_use, dx, dy, dz, B);
+                c0 = B[0] * d0; c1 = B[0] * d1; c2 = B[0] * d2;
+                int Ku = (n_use + 1) * (n_use + 1);
+#pragma unroll
+                for (int k = 1; k < K; ++k)
+                    if (k < Ku) {
+                        c0 += B[k] * r[3 * (k - 1)]; c1 += B[k] * r[3 * (k - 1) + 1]; c2 += B[k] * r[3 * (k - 1) + 2];
+                    }
+                c0 = fmaxf(c0 + 0.5f, 0.f); c1 = fmaxf(c1 + 0.5f, 0.f); c2 = fmaxf(c2 + 0.5f, 0.f);
+            }
+        }
+        rgbs[3 * o] = c0; rgbs[3 * o + 1] = c1; rgbs[3 * o + 2] = c2;
+    }
+}
+
+// Backward over C views: the parameter record is read once, the per-view VJPs (same device functions as the single-view kernel) are summed
+// in registers IN VIEW ORDER -- ((g_0 + g_1) + g_2) ..., the order C accumulating single-view launches produce -- and the 59 gradient floats
+// are written (or, ACC, added to what is there) ONCE per batch: N * (56 + C * 64) bytes read + N * 236 written instead of C * N * 344.
+template <int K, bool ACC>
+__global__ __launch_bounds__(256) void k_project_sh_bwd_views(int64_t N, CamBatch cb, int n_use,
+                                                              const float *__restrict__ means, const float *__restrict__ log_scales,
+                                                              const float *__restrict__ quats, const float *__restrict__ op_logit,
+                                                              const float *__restrict__ rgbs,
+                                                              const int32_t *__restrict__ radii, const float *__restrict__ conics,
+                                                              const float *__restrict__ v_xy, const float *__restrict__ v_conic,
+                                                              const float *__restrict__ v_rgbs, const float *__restrict__ v_opac,
+                                                              float *__restrict__ v_means, float *__restrict__ v_ls,
+                                                              float *__restrict__ v_quats, float *__restrict__ v_oplogit,
+                                                              float *__restrict__ v_dc, float *__restrict__ v_rest)
+{
+    constexpr int R = (K - 1) * 3;
+    __shared__ __attribute__((aligned(16))) float svr[R > 0 ? 256 * R : 4];
+    const int tid = threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.x * 256;
+    const int64_t i = i0 + tid;
+    float *vr = svr + tid * R;
+    if (i < N) {
+        float am[3] = {0.f, 0.f, 0.f}, as[3] = {0.f, 0.f, 0.f}, aq[4] = {0.f, 0.f, 0.f, 0.f}, aop = 0.f, adc[3] = {0.f, 0.f, 0.f};
+        // (the 45 features_rest sums live in the lane's own LDS row -- the staging buffer of the coalesced store below; in registers the
+        // kernel needs 173 VGPRs = 2 workgroups per CU, with them in LDS the 46 KB of LDS is the limit again: 3 per CU)
+#pragma unroll
+        for (int k = 0; k < R; ++k) vr[k] = 0.f;
+        bool first = true;          // the first contributing view ASSIGNS (0 + g would turn a -0 into +0: keep the single-view bits)
+        const float p0 = means[3 * i], p1 = means[3 * i + 1], p2 = means[3 * i + 2];
+        const float s0 = expf(log_scales[3 * i]), s1 = expf(log_scales[3 * i + 1]), s2 = expf(log_scales[3 * i + 2]);
+        const float4 qr = *reinterpret_cast<const float4 *>(quats + 4 * i);
+        const float qn = sqrtf(((qr.x * qr.x + qr.y * qr.y) + qr.z * qr.z) + qr.w * qr.w);
+        const float q0 = qr.x / qn, q1 = qr.y / qn, q2 = qr.z / qn, q3 = qr.w / qn;
+        const float op = sigmoidf(op_logit[i]);
+        for (int v = 0; v < cb.C; ++v) {
+            const int64_t o = (int64_t)v * N + i;
+            if (radii[o] <= 0) continue;
+            const Cam &cam = cb.cam[v];
+            ProjGrad g;
+            project_one_bwd(cam, p0, p1, p2, s0, s1, s2, q0, q1, q2, q3, conics[3 * o], conics[3 * o + 1], conics[3 * o + 2],
+                            v_xy[2 * o], v_xy[2 * o + 1], 0.f, v_conic[3 * o], v_conic[3 * o + 1], v_conic[3 * o + 2], g);
+            const float dq = q0 * g.vq[0] + q1 * g.vq[1] + q2 * g.vq[2] + q3 * g.vq[3];
+            const float gq[4] = {(g.vq[0] - q0 * dq) / qn, (g.vq[1] - q1 * dq) / qn, (g.vq[2] - q2 * dq) / qn, (g.vq[3] - q3 * dq) / qn};
+            const float gls[3] = {g.vs[0] * s0, g.vs[1] * s1, g.vs[2] * s2};
+            const float gop = v_opac[o] * op * (1.f - op);
+            const float r0 = rgbs[3 * o], r1 = rgbs[3 * o + 1], r2 = rgbs[3 * o + 2];
+            float gdc[3], v0 = 0.f, v1 = 0.f, v2 = 0.f;
+            float B[16];
+            int Ku = 0;
+            if (n_use < 0) {
+                gdc[0] = v_rgbs[3 * o] * r0 * (1.f - r0); gdc[1] = v_rgbs[3 * o + 1] * r1 * (1.f - r1); gdc[2] = v_rgbs[3 * o + 2] * r2 * (1.f - r2);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) B[k] = 0.f;
+            } else {
+                float dx = p0 - cam.ox, dy = p1 - cam.oy, dz = p2 - cam.oz;
+                float dn = sqrtf((dx * dx + dy * dy) + dz * dz);
+                dx = dx / dn; dy = dy / dn; dz = dz / dn;
+                sh_basis(n_use, dx, dy, dz, B);
+                Ku = (n_use + 1) * (n_use + 1);
+                v0 = r0 > 0.f ? v_rgbs[3 * o] : 0.f;
+                v1 = r1 > 0.f ? v_rgbs[3 * o + 1] : 0.f;
+                v2 = r2 > 0.f ? v_rgbs[3 * o + 2] : 0.f;
+                gdc[0] = B[0] * v0; gdc[1] = B[0] * v1; gdc[2] = B[0] * v2;
+            }
+            if (first) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { am[k] = g.vm[k]; as[k] = gls[k]; adc[k] = gdc[k]; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) aq[k] = gq[k];
+                aop = gop;
+#pragma unroll
+                for (int k = 1; k < K; ++k) {
+                    const float b = k < Ku ? B[k] : 0.f;
+                    vr[3 * (k - 1)] = b * v0; vr[3 * (k - 1) + 1] = b * v1; vr[3 * (k - 1) + 2] = b * v2;
+                }
+                first = false;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { am[k] = am[k] + g.vm[k]; as[k] = as[k] + gls[k]; adc[k] = adc[k] + gdc[k]; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) aq[k] = aq[k] + gq[k];
+                aop = aop + gop;
+#pragma unroll
+                for (int k = 1; k < K; ++k) {
+                    const float b = k < Ku ? B[k] : 0.f;
+                    vr[3 * (k - 1)] = vr[3 * (k - 1)] + b * v0; vr[3 * (k - 1) + 1] = vr[3 * (k - 1) + 1] + b * v1;
+                    vr[3 * (k - 1) + 2] = vr[3 * (k - 1) + 2] + b * v2;
+                }
+            }
+        }
+        if (ACC) {
+            if (!first) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { v_means[3 * i + k] += am[k]; v_ls[3 * i + k] += as[k]; v_dc[3 * i + k] += adc[k]; }
+                float4 o4 = *reinterpret_cast<const float4 *>(v_quats + 4 * i);
+                o4.x += aq[0]; o4.y += aq[1]; o4.z += aq[2]; o4.w += aq[3];
+                *reinterpret_cast<float4 *>(v_quats + 4 * i) = o4;
+                v_oplogit[i] += aop;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { v_means[3 * i + k] = am[k]; v_ls[3 * i + k] = as[k]; v_dc[3 * i + k] = adc[k]; }
+            *reinterpret_cast<float4 *>(v_quats + 4 * i) = make_float4(aq[0], aq[1], aq[2], aq[3]);
+            v_oplogit[i] = aop;
+        }
+    }
+    if (R > 0) {
+        __syncthreads();
+        const int64_t cnt = ((N - i0 < 256 ? N - i0 : 256)) * R;
+        float *dst = v_rest + i0 * R;
+        for (int64_t j = tid; j < cnt / 4; j += 256) {
+            float4 v = reinterpret_cast<const float4 *>(svr)[j];
+            if (ACC) { const float4 o = reinterpret_cast<const float4 *>(dst)[j]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            reinterpret_cast<float4 *>(dst)[j] = v;
+        }
+        for (int64_t j = (cnt / 4) * 4 + tid; j < cnt; j += 256) dst[j] = ACC ? dst[j] + svr[j] : svr[j];
+    }
+}
+
 // img_out == img_raw: in place.  Otherwise the un-clamped image stays where the compositing wrote it (the backward needs it for the
 // clamp's gradient mask) and the clamped one goes to img_out: no separate copy pass.
 __global__ __launch_bounds__(256) void k_finalize(int64_t npix, const float *img_raw, float *img_out, float *__restrict__ extra,
@@ -710,6 +913,68 @@ int gc_project_sh_bwd_accumulate(int64_t N, const float *means, const float *log
                       float *v_opacity_logits, float *v_features_dc, float *v_features_rest, void *stream)
 {
     return project_sh_bwd_impl(true, N, means, log_scales, quats, opacity_logits, rgbs, sh_degree, degrees_to_use, viewmat, projmat, cam_origin, fx, fy, cx, cy, img_h, img_w, radii, conics, v_xy, v_conic, v_rgbs, v_opac, v_means, v_log_scales, v_quats, v_opacity_logits, v_features_dc, v_features_rest, stream);
+}
+
+/* ---- C views per launch (round 5).  cams: HOST float array [C][GC_VIEW_CAM_FLOATS = 35] = viewmat[12] | projmat[16] | cam_origin[3] |
+ * fx fy cx cy per view; all views share H, W and the tile grid.  Views are processed in groups of 8 (one launch per group: the cameras
+ * travel as kernel arguments); outputs are [C][N][..] except opac [N].  tile_boxes / depth_pairs optional (NULL). */
+static int fill_cams(CamBatch &cb, const float *cams, int v0, int nv, int img_h, int img_w, int tx, int ty, float clip)
+{
+    cb.C = nv;
+    for (int v = 0; v < nv; ++v) {
+        const float *c = cams + (size_t)(v0 + v) * 35;
+        cb.cam[v] = make_cam(c, c + 12, c[31], c[32], c[33], c[34], img_h, img_w, tx, ty, clip, 1.f, c + 28);
+    }
+    return 0;
+}
+
+int gc_project_sh_fwd_views(int64_t N, int C, const float *means, const float *log_scales, const float *quats,
+                            const float *opacity_logits, const float *features_dc, const float *features_rest,
+                            int sh_degree, int degrees_to_use, const float *cams, int img_h, int img_w,
+                            int tiles_x, int tiles_y, float clip_thresh, float *xys, float *depths, int32_t *radii,
+                            float *conics, int32_t *num_tiles_hit, float *rgbs, float *opac, uint32_t *tile_boxes,
+                            uint32_t *depth_pairs, void *stream)
+{
+    GC_REQUIRE(sh_degree >= 0 && sh_degree <= 3 && degrees_to_use >= -1 && degrees_to_use <= sh_degree, "SH degree must be 0..3 (degrees_to_use -1: sigmoid colour mode)");
+    GC_REQUIRE(cams && C >= 1, "cams is a host pointer and must not be NULL");
+    GC_REQUIRE(!tile_boxes || (tiles_x <= 255 && tiles_y <= 255), "packed boxes hold at most 255 x 255 tiles");
+    if (N == 0) return GC_OK;
+    for (int v0 = 0; v0 < C; v0 += MAXV) {
+        CamBatch cb;
+        fill_cams(cb, cams, v0, C - v0 < MAXV ? C - v0 : MAXV, img_h, img_w, tiles_x, tiles_y, clip_thresh);
+        const size_t o = (size_t)v0 * (size_t)N;
+        GC_SH_DISPATCH(k_project_sh_fwd_views, N, cb, degrees_to_use, means, log_scales, quats, opacity_logits, features_dc, features_rest,
+                       xys + 2 * o, depths + o, radii + o, conics + 3 * o, num_tiles_hit + o, rgbs + 3 * o, opac,
+                       tile_boxes ? tile_boxes + o : nullptr, depth_pairs ? (uint2 *)depth_pairs + o : nullptr)
+    }
+    return gc::check_launch("gc_project_sh_fwd_views");
+}
+
+/* Backward over C views: rgbs / radii / conics / v_xy / v_conic / v_rgbs / v_opac are [C][N][..]; the six leaf gradients are the SUM over
+ * the views, written (accumulate = 0) or added to the buffers' contents (accumulate = 1) once per group of 8 views. */
+int gc_project_sh_bwd_views(int64_t N, int C, int accumulate, const float *means, const float *log_scales, const float *quats,
+                            const float *opacity_logits, const float *rgbs, int sh_degree, int degrees_to_use, const float *cams,
+                            int img_h, int img_w, const int32_t *radii, const float *conics, const float *v_xy, const float *v_conic,
+                            const float *v_rgbs, const float *v_opac, float *v_means, float *v_log_scales, float *v_quats,
+                            float *v_opacity_logits, float *v_features_dc, float *v_features_rest, void *stream)
+{
+    GC_REQUIRE(sh_degree >= 0 && sh_degree <= 3 && degrees_to_use >= -1 && degrees_to_use <= sh_degree, "SH degree must be 0..3 (degrees_to_use -1: sigmoid colour mode)");
+    GC_REQUIRE(cams && C >= 1, "cams is a host pointer and must not be NULL");
+    if (N == 0) return GC_OK;
+    for (int v0 = 0; v0 < C; v0 += MAXV) {
+        CamBatch cb;
+        fill_cams(cb, cams, v0, C - v0 < MAXV ? C - v0 : MAXV, img_h, img_w, 0, 0, 0.f);
+        const size_t o = (size_t)v0 * (size_t)N;
+        const bool acc = accumulate || v0 > 0;
+#define GC_BWDV_ARGS N, cb, degrees_to_use, means, log_scales, quats, opacity_logits, rgbs + 3 * o, radii + o, conics + 3 * o, v_xy + 2 * o, v_conic + 3 * o, v_rgbs + 3 * o, v_opac + o, v_means, v_log_scales, v_quats, v_opacity_logits, v_features_dc, v_features_rest
+#define GC_BWDV_K(KK) \
+        do { if (acc) hipLaunchKernelGGL((k_project_sh_bwd_views<KK, true>), dim3(gc::cdiv(N, 256)), dim3(256), 0, gc::S(stream), GC_BWDV_ARGS); \
+             else hipLaunchKernelGGL((k_project_sh_bwd_views<KK, false>), dim3(gc::cdiv(N, 256)), dim3(256), 0, gc::S(stream), GC_BWDV_ARGS); } while (0)
+        switch (sh_degree) { case 0: GC_BWDV_K(1); break; case 1: GC_BWDV_K(4); break; case 2: GC_BWDV_K(9); break; default: GC_BWDV_K(16); break; }
+#undef GC_BWDV_K
+#undef GC_BWDV_ARGS
+    }
+    return gc::check_launch("gc_project_sh_bwd_views");
 }
 
 int gc_raster_finalize(int64_t num_pixels, float *out_img, float *out_extra, const float *final_Ts, float *alpha,

@@ -18,8 +18,10 @@
 // is prefixed by 256 lanes (one digit each) and seeded with the global digit/workgroup offset.
 #include "common.h"
 
-extern "C" int gc_raster_scan_tiles(int64_t N, const int32_t *in, int32_t *out, int32_t *count_dev, void *workspace,
-                                    size_t workspace_bytes, void *stream);
+// raster_bin.hip (internal, not in the public header): scan of C views' tile counts, optionally gathered through `order` first;
+// the three scan kernels run with grid.y = view on per-view scratch regions `ws_view_stride` bytes apart
+extern "C" int gc_raster_scan_tiles_views(int64_t N, int C, const int32_t *in, const int32_t *order, int32_t *out, int32_t *count_dev,
+                                          void *workspace, size_t workspace_bytes, int64_t ws_view_stride, void *stream);
 extern "C" size_t gc_raster_scan_workspace_bytes(int64_t N);
 
 namespace {
@@ -43,6 +45,16 @@ __device__ __forceinline__ int64_t live_count(int64_t n, const int32_t *n_dev)
 // one to arrive (ticket) turns the totals into exclusive offsets in place.  Consumers add sums[entry / 2048] themselves -- the generic
 // three-kernel scan (local / sums / add, raster_bin.hip) costs three launches of 5-8 us for a 1 MB table, seven times per view.
 constexpr int TS_CHUNK = 2048;
+
+// Batched views (round 5: gc_raster_depth_order_views / gc_raster_bin_tiles_views).  Every kernel of this file takes the view (camera) index
+// from blockIdx.y: its workspace arrays (keys / vals / digit tables / scan sums / ticket) live in a per-view region of `ws` 4-byte words, the
+// external per-view arrays have their own strides.  A single-view launch has gridDim.y == 1 and every offset is 0.
+struct VS {
+    int64_t ws;        // workspace region per view, in 4-byte words
+    int64_t ext;       // external per-view output / input arrays ([C][n] int32: depth_order, gaussian_ids_sorted): elements per view
+    int64_t src;       // per-Gaussian source arrays ([C][N]: depths, radii, num_tiles_hit, tile boxes, xys / 2)
+    int nd;            // stride of the device-side counts (n_dev / overflow): 1 per view (0 when unused)
+};
 __device__ __forceinline__ int block_incl_scan256(int v, int *total, int *wsum /* LDS[4] */)
 {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -60,11 +72,12 @@ __device__ __forceinline__ int block_incl_scan256(int v, int *total, int *wsum /
 }
 
 __global__ __launch_bounds__(256) void k_table_scan(int64_t n, const int32_t *__restrict__ in, int32_t *__restrict__ out,
-                                                    int32_t *sums, int32_t *ticket)
+                                                    int32_t *sums, int32_t *ticket, VS vs)
 {
     __shared__ int wsum[4];
     __shared__ int s_last;
     const int tid = threadIdx.x;
+    { const int64_t o = (int64_t)blockIdx.y * vs.ws; in += o; out += o; sums += o; ticket += o; }
     const int64_t base = (int64_t)blockIdx.x * TS_CHUNK + (int64_t)tid * 8;
     int v[8], run = 0;
 #pragma unroll
@@ -96,8 +109,10 @@ __global__ __launch_bounds__(256) void k_table_scan(int64_t n, const int32_t *__
 // PAIR: keys points at (key, value) uint2 pairs -- the depth passes keep the pair together so that a scattered item is ONE 8-byte store
 template <bool PAIR>
 __global__ __launch_bounds__(RT) void k_radix_hist(const uint32_t *__restrict__ keys, int64_t n, const int32_t *__restrict__ n_dev,
-                                                   int shift, unsigned dmask, int nblocks, int32_t *__restrict__ hist /* [digits][nblocks] */)
+                                                   int shift, unsigned dmask, int nblocks, int32_t *__restrict__ hist /* [digits][nblocks] */, VS vs,
+                                                   int keys_ext /* keys = external [C][vs.ext] pairs, not a workspace buffer */)
 {
+    { const int64_t o = (int64_t)blockIdx.y * vs.ws; keys += keys_ext ? (int64_t)blockIdx.y * 2 * vs.ext : o; hist += o; if (n_dev) n_dev += blockIdx.y * vs.nd; }
     n = live_count(n, n_dev);
     __shared__ int h[256];
     h[threadIdx.x] = 0;
@@ -118,8 +133,16 @@ __global__ __launch_bounds__(RT) void k_radix_scatter(const uint32_t *__restrict
                                                       uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int64_t n,
                                                       const int32_t *__restrict__ n_dev, int shift, int nblocks,
                                                       const int32_t *__restrict__ hist, const int32_t *__restrict__ offs,
-                                                      const int32_t *__restrict__ sums)
+                                                      const int32_t *__restrict__ sums, VS vs, int vals_ext, int keys_ext)
 {
+    {   // view offsets: everything in the per-view workspace region, the last pass's values in the external [C][n] array
+        const int64_t o = (int64_t)blockIdx.y * vs.ws;
+        keys += keys_ext ? (int64_t)blockIdx.y * 2 * vs.ext : o; hist += o; offs += o; sums += o;
+        if (vals) vals += o;
+        if (keys_out) keys_out += o;
+        if (vals_out) vals_out += vals_ext ? (int64_t)blockIdx.y * vs.ext : o;
+        if (n_dev) n_dev += blockIdx.y * vs.nd;
+    }
     n = live_count(n, n_dev);
     extern __shared__ int tbl[];   // [RI*4][256]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -189,8 +212,14 @@ __global__ __launch_bounds__(RT) void k_radix_scatter_staged(const uint32_t *__r
                                                              uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int64_t n,
                                                              const int32_t *__restrict__ n_dev, int shift, int nblocks,
                                                              const int32_t *__restrict__ hist, const int32_t *__restrict__ offs,
-                                                             const int32_t *__restrict__ sums)
+                                                             const int32_t *__restrict__ sums, VS vs, int vals_ext)
 {
+    {
+        const int64_t o = (int64_t)blockIdx.y * vs.ws;
+        keys += o; vals += o; hist += o; offs += o; sums += o; keys_out += o;
+        vals_out += vals_ext ? (int64_t)blockIdx.y * vs.ext : o;
+        if (n_dev) n_dev += blockIdx.y * vs.nd;
+    }
     constexpr int ND = 1 << DB, NS = RI * 4;      // digits, (round, wave) slots
     constexpr int PARTS = RT / ND, SPP = NS / PARTS;   // prefix step: PARTS lanes per digit, SPP slots each
     static_assert(ND <= 64 && NS % PARTS == 0, "digit table");
@@ -272,19 +301,12 @@ __global__ __launch_bounds__(RT) void k_radix_scatter_staged(const uint32_t *__r
 }
 
 __global__ __launch_bounds__(256) void k_depth_keys(int64_t N, const float *__restrict__ depths, const int32_t *__restrict__ radii,
-                                                    uint2 *__restrict__ pairs)
+                                                    uint2 *__restrict__ pairs, VS vs)
 {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
+    depths += blockIdx.y * vs.src; radii += blockIdx.y * vs.src; pairs += blockIdx.y * (vs.ws / 2);
     pairs[i] = make_uint2(radii[i] > 0 ? __float_as_uint(depths[i]) : 0xFFFFFFFFu, (uint32_t)i);
-}
-
-__global__ __launch_bounds__(256) void k_gather_tiles(int64_t N, const uint32_t *__restrict__ order, const int32_t *__restrict__ nth,
-                                                      int32_t *__restrict__ nth_sorted)
-{
-    int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= N) return;
-    nth_sorted[j] = nth[order[j]];
 }
 
 // emission in depth order: pair (tile id, gaussian id) for every tile of the box of order[j].  The 256 Gaussians of a workgroup own ONE
@@ -296,8 +318,14 @@ __global__ __launch_bounds__(256) void k_emit_sorted(int64_t N, int64_t M_cap, c
                                                      const uint32_t *__restrict__ tile_box /* packed boxes instead of (xys, radii), or NULL */,
                                                      const int32_t *__restrict__ cum_sorted, int tiles_x, int tiles_y,
                                                      uint32_t *__restrict__ tile_keys, uint32_t *__restrict__ gids,
-                                                     unsigned dmask, int nblocks, int32_t *__restrict__ hist /* [digits][nblocks], zeroed */)
+                                                     unsigned dmask, int nblocks, int32_t *__restrict__ hist /* [digits][nblocks], zeroed */, VS vs)
 {
+    {
+        const int64_t o = (int64_t)blockIdx.y * vs.ws, e = (int64_t)blockIdx.y * vs.src;
+        order += e; cum_sorted += e; tile_keys += o; gids += o; hist += o;
+        if (tile_box) tile_box += e;
+        if (xys) { xys += 2 * e; radii += e; }
+    }
     __shared__ uint32_t sT[EW], sG[EW];
     __shared__ int64_t sRange[2];
     __shared__ int sH[2 * 64];                    // first tile pass's digit counts of the (at most two) 4096-blocks a window touches
@@ -368,8 +396,15 @@ __global__ __launch_bounds__(256) void k_emit_sorted(int64_t N, int64_t M_cap, c
 __global__ __launch_bounds__(256) void k_tile_bins32(int64_t M, const int32_t *__restrict__ m_dev, int32_t *__restrict__ overflow,
                                                      int num_tiles, const uint32_t *__restrict__ tkeys,
                                                      const uint32_t *__restrict__ gids, const float *__restrict__ depths,
-                                                     int32_t *__restrict__ bins, int64_t *__restrict__ keys64, int32_t *__restrict__ ids_out)
+                                                     int32_t *__restrict__ bins, int64_t *__restrict__ keys64, int32_t *__restrict__ ids_out, VS vs)
 {
+    {
+        const int64_t o = (int64_t)blockIdx.y * vs.ws;
+        tkeys += o; bins += (int64_t)blockIdx.y * 2 * num_tiles; depths += blockIdx.y * vs.src;
+        gids += (int64_t)blockIdx.y * vs.ext;             // (the last radix pass wrote the ids into the external [C][M_cap] array)
+        if (keys64) keys64 += (int64_t)blockIdx.y * vs.ext;
+        if (m_dev) { m_dev += blockIdx.y * vs.nd; overflow += blockIdx.y * vs.nd; }
+    }
     if (m_dev && overflow && blockIdx.x == 0 && threadIdx.x == 0) *overflow = (int64_t)*m_dev > M ? 1 : 0;
     M = live_count(M, m_dev);
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -421,37 +456,79 @@ void set_attr()
     gc::ensure_dynamic_lds(once_p, (const void *)k_radix_scatter<true>, RI * 4 * 256 * 4);
 }
 
-// one stable radix pass of `dbits` bits (8: the direct scatter; 5 / 6: the LDS-staged scatter of the tile passes)
+// one stable radix pass of `dbits` bits (8: the direct scatter; 5 / 6: the LDS-staged scatter of the tile passes) over C views at once
+// (grid.y = view; per-view workspace regions of vs.ws words).  vals_ext: `vo` is the external [C][vs.ext] array, not a workspace buffer.
 int radix_pass(const uint32_t *ki, const uint32_t *vi, uint32_t *ko, uint32_t *vo, int64_t n, const int32_t *n_dev, int shift,
-               const Plan &p, unsigned char *w, hipStream_t s, int dbits = 8, bool pair = false, bool have_hist = false)
+               const Plan &p, unsigned char *w, hipStream_t s, int C, const VS &vs, int vals_ext, int dbits = 8, bool pair = false,
+               bool have_hist = false, int keys_ext = 0)
 {
     int32_t *hist = (int32_t *)(w + p.off_hist), *offs = (int32_t *)(w + p.off_offs), *cnt = (int32_t *)(w + p.off_cnt);
     const int nd = 1 << dbits;
+    const dim3 g((unsigned)p.nb, (unsigned)C);
     if (have_hist) {}                     // the producer of `ki` already accumulated this pass's histogram (k_emit_sorted)
-    else if (pair) hipLaunchKernelGGL(k_radix_hist<true>, dim3(p.nb), dim3(RT), 0, s, ki, n, n_dev, shift, (unsigned)(nd - 1), p.nb, hist);
-    else hipLaunchKernelGGL(k_radix_hist<false>, dim3(p.nb), dim3(RT), 0, s, ki, n, n_dev, shift, (unsigned)(nd - 1), p.nb, hist);
+    else if (pair) hipLaunchKernelGGL(k_radix_hist<true>, g, dim3(RT), 0, s, ki, n, n_dev, shift, (unsigned)(nd - 1), p.nb, hist, vs, keys_ext);
+    else hipLaunchKernelGGL(k_radix_hist<false>, g, dim3(RT), 0, s, ki, n, n_dev, shift, (unsigned)(nd - 1), p.nb, hist, vs, 0);
     // cnt[0] is the scan's ticket (zeroed once per phase, self-resetting); the scan scratch holds the per-2048-entry offsets
     int32_t *sums = (int32_t *)(w + p.off_scan);
     const int64_t ne = nd * (int64_t)p.nb;
-    hipLaunchKernelGGL(k_table_scan, dim3((unsigned)((ne + TS_CHUNK - 1) / TS_CHUNK)), dim3(256), 0, s, ne, hist, offs, sums, cnt);
+    hipLaunchKernelGGL(k_table_scan, dim3((unsigned)((ne + TS_CHUNK - 1) / TS_CHUNK), (unsigned)C), dim3(256), 0, s, ne, hist, offs, sums, cnt, vs);
     if (dbits == 5)
-        hipLaunchKernelGGL(k_radix_scatter_staged<5>, dim3(p.nb), dim3(RT), 0, s, ki, vi, ko, vo, n, n_dev, shift, p.nb, hist, offs, sums);
+        hipLaunchKernelGGL(k_radix_scatter_staged<5>, g, dim3(RT), 0, s, ki, vi, ko, vo, n, n_dev, shift, p.nb, hist, offs, sums, vs, vals_ext);
     else if (dbits == 6)
-        hipLaunchKernelGGL(k_radix_scatter_staged<6>, dim3(p.nb), dim3(RT), 0, s, ki, vi, ko, vo, n, n_dev, shift, p.nb, hist, offs, sums);
+        hipLaunchKernelGGL(k_radix_scatter_staged<6>, g, dim3(RT), 0, s, ki, vi, ko, vo, n, n_dev, shift, p.nb, hist, offs, sums, vs, vals_ext);
     else if (pair)
-        hipLaunchKernelGGL(k_radix_scatter<true>, dim3(p.nb), dim3(RT), (size_t)RI * 4 * 256 * sizeof(int), s, ki, vi, ko, vo, n, n_dev,
-                           shift, p.nb, hist, offs, sums);
+        hipLaunchKernelGGL(k_radix_scatter<true>, g, dim3(RT), (size_t)RI * 4 * 256 * sizeof(int), s, ki, vi, ko, vo, n, n_dev,
+                           shift, p.nb, hist, offs, sums, vs, vals_ext, keys_ext);
     else
-        hipLaunchKernelGGL(k_radix_scatter<false>, dim3(p.nb), dim3(RT), (size_t)RI * 4 * 256 * sizeof(int), s, ki, vi, ko, vo, n, n_dev,
-                           shift, p.nb, hist, offs, sums);
+        hipLaunchKernelGGL(k_radix_scatter<false>, g, dim3(RT), (size_t)RI * 4 * 256 * sizeof(int), s, ki, vi, ko, vo, n, n_dev,
+                           shift, p.nb, hist, offs, sums, vs, vals_ext, 0);
     return GC_OK;
+}
+
+// per-view region of the depth-order workspace: the radix plan + nothing else (the gathered tile counts are no longer materialised)
+size_t depth_region(int64_t N) { return make_plan(N > 0 ? N : 1).total; }
+
+int depth_order_impl(int64_t N, int C, const float *depths, const int32_t *radii, const uint32_t *pairs_in, const int32_t *num_tiles_hit,
+                     int32_t *depth_order, int32_t *cum_sorted, int32_t *count_dev, void *workspace, size_t workspace_bytes,
+                     void *stream, const char *what)
+{
+    hipStream_t s = gc::S(stream);
+    if (N == 0) return hipMemsetAsync(count_dev, 0, 4 * (size_t)C, s) == hipSuccess ? GC_OK : GC_ELAUNCH;
+    if (!((pairs_in || (depths && radii)) && num_tiles_hit && depth_order && cum_sorted && workspace)) { gc::set_error("%s: null pointer", what); return GC_EINVAL; }
+    const Plan p = make_plan(N);
+    const size_t region = depth_region(N);
+    if (workspace_bytes < region * (size_t)C) { gc::set_error("%s: workspace too small", what); return GC_ENOSPC; }
+    set_attr();
+    unsigned char *w = (unsigned char *)workspace;
+    VS vs; vs.ws = (int64_t)(region / 4); vs.ext = N; vs.src = N; vs.nd = 0;
+    uint32_t *k0 = (uint32_t *)(w + p.off_keys[0]), *k1 = (uint32_t *)(w + p.off_keys[1]);
+    // (key, id) pairs ping-pong between the two halves of the view's region (each half = the keys + vals regions of the plan, >= 8 N bytes)
+    uint32_t *pa = k0, *pb = k1;
+    for (int c = 0; c < C; ++c)                                                            // tickets of k_table_scan
+        if (hipMemsetAsync(w + region * (size_t)c + p.off_cnt, 0, 4, s) != hipSuccess) return GC_ELAUNCH;
+    // pairs_in: the projection kernel already wrote the (depth bits | 0xFFFFFFFF, id) pairs ([C][N] uint2): the first pass reads them in place
+    if (!pairs_in)
+        hipLaunchKernelGGL(k_depth_keys, dim3(gc::cdiv(N, 256), (unsigned)C), dim3(256), 0, s, N, depths, radii, (uint2 *)pa, vs);
+    for (int pass = 0; pass < 4; ++pass) {   // visible depths are > 0: the float bit pattern is monotone
+        const bool ext = pass == 0 && pairs_in;
+        int rc = radix_pass(ext ? pairs_in : pa, nullptr, pass == 3 ? nullptr : pb, (uint32_t *)depth_order, N, nullptr, 8 * pass, p, w, s, C, vs, 1,
+                            8, true, false, ext ? 1 : 0);
+        if (rc != GC_OK) return rc;
+        uint32_t *t = pa; pa = pb; pb = t;
+    }
+    // inclusive scan of the tile counts TAKEN IN DEPTH ORDER (the gather is fused into the scan's load), per view
+    int rc = gc_raster_scan_tiles_views(N, C, num_tiles_hit, depth_order, cum_sorted, count_dev, w + p.off_scan, p.scan_bytes,
+                                        (int64_t)region, (void *)s);
+    if (rc != GC_OK) return rc;
+    return gc::check_launch(what);
 }
 
 }  // namespace
 
 extern "C" {
 
-size_t gc_raster_depth_order_workspace_bytes(int64_t N) { return make_plan(N > 0 ? N : 1).total + al(4 * (size_t)(N > 0 ? N : 1)); }
+size_t gc_raster_depth_order_workspace_bytes(int64_t N) { return depth_region(N); }
+size_t gc_raster_depth_order_views_workspace_bytes(int64_t N, int C) { return depth_region(N) * (size_t)(C > 0 ? C : 1); }
 
 /* Phase 1 (no host sync): depth_order[N] = Gaussian ids sorted by (depth bits, id), culled (radii <= 0) last;
  * cum_sorted[N] = inclusive scan of num_tiles_hit taken in that order; *count_dev = M. */
@@ -460,36 +537,29 @@ int gc_raster_depth_order(int64_t N, const float *depths, const int32_t *radii, 
                           void *stream)
 {
     GC_REQUIRE(N >= 0 && count_dev, "bad arguments");
-    hipStream_t s = gc::S(stream);
-    if (N == 0) return hipMemsetAsync(count_dev, 0, 4, s) == hipSuccess ? GC_OK : GC_ELAUNCH;
-    GC_REQUIRE(depths && radii && num_tiles_hit && depth_order && cum_sorted && workspace, "null pointer");
-    const Plan p = make_plan(N);
-    if (workspace_bytes < gc_raster_depth_order_workspace_bytes(N)) { gc::set_error("gc_raster_depth_order: workspace too small"); return GC_ENOSPC; }
-    set_attr();
-    unsigned char *w = (unsigned char *)workspace;
-    uint32_t *k0 = (uint32_t *)(w + p.off_keys[0]), *k1 = (uint32_t *)(w + p.off_keys[1]);
-    int32_t *nth_s = (int32_t *)(w + p.total);
-    // (key, id) pairs ping-pong between the two halves of the workspace (each half = the keys + vals regions of the plan, >= 8 N bytes)
-    uint32_t *pa = k0, *pb = k1;
-    if (hipMemsetAsync(w + p.off_cnt, 0, 4, s) != hipSuccess) return GC_ELAUNCH;          // ticket of k_table_scan
-    hipLaunchKernelGGL(k_depth_keys, dim3(gc::cdiv(N, 256)), dim3(256), 0, s, N, depths, radii, (uint2 *)pa);
-    for (int pass = 0; pass < 4; ++pass) {   // visible depths are > 0: the float bit pattern is monotone
-        int rc = radix_pass(pa, nullptr, pass == 3 ? nullptr : pb, (uint32_t *)depth_order, N, nullptr, 8 * pass, p, w, s, 8, true);
-        if (rc != GC_OK) return rc;
-        uint32_t *t = pa; pa = pb; pb = t;
-    }
-    hipLaunchKernelGGL(k_gather_tiles, dim3(gc::cdiv(N, 256)), dim3(256), 0, s, N, (const uint32_t *)depth_order, num_tiles_hit, nth_s);
-    int rc = gc_raster_scan_tiles(N, nth_s, cum_sorted, count_dev, w + p.off_scan, p.scan_bytes, (void *)s);
-    if (rc != GC_OK) return rc;
-    return gc::check_launch("gc_raster_depth_order");
+    return depth_order_impl(N, 1, depths, radii, nullptr, num_tiles_hit, depth_order, cum_sorted, count_dev, workspace, workspace_bytes, stream,
+                            "gc_raster_depth_order");
+}
+
+/* The same for C views in ONE set of launches (grid.y = view): depths / radii / num_tiles_hit / depth_order / cum_sorted are [C][N],
+ * count_dev[C].  depth_pairs (optional, [C][N] uint2 = (depth bits or 0xFFFFFFFF when culled, Gaussian id), as gc_project_sh_fwd_views
+ * writes them) replaces the (depths, radii) read. */
+int gc_raster_depth_order_views(int64_t N, int C, const float *depths, const int32_t *radii, const uint32_t *depth_pairs,
+                                const int32_t *num_tiles_hit, int32_t *depth_order, int32_t *cum_sorted, int32_t *count_dev,
+                                void *workspace, size_t workspace_bytes, void *stream)
+{
+    GC_REQUIRE(N >= 0 && C >= 1 && C <= 65535 && count_dev, "bad arguments");
+    return depth_order_impl(N, C, depths, radii, depth_pairs, num_tiles_hit, depth_order, cum_sorted, count_dev, workspace, workspace_bytes,
+                            stream, "gc_raster_depth_order_views");
 }
 
 size_t gc_raster_bin_workspace_bytes(int64_t M) { return make_plan(M > 0 ? M : 1).total; }
+size_t gc_raster_bin_views_workspace_bytes(int64_t M_cap, int C) { return make_plan(M_cap > 0 ? M_cap : 1).total * (size_t)(C > 0 ? C : 1); }
 
 }  // extern "C"
 
 namespace {
-int bin_tiles_impl(int64_t N, int64_t M, const int32_t *m_dev, int32_t *overflow_dev, const int32_t *depth_order,
+int bin_tiles_impl(int64_t N, int C, int64_t M, const int32_t *m_dev, int32_t *overflow_dev, const int32_t *depth_order,
                    const int32_t *cum_sorted, const float *xys, const float *depths, const int32_t *radii, const uint32_t *tile_boxes,
                    int tiles_x, int tiles_y,
                    int32_t *gaussian_ids_sorted, int32_t *tile_bins, int64_t *isect_ids_sorted, void *workspace,
@@ -497,18 +567,18 @@ int bin_tiles_impl(int64_t N, int64_t M, const int32_t *m_dev, int32_t *overflow
 {
     const int num_tiles = tiles_x * tiles_y;
     hipStream_t s = gc::S(stream);
-    if (hipMemsetAsync(tile_bins, 0, sizeof(int32_t) * 2 * (size_t)num_tiles, s) != hipSuccess) return GC_ELAUNCH;
-    if (overflow_dev && hipMemsetAsync(overflow_dev, 0, 4, s) != hipSuccess) return GC_ELAUNCH;
+    if (hipMemsetAsync(tile_bins, 0, sizeof(int32_t) * 2 * (size_t)num_tiles * C, s) != hipSuccess) return GC_ELAUNCH;
+    if (overflow_dev && hipMemsetAsync(overflow_dev, 0, 4 * (size_t)C, s) != hipSuccess) return GC_ELAUNCH;
     if (M == 0 || N == 0) return GC_OK;
     if (num_tiles > 65536) { gc::set_error("%s: at most 65536 tiles", what); return GC_EINVAL; }
     if (!(depth_order && cum_sorted && ((xys && radii) || tile_boxes) && depths && gaussian_ids_sorted && workspace)) { gc::set_error("%s: null pointer", what); return GC_EINVAL; }
     const Plan p = make_plan(M);
-    if (workspace_bytes < p.total) { gc::set_error("%s: workspace too small", what); return GC_ENOSPC; }
+    if (workspace_bytes < p.total * (size_t)C) { gc::set_error("%s: workspace too small", what); return GC_ENOSPC; }
     set_attr();
     unsigned char *w = (unsigned char *)workspace;
+    VS vs; vs.ws = (int64_t)(p.total / 4); vs.ext = M; vs.src = N; vs.nd = m_dev ? 1 : 0;
     uint32_t *k0 = (uint32_t *)(w + p.off_keys[0]), *v0 = (uint32_t *)(w + p.off_vals[0]);
     uint32_t *k1 = (uint32_t *)(w + p.off_keys[1]), *v1 = (uint32_t *)(w + p.off_vals[1]);
-    if (hipMemsetAsync(w + p.off_cnt, 0, 4, s) != hipSuccess) return GC_ELAUNCH;          // ticket of k_table_scan
     // the tile-id bits are split evenly over two passes (1024 tiles: 5 + 5, 4096: 6 + 6) and scattered through LDS; above 12 bits
     // (or for a single pass) the 8-bit direct scatter runs
     int tbits = 1;
@@ -516,19 +586,24 @@ int bin_tiles_impl(int64_t N, int64_t M, const int32_t *m_dev, int32_t *overflow
     const int passes = tbits <= 6 ? 1 : 2;
     const int dbits = tbits <= 5 ? 5 : (tbits <= 6 ? 6 : (tbits <= 10 ? 5 : (tbits <= 12 ? 6 : 8)));
     const bool fused_hist = dbits <= 6;          // the emission also counts the first pass's digits (64 LDS counters per 4096-block)
-    if (fused_hist && hipMemsetAsync(w + p.off_hist, 0, sizeof(int32_t) * ((size_t)1 << dbits) * p.nb, s) != hipSuccess) return GC_ELAUNCH;
-    hipLaunchKernelGGL(k_emit_sorted, dim3(gc::cdiv(N, 256)), dim3(256), 0, s, N, M, (const uint32_t *)depth_order, xys, radii,
-                       tile_boxes, cum_sorted, tiles_x, tiles_y, k0, v0, fused_hist ? (1u << dbits) - 1u : 0u, fused_hist ? p.nb : 0,
-                       (int32_t *)(w + p.off_hist));
-    uint32_t *ks = k0, *vs = v0;
-    for (int pass = 0; pass < passes; ++pass) {
-        uint32_t *ko = ks == k0 ? k1 : k0, *vo = pass == passes - 1 ? (uint32_t *)gaussian_ids_sorted : (vs == v0 ? v1 : v0);
-        int rc = radix_pass(ks, vs, ko, vo, M, m_dev, dbits * pass, p, w, s, dbits, false, fused_hist && pass == 0);
-        if (rc != GC_OK) return rc;
-        ks = ko; vs = vo;
+    for (int c = 0; c < C; ++c) {
+        unsigned char *wc = w + p.total * (size_t)c;
+        if (hipMemsetAsync(wc + p.off_cnt, 0, 4, s) != hipSuccess) return GC_ELAUNCH;          // ticket of k_table_scan
+        if (fused_hist && hipMemsetAsync(wc + p.off_hist, 0, sizeof(int32_t) * ((size_t)1 << dbits) * p.nb, s) != hipSuccess) return GC_ELAUNCH;
     }
-    hipLaunchKernelGGL(k_tile_bins32, dim3(gc::cdiv(M, 256)), dim3(256), 0, s, M, m_dev, overflow_dev, num_tiles, ks, vs, depths,
-                       tile_bins, isect_ids_sorted, (int32_t *)nullptr);
+    hipLaunchKernelGGL(k_emit_sorted, dim3(gc::cdiv(N, 256), (unsigned)C), dim3(256), 0, s, N, M, (const uint32_t *)depth_order, xys, radii,
+                       tile_boxes, cum_sorted, tiles_x, tiles_y, k0, v0, fused_hist ? (1u << dbits) - 1u : 0u, fused_hist ? p.nb : 0,
+                       (int32_t *)(w + p.off_hist), vs);
+    uint32_t *ks = k0, *vsrc = v0;
+    for (int pass = 0; pass < passes; ++pass) {
+        const bool last = pass == passes - 1;
+        uint32_t *ko = ks == k0 ? k1 : k0, *vo = last ? (uint32_t *)gaussian_ids_sorted : (vsrc == v0 ? v1 : v0);
+        int rc = radix_pass(ks, vsrc, ko, vo, M, m_dev, dbits * pass, p, w, s, C, vs, last ? 1 : 0, dbits, false, fused_hist && pass == 0);
+        if (rc != GC_OK) return rc;
+        ks = ko; vsrc = vo;
+    }
+    hipLaunchKernelGGL(k_tile_bins32, dim3(gc::cdiv(M, 256), (unsigned)C), dim3(256), 0, s, M, m_dev, overflow_dev, num_tiles, ks, vsrc, depths,
+                       tile_bins, isect_ids_sorted, (int32_t *)nullptr, vs);
     return gc::check_launch(what);
 }
 }  // namespace
@@ -543,7 +618,7 @@ int gc_raster_bin_tiles(int64_t N, int64_t M, const int32_t *depth_order, const 
                         int32_t *tile_bins, int64_t *isect_ids_sorted, void *workspace, size_t workspace_bytes, void *stream)
 {
     GC_REQUIRE(N >= 0 && M >= 0 && tile_bins, "bad arguments");
-    return bin_tiles_impl(N, M, nullptr, nullptr, depth_order, cum_sorted, xys, depths, radii, nullptr, tiles_x, tiles_y, gaussian_ids_sorted,
+    return bin_tiles_impl(N, 1, M, nullptr, nullptr, depth_order, cum_sorted, xys, depths, radii, nullptr, tiles_x, tiles_y, gaussian_ids_sorted,
                           tile_bins, isect_ids_sorted, workspace, workspace_bytes, stream, "gc_raster_bin_tiles");
 }
 
@@ -557,7 +632,7 @@ int gc_raster_bin_tiles_dev(int64_t N, int64_t M_cap, const int32_t *count_dev, 
                             void *workspace, size_t workspace_bytes, void *stream)
 {
     GC_REQUIRE(N >= 0 && M_cap >= 0 && tile_bins && count_dev && overflow_dev, "bad arguments");
-    return bin_tiles_impl(N, M_cap, count_dev, overflow_dev, depth_order, cum_sorted, xys, depths, radii, nullptr, tiles_x, tiles_y,
+    return bin_tiles_impl(N, 1, M_cap, count_dev, overflow_dev, depth_order, cum_sorted, xys, depths, radii, nullptr, tiles_x, tiles_y,
                           gaussian_ids_sorted, tile_bins, isect_ids_sorted, workspace, workspace_bytes, stream, "gc_raster_bin_tiles_dev");
 }
 
@@ -571,8 +646,22 @@ int gc_raster_bin_tiles_boxes(int64_t N, int64_t M, const int32_t *count_dev, in
 {
     GC_REQUIRE(N >= 0 && M >= 0 && tile_bins && tile_boxes && ((count_dev == nullptr) == (overflow_dev == nullptr)), "bad arguments");
     GC_REQUIRE(tiles_x <= 255 && tiles_y <= 255, "packed boxes hold at most 255 x 255 tiles");
-    return bin_tiles_impl(N, M, count_dev, overflow_dev, depth_order, cum_sorted, nullptr, depths, nullptr, tile_boxes, tiles_x, tiles_y,
+    return bin_tiles_impl(N, 1, M, count_dev, overflow_dev, depth_order, cum_sorted, nullptr, depths, nullptr, tile_boxes, tiles_x, tiles_y,
                           gaussian_ids_sorted, tile_bins, isect_ids_sorted, workspace, workspace_bytes, stream, "gc_raster_bin_tiles_boxes");
+}
+
+/* Phase 2 for C views in one set of launches (always sync-free, always on the packed tight boxes): count_dev[C] / overflow_dev[C],
+ * depth_order / cum_sorted / tile_boxes / depths [C][N], gaussian_ids_sorted [C][M_cap], tile_bins [C][T][2], isect_ids_sorted [C][M_cap]
+ * or NULL; workspace >= gc_raster_bin_views_workspace_bytes(M_cap, C). */
+int gc_raster_bin_tiles_views(int64_t N, int C, int64_t M_cap, const int32_t *count_dev, int32_t *overflow_dev, const int32_t *depth_order,
+                              const int32_t *cum_sorted, const uint32_t *tile_boxes, const float *depths, int tiles_x, int tiles_y,
+                              int32_t *gaussian_ids_sorted, int32_t *tile_bins, int64_t *isect_ids_sorted, void *workspace,
+                              size_t workspace_bytes, void *stream)
+{
+    GC_REQUIRE(N >= 0 && C >= 1 && C <= 65535 && M_cap >= 0 && tile_bins && tile_boxes && count_dev && overflow_dev, "bad arguments");
+    GC_REQUIRE(tiles_x <= 255 && tiles_y <= 255, "packed boxes hold at most 255 x 255 tiles");
+    return bin_tiles_impl(N, C, M_cap, count_dev, overflow_dev, depth_order, cum_sorted, nullptr, depths, nullptr, tile_boxes, tiles_x, tiles_y,
+                          gaussian_ids_sorted, tile_bins, isect_ids_sorted, workspace, workspace_bytes, stream, "gc_raster_bin_tiles_views");
 }
 
 }  // extern "C"

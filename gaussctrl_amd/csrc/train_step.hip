@@ -33,7 +33,12 @@ __global__ __launch_bounds__(256) void k_ssim_stats(const float *__restrict__ x,
     __shared__ float sx[TS + 2 * HALF][TS + 2 * HALF + 1], sy[TS + 2 * HALF][TS + 2 * HALF + 1];
     __shared__ float hb[5][TS + 2 * HALF][TS + 1];
     __shared__ float red[2][4];
-    const int c = blockIdx.z, tx0 = blockIdx.x * TS, ty0 = blockIdx.y * TS, tid = threadIdx.x;
+    const int img = blockIdx.z / C, c = blockIdx.z - img * C, tx0 = blockIdx.x * TS, ty0 = blockIdx.y * TS, tid = threadIdx.x;
+    {   // image `img` of a batch (gc_l1_ssim_fwd_bwd_views): [B][H][W][C] tensors, per-image slot lines
+        const size_t o = (size_t)img * H * W * C;
+        x += o; y += o; dmu += o; dxx += o; dxy += o;
+        ssim_sum += (size_t)img * 2 * NSLOT * SLOT_PITCH; l1_sum += (size_t)img * 2 * NSLOT * SLOT_PITCH;
+    }
     constexpr int TW = TS + 2 * HALF;
     for (int i = tid; i < TW * TW; i += 256) {
         const int ly = i / TW, lx = i - ly * TW;
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(256) void k_ssim_stats(const float *__restrict__ x,
     if ((tid & 63) == 0) { red[0][tid >> 6] = ssim; red[1][tid >> 6] = l1; }
     __syncthreads();
     if (tid == 0) {
-        const int slot = (int)((blockIdx.x + blockIdx.y * 5 + blockIdx.z * 11) & (NSLOT - 1));
+        const int slot = (int)((blockIdx.x + blockIdx.y * 5 + c * 11) & (NSLOT - 1));
         unsafeAtomicAdd(ssim_sum + slot * SLOT_PITCH, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
         unsafeAtomicAdd(l1_sum + slot * SLOT_PITCH, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
     }
@@ -104,7 +109,13 @@ __global__ __launch_bounds__(256) void k_ssim_grad(const float *__restrict__ x, 
                                                    const float *__restrict__ dxy, float lambda_, float inv_n, float inv_n_ssim, float scale,
                                                    float *__restrict__ v_x, const float *__restrict__ slots, float *__restrict__ loss_out)
 {
-    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 64) {      // fold the partial sums of k_ssim_stats
+    const int img = blockIdx.z / C;
+    {
+        const size_t o = (size_t)img * H * W * C;
+        x += o; y += o; dmu += o; dxx += o; dxy += o; v_x += o;
+        slots += (size_t)img * 2 * NSLOT * SLOT_PITCH; loss_out += 2 * img;
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == img * C && threadIdx.x < 64) {      // fold the partial sums of k_ssim_stats
         float v = slots[threadIdx.x * SLOT_PITCH];     // slots [0, NSLOT): SSIM, [NSLOT, 2 NSLOT): L1
 #pragma unroll
         for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
@@ -113,7 +124,7 @@ __global__ __launch_bounds__(256) void k_ssim_grad(const float *__restrict__ x, 
     constexpr int TW = TS + 2 * HALF;
     __shared__ float s[3][TW][TW + 1];
     __shared__ float hb[3][TW][TS + 1];
-    const int c = blockIdx.z, tx0 = blockIdx.x * TS, ty0 = blockIdx.y * TS, tid = threadIdx.x;
+    const int c = blockIdx.z - img * C, tx0 = blockIdx.x * TS, ty0 = blockIdx.y * TS, tid = threadIdx.x;
     for (int i = tid; i < TW * TW; i += 256) {
         const int ly = i / TW, lx = i - ly * TW;
         const int gy = ty0 + ly - HALF, gx = tx0 + lx - HALF;
@@ -181,6 +192,31 @@ Gauss make_window()
 extern "C" {
 
 size_t gc_l1_ssim_workspace_bytes(int H, int W, int C) { return sizeof(float) * (3 * (size_t)H * W * C + 32 + 2 * NSLOT * SLOT_PITCH); }
+size_t gc_l1_ssim_views_workspace_bytes(int B, int H, int W, int C)
+{
+    return sizeof(float) * ((size_t)(B > 0 ? B : 1) * (3 * (size_t)H * W * C + 2 * NSLOT * SLOT_PITCH) + 32);
+}
+
+static int l1_ssim_impl(const char *what, int B, const float *pred, const float *target, int H, int W, int C, float lambda_, float grad_scale,
+                        int valid_window, float *loss_out, float *v_pred, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!(pred && target && loss_out && v_pred && workspace)) { gc::set_error("%s: null argument", what); return GC_EINVAL; }
+    if (valid_window && !(H > 2 * HALF && W > 2 * HALF)) { gc::set_error("%s: valid-window SSIM needs an image larger than 11 x 11", what); return GC_EINVAL; }
+    if ((int64_t)B * C > 65535) { gc::set_error("%s: at most 65535 image planes per call", what); return GC_EINVAL; }
+    hipStream_t s = gc::S(stream);
+    const size_t n = (size_t)H * W * C;
+    // workspace: dmu / dxx / dxy as [B][n] each, then B slot blocks (each block's lines start on a 128-byte boundary of the float array)
+    float *dmu = (float *)workspace, *dxx = dmu + n * B, *dxy = dxx + n * B, *slots = dxy + (n * B + 31) / 32 * 32;
+    static_assert(2 * NSLOT == 64, "k_ssim_grad folds the slots with one wave");
+    if (hipMemsetAsync(slots, 0, (size_t)B * 2 * NSLOT * SLOT_PITCH * sizeof(float), s) != hipSuccess) return GC_ELAUNCH;
+    const Gauss gw = make_window();
+    dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, C * B);
+    const size_t n_ssim = valid_window ? (size_t)(H - 2 * HALF) * (W - 2 * HALF) * C : n;
+    hipLaunchKernelGGL(k_ssim_stats, grid, dim3(256), 0, s, pred, target, H, W, C, valid_window, gw, slots, dmu, dxx, dxy, slots + NSLOT * SLOT_PITCH);
+    hipLaunchKernelGGL(k_ssim_grad, grid, dim3(256), 0, s, pred, target, H, W, C, gw, dmu, dxx, dxy, lambda_, 1.f / (float)n,
+                       1.f / (float)n_ssim, grad_scale, v_pred, slots, loss_out);
+    return gc::check_launch(what);
+}
 
 /* loss = (1-lambda)*mean|x-y| + lambda*(1 - mean SSIM(x,y)); pred x / target y: float32 [H,W,C] channels-last.
  * valid_window = 1: SSIM averaged over the (H-10) x (W-10) x C pixels with a full window (pytorch_msssim, splatfacto's loss);
@@ -190,21 +226,20 @@ size_t gc_l1_ssim_workspace_bytes(int H, int W, int C) { return sizeof(float) * 
 int gc_l1_ssim_fwd_bwd(const float *pred, const float *target, int H, int W, int C, float lambda_, float grad_scale, int valid_window,
                        float *loss_out, float *v_pred, void *workspace, size_t workspace_bytes, void *stream)
 {
-    GC_REQUIRE(pred && target && loss_out && v_pred && workspace, "null argument");
-    GC_REQUIRE(!valid_window || (H > 2 * HALF && W > 2 * HALF), "valid-window SSIM needs an image larger than 11 x 11");
     if (workspace_bytes < gc_l1_ssim_workspace_bytes(H, W, C)) { gc::set_error("gc_l1_ssim_fwd_bwd: workspace too small"); return GC_ENOSPC; }
-    hipStream_t s = gc::S(stream);
-    const size_t n = (size_t)H * W * C;
-    float *dmu = (float *)workspace, *dxx = dmu + n, *dxy = dxx + n, *slots = dxy + (n + 31) / 32 * 32;        // (the slot lines start on a 128-byte boundary of the float array)
-    static_assert(2 * NSLOT == 64, "k_ssim_grad folds the slots with one wave");
-    if (hipMemsetAsync(slots, 0, 2 * NSLOT * SLOT_PITCH * sizeof(float), s) != hipSuccess) return GC_ELAUNCH;
-    const Gauss gw = make_window();
-    dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, C);
-    const size_t n_ssim = valid_window ? (size_t)(H - 2 * HALF) * (W - 2 * HALF) * C : n;
-    hipLaunchKernelGGL(k_ssim_stats, grid, dim3(256), 0, s, pred, target, H, W, C, valid_window, gw, slots, dmu, dxx, dxy, slots + NSLOT * SLOT_PITCH);
-    hipLaunchKernelGGL(k_ssim_grad, grid, dim3(256), 0, s, pred, target, H, W, C, gw, dmu, dxx, dxy, lambda_, 1.f / (float)n,
-                       1.f / (float)n_ssim, grad_scale, v_pred, slots, loss_out);
-    return gc::check_launch("gc_l1_ssim_fwd_bwd");
+    return l1_ssim_impl("gc_l1_ssim_fwd_bwd", 1, pred, target, H, W, C, lambda_, grad_scale, valid_window, loss_out, v_pred, workspace,
+                        workspace_bytes, stream);
+}
+
+/* B image pairs in one pair of launches: pred / target / v_pred [B][H][W][C], loss_out [B][2] (each view's own sums: every view's loss is
+ * the mean over ITS pixels, as B calls of the single-image form would give); workspace >= gc_l1_ssim_views_workspace_bytes. */
+int gc_l1_ssim_fwd_bwd_views(int B, const float *pred, const float *target, int H, int W, int C, float lambda_, float grad_scale,
+                             int valid_window, float *loss_out, float *v_pred, void *workspace, size_t workspace_bytes, void *stream)
+{
+    GC_REQUIRE(B >= 1, "bad arguments");
+    if (workspace_bytes < gc_l1_ssim_views_workspace_bytes(B, H, W, C)) { gc::set_error("gc_l1_ssim_fwd_bwd_views: workspace too small"); return GC_ENOSPC; }
+    return l1_ssim_impl("gc_l1_ssim_fwd_bwd_views", B, pred, target, H, W, C, lambda_, grad_scale, valid_window, loss_out, v_pred, workspace,
+                        workspace_bytes, stream);
 }
 
 /* torch.optim.Adam step (betas, eps as given; step = 1-based iteration count) on one flat fp32 tensor. */

@@ -31,7 +31,14 @@ class _NextTrainMixin:
     def _init_sampling(self, n: int):
         self.train_unseen_cameras = list(range(n))
 
+    view_sync = None        # optional callable(local draw or None) -> view index every rank uses (GaussCtrlPipeline, train_mode "parity")
+
     def _pop_view(self) -> int:
+        if self.view_sync is not None:
+            return self.view_sync(self._draw_view)
+        return self._draw_view()
+
+    def _draw_view(self) -> int:
         i = self.train_unseen_cameras.pop(random.randint(0, len(self.train_unseen_cameras) - 1))
         if len(self.train_unseen_cameras) == 0:
             self.train_unseen_cameras = list(range(len(self.train_data)))

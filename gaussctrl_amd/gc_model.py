@@ -135,6 +135,10 @@ class GaussCtrlModel(_ModelBase):
         # :162-169: SH of degree n (+0.5, clamp) when config.sh_degree > 0, else sigmoid(features_dc) (encoded as n = -1)
         n = min(self.step // self.config.sh_degree_interval, self.config.sh_degree) if self.config.sh_degree > 0 else -1
         aux = self._aux = ops.RenderAux()
+        if self.training and getattr(self, "grad_into", None) is not None and self.crop_box is None:
+            # the fused backward writes the six leaf gradients straight into the caller's buffers (dist.FlatGrads: ONE flat allocation that
+            # RCCL reduces in place) and autograd gets None for them: GaussCtrlPipeline.train_iteration, train_mode "throughput"
+            aux.grad_into, aux.grad_accumulate = self.grad_into, False
         rgb, alpha, depth = ops.render_view(*p, cam, background, not self.training, n, aux)
         self.xys, self.radii = aux.xys, aux.radii
         if aux.M == 0:                                                          # :155-156
@@ -156,6 +160,35 @@ class GaussCtrlModel(_ModelBase):
         self.training = False
         outs = self.get_outputs(camera.to(self.device))
         self.training = True
+        return outs
+
+    @torch.no_grad()
+    def get_outputs_for_cameras(self, cameras: List[Cameras], obb_box=None) -> List[Dict[str, torch.Tensor]]:
+        """get_outputs_for_camera for a LIST of cameras of this scene through ONE batched launch set (ops.render_views: the parameter
+        record is read once per batch, the sort / binning / compositing kernels run with the view as a grid dimension).  The reference has
+        no such call -- render_reverse asks for one camera at a time (gc_pipeline.py:124-130); per view the outputs are bit-identical to
+        get_outputs_for_camera.  Falls back to it when a crop box is set or the cameras differ in size."""
+        cams = [c.to(self.device) for c in cameras]
+        sizes = {(int(c.width.reshape(-1)[0]), int(c.height.reshape(-1)[0])) for c in cams}
+        if obb_box is not None or len(cams) < 2 or len(sizes) != 1 or max(sizes.pop()) > 255 * 16:
+            return [self.get_outputs_for_camera(c, obb_box) for c in cameras]
+        self.set_crop(None)
+        W, H = int(cams[0].width.reshape(-1)[0]), int(cams[0].height.reshape(-1)[0])
+        gcams = [camera_to_gsplat(c.camera_to_worlds[0].detach().cpu().numpy(), float(c.fx.reshape(-1)[0]), float(c.fy.reshape(-1)[0]),
+                                  float(c.cx.reshape(-1)[0]), float(c.cy.reshape(-1)[0]), W, H) for c in cams]
+        background = self.background_color.to(self.device)
+        n = min(self.step // self.config.sh_degree_interval, self.config.sh_degree) if self.config.sh_degree > 0 else -1
+        aux = self._aux = ops.RenderAux()
+        rgb, alpha, depth = ops.render_views(self.means, self.scales, self.quats, self.opacities, self.features_dc, self.features_rest,
+                                             gcams, background, True, n, aux)
+        self.last_size = (H, W)
+        cnt = aux.M[0].cpu()
+        outs = []
+        for k in range(len(cams)):
+            if int(cnt[k]) == 0:                                                # :155-156
+                outs.append({"rgb": background.repeat(H, W, 1)})
+            else:
+                outs.append({"rgb": rgb[k], "depth": depth[k][..., None], "accumulation": alpha[k][..., None]})
         return outs
 
     # ------------------------------------------------------------------------------------ inherited splatfacto loss

@@ -72,8 +72,15 @@ class GaussCtrlPipelineConfig(_PipelineConfigBase):
                                        # read-only reference bank; 1 = strictly one after the other, as the reference runs them)
     round_like_reference: bool = False  # True: round the rendered rgb / depth to fp16 before inversion, disparity and the mask composite,
                                        # exactly where the reference does (gc_pipeline.py:132-133,155); False keeps the fp32 renders
-    batch_invariant: bool = False      # kernel planning that makes a view's result independent of its chunk / rank count (sd.ops.KernelOptions)
+    batch_invariant: Optional[bool] = None    # kernel planning that makes a view's result independent of its chunk / rank count
+                                       # (sd.ops.KernelOptions.batch_invariant): True / False set it explicitly, None keeps the process-wide setting
     kernel_options: Optional[object] = None   # a gaussctrl_amd.sd.ops.KernelOptions replacing the process-wide kernel switches (None: keep)
+    render_batch: int = 8              # render_reverse renders this many cameras per batched launch set (GaussCtrlModel.get_outputs_for_cameras;
+                                       # 1 = one camera per call, as the reference does at gc_pipeline.py:124-130; per view the results are identical)
+    train_mode: str = "parity"         # world_size > 1: "parity" = every rank takes the SAME single-view step on replicated
+                                       # parameters (the reference's 500 single-view iterations, gc_trainer.py:186-201; no gradient collective:
+                                       # replicas stay bit-identical), "throughput" = each rank renders its own view of the step, the N x 59
+                                       # gradients are averaged by one flat in-place RCCL all-reduce (dist.FlatGrads) -- an N-view batch per step
     synthetic_weights: bool = False    # True: seeded random SD1.5-shaped weights + hashed prompt embeddings (bench / tests; there
                                        # are no checkpoints on the build machines).  False: checkpoints are REQUIRED -- no silent fallback.
 
@@ -136,8 +143,8 @@ class GaussCtrlPipeline(_PipelineBase):
             return sd
         if config.kernel_options is not None:
             sdops.configure(options=config.kernel_options)
-        if config.batch_invariant:
-            sdops.configure(batch_invariant=True)
+        if config.batch_invariant is not None:          # explicit both ways: a later pipeline with False resets what an earlier one set
+            sdops.configure(batch_invariant=bool(config.batch_invariant))
         def prepared(name, shapes, seed):
             sd = get(name, shapes, seed)
             out = prepare(sd, self.dtype, dev, heads=8)
@@ -191,8 +198,15 @@ class GaussCtrlPipeline(_PipelineBase):
         """Render rgb + depth of every (local) view and DDIM-invert the renders to z_0 (batched)."""
         views = self._my_views() if views is None else list(views)
         td = self.datamanager.train_data
+        rb = max(1, int(self.config.render_batch))
+        batched = rb > 1 and hasattr(self.model, "get_outputs_for_cameras")
+        outs = {}
+        for s0 in range(0, len(views), rb) if batched else ():
+            grp = views[s0:s0 + rb]
+            for cam_idx, out in zip(grp, self.model.get_outputs_for_cameras([self.datamanager.cameras[i] for i in grp])):
+                outs[cam_idx] = out
         for cam_idx in views:
-            out = self._model.get_outputs_for_camera(self.datamanager.cameras[cam_idx])
+            out = outs.pop(cam_idx) if batched else self._model.get_outputs_for_camera(self.datamanager.cameras[cam_idx])
             rgb, depth = out["rgb"], out["depth"][..., 0]
             if self.config.round_like_reference:                              # :132-133 `.to(torch.float16)` (values kept in fp32 storage)
                 rgb, depth = rgb.to(torch.float16).float(), depth.to(torch.float16).float()
@@ -354,30 +368,83 @@ class GaussCtrlPipeline(_PipelineBase):
         model_outputs = self._model(camera)
         metrics_dict = self._model.get_metrics_dict(model_outputs, batch)
         loss_dict = self._model.get_loss_dict(model_outputs, batch, metrics_dict)
-        if self.world_size > 1:                 # gradient reduction happens after backward: see reduce_gradients()
-            pass
-        return model_outputs, loss_dict, metrics_dict
+        return model_outputs, loss_dict, metrics_dict          # (world_size > 1: the gradient reduction happens after backward, train_iteration)
 
     def reduce_gradients(self):
-        """world_size > 1: one RCCL all-reduce of the N x 59 fp32 Gaussian gradients (collective 2)."""
+        """world_size > 1, stand-alone callers: one flat all-reduce (average) of whatever .grad tensors the parameters hold (gather copy +
+        blocking collective + copy back).  train_iteration does NOT use this: it reduces the FlatGrads buffer the backward wrote, in place."""
         from .dist import allreduce_gradients
         allreduce_gradients(list(self._model.parameters()), self.world_size)
 
     def get_param_groups(self):
         return self._model.get_param_groups()
 
+    _GRAD_KEYS = ("means", "scales", "quats", "opacities", "features_dc", "features_rest")
+
+    def _flat_grads(self):
+        """the six leaf gradients as views of ONE flat fp32 buffer (dist.FlatGrads) that the fused backward writes and RCCL reduces in place"""
+        from .dist import FlatGrads
+        m = self.model
+        fg = getattr(self, "_fg", None)
+        if fg is None or fg.views["means"].shape != m.means.shape or fg.flat.device != m.means.device:
+            fg = self._fg = FlatGrads({k: getattr(m, k) for k in self._GRAD_KEYS})
+        return fg
+
+    def _sync_view(self, draw):
+        """train_mode "parity": every rank trains on the view rank 0 drew (a 1-int control-path broadcast; no data-path collective)"""
+        import torch.distributed as dist
+        box = [draw() if self.local_rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return int(box[0])
+
     def train_iteration(self, optimizers: dict, step: int):
         """One splat-optimisation iteration as GaussCtrlTrainer.train_iteration runs it (gc_trainer.py:257-301): zero grads,
-        forward + loss (gc_pipeline.py:276-287), backward, [gradient all-reduce when world_size > 1], Adam steps
-        (gc_config.py:58-87).  Returns (loss, loss_dict, metrics_dict)."""
+        forward + loss (gc_pipeline.py:276-287), backward, Adam steps (gc_config.py:58-87).  Returns (loss, loss_dict, metrics_dict).
+        world_size > 1:
+          train_mode "parity"     -- the reference's schedule: ONE view per step (gc_trainer.py:186-201).  Every rank renders the view rank 0
+                                     drew, on replicated parameters: identical gradients, identical Adam steps, no gradient collective;
+          train_mode "throughput" -- each rank renders the view ITS datamanager draws (an N-view batch per step); the fused backward writes
+                                     the six leaf gradients into one flat buffer (dist.FlatGrads / RenderAux.grad_into: no autograd .grad
+                                     tensors, no gather copy), the loss carries the 1 / N so that ONE in-place RCCL all-reduce (sum) of that
+                                     buffer yields the batch mean, and the optimizers read the buffer's views -- the path bench.py measures."""
         for opt in optimizers.values():
             opt.zero_grad(set_to_none=True)
-        _, loss_dict, metrics_dict = self.get_train_loss_dict(step)
-        loss = sum(loss_dict.values())
-        loss.backward()
-        self.reduce_gradients()
+        loss, loss_dict, metrics_dict = self.train_forward_backward(step)
         for opt in optimizers.values():
             opt.step()
+        return loss, loss_dict, metrics_dict
+
+    def train_forward_backward(self, step: int, accumulating: bool = False):
+        """forward + loss + backward of one training step, gradients left where the optimizers read them (world_size > 1: per train_mode,
+        see train_iteration).  accumulating: the caller accumulates gradients over several steps (gc_trainer gradient_accumulation_steps
+        > 1): the autograd .grad path with a flat all-reduce of the accumulated tensors is used instead of the write-once flat buffer."""
+        multi = self.world_size > 1
+        mode = self.config.train_mode if multi else "single"
+        if mode not in ("single", "parity", "throughput"):
+            raise ValueError(f"train_mode must be 'parity' or 'throughput', not {mode!r}")
+        m = self.model
+        fg = None
+        if mode == "throughput" and not accumulating:
+            fg = self._flat_grads()
+            m.grad_into = fg.views
+        self.datamanager.view_sync = self._sync_view if mode == "parity" else None
+        try:
+            _, loss_dict, metrics_dict = self.get_train_loss_dict(step)
+        finally:
+            m.grad_into = None
+        loss = sum(loss_dict.values())
+        if fg is not None:
+            (loss / self.world_size).backward()
+            if getattr(m, "_aux", None) is None or m._aux.xys_grad is None:
+                fg.flat.zero_()                          # this rank's view rendered nothing (gc_model.py:155-156): it contributes zeros
+            fg.reduce_async(self.world_size)
+            fg.wait()
+            for k in self._GRAD_KEYS:
+                getattr(m, k).grad = fg.views[k]
+        else:
+            loss.backward()
+            if mode == "throughput":
+                self.reduce_gradients()
         return loss.detach(), loss_dict, metrics_dict
 
     def forward(self):

@@ -138,16 +138,23 @@ else:
             for g, opt in self.optimizers.items():                       # zero_grad_some
                 if step % acc(g) == 0:
                     opt.zero_grad(set_to_none=True)
-            _, loss_dict, metrics_dict = self.pipeline.get_train_loss_dict(step=step)
-            loss = sum(loss_dict.values())
-            loss.backward()
-            self.pipeline.reduce_gradients()                             # world_size > 1: RCCL all-reduce of the N x 59 gradients
+            # forward + loss + backward; world_size > 1: GaussCtrlPipelineConfig.train_mode -- "parity" (every rank takes rank 0's view: the
+            # reference's single-view schedule on replicas, no gradient collective) or "throughput" (one view per rank, the fused backward
+            # writes one flat buffer that RCCL all-reduces in place: dist.FlatGrads)
+            if hasattr(self.pipeline, "train_forward_backward"):
+                loss, loss_dict, metrics_dict = self.pipeline.train_forward_backward(step, accumulating=any(acc(g) > 1 for g in self.optimizers))
+            else:                                                        # a plain VanillaPipeline-shaped object (gc_trainer.py:272-275)
+                _, loss_dict, metrics_dict = self.pipeline.get_train_loss_dict(step=step)
+                loss = sum(loss_dict.values())
+                loss.backward()
+                self.pipeline.reduce_gradients()
+                loss = loss.detach()
             for g, opt in self.optimizers.items():                       # optimizer_scaler_step_some
                 if step % acc(g) == acc(g) - 1:
                     for pg in opt.param_groups:
                         pg["lr"] = self.lr_at(g, step)                   # scheduler value for this step (scheduler_step_all, :294-298)
                     opt.step()
-            return loss.detach(), loss_dict, metrics_dict
+            return loss, loss_dict, metrics_dict
 
 
 # ------------------------------------------------------------------------------------------------------------------------

@@ -419,3 +419,143 @@ def render_view(means, log_scales, quats, opacities, features_dc, features_rest,
     Returns (rgb[H,W,3] clamped to <=1, alpha[H,W], depth[H,W] (normalised, 1000 where alpha==0) or empty)."""
     return _RenderView.apply(means, log_scales, quats, opacities, features_dc, features_rest, cam, background, want_depth,
                              sh_degree_to_use, aux)
+
+
+# --------------------------------------------------------------------------------------------- batched views (round 5)
+def _cams_host(cams: list):
+    """list of `cam` dicts (camera_to_gsplat) -> ctypes float array [C][GC_VIEW_CAM_FLOATS = 35]"""
+    flat = []
+    for cam in cams:
+        flat += list(cam["viewmat"])[:12] + list(cam["fullproj"])[:16] + list(cam["origin"])[:3] + [cam["fx"], cam["fy"], cam["cx"], cam["cy"]]
+    return L.host_floats(flat)
+
+
+class _RenderViews(torch.autograd.Function):
+    """C cameras of one scene through ONE set of launches (include/gaussctrl_hip.h "Batched views"): the parameter record is read once
+    per batch by the projection / SH kernel and once by its backward, the sort / binning / compositing kernels run with the view as a
+    grid dimension.  Per view the result is bit-identical to _RenderView (same device code); the leaf gradients are the sum over the
+    views.  The reference has no such call: it renders one camera per get_outputs (gc_pipeline.py:124-130, gc_trainer.py:186-201)."""
+
+    @staticmethod
+    def forward(ctx, means, log_scales, quats, opacities, features_dc, features_rest, cams, backgrounds, want_depth, sh_degree_to_use, aux):
+        _need_gpu(means)
+        lib = L.lib()
+        st = L.stream_ptr()
+        N = means.shape[0]
+        dev = means.device
+        C = len(cams)
+        H, W = cams[0]["H"], cams[0]["W"]
+        assert all(c["H"] == H and c["W"] == W for c in cams), "the views of a batch share one image size"
+        tb = ((W + TILE - 1) // TILE, (H + TILE - 1) // TILE, 1)
+        T = tb[0] * tb[1]
+        if tb[0] > 255 or tb[1] > 255:
+            raise ValueError("render_views: at most 255 x 255 tiles (packed tile boxes)")
+        K = features_rest.shape[1] + 1
+        sh_degree = {1: 0, 4: 1, 9: 2, 16: 3}[K]
+        m, ls, q = _c(means), _c(log_scales), _c(quats)
+        op, dc, rest = _c(opacities).reshape(-1), _c(features_dc), _c(features_rest)
+        CH = _cams_host(cams)
+        f32 = dict(device=dev, dtype=torch.float32); i32 = dict(device=dev, dtype=torch.int32)
+        xys = torch.empty(C, N, 2, **f32); depths = torch.empty(C, N, **f32); radii = torch.empty(C, N, **i32)
+        conics = torch.empty(C, N, 3, **f32); nth = torch.empty(C, N, **i32); rgbs = torch.empty(C, N, 3, **f32)
+        opac = torch.empty(N, **f32); boxes = torch.empty(C, N, **i32); pairs = torch.empty(C, N, 2, **i32)
+        L.check(lib.gc_project_sh_fwd_views(
+            L.i64(N), L.i32(C), L.ptr(m), L.ptr(ls), L.ptr(q), L.ptr(op), L.ptr(dc), L.ptr(rest), L.i32(sh_degree), L.i32(sh_degree_to_use),
+            CH, L.i32(H), L.i32(W), L.i32(tb[0]), L.i32(tb[1]), L.f32(0.01), L.ptr(xys), L.ptr(depths), L.ptr(radii), L.ptr(conics),
+            L.ptr(nth), L.ptr(rgbs), L.ptr(opac), L.ptr(boxes), L.ptr(pairs), st), "gc_project_sh_fwd_views")
+        order = torch.empty(C, N, **i32); cum = torch.empty(C, N, **i32); cnt = torch.empty(C, **i32)
+        wb = int(lib.gc_raster_depth_order_views_workspace_bytes(L.i64(N), L.i32(C)))
+        ws = torch.empty(wb, dtype=torch.uint8, device=dev)
+        L.check(lib.gc_raster_depth_order_views(L.i64(N), L.i32(C), None, None, L.ptr(pairs), L.ptr(nth), L.ptr(order), L.ptr(cum), L.ptr(cnt),
+                                                L.ptr(ws), L.C.c_size_t(wb), st), "gc_raster_depth_order_views")
+        del pairs
+        m_cap = None if aux is None else aux.m_cap
+        if m_cap is None:                     # one readback of the C counts sizes the lists exactly (the sync-free form passes a capacity)
+            M_cap = max(int(cnt.max().item()), 1)
+        else:
+            M_cap = int(m_cap)
+        ids_s = torch.empty(C, M_cap, **i32); bins = torch.empty(C, T, 2, **i32); ovf = torch.empty(C, **i32)
+        bb = int(lib.gc_raster_bin_views_workspace_bytes(L.i64(M_cap), L.i32(C)))
+        del ws
+        bws = torch.empty(bb, dtype=torch.uint8, device=dev)
+        L.check(lib.gc_raster_bin_tiles_views(L.i64(N), L.i32(C), L.i64(M_cap), L.ptr(cnt), L.ptr(ovf), L.ptr(order), L.ptr(cum), L.ptr(boxes),
+                                              L.ptr(depths), L.i32(tb[0]), L.i32(tb[1]), L.ptr(ids_s), L.ptr(bins), None, L.ptr(bws),
+                                              L.C.c_size_t(bb), st), "gc_raster_bin_tiles_views")
+        del bws
+        bg = _c(backgrounds)
+        shared_bg = 1 if bg.dim() == 1 else 0
+        assert bg.numel() == (3 if shared_bg else 3 * C)
+        img = torch.empty(C, H, W, 3, **f32); fT = torch.empty(C, H, W, **f32); fi = torch.empty(C, H, W, **i32)
+        dep = torch.empty(C, H, W, **f32) if want_depth else None
+        L.check(lib.gc_rasterize_fwd_views(L.i32(C), L.i64(N), L.i64(M_cap), L.i32(1), L.i32(shared_bg), L.i32(H), L.i32(W), L.i32(tb[0]),
+                                           L.i32(tb[1]), L.ptr(ids_s), L.ptr(bins), L.ptr(xys), L.ptr(conics), L.ptr(rgbs), L.ptr(opac),
+                                           L.ptr(depths if want_depth else None), L.ptr(bg), L.ptr(img), L.ptr(dep), L.ptr(fT), L.ptr(fi), st),
+                "gc_rasterize_fwd_views")
+        alpha = torch.empty(C, H, W, **f32)
+        if any(ctx.needs_input_grad[:6]):
+            pre_clamp, img = img, torch.empty_like(img)
+            L.check(lib.gc_raster_finalize_into(L.i64(C * H * W), L.ptr(pre_clamp), L.ptr(img), L.ptr(dep), L.ptr(fT), L.ptr(alpha), st),
+                    "gc_raster_finalize_into")
+        else:
+            pre_clamp = None
+            L.check(lib.gc_raster_finalize(L.i64(C * H * W), L.ptr(img), L.ptr(dep), L.ptr(fT), L.ptr(alpha), st), "gc_raster_finalize")
+        if aux is not None:
+            aux.xys, aux.radii, aux.num_tiles_hit, aux.depths, aux.tile_boxes = xys, radii, nth, depths, boxes
+            aux.M = (cnt, ovf)                          # per-view device counts / overflow flags ([C] each)
+            aux.gaussian_ids_sorted, aux.tile_bins, aux.final_index, aux.isect_ids_sorted = ids_s, bins, fi, None
+            aux.xys_grad = None
+        ctx.save_for_backward(m, ls, q, op, dc, rest, radii, conics, xys, rgbs, opac, ids_s, bins, bg, fT, fi, pre_clamp)
+        ctx.meta = (cams, CH, tb, N, C, M_cap, shared_bg, sh_degree, int(sh_degree_to_use))
+        ctx.aux = aux
+        if dep is not None:
+            ctx.mark_non_differentiable(dep)
+        else:
+            dep = torch.empty(0, device=dev)
+        return img, alpha, dep
+
+    @staticmethod
+    def backward(ctx, v_img, v_alpha, v_dep):
+        (m, ls, q, op, dc, rest, radii, conics, xys, rgbs, opac, ids_s, bins, bg, fT, fi, pre_clamp) = ctx.saved_tensors
+        cams, CH, tb, N, C, M_cap, shared_bg, sh_degree, n_use = ctx.meta
+        H, W = cams[0]["H"], cams[0]["W"]
+        dev = m.device
+        lib = L.lib()
+        st = L.stream_ptr()
+        vo = _c(v_img) if v_img is not None else torch.zeros(C, H, W, 3, device=dev)
+        va = _c(v_alpha) if v_alpha is not None else None
+        vbuf = torch.zeros(C * N * 9, device=dev)                      # v_xy | v_conic | v_colors | v_opacity, each [C][N][..]
+        v_xy = vbuf[:2 * C * N].view(C, N, 2); v_conic = vbuf[2 * C * N:5 * C * N].view(C, N, 3)
+        v_col = vbuf[5 * C * N:8 * C * N].view(C, N, 3); v_op = vbuf[8 * C * N:].view(C, N)
+        L.check(lib.gc_rasterize_bwd_views(L.i32(C), L.i64(N), L.i64(M_cap), L.i32(1), L.i32(shared_bg), L.i32(H), L.i32(W), L.i32(tb[0]),
+                                           L.i32(tb[1]), L.ptr(ids_s), L.ptr(bins), L.ptr(xys), L.ptr(conics), L.ptr(rgbs), L.ptr(opac), L.ptr(bg),
+                                           L.ptr(fT), L.ptr(fi), L.ptr(vo), L.ptr(va), L.ptr(pre_clamp), L.ptr(v_xy), L.ptr(v_conic),
+                                           L.ptr(v_col), L.ptr(v_op), st), "gc_rasterize_bwd_views")
+        if ctx.aux is not None:
+            ctx.aux.xys_grad = v_xy
+        into = ctx.aux.grad_into if ctx.aux is not None else None
+        acc = 0
+        if into is not None:
+            vm, vls, vq, vop, vdc, vrest = (into[k] for k in ("means", "scales", "quats", "opacities", "features_dc", "features_rest"))
+            for t, ref in ((vm, m), (vls, ls), (vq, q), (vdc, dc), (vrest, rest)):
+                assert t.is_contiguous() and t.dtype == torch.float32 and t.shape == ref.shape and t.device == dev
+            assert vop.is_contiguous() and vop.dtype == torch.float32 and vop.numel() == N and vop.device == dev
+            acc = 1 if ctx.aux.grad_accumulate else 0
+        else:
+            vm = torch.empty(N, 3, device=dev); vls = torch.empty(N, 3, device=dev); vq = torch.empty(N, 4, device=dev)
+            vop = torch.empty(N, device=dev); vdc = torch.empty(N, 3, device=dev); vrest = torch.empty(rest.shape, device=dev)
+        L.check(lib.gc_project_sh_bwd_views(
+            L.i64(N), L.i32(C), L.i32(acc), L.ptr(m), L.ptr(ls), L.ptr(q), L.ptr(op), L.ptr(rgbs), L.i32(sh_degree), L.i32(n_use), CH,
+            L.i32(H), L.i32(W), L.ptr(radii), L.ptr(conics), L.ptr(v_xy), L.ptr(v_conic), L.ptr(v_col), L.ptr(v_op), L.ptr(vm), L.ptr(vls),
+            L.ptr(vq), L.ptr(vop), L.ptr(vdc), L.ptr(vrest), st), "gc_project_sh_bwd_views")
+        if into is not None:
+            return (None,) * 11
+        return vm, vls, vq, vop[:, None], vdc, vrest, None, None, None, None, None
+
+
+def render_views(means, log_scales, quats, opacities, features_dc, features_rest, cams: list, backgrounds, want_depth: bool,
+                 sh_degree_to_use: int = 3, aux: RenderAux | None = None):
+    """render_view for a LIST of cameras of one scene in one set of launches.  backgrounds: [3] (shared) or [C,3].
+    Returns (rgb [C,H,W,3] clamped to <= 1, alpha [C,H,W], depth [C,H,W] or empty).  aux.M = (count [C], overflow [C]) device tensors;
+    aux.m_cap = per-view intersection capacity for the sync-free form (else the C counts are read back once to size the lists)."""
+    return _RenderViews.apply(means, log_scales, quats, opacities, features_dc, features_rest, list(cams), backgrounds, want_depth,
+                              sh_degree_to_use, aux)

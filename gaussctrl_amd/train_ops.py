@@ -46,6 +46,36 @@ def l1_ssim_loss(pred, target, ssim_lambda: float = 0.2, valid_window: bool = Tr
     return _L1SSIM.apply(pred, target, float(ssim_lambda), bool(valid_window))
 
 
+class _L1SSIMViews(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, lam, valid):
+        if not pred.is_cuda:
+            raise L.GaussCtrlHipError("l1_ssim_loss_views needs GPU tensors (HIP path only; no CPU fallback)")
+        lib = L.lib()
+        B, H, W, Cc = pred.shape
+        p = pred.detach().float().contiguous(); t = target.detach().float().contiguous()
+        nbytes = lib.gc_l1_ssim_views_workspace_bytes(B, H, W, Cc)
+        ws = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=p.device)
+        sums = torch.empty(B, 2, dtype=torch.float32, device=p.device)
+        v = torch.empty_like(p)
+        L.check(lib.gc_l1_ssim_fwd_bwd_views(B, L.ptr(p), L.ptr(t), H, W, Cc, L.f32(lam), L.f32(1.0), int(valid), L.ptr(sums), L.ptr(v), L.ptr(ws),
+                                             C.c_size_t(nbytes), L.stream_ptr()), "gc_l1_ssim_fwd_bwd_views")
+        ctx.save_for_backward(v)
+        n = float(H * W * Cc)
+        n_ssim = float((H - 10) * (W - 10) * Cc) if valid else n
+        return (1.0 - lam) * sums[:, 1] / n + lam * (1.0 - sums[:, 0] / n_ssim)
+
+    @staticmethod
+    def backward(ctx, g):
+        (v,) = ctx.saved_tensors
+        return v * g.reshape(-1, 1, 1, 1), None, None, None
+
+
+def l1_ssim_loss_views(pred, target, ssim_lambda: float = 0.2, valid_window: bool = True):
+    """pred, target: [B,H,W,3] float32 -> [B] losses (each view's own l1_ssim_loss), one pair of launches for the batch."""
+    return _L1SSIMViews.apply(pred, target, float(ssim_lambda), bool(valid_window))
+
+
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-15):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))

@@ -229,6 +229,64 @@ int gc_l1_ssim_fwd_bwd(const float *pred, const float *target, int H, int W, int
 int gc_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
                  float beta2, float eps, int step, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------------------------
+ * Batched views (round 5): C cameras of ONE scene per set of launches.  The reference renders its views one at a time
+ * (gaussctrl/gc_pipeline.py:124-130 render_reverse, gaussctrl/gc_trainer.py:186-201 one view per training step); every stage below is
+ * the single-view entry point above with a leading view dimension -- grid.y / grid.z = view for the sort and compositing kernels, a loop
+ * over the views INSIDE the per-Gaussian kernels so that the 236-byte parameter record is read once per batch, not once per view.
+ * Layout: per-view arrays are [C][N][..] / [C][M_cap] / [C][T][2] / [C][H][W][..]; all views share H, W and the tile grid; always the
+ * sync-free form (count_dev[C] / overflow_dev[C] stay on the device, M_cap = per-view capacity).  Results per view are bit-identical to
+ * the single-view entry points (same device code), gradients sum over the views in view order.
+ * ------------------------------------------------------------------------------------------------------------------------------ */
+#define GC_VIEW_CAM_FLOATS 35   /* per view, HOST floats: viewmat[12] | projmat[16] | cam_origin[3] | fx fy cx cy */
+
+/* gc_project_sh_fwd[_boxes] for C views (launches of <= 8 views; the cameras travel as kernel arguments).  opac[N] is written once (it does
+ * not depend on the camera).  tile_boxes [C][N] (NULL: gsplat's boxes in num_tiles_hit); depth_pairs [C][N][2] u32 or NULL = (depth bits, or
+ * 0xFFFFFFFF when culled, Gaussian id): the input pairs of gc_raster_depth_order_views, saving its key-building pass. */
+int gc_project_sh_fwd_views(int64_t N, int C, const float *means, const float *log_scales, const float *quats,
+                            const float *opacity_logits, const float *features_dc, const float *features_rest,
+                            int sh_degree, int degrees_to_use, const float *cams, int img_h, int img_w,
+                            int tiles_x, int tiles_y, float clip_thresh, float *xys, float *depths, int32_t *radii,
+                            float *conics, int32_t *num_tiles_hit, float *rgbs, float *opac, uint32_t *tile_boxes,
+                            uint32_t *depth_pairs, void *stream);
+/* gc_project_sh_bwd for C views: the six leaf gradients are the sum over the views (view order), written (accumulate = 0) or added to the
+ * buffers' contents (accumulate = 1) once per batch. */
+int gc_project_sh_bwd_views(int64_t N, int C, int accumulate, const float *means, const float *log_scales, const float *quats,
+                            const float *opacity_logits, const float *rgbs, int sh_degree, int degrees_to_use, const float *cams,
+                            int img_h, int img_w, const int32_t *radii, const float *conics, const float *v_xy, const float *v_conic,
+                            const float *v_rgbs, const float *v_opac, float *v_means, float *v_log_scales, float *v_quats,
+                            float *v_opacity_logits, float *v_features_dc, float *v_features_rest, void *stream);
+/* gc_raster_scan_tiles for C views, the input optionally gathered through `order` first (in[order[i]]; NULL: plain).  The scan scratch of
+ * view c starts ws_view_stride bytes after that of view c - 1 (>= gc_raster_scan_workspace_bytes(N), multiple of 4; ignored for C = 1). */
+int gc_raster_scan_tiles_views(int64_t N, int C, const int32_t *num_tiles_hit, const int32_t *order, int32_t *cum_tiles_hit,
+                               int32_t *count_dev, void *workspace, size_t workspace_bytes, int64_t ws_view_stride, void *stream);
+size_t gc_raster_depth_order_views_workspace_bytes(int64_t N, int C);
+int gc_raster_depth_order_views(int64_t N, int C, const float *depths, const int32_t *radii, const uint32_t *depth_pairs,
+                                const int32_t *num_tiles_hit, int32_t *depth_order, int32_t *cum_sorted, int32_t *count_dev,
+                                void *workspace, size_t workspace_bytes, void *stream);
+size_t gc_raster_bin_views_workspace_bytes(int64_t M_cap, int C);
+int gc_raster_bin_tiles_views(int64_t N, int C, int64_t M_cap, const int32_t *count_dev, int32_t *overflow_dev,
+                              const int32_t *depth_order, const int32_t *cum_sorted, const uint32_t *tile_boxes, const float *depths,
+                              int tiles_x, int tiles_y, int32_t *gaussian_ids_sorted, int32_t *tile_bins, int64_t *isect_ids_sorted,
+                              void *workspace, size_t workspace_bytes, void *stream);
+/* compositing of C views in one launch.  opacities [N] (shared_opacities = 1) or [C][N]; background [3] (shared_background = 1) or [C][3]. */
+int gc_rasterize_fwd_views(int C, int64_t N, int64_t M_cap, int shared_opacities, int shared_background, int img_h, int img_w,
+                           int tiles_x, int tiles_y, const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
+                           const float *conics, const float *colors, const float *opacities, const float *extra,
+                           const float *background, float *out_img, float *out_extra, float *final_Ts, int32_t *final_index,
+                           void *stream);
+/* v_xy [C][N][2] v_conic [C][N][3] v_colors [C][N][3] v_opacity [C][N] must be ZERO on entry; pre_clamp [C][H][W][3] or NULL. */
+int gc_rasterize_bwd_views(int C, int64_t N, int64_t M_cap, int shared_opacities, int shared_background, int img_h, int img_w,
+                           int tiles_x, int tiles_y, const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
+                           const float *conics, const float *colors, const float *opacities, const float *background,
+                           const float *final_Ts, const int32_t *final_index, const float *v_out, const float *v_out_alpha,
+                           const float *pre_clamp, float *v_xy, float *v_conic, float *v_colors, float *v_opacity, void *stream);
+/* gc_l1_ssim_fwd_bwd for B image pairs [B][H][W][C]; loss_out [B][2] (every view's own sums). */
+size_t gc_l1_ssim_views_workspace_bytes(int B, int H, int W, int C);
+int gc_l1_ssim_fwd_bwd_views(int B, const float *pred, const float *target, int H, int W, int C, float lambda_, float grad_scale,
+                             int valid_window, float *loss_out, float *v_pred, void *workspace, size_t workspace_bytes, void *stream);
+
+
 /* ===================================================================================== */
 /* Part B -- ControlNet + UNet denoise step (replaces the diffusers / cuBLAS / cuDNN calls behind  */
 /* gaussctrl/gc_pipeline.py:142-145,209-219 and the attention processor gaussctrl/utils.py:25-133) */

@@ -169,3 +169,98 @@ def test_reference_trajectory_shards_allgather_layout(world):
     ret = mgr.dict()
     mp.spawn(_shard_worker, args=(world, 29650 + world + os.getpid() % 200, ret), nprocs=world, join=True)
     assert all(ret[r] for r in range(world)), dict(ret)
+
+
+# ------------------------------------------------------------------------------------------------ train modes
+class _FusedFake(torch.autograd.Function):
+    """stand-in of the fused render + backward with the RenderAux.grad_into contract: loss_view = sum_k w_view * (p_k ** 2).sum(); when the
+    model carries `grad_into` the backward WRITES the leaf gradients into those buffers and hands autograd None (as gsplat_ops._RenderView)."""
+
+    @staticmethod
+    def forward(ctx, w, into, aux, *ps):
+        ctx.save_for_backward(*ps)
+        ctx.w, ctx.into, ctx.aux = w, into, aux
+        return sum((p ** 2).sum() for p in ps) * w
+
+    @staticmethod
+    def backward(ctx, g):
+        grads = [2 * p * ctx.w * g for p in ctx.saved_tensors]
+        ctx.aux.xys_grad = grads[0]
+        if ctx.into is not None:
+            for k, gk in zip(("means", "scales", "quats", "opacities", "features_dc", "features_rest"), grads):
+                ctx.into[k].copy_(gk)
+            return (None,) * (3 + len(grads))
+        return (None, None, None) + tuple(grads)
+
+
+def _train_mode_worker(rank, world, port, mode, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import random
+        from gaussctrl_amd.gc_datamanager import _NextTrainMixin
+        from gaussctrl_amd.gc_pipeline import GaussCtrlPipeline
+
+        class Model(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                g = torch.Generator().manual_seed(0)                     # replicated parameters
+                shapes = dict(means=(5, 3), scales=(5, 3), quats=(5, 4), opacities=(5, 1), features_dc=(5, 3), features_rest=(5, 15, 3))
+                for k, s in shapes.items():
+                    setattr(self, k, torch.nn.Parameter(torch.randn(*s, generator=g)))
+                self.grad_into = None
+                self._aux = None
+
+            def forward(self, view):
+                self._aux = type("Aux", (), {"xys_grad": None})()
+                ps = [getattr(self, k) for k in GaussCtrlPipeline._GRAD_KEYS]
+                return {"loss": _FusedFake.apply(float(view + 1), self.grad_into, self._aux, *ps)}
+
+            def get_metrics_dict(self, out, batch): return {}
+            def get_loss_dict(self, out, batch, metrics=None): return {"main_loss": out["loss"]}
+
+        class DM(_NextTrainMixin):
+            def __init__(self):
+                self.train_data = list(range(6)); self._init_sampling(6); self.seen = []
+
+            def next_train(self, step):
+                i = self._pop_view(); self.seen.append(i)
+                return i, {}
+
+        random.seed(100 + rank)                                          # ranks draw DIFFERENT views unless the mode syncs them
+        pipe = object.__new__(GaussCtrlPipeline)
+        torch.nn.Module.__init__(pipe)
+        pipe.world_size, pipe.local_rank = world, rank
+        pipe.config = type("C", (), {"train_mode": mode})()
+        pipe.datamanager, pipe._model = DM(), Model()
+        opts = {"all": torch.optim.SGD(pipe._model.parameters(), lr=0.0)}
+        out = []
+        for step in range(4):
+            loss, _, _ = pipe.train_iteration(opts, step)
+            out.append((float(loss), pipe.datamanager.seen[-1], {k: getattr(pipe._model, k).grad.clone() for k in GaussCtrlPipeline._GRAD_KEYS},
+                        pipe._model.means.grad.data_ptr() == pipe._fg.views["means"].data_ptr() if mode == "throughput" else None))
+        ret[rank] = (out, {k: getattr(pipe._model, k).detach().clone() for k in GaussCtrlPipeline._GRAD_KEYS})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["parity", "throughput"])
+def test_train_modes_world2(mode):
+    """GaussCtrlPipeline.train_iteration at world_size 2 over gloo with a stand-in model that honours the grad_into contract:
+    parity     -- both ranks train on the view rank 0 drew (control-path broadcast), gradients equal the single-view gradient, no reduction;
+    throughput -- each rank its own view, the loss carries 1 / N, the flat buffer is all-reduced in place: every rank ends with the MEAN of
+                  the two views' gradients, and the optimizers read views of that one buffer (no autograd .grad tensors, no gather copy)."""
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_train_mode_worker, args=(2, 29800 + os.getpid() % 150 + (0 if mode == "parity" else 1), mode, ret), nprocs=2, join=True)
+    (o0, p0), (o1, p1) = ret[0], ret[1]
+    for (l0, v0, g0, f0), (l1, v1, g1, f1) in zip(o0, o1):
+        for k in g0:
+            assert torch.equal(g0[k], g1[k]), (mode, k)                  # replicas stay in lock step in both modes
+        if mode == "parity":
+            assert v0 == v1 and l0 == l1
+            assert torch.allclose(g0["means"], 2 * p0["means"] * (v0 + 1))
+        else:
+            assert f0 and f1
+            assert torch.allclose(g0["means"], 2 * p0["means"] * ((v0 + 1) + (v1 + 1)) / 2)
+    if mode == "throughput":
+        assert any(a[1] != b[1] for a, b in zip(o0, o1)), "the ranks drew the same views: the test would not tell mean from single"
