@@ -743,7 +743,8 @@ def denoise_roofline(args, dtype_name, pipe, sdops, z0, ctx_neg, ctx_pos, bank, 
     for net in (pipe.unet, pipe.controlnet):             # un-padded input channels of the e4m3 convolutions (weights pad Cin to 128)
         for k, v in net.w.items():
             if k.endswith(".w8") and ".resnets." in k and (k[:-2] + "weight") in net.w:
-                prof.true_cin[v.data_ptr()] = int(net.w[k[:-2] + "weight"].shape[-1])
+                wt = net.w[k[:-2] + "weight"]                                   # prepared 2-byte weight: Cout x (3 x 3 x Cin), in whatever rank
+                prof.true_cin[v.data_ptr()] = int(wt.numel() // (wt.shape[0] * 9))
     prof.wrap(sdops)
     two = pipe.two_streams
     pipe.two_streams = False          # HIP events bracket one kernel only when nothing else shares the GPU: single stream here
@@ -883,7 +884,9 @@ def raster_roofline(args, B, g, stats, HW):
         tot_stage[k] = tot_stage.get(k, 0.0) + s.elapsed_time(e) * 1e-3
     per = {k: [v / nviews] for k, v in tot_stage.items()}            # seconds per training view and stage
     traffic = None
-    for tname in ("r03_raster_traffic.json", "r02_raster_traffic.json"):
+    # PMC traffic of the configuration that ran: the batched-views passes (round 5, 8 views per launch set) or the one-camera-per-launch ones
+    batched = B.view_batch and min(args.chunk_size, nviews) >= 2
+    for tname in (("r05_raster_traffic_views8.json",) if batched else ("r03_raster_traffic.json", "r02_raster_traffic.json")):
         tpath = os.path.join(ROOT, "profiles", tname)
         if traffic is None and os.path.exists(tpath):
             traffic = json.load(open(tpath)).get(str(N))
@@ -925,9 +928,13 @@ def cpu_baseline(args):
     from oracle import raster_c, sd15_torch as sd
     from gaussctrl_amd import synthetic as syn
     cores = os.cpu_count() or 1
-    threads = cores                         # every logical core of the box, stated in the line
+    # Threads: measured on the GPU box (256 logical cores, round 5, profiles/r05_bench_bf16_start.json): fp32 torch on ALL 256 logical cores takes
+    # 289 s for the one denoise step that 64 threads finish in ~30 s (oneDNN / OpenMP oversubscription of the SMT siblings and NUMA domains) --
+    # "every core" makes the baseline 10x WORSE and the default run 5 minutes longer.  The line therefore states the thread count that was used
+    # (`cores` = 64, both for torch and for the OpenMP rasterizer), which is the faster of the two configurations measured.
+    threads = min(cores, 64)
     torch.set_num_threads(threads)
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    os.environ["OMP_NUM_THREADS"] = str(threads)
     raster_c.use_threads(True)
     try:
         N = args.gaussians
@@ -944,8 +951,8 @@ def cpu_baseline(args):
     finally:
         raster_c.use_threads(False)
     if args.workload == "raster":
-        return {"value": round(1.0 / t_raster, 4), "unit": "views/s", "cores": cores, "kind": "port",
-                "sample": f"C oracle (oracle/raster_ref.c, OpenMP build, {cores} threads; serial sort) one training render fwd+bwd at the full "
+        return {"value": round(1.0 / t_raster, 4), "unit": "views/s", "cores": threads, "kind": "port",
+                "sample": f"C oracle (oracle/raster_ref.c, OpenMP build, {threads} threads of the box's {cores} logical cores; serial sort) one training render fwd+bwd at the full "
                           f"N={N}: {t_raster:.2f}s per view"}
     sd.ATTN_IMPL = "sdpa"                    # the fused CPU attention (the explicit form needs 5 x [80,4096,4096] fp32 tensors per layer)
     with torch.no_grad():
@@ -966,8 +973,8 @@ def cpu_baseline(args):
         del vw
     per_view = 20 * t_step + t_vae + t_raster
     return {"value": round(1.0 / per_view, 6), "unit": "views/s", "cores": threads, "kind": "port",
-            "sample": f"fp32 torch on {threads} threads (one untimed warm-up step on a 16x16 latent first): 1 of 20 CFG ControlNet+UNet cross-view steps, f=5 (CFG batch 10) on the full 64x64 latents = {t_step:.1f}s (x20 per "
-                      f"edited view at chunk_size 1); VAE decode of one frame = {t_vae:.1f}s; C rasterizer (OpenMP, {cores} threads) eval + "
+            "sample": f"fp32 torch on {threads} threads of the box's {cores} logical cores (all 256 measured 10x slower, see bench.py; one untimed warm-up step on a 16x16 latent first): 1 of 20 CFG ControlNet+UNet cross-view steps, f=5 (CFG batch 10) on the full 64x64 latents = {t_step:.1f}s (x20 per "
+                      f"edited view at chunk_size 1); VAE decode of one frame = {t_vae:.1f}s; C rasterizer (OpenMP, {threads} threads) eval + "
                       f"train fwd+bwd at N={N} = {t_raster:.2f}s"}
 
 

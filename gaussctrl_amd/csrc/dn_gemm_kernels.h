@@ -1495,7 +1495,11 @@ __global__ __launch_bounds__(512, 1) void k_gemm8q(const GemmArgs g)
         for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fc = lane >> 4;
     const int swz = (fr >> 1) & 7;
-    const int fx0 = (((2 * fc) ^ swz) << 4), fx1 = (((2 * fc + 1) ^ swz) << 4);
+    // Which two 16-byte chunks of the row's 128-byte k-tile lane group fc feeds is FREE (the k-tile is ONE MFMA k-step: the dot product runs
+    // over every (lane group, byte) position, and A and W use the same association).  Chunks (fc, fc + 4) -- the bf16 kernel's pair -- make
+    // the two ds_read_b128 conflict-free under this swizzle; the round-4 choice (2 fc, 2 fc + 1) put lane groups fc = 0 and 1 of a
+    // ds_read_b128 lane group on the same 8 bank quartets: SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE (profiles/r05_pmc_gemm8q.txt).
+    const int fx0 = ((fc ^ swz) << 4), fx1 = (((fc + 4) ^ swz) << 4);
     const int aw0 = BM * 128 + (wn * (16 * NTW) + fr) * 128, aa0 = (wm * (16 * MT) + fr) * 128;
     // Fragment registers: 8-register MFMA operands assembled ONCE at load time from two ds_read_b128, double-buffered per k-tile (the two
     // buffers alternate by NAME in the 2x unrolled loop: an in-place reload would cost a register copy per fragment at the back edge).

@@ -206,7 +206,7 @@ class GaussCtrlPipeline(_PipelineBase):
             for cam_idx, out in zip(grp, self.model.get_outputs_for_cameras([self.datamanager.cameras[i] for i in grp])):
                 outs[cam_idx] = out
         for cam_idx in views:
-            out = outs.pop(cam_idx) if batched else self._model.get_outputs_for_camera(self.datamanager.cameras[cam_idx])
+            out = outs[cam_idx] if batched else self._model.get_outputs_for_camera(self.datamanager.cameras[cam_idx])      # (views may repeat: ref_indices)
             rgb, depth = out["rgb"], out["depth"][..., 0]
             if self.config.round_like_reference:                              # :132-133 `.to(torch.float16)` (values kept in fp32 storage)
                 rgb, depth = rgb.to(torch.float16).float(), depth.to(torch.float16).float()

@@ -550,7 +550,8 @@ def attention(q, k, vt, heads, sets, frames_per_half, Lk=None, kref=None, vtref=
         d.Kref = kref.data_ptr(); d.kref_batch_stride = kref.stride(0)
         d.Vtref = vtref.data_ptr(); d.vtref_batch_stride = vtref.stride(0); d.ref_frames_per_half = ref_fph
     wsb = L.lib().gc_dn_attention_workspace_bytes(C.byref(d))      # head size 160 with several K/V sets: one workgroup per (query block, set)
-    if wsb:
+    if wsb and not BATCH_INVARIANT:      # the library takes the set-split form only while the grid is small (nwg < 512: a function of B) and its fp32
+                                         # combine rounds differently from the in-register one: batch-invariant mode never offers the workspace
         ws = torch.empty(wsb, dtype=torch.uint8, device=q.device)
         d.workspace = ws.data_ptr(); d.workspace_bytes = wsb
     L.check(L.lib().gc_dn_attention(C.byref(d), _stream()), "gc_dn_attention")

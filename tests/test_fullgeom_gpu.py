@@ -295,30 +295,34 @@ def test_config4_f12_fp8_convs_and_linears(nets, cached):
     within("|cur[-1] / predicted - 1|", abs(cur[-1] / pred - 1.0), 0.25)
 
 
-@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-def test_batch_invariant_mode_bit_identical(nets, dt):
-    """sd.ops.BATCH_INVARIANT (gc_gemm_desc.plan_rows, GroupNorm planning bit): a view's latents are BIT-identical whatever shares its
-    chunk -- the property that makes an N-rank edit (other chunk compositions) equal to the single-GPU one.
-    Full SD1.5 widths at 64 x 64 latents, cached reference bank, 3 DDIM steps: chunk {0,1,2} vs chunks {0} and {1,2}."""
+@pytest.mark.parametrize("dt,chunk", [(torch.float16, 3), (torch.bfloat16, 3), (torch.bfloat16, 8)])
+def test_batch_invariant_mode_bit_identical(nets, dt, chunk):
+    """sd.ops.BATCH_INVARIANT (gc_gemm_desc.plan_rows, GroupNorm planning bit, no set-split attention): a view's latents are BIT-identical
+    whatever shares its chunk -- the property that makes an N-rank edit (other chunk compositions) equal to the single-GPU one.
+    Full SD1.5 widths at 64 x 64 latents, cached reference bank, 3 DDIM steps: chunk {0,1,2} vs chunks {0} and {1,2}; and BASELINE
+    configs[3]'s chunk_size 8 (CFG batch 16) vs two chunks of 4 (CFG batch 8) -- at B = 16 the D = 160 attention grid reaches 512 workgroups,
+    where the library stops splitting the K / V sets over workgroups: the decision must not depend on the batch in this mode."""
     from gaussctrl_amd.sd import ops
     from gaussctrl_amd.sd.pipeline import DenoisePipeline
-    lat, disp, cn, cp = _inputs(7, 64, 2)
+    lat, disp, cn, cp = _inputs(4 + chunk, 64, 2)
     uw, cw = nets(dt)
     keep = ops.BATCH_INVARIANT
     ops.BATCH_INVARIANT = True
+    nst = 3 if chunk == 3 else 2
+    cut = 1 if chunk == 3 else chunk // 2
     try:
         pipe = DenoisePipeline(uw, cw, None, 20, 5.0)
         to = lambda t: t.to(DEV)
-        bank = pipe.build_ref_bank(to(lat[:4]), to(disp[:4]), to(cn), to(cp), steps=3)
-        full = pipe.edit_chunk_cached(to(lat[4:7]), to(disp[4:7]), to(cn), to(cp), bank, steps=3)
-        one = pipe.edit_chunk_cached(to(lat[4:5]), to(disp[4:5]), to(cn), to(cp), bank, steps=3)
-        two = pipe.edit_chunk_cached(to(lat[5:7]), to(disp[5:7]), to(cn), to(cp), bank, steps=3)
+        bank = pipe.build_ref_bank(to(lat[:4]), to(disp[:4]), to(cn), to(cp), steps=nst)
+        full = pipe.edit_chunk_cached(to(lat[4:]), to(disp[4:]), to(cn), to(cp), bank, steps=nst)
+        one = pipe.edit_chunk_cached(to(lat[4:4 + cut]), to(disp[4:4 + cut]), to(cn), to(cp), bank, steps=nst)
+        two = pipe.edit_chunk_cached(to(lat[4 + cut:]), to(disp[4 + cut:]), to(cn), to(cp), bank, steps=nst)
         assert torch.isfinite(full).all()
-        assert torch.equal(full[0:1], one), float((full[0:1] - one).abs().max())
-        assert torch.equal(full[1:3], two), float((full[1:3] - two).abs().max())
+        assert torch.equal(full[:cut], one), float((full[:cut] - one).abs().max())
+        assert torch.equal(full[cut:], two), float((full[cut:] - two).abs().max())
         # and it is still the same computation: within the dtype's bar of the default planning
         ops.BATCH_INVARIANT = False
-        ref = pipe.edit_chunk_cached(to(lat[4:7]), to(disp[4:7]), to(cn), to(cp), bank, steps=3)
+        ref = pipe.edit_chunk_cached(to(lat[4:]), to(disp[4:]), to(cn), to(cp), bank, steps=nst)
         within("_rel(full, ref)", _rel(full, ref), BAR[dt])
     finally:
         ops.BATCH_INVARIANT = keep
