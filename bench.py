@@ -241,7 +241,7 @@ class Bench:
         self.bg = torch.zeros(3, device=dev)
         self.pipe = None
         if self.edit:
-            fold_ln = os.environ.get("GC_DN_FOLD_LN", "0") != "0"          # A/B switches of the round-2 normalisation fusions (default: off)
+            fold_ln = int(os.environ.get("GC_DN_FOLD_LN", "0"))            # A/B switch of the LayerNorm fold (0 off = default, 1 every block, 2 levels 1-3 only)
             usd, csd = arch.random_state_dict(arch.unet_shapes(), 100, dev), arch.random_state_dict(arch.controlnet_shapes(), 200, dev)
             uw = prepare(usd, dt, dev, heads=8, fold_ln=fold_ln)
             cw = prepare(csd, dt, dev, heads=8, fold_ln=fold_ln)

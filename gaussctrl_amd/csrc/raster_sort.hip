@@ -207,17 +207,21 @@ __global__ __launch_bounds__(RT) void k_radix_scatter(const uint32_t *__restrict
 // table is small and the 4096 items of the workgroup are first put in digit order in LDS and then streamed out: consecutive lanes write
 // consecutive addresses inside each digit run (full-line stores).  The direct form above issues one isolated 4-byte store per item and
 // array -- 2 M of them per pass, which is what bounded it (329 us per pass at M = 20 M vs 110 us of bytes at 3 TB/s).
-template <int DB>
+// PK (round 5): the pair travels as ONE word, (tile << idb) | gaussian id (N <= 2^idb, tile bits + idb <= 32): `vals` is not read, the
+// non-final pass writes 4 bytes per pair instead of 8; the final pass (vals_out != NULL) writes the packed word (k_tile_bins32 reads the tiles
+// from it) AND the plain id into gaussian_ids_sorted.
+template <int DB, bool PK>
 __global__ __launch_bounds__(RT) void k_radix_scatter_staged(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
                                                              uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int64_t n,
                                                              const int32_t *__restrict__ n_dev, int shift, int nblocks,
                                                              const int32_t *__restrict__ hist, const int32_t *__restrict__ offs,
-                                                             const int32_t *__restrict__ sums, VS vs, int vals_ext)
+                                                             const int32_t *__restrict__ sums, VS vs, int vals_ext, uint32_t idmask)
 {
     {
         const int64_t o = (int64_t)blockIdx.y * vs.ws;
-        keys += o; vals += o; hist += o; offs += o; sums += o; keys_out += o;
-        vals_out += vals_ext ? (int64_t)blockIdx.y * vs.ext : o;
+        keys += o; hist += o; offs += o; sums += o; keys_out += o;
+        if (!PK) vals += o;
+        if (vals_out) vals_out += vals_ext ? (int64_t)blockIdx.y * vs.ext : o;
         if (n_dev) n_dev += blockIdx.y * vs.nd;
     }
     constexpr int ND = 1 << DB, NS = RI * 4;      // digits, (round, wave) slots
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(RT) void k_radix_scatter_staged(const uint32_t *__r
     __shared__ int tbl[NS * ND];
     __shared__ int part[PARTS * ND];
     __shared__ int lbase[ND], gbase[ND];          // start of the digit's run inside the workgroup's 4096 items / in the output
-    __shared__ uint32_t sk[RB], sv[RB];
+    __shared__ uint32_t sk[RB], sv[PK ? 1 : RB];
     n = live_count(n, n_dev);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     for (int i = tid; i < NS * ND; i += RT) tbl[i] = 0;
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(RT) void k_radix_scatter_staged(const uint32_t *__r
         const int64_t i = base + j * RT + tid;
         const bool ok = i < n;
         k[j] = ok ? keys[i] : 0xFFFFFFFFu;
-        v[j] = ok ? vals[i] : 0u;
+        v[j] = (ok && !PK) ? vals[i] : 0u;
         const unsigned d = (k[j] >> shift) & (ND - 1);
         unsigned long long m = __ballot(ok);
 #pragma unroll
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(RT) void k_radix_scatter_staged(const uint32_t *__r
             const int sl = j * 4 + wid;
             const int lp = lbase[d] + part[(sl / SPP) * ND + d] + tbl[sl * ND + d] + rk[j];
             sk[lp] = k[j];
-            sv[lp] = v[j];
+            if (!PK) sv[lp] = v[j];
         }
     }
     __syncthreads();
@@ -296,7 +300,8 @@ __global__ __launch_bounds__(RT) void k_radix_scatter_staged(const uint32_t *__r
         const unsigned d = (kk >> shift) & (ND - 1);
         const int pos = gbase[d] + (i - lbase[d]);
         keys_out[pos] = kk;
-        vals_out[pos] = sv[i];
+        if (PK) { if (vals_out) vals_out[pos] = kk & idmask; }
+        else vals_out[pos] = sv[i];
     }
 }
 
@@ -318,7 +323,8 @@ __global__ __launch_bounds__(256) void k_emit_sorted(int64_t N, int64_t M_cap, c
                                                      const uint32_t *__restrict__ tile_box /* packed boxes instead of (xys, radii), or NULL */,
                                                      const int32_t *__restrict__ cum_sorted, int tiles_x, int tiles_y,
                                                      uint32_t *__restrict__ tile_keys, uint32_t *__restrict__ gids,
-                                                     unsigned dmask, int nblocks, int32_t *__restrict__ hist /* [digits][nblocks], zeroed */, VS vs)
+                                                     unsigned dmask, int nblocks, int32_t *__restrict__ hist /* [digits][nblocks], zeroed */, VS vs,
+                                                     int idb /* > 0: packed pairs, (tile << idb) | id in tile_keys, gids unused */)
 {
     {
         const int64_t o = (int64_t)blockIdx.y * vs.ws, e = (int64_t)blockIdx.y * vs.src;
@@ -383,7 +389,8 @@ __global__ __launch_bounds__(256) void k_emit_sorted(int64_t N, int64_t M_cap, c
         for (int64_t i = tid; i < cnt; i += 256)
             if (w0 + i < M_cap) {
                 const uint32_t t = sT[i];
-                tile_keys[w0 + i] = t; gids[w0 + i] = sG[i];
+                if (idb) tile_keys[w0 + i] = (t << idb) | sG[i];
+                else { tile_keys[w0 + i] = t; gids[w0 + i] = sG[i]; }
                 atomicAdd(&sH[(int)((w0 + i) / RB - b0) * 64 + (int)(t & dmask)], 1);     // saves the pass's k_radix_hist (a read of all M keys)
             }
         __syncthreads();
@@ -396,7 +403,8 @@ __global__ __launch_bounds__(256) void k_emit_sorted(int64_t N, int64_t M_cap, c
 __global__ __launch_bounds__(256) void k_tile_bins32(int64_t M, const int32_t *__restrict__ m_dev, int32_t *__restrict__ overflow,
                                                      int num_tiles, const uint32_t *__restrict__ tkeys,
                                                      const uint32_t *__restrict__ gids, const float *__restrict__ depths,
-                                                     int32_t *__restrict__ bins, int64_t *__restrict__ keys64, int32_t *__restrict__ ids_out, VS vs)
+                                                     int32_t *__restrict__ bins, int64_t *__restrict__ keys64, int32_t *__restrict__ ids_out, VS vs,
+                                                     int idb /* > 0: tkeys hold (tile << idb) | id */)
 {
     {
         const int64_t o = (int64_t)blockIdx.y * vs.ws;
@@ -409,7 +417,7 @@ __global__ __launch_bounds__(256) void k_tile_bins32(int64_t M, const int32_t *_
     M = live_count(M, m_dev);
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= M) return;
-    const int t = (int)tkeys[i];
+    const int t = (int)(tkeys[i] >> idb);
     if (ids_out || keys64) {            // the last radix pass normally writes the ids straight into gaussian_ids_sorted (ids_out == NULL)
         const uint32_t g = gids[i];
         if (ids_out) ids_out[i] = (int32_t)g;
@@ -417,7 +425,7 @@ __global__ __launch_bounds__(256) void k_tile_bins32(int64_t M, const int32_t *_
     }
     if (i == 0) bins[2 * t] = 0;
     else {
-        const int tp = (int)tkeys[i - 1];
+        const int tp = (int)(tkeys[i - 1] >> idb);
         if (tp != t) { bins[2 * tp + 1] = (int32_t)i; bins[2 * t] = (int32_t)i; }
     }
     if (i == M - 1) bins[2 * t + 1] = (int32_t)M;
@@ -460,7 +468,7 @@ void set_attr()
 // (grid.y = view; per-view workspace regions of vs.ws words).  vals_ext: `vo` is the external [C][vs.ext] array, not a workspace buffer.
 int radix_pass(const uint32_t *ki, const uint32_t *vi, uint32_t *ko, uint32_t *vo, int64_t n, const int32_t *n_dev, int shift,
                const Plan &p, unsigned char *w, hipStream_t s, int C, const VS &vs, int vals_ext, int dbits = 8, bool pair = false,
-               bool have_hist = false, int keys_ext = 0)
+               bool have_hist = false, int keys_ext = 0, int idb = 0)
 {
     int32_t *hist = (int32_t *)(w + p.off_hist), *offs = (int32_t *)(w + p.off_offs), *cnt = (int32_t *)(w + p.off_cnt);
     const int nd = 1 << dbits;
@@ -472,10 +480,15 @@ int radix_pass(const uint32_t *ki, const uint32_t *vi, uint32_t *ko, uint32_t *v
     int32_t *sums = (int32_t *)(w + p.off_scan);
     const int64_t ne = nd * (int64_t)p.nb;
     hipLaunchKernelGGL(k_table_scan, dim3((unsigned)((ne + TS_CHUNK - 1) / TS_CHUNK), (unsigned)C), dim3(256), 0, s, ne, hist, offs, sums, cnt, vs);
-    if (dbits == 5)
-        hipLaunchKernelGGL(k_radix_scatter_staged<5>, g, dim3(RT), 0, s, ki, vi, ko, vo, n, n_dev, shift, p.nb, hist, offs, sums, vs, vals_ext);
+    const uint32_t idmask = idb ? ((1u << idb) - 1u) : 0u;
+    if (dbits == 5 && idb)
+        hipLaunchKernelGGL((k_radix_scatter_staged<5, true>), g, dim3(RT), 0, s, ki, vi, ko, vo, n, n_dev, shift, p.nb, hist, offs, sums, vs, vals_ext, idmask);
+    else if (dbits == 6 && idb)
+        hipLaunchKernelGGL((k_radix_scatter_staged<6, true>), g, dim3(RT), 0, s, ki, vi, ko, vo, n, n_dev, shift, p.nb, hist, offs, sums, vs, vals_ext, idmask);
+    else if (dbits == 5)
+        hipLaunchKernelGGL((k_radix_scatter_staged<5, false>), g, dim3(RT), 0, s, ki, vi, ko, vo, n, n_dev, shift, p.nb, hist, offs, sums, vs, vals_ext, idmask);
     else if (dbits == 6)
-        hipLaunchKernelGGL(k_radix_scatter_staged<6>, g, dim3(RT), 0, s, ki, vi, ko, vo, n, n_dev, shift, p.nb, hist, offs, sums, vs, vals_ext);
+        hipLaunchKernelGGL((k_radix_scatter_staged<6, false>), g, dim3(RT), 0, s, ki, vi, ko, vo, n, n_dev, shift, p.nb, hist, offs, sums, vs, vals_ext, idmask);
     else if (pair)
         hipLaunchKernelGGL(k_radix_scatter<true>, g, dim3(RT), (size_t)RI * 4 * 256 * sizeof(int), s, ki, vi, ko, vo, n, n_dev,
                            shift, p.nb, hist, offs, sums, vs, vals_ext, keys_ext);
@@ -591,19 +604,24 @@ int bin_tiles_impl(int64_t N, int C, int64_t M, const int32_t *m_dev, int32_t *o
         if (hipMemsetAsync(wc + p.off_cnt, 0, 4, s) != hipSuccess) return GC_ELAUNCH;          // ticket of k_table_scan
         if (fused_hist && hipMemsetAsync(wc + p.off_hist, 0, sizeof(int32_t) * ((size_t)1 << dbits) * p.nb, s) != hipSuccess) return GC_ELAUNCH;
     }
+    // packed pairs: (tile << idb) | id in ONE word when the id and tile bits fit 32 and the staged (5 / 6-bit) scatter runs -- 1 024 tiles and
+    // N <= 4 M: every pass moves 4 bytes per pair instead of 8 (emit 4, pass 1 4 + 4, pass 2 4 + 8, bins 4 = 28 instead of 44 bytes per pair)
+    int idb = 1;
+    while (((int64_t)1 << idb) < N) ++idb;
+    if (!(dbits <= 6 && passes * dbits + idb <= 32)) idb = 0;
     hipLaunchKernelGGL(k_emit_sorted, dim3(gc::cdiv(N, 256), (unsigned)C), dim3(256), 0, s, N, M, (const uint32_t *)depth_order, xys, radii,
                        tile_boxes, cum_sorted, tiles_x, tiles_y, k0, v0, fused_hist ? (1u << dbits) - 1u : 0u, fused_hist ? p.nb : 0,
-                       (int32_t *)(w + p.off_hist), vs);
+                       (int32_t *)(w + p.off_hist), vs, idb);
     uint32_t *ks = k0, *vsrc = v0;
     for (int pass = 0; pass < passes; ++pass) {
         const bool last = pass == passes - 1;
-        uint32_t *ko = ks == k0 ? k1 : k0, *vo = last ? (uint32_t *)gaussian_ids_sorted : (vsrc == v0 ? v1 : v0);
-        int rc = radix_pass(ks, vsrc, ko, vo, M, m_dev, dbits * pass, p, w, s, C, vs, last ? 1 : 0, dbits, false, fused_hist && pass == 0);
+        uint32_t *ko = ks == k0 ? k1 : k0, *vo = last ? (uint32_t *)gaussian_ids_sorted : (idb ? (uint32_t *)nullptr : (vsrc == v0 ? v1 : v0));
+        int rc = radix_pass(ks, vsrc, ko, vo, M, m_dev, idb + dbits * pass, p, w, s, C, vs, last ? 1 : 0, dbits, false, fused_hist && pass == 0, 0, idb);
         if (rc != GC_OK) return rc;
         ks = ko; vsrc = vo;
     }
-    hipLaunchKernelGGL(k_tile_bins32, dim3(gc::cdiv(M, 256), (unsigned)C), dim3(256), 0, s, M, m_dev, overflow_dev, num_tiles, ks, vsrc, depths,
-                       tile_bins, isect_ids_sorted, (int32_t *)nullptr, vs);
+    hipLaunchKernelGGL(k_tile_bins32, dim3(gc::cdiv(M, 256), (unsigned)C), dim3(256), 0, s, M, m_dev, overflow_dev, num_tiles, ks,
+                       (const uint32_t *)gaussian_ids_sorted, depths, tile_bins, isect_ids_sorted, (int32_t *)nullptr, vs, idb);
     return gc::check_launch(what);
 }
 }  // namespace

@@ -230,6 +230,9 @@ class GaussCtrlPipeline(_PipelineBase):
         td = self.datamanager.train_data
         cn, cp = self._encode(self.negative_prompts), self._encode(self.positive_prompt)
         owner = self.config.ref_bank_owner if (self.world_size > 1 and self.config.cache_reference_kv) else -1
+        if self.config.ref_bank_allgather and self.config.cache_reference_kv and self.world_size > 1 and self.world_size not in (2, 4, 8):
+            raise ValueError(f"ref_bank_allgather shards the 2 x 4 reference samples over 2, 4 or 8 ranks, not {self.world_size}: "
+                             "use ref_bank_owner (broadcast) or the replicated default")
         gather = bool(self.config.ref_bank_allgather) and self.config.cache_reference_kv and self.world_size in (2, 4, 8)
         if gather:
             owner = -1

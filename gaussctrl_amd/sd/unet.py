@@ -293,7 +293,7 @@ class SDNet:
 
     def tail_eligible(self, p, ctx) -> bool:
         """static part of the fused-tail predicate for transformer block `p` (the shape part is checked per call)"""
-        return bool(self.fused_tail and (p + ".tail.a") in self.w and not self.ln_folded and not self.fuse_stats
+        return bool(self.fused_tail and (p + ".tail.a") in self.w and (p + ".transformer_blocks.0.attn1.to_qkv.colsum") not in self.w and not self.fuse_stats
                     and ctx.shape[1] <= 96 and ctx.shape[0] <= 2)
 
     def transformer(self, p, x, xs, ctx, actx: AttnCtx):
@@ -303,7 +303,7 @@ class SDNet:
         w = self.w
         B, H, W_, Cc = x.shape
         t = p + ".transformer_blocks.0"
-        fold = self.ln_folded
+        fold = self.ln_folded and (t + ".attn1.to_qkv.colsum") in w          # (prepare(fold_ln=2) folds only the blocks without a fused tail)
         # (the tail kernel reads one text block per CFG half: ctx rows <= 2 and an equal number of frames per row; anything else -- e.g. a
         # direct caller with one ctx row per frame -- takes the per-op path)
         tail = self.tail_eligible(p, ctx) and (H * W_) % 128 == 0 and B % ctx.shape[0] == 0

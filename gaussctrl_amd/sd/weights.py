@@ -160,7 +160,9 @@ def prepare(sd: dict, dtype, device, heads=None, fold_ln=False) -> dict:
             out[k] = v.float().contiguous()       # norm affine, linear / 1x1 biases
     out["_attn_q_prescaled"] = bool(heads)
     out["_ln_folded"] = bool(fold_ln)
-    if heads == 8 and not fold_ln:                     # level-0 transformers (C = 320): operand streams of the one-launch tail (dn_ttail.hip)
+    # fold_ln == 2: fold only the blocks that have no one-launch head / tail (C = 640 / 1280); the C = 320 blocks keep their LayerNorms inside
+    # the row-resident kernels
+    if heads == 8 and fold_ln in (False, 0, 2):        # level-0 transformers (C = 320): operand streams of the one-launch tail (dn_ttail.hip)
         def master(name):
             v = sd[name].to(device).float()
             return v * ((v.shape[0] // heads) ** -0.5 * LOG2E) if name.endswith((".attn1.to_q.weight", ".attn2.to_q.weight")) else v
@@ -173,7 +175,7 @@ def prepare(sd: dict, dtype, device, heads=None, fold_ln=False) -> dict:
         if k.endswith(".attn1.to_q.weight"):            # fused Q|K|V projection of the self-attention layers
             a = k[:-len("to_q.weight")]
             t = a[:-len("attn1.")]                       # "...transformer_blocks.0."
-            if fold_ln:
+            if fold_ln and not (fold_ln == 2 and (t[:-len("transformer_blocks.0.")] + "tail.a") in out):
                 # LayerNorm folded into the GEMM that consumes it (gc_gemm_desc.ln_*): W' = W diag(gamma) rounded ONCE from fp32,
                 # bias' = b + W beta, colsum = sum_k W'[n][k] of the ROUNDED weights (the epilogue subtracts mean * colsum exactly)
                 qkv32 = torch.cat([_f32(sd, out, a + "to_q.weight", heads, device), _f32(sd, out, a + "to_k.weight", None, device),
@@ -199,7 +201,7 @@ def prepare(sd: dict, dtype, device, heads=None, fold_ln=False) -> dict:
         if k.endswith("ff.net.0.proj.weight"):
             b = k[:-6] + "bias"
             out[k], out[b] = geglu_permute(out[k], out[b])
-            if fold_ln:
+            if fold_ln and (k[:-len("ff.net.0.proj.weight")] + "attn1.to_qkv.colsum") in out:
                 out[k[:-6] + "colsum"] = out[k].float().sum(1).contiguous()      # of the rounded, permuted rows
     return out
 

@@ -43,6 +43,16 @@ def test_loader_symbol_list_matches_header(built):
     assert l.gc_raster_scan_workspace_bytes(ctypes.c_int64(5000)) >= 3 * 4
 
 
+def test_documented_entry_point_count_is_current():
+    """DESIGN.md / INTEGRATION.md state how many entry points the header declares: the number must be the header's (it went stale twice)"""
+    n = len(_declared())
+    for doc in ("DESIGN.md", "INTEGRATION.md"):
+        text = open(os.path.join(ROOT, doc)).read()
+        found = [int(m) for m in re.findall(r"(\d+) (?:`extern \"C\"` )?entry points", text)]
+        assert found, doc
+        assert all(f == n for f in found), (doc, found, n)
+
+
 def test_product_path_refuses_cpu_tensors(built):
     import torch
     from gaussctrl_amd import gsplat_ops as ops

@@ -146,3 +146,70 @@ def test_two_ranks_one_gpu_match_single_rank(owner, invariant, monkeypatch):
         assert np.allclose(losses, ref_losses, rtol=2e-2, atol=1e-3), (losses, ref_losses)
         assert np.abs(means - ref_means.numpy()).max() < 1e-3
     assert np.array_equal(ret[0][0], ret[1][0])              # both ranks hold the same gathered images
+
+
+# ------------------------------------------------------------------------------------------------ RefShard at world 4 / 8, end to end
+def _shard_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gaussctrl_amd.dist import RefShard
+        from gaussctrl_amd.sd import ops as sdops
+        sdops.configure(batch_invariant=True)
+        pipe, inputs = _tiny_pipe()
+        tr = pipe.begin_ref_bank_sharded(*inputs, RefShard(world, rank), steps=3)
+        bank = pipe.advance_ref_bank(tr, None)
+        assert bank is not None and bank.mode == "use"
+        # the bank a rank ends with is COMPLETE (8 samples per layer and step) and serves an edit chunk
+        g = torch.Generator().manual_seed(9)
+        lat = torch.randn(2, 4, 8, 8, generator=g).to("cuda:0"); disp = torch.rand(2, 3, 64, 64, generator=g).to("cuda:0")
+        out = pipe.edit_chunk_cached(lat, disp, inputs[2], inputs[3], bank, steps=3)
+        ret[rank] = ({str(k): (_h(v[0]), _h(v[1]), tuple(v[0].shape)) for k, v in bank.store.items()}, out.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def _tiny_pipe():
+    """narrow SD-topology UNet / ControlNet (oracle TINY shapes, seeded weights) in f16: the networks of __graft_entry__.smoke()"""
+    from gaussctrl_amd.sd.pipeline import DenoisePipeline
+    from gaussctrl_amd.sd.weights import prepare
+    from oracle import sd15_torch as sd
+    cfg = sd.TINY
+    uw, cw = sd.make_unet_weights(cfg, 1), sd.make_controlnet_weights(cfg, 2)
+    pcfg = dict(block_out_channels=cfg["block_out_channels"], layers_per_block=2, heads=cfg["heads"], cross_dim=cfg["cross_dim"],
+                groups=cfg["groups"], attn_levels=cfg["attn_levels"], n_cond_blocks=6)
+    dev = "cuda:0"
+    pipe = DenoisePipeline(prepare(uw, torch.float16, dev, heads=cfg["heads"]), prepare(cw, torch.float16, dev, heads=cfg["heads"]), None, 20, 5.0)
+    pipe.unet.cfg = pcfg; pipe.controlnet.cfg = pcfg
+    g = torch.Generator().manual_seed(3)
+    lat = torch.randn(4, 4, 8, 8, generator=g).to(dev); disp = torch.rand(4, 3, 64, 64, generator=g).to(dev)
+    cn = torch.randn(1, cfg["text_len"], cfg["cross_dim"], generator=g).to(dev); cp = torch.randn(1, cfg["text_len"], cfg["cross_dim"], generator=g).to(dev)
+    return pipe, (lat, disp, cn, cp)
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_ref_shard_world4_and_8_end_to_end(world, monkeypatch):
+    """dist.RefShard with ONE frame (world 4) and ONE SAMPLE = a single CFG half (world 8) per rank -- rep = 1 in _begin, the eps pairs
+    all-gathered every DDIM step, a one-row text K / V^T cache -- through DenoisePipeline.begin_ref_bank_sharded on `world` ranks sharing one
+    GPU over gloo (small SD-topology networks): every rank ends with the complete bank, BIT-identical (batch-invariant planning) to the bank
+    build_ref_bank computes on one rank, and an edit chunk served from it is bit-identical too (advisor finding, round 4: the world-8 path
+    had only a CPU layout test)."""
+    from gaussctrl_amd.sd import ops as sdops
+    monkeypatch.setattr(sdops, "BATCH_INVARIANT", True)
+    pipe, inputs = _tiny_pipe()
+    ref_bank = pipe.build_ref_bank(*inputs, steps=3)
+    g = torch.Generator().manual_seed(9)
+    lat = torch.randn(2, 4, 8, 8, generator=g).to("cuda:0"); disp = torch.rand(2, 3, 64, 64, generator=g).to("cuda:0")
+    ref_out = pipe.edit_chunk_cached(lat, disp, inputs[2], inputs[3], ref_bank, steps=3).cpu().numpy()
+    ref = {str(k): (_h(v[0]), _h(v[1]), tuple(v[0].shape)) for k, v in ref_bank.store.items()}
+    del pipe
+    torch.cuda.empty_cache()
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_shard_worker, args=(world, 29900 + os.getpid() % 90 + world, ret), nprocs=world, join=True)
+    assert len(ref) > 0
+    for r in range(world):
+        bank, out = ret[r]
+        assert set(bank) == set(ref), r
+        bad = [k for k in ref if bank[k] != ref[k]]
+        assert not bad, (r, len(bad), bad[:3])
+        assert np.array_equal(out, ref_out), (r, float(np.abs(out - ref_out).max()))

@@ -433,8 +433,12 @@ def test_tight_tile_boxes_same_images_and_gradients():
             for name, a, b in (("tight vs fp64", out[True][2][k], r), ("gsplat boxes vs fp64", out[False][2][k], r),
                                ("tight vs gsplat boxes", out[True][2][k], out[False][2][k])):
                 d = a - b
-                within(f"{k} {name} max-norm", np.abs(d).max(), 1e-2 * np.abs(r).max() + 1e-6 * scale)
-                within(f"{k} {name} rel L2", np.linalg.norm(d), 5e-3 * np.linalg.norm(r) + 1e-6 * scale)
+                # the measured atomic-order noise sits on the needles' SCALE and ROTATION rows (ill-conditioned projection backward): only those
+                # two tensors get the loose bars; means / opacities / colours keep the rasterizer's usual 1e-3 of max, so a 5e-3 regression in a
+                # well-conditioned tensor still fails here (advisor finding, round 4)
+                loose = k in ("scales", "quats")
+                within(f"{k} {name} max-norm", np.abs(d).max(), (1e-2 if loose else 1e-3) * np.abs(r).max() + 1e-6 * scale)
+                within(f"{k} {name} rel L2", np.linalg.norm(d), (5e-3 if loose else 1e-3) * np.linalg.norm(r) + 1e-6 * scale)
         print(f"seed {seed}: M tight {out[True][3]} / gsplat {out[False][3]} = {out[True][3] / out[False][3]:.3f}")
 
 
