@@ -241,7 +241,10 @@ class Bench:
         self.bg = torch.zeros(3, device=dev)
         self.pipe = None
         if self.edit:
-            fold_ln = int(os.environ.get("GC_DN_FOLD_LN", "0"))            # A/B switch of the LayerNorm fold (0 off = default, 1 every block, 2 levels 1-3 only)
+            # LayerNorm fold (round 5 default): the LayerNorms of the C = 640 / 1280 transformer blocks live in their producer / consumer GEMM
+            # epilogues (weights.prepare(fold_ln=2), dn_gemm_ln.hip).  GC_DN_FOLD_LN=0 restores the stand-alone kernels (A/B), 1 folds every
+            # block (the C = 320 ones then leave the row-resident head / tail kernels).  The fp8 linears take e4m3 from the LayerNorm kernel: no fold.
+            fold_ln = int(os.environ.get("GC_DN_FOLD_LN", "0" if (dtype_name == "fp8" and args.fp8_linears) else "2"))
             usd, csd = arch.random_state_dict(arch.unet_shapes(), 100, dev), arch.random_state_dict(arch.controlnet_shapes(), 200, dev)
             uw = prepare(usd, dt, dev, heads=8, fold_ln=fold_ln)
             cw = prepare(csd, dt, dev, heads=8, fold_ln=fold_ln)

@@ -94,6 +94,16 @@ extern "C" size_t gc_dn_gemm_workspace_bytes(const gc_gemm_desc *d)
 }
 
 namespace {
+// lean LayerNorm fold (dn_gemm_ln.hip): 1 = this problem is a producer of row partials on the lean epilogue, 2 = a LayerNorm-folded consumer,
+// 0 = neither (or kernel_variant bit 0x800 asks for the round-2 FUSE epilogue: A/B and tests)
+int ln_lean_kind(const gc_gemm_desc *d)
+{
+    if ((d->kernel_variant & 0x800) || d->fp8 || d->mode != 0 || d->K % 64 != 0 || d->out_group_stats || d->out_chan_parts || d->N < 4) return 0;
+    if (d->out_row_stats && !d->ln_row_stats)
+        return (!d->geglu && d->act == 0 && !d->out_f32 && !d->out_t && d->out && (!d->rowvec || d->rows_per_batch >= 256)) ? 1 : 0;
+    if (d->ln_row_stats && !d->out_row_stats) return 2;
+    return 0;
+}
 // kernel choice of one problem (shared by the launcher and the row-statistics layout query)
 struct Sel { int mode, ntw, splits, tps, mt8; };     // mt8 > 0: 8-wave kernel with MT = mt8; 0: 4-wave kernel
 int select(const gc_gemm_desc *d, Sel *o, bool want_parts)
@@ -128,7 +138,7 @@ int select(const gc_gemm_desc *d, Sel *o, bool want_parts)
         if (!mt && mode == 0 && !force_mt) mt = 2;       // small linears: the 8-wave kernel's fill + epilogue is the shorter one (12.6 vs 20.9 us at M = 384)
         // part-filled single-round grids of short-K linears: 64-row tiles, two workgroups per CU (all resident when <= 512 tiles)
         if (mode == 0 && !force_mt && ntw == 4 && d->K % 64 == 0 && !d->geglu && !d->out_t && !(kv & 0x100) &&
-            !(d->ln_row_stats || d->out_row_stats || d->out_group_stats) && !want_parts) {
+            (!(d->ln_row_stats || d->out_row_stats || d->out_group_stats) || ln_lean_kind(d)) && !want_parts) {
             const int64_t t1 = ((d->M + 63) / 64) * nbn, t2 = ((d->M + 127) / 128) * nbn;
             if (mt == 2 && t2 <= 256 && t1 <= 512 && t1 > 128 && nk_host <= 24) mt = 1;      // (same accumulation order as MT 2)
         }
@@ -291,7 +301,8 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
     const int bn = 32 * sel.ntw;
     const int64_t nbn = (d->N + bn - 1) / bn;
     g.persist = 0;
-    if (sel.mt8 == 4 && sel.ntw == 4 && sel.mode == 0 && sel.splits == 1 && d->K % 64 == 0 && d->K <= 64 * 24 && !fuse_of(g) && !g.chan_parts &&
+    const int lnk = (sel.mt8 && sel.splits == 1) ? ln_lean_kind(d) : 0;
+    if (sel.mt8 == 4 && sel.ntw == 4 && sel.mode == 0 && sel.splits == 1 && d->K % 64 == 0 && d->K <= 64 * 24 && (!fuse_of(g) || lnk == 2) && !g.chan_parts &&
         !g.rowvec && !g.out_t && !g.out_f32 && g.out && g.act != 2 && !(d->kernel_variant & 0x200)) {
         // multi-round short-K linear (the GEGLU FF-up projections): persistent workgroups, next tile's fill under this tile's epilogue
         const int64_t tiles = ((d->M + 255) / 256) * nbn;
@@ -300,7 +311,8 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
     if (sel.mt8) {
         const int64_t nbm8 = (d->M + 64 * sel.mt8 - 1) / (64 * sel.mt8);
         const dim3 grid8((unsigned)(nbm8 * nbn), (unsigned)sel.splits);
-        if (fuse_of(g)) dn_gemm_launch_fuse(g, d->dtype, sel.mode, sel.ntw, sel.mt8, grid8, s);
+        if (lnk) dn_gemm_launch_ln(g, d->dtype, lnk, lean_of(g, sel.mode) && g.persist == 0, sel.ntw, sel.mt8, grid8, s);
+        else if (fuse_of(g)) dn_gemm_launch_fuse(g, d->dtype, sel.mode, sel.ntw, sel.mt8 < 2 ? 2 : sel.mt8, grid8, s);
         else if (g.chan_parts && sel.splits == 1) dn_gemm_launch_cs(g, d->dtype, sel.mode, sel.ntw, sel.mt8, grid8, s);
         else if (lean_of(g, sel.mode) && g.persist == 0 && !(d->kernel_variant & 0x400)) dn_gemm_launch_lean(g, d->dtype, sel.mode, sel.ntw, sel.mt8, grid8, s);
         else dn_gemm_launch_plain(g, d->dtype, sel.mode, sel.ntw, sel.mt8, grid8, s);

@@ -713,10 +713,16 @@ __device__ __forceinline__ void glds16_s(const void *sbase, unsigned voff, unsig
 // transposed output; checked by the launcher).  The full epilogue is ~470 instructions per accumulator block x MT NTW blocks (7 000 of the
 // kernel's 9 400 instructions, 56 KB: more than the instruction cache) although a launch executes a small part of it; every wave fetches
 // its way through the rest.  CS implies LEAN.
-template <class T, int MODE, int NTW, int MT, bool FUSE, bool CS = false, bool LEAN_ = false>
+// LNV (round 5): the LayerNorm fold WITHOUT the everything-epilogue of FUSE -- 1 = producer: the lean epilogue also leaves, per row and wave
+// column, the (sum, sum^2) of the values as stored ([slots][M][2], plain stores: GemmArgs::out_row_stats); 2 = consumer: Act rows are the
+// un-normalised x, W carries gamma: v = rstd[m] (acc - mean[m] colsum[n]) + bias'[n], the row's (mean, rstd) summed over the producer's slots at
+// kernel start (row_stats_prologue) -- on the lean epilogue (attn2.to_q) and on the plain one (Q|K|V^T, GEGLU).
+template <class T, int MODE, int NTW, int MT, bool FUSE, bool CS = false, bool LEAN_ = false, int LNV = 0>
 __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g)
 {
     static_assert(!(FUSE && CS), "one statistics epilogue at a time");
+    static_assert(LNV == 0 || (!FUSE && !CS && MODE == 3), "lean LayerNorm fold: K % 64 == 0 linears on the non-FUSE epilogues");
+    static_assert(LNV != 1 || LEAN_, "row partials come from the lean epilogue");
     constexpr bool LEAN = LEAN_ || CS;
     constexpr int BM = 64 * MT;
     constexpr bool CONVF = MODE == 2 || MODE == 4, UPS = MODE == 4;   // MODE 4 = MODE 2 + fused nearest-x2 upsample
@@ -938,6 +944,9 @@ __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g
         issue(0, 0);
         if (nk > 1) issue(1, 1);
         if (nk > 2) issue(2, 2);
+        // lean LayerNorm-folded consumer: the rows' statistics are summed over the producer's slabs HERE, under the first k-tiles' flight (the
+        // prologue ends in vmcnt(0): it waits for those tiles too, which the loop would do next anyway)
+        if constexpr (LNV == 2) row_stats_prologue<BM>(g, m_base, srow);
         if (nk > 2) wait_tiles(std::integral_constant<int, 2>{}); else if (nk > 1) wait_tiles(std::integral_constant<int, 1>{}); else wait_tiles(std::integral_constant<int, 0>{});
         __builtin_amdgcn_s_barrier();
         load_frag(f0, 0, 0);
@@ -1022,17 +1031,36 @@ __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g
                 rs[mt][nt] = *reinterpret_cast<const uint2 *>(resp + (has_res ? (mc * g.ldr + nc) * 2 : 0));
             }
         }
+        float4 csm[LNV == 2 ? NTW : 1];
+        if constexpr (LNV == 2) {
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int64_t n = n_lane + nt * 16, nc = n < g.N ? n : g.N - 4;
+                csm[nt] = *reinterpret_cast<const float4 *>(g.colsum + nc);
+            }
+        }
         uint2 pks[CS ? MT : 1][CS ? NTW : 1];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int64_t m = m_base + wm * (16 * MT) + mt * 16 + fr;
             const bool second = m >= m_rv;
+            float mean = 0.f, rstd = 1.f;
+            if constexpr (LNV == 2) {       // the row's statistics, summed over the producer's column slabs by row_stats_prologue
+                const float2 st = *reinterpret_cast<const float2 *>(srow + 2 * (wm * (16 * MT) + mt * 16 + fr));
+                mean = st.x * g.ln_inv_k;
+                rstd = rsqrtf(fmaxf(st.y * g.ln_inv_k - mean * mean, 0.f) + g.ln_eps);
+            }
+            float rsum = 0.f, rsq = 0.f;
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
                 const int64_t n = n_lane + nt * 16;
                 const float4 rv = second ? rvB[nt] : rvA[nt];
-                float v[4] = {acc[nt][mt][0] + bia[nt].x + rv.x, acc[nt][mt][1] + bia[nt].y + rv.y,
-                              acc[nt][mt][2] + bia[nt].z + rv.z, acc[nt][mt][3] + bia[nt].w + rv.w};
+                float a0 = acc[nt][mt][0], a1 = acc[nt][mt][1], a2 = acc[nt][mt][2], a3 = acc[nt][mt][3];
+                if constexpr (LNV == 2) {
+                    a0 = rstd * (a0 - mean * csm[nt].x); a1 = rstd * (a1 - mean * csm[nt].y);
+                    a2 = rstd * (a2 - mean * csm[nt].z); a3 = rstd * (a3 - mean * csm[nt].w);
+                }
+                float v[4] = {a0 + bia[nt].x + rv.x, a1 + bia[nt].y + rv.y, a2 + bia[nt].z + rv.z, a3 + bia[nt].w + rv.w};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] *= g.out_scale;
                 v[0] += T::to_f((unsigned short)(rs[mt][nt].x & 0xffff)); v[1] += T::to_f((unsigned short)(rs[mt][nt].x >> 16));
@@ -1041,6 +1069,19 @@ __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g
                 const bool ok = m < g.M && n < g.N;
                 if (ok) *reinterpret_cast<uint2 *>((unsigned char *)g.out + (m * g.ldc + n) * 2) = pk;
                 if constexpr (CS) pks[mt][nt] = ok ? pk : make_uint2(0u, 0u);      // statistics of the values as STORED
+                if constexpr (LNV == 1) {   // row partials of the values as STORED (columns past N contribute nothing)
+                    const float w_ = n < g.N ? 1.f : 0.f;
+                    const float t0 = w_ * T::to_f((unsigned short)(pk.x & 0xffff)), t1 = w_ * T::to_f((unsigned short)(pk.x >> 16));
+                    const float t2 = w_ * T::to_f((unsigned short)(pk.y & 0xffff)), t3 = w_ * T::to_f((unsigned short)(pk.y >> 16));
+                    rsum += (t0 + t1) + (t2 + t3); rsq += (t0 * t0 + t1 * t1) + (t2 * t2 + t3 * t3);
+                }
+            }
+            if constexpr (LNV == 1) {       // the 4 lanes fc = 0..3 of a row hold disjoint column quads: combine, ONE plain store per (row, wave column)
+                rsum += __shfl_xor(rsum, 16, 64); rsq += __shfl_xor(rsq, 16, 64);
+                rsum += __shfl_xor(rsum, 32, 64); rsq += __shfl_xor(rsq, 32, 64);
+                const int64_t slot = (n_base + wn * (16 * NTW)) / (16 * NTW);
+                if (fc == 0 && m < g.M && n_base + wn * (16 * NTW) < g.N)
+                    *reinterpret_cast<float2 *>(g.out_row_stats + (slot * g.M + m) * 2) = make_float2(rsum, rsq);
             }
         }
         if constexpr (CS) {
@@ -1102,16 +1143,26 @@ __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g
             }
         }
     } else {
-    float4 bia[NTW];
+    float4 bia[NTW], csm[LNV == 2 ? NTW : 1];
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         const int64_t n = n_lane + nt * 16;
         bia[nt] = (g.bias && n < g.N) ? *reinterpret_cast<const float4 *>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (LNV == 2) csm[nt] = n < g.N ? *reinterpret_cast<const float4 *>(g.colsum + n) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int64_t m = m_base + wm * (16 * MT) + mt * 16 + fr;
         if (m >= g.M) continue;
+        if constexpr (LNV == 2) {       // LayerNorm fold: normalise this m-tile's accumulators in place (gate columns of GEGLU included)
+            const float2 st = *reinterpret_cast<const float2 *>(srow + 2 * (wm * (16 * MT) + mt * 16 + fr));
+            const float mean = st.x * g.ln_inv_k, rstd = rsqrtf(fmaxf(st.y * g.ln_inv_k - mean * mean, 0.f) + g.ln_eps);
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                acc[nt][mt][0] = rstd * (acc[nt][mt][0] - mean * csm[nt].x); acc[nt][mt][1] = rstd * (acc[nt][mt][1] - mean * csm[nt].y);
+                acc[nt][mt][2] = rstd * (acc[nt][mt][2] - mean * csm[nt].z); acc[nt][mt][3] = rstd * (acc[nt][mt][3] - mean * csm[nt].w);
+            }
+        }
         float4 rv[NTW];
         uint2 rs[NTW];
         const int64_t bidx = g.rowvec ? m / g.rows_per_batch : 0;
@@ -1177,9 +1228,10 @@ __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g
 // launch slot, pipeline fill and epilogue.  Here one workgroup per CU walks tiles bid, bid + G, ...; when the k loop of a tile ends
 // it issues the first three k-tiles of the NEXT tile (the LDS ring is free, the accumulators are not touched by the DMA) and only
 // then runs the epilogue, so fill latency and epilogue overlap and there is no per-tile dispatch.
-template <class T, int NTW, int MT>
+template <class T, int NTW, int MT, int LNV = 0>
 __global__ __launch_bounds__(512, 1) void k_gemm8p(const GemmArgs g)
 {
+    static_assert(LNV == 0 || LNV == 2, "persistent kernel: plain or LayerNorm-folded consumer");
     constexpr int BM = 64 * MT, BN = 32 * NTW, STAGE = BM * 128 + BN * 128, NS = 3;
     constexpr int AG = BM / 8, WG = BN / 8, AI = AG / 8, WI = (WG + 7) / 8;
     static_assert(WG % 8 == 0, "every wave issues the same number of W loads");
@@ -1192,6 +1244,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm8p(const GemmArgs g)
     const int64_t ntiles = ((g.M + BM - 1) / BM) * nbn;
     const int nk = (int)(g.K / BK);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    float *srow = reinterpret_cast<float *>(smem + NS * STAGE);          // LNV 2: [BM][2] row sums of the current tile, behind the ring
     const int lr = lane >> 3, ls = lane & 7;
     const unsigned char *Ab = (const unsigned char *)g.A, *Wb = (const unsigned char *)g.W;
     // dispatch-order tile d -> XCD d % 8 (gridDim.x is a multiple of 8); remapped so that consecutive tiles share an XCD's L2
@@ -1316,6 +1369,13 @@ __global__ __launch_bounds__(512, 1) void k_gemm8p(const GemmArgs g)
         const bool more = d < ntiles;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                 // every wave has read its last fragments
+        if constexpr (LNV == 2) {
+            // LayerNorm fold: (sum, sum^2) of this tile's BM rows over the producer's column slabs -> LDS, 512 threads, 4 loads in flight each
+            // (a per-lane slot loop in the epilogue is a chain of 10-20 dependent L2 round trips per m-tile: measured slower than the LayerNorm
+            // launch it replaces).  Before the next tile's DMA: the prologue ends in vmcnt(0), which must not wait for that DMA.
+            row_stats_prologue<BM>(g, cm, srow);
+            __builtin_amdgcn_s_barrier();                             // every thread's LDS adds have landed before the epilogue reads
+        }
         if (more) {
             tile_of(d, m_base, n_base);
             set_offsets(m_base, n_base);
@@ -1326,16 +1386,30 @@ __global__ __launch_bounds__(512, 1) void k_gemm8p(const GemmArgs g)
         // ---- epilogue of tile (cm, cn): bias, GEGLU / activation, scale, residual; 8-byte stores
         {
             const int64_t n_lane = cn + wn * (16 * NTW) + fc * 4;
-            float4 bia[NTW];
+            float4 bia[NTW], csm[LNV == 2 ? NTW : 1];
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
                 const int64_t n = n_lane + nt * 16;
                 bia[nt] = (g.bias && n < g.N) ? *reinterpret_cast<const float4 *>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (LNV == 2) csm[nt] = n < g.N ? *reinterpret_cast<const float4 *>(g.colsum + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            float2 st[LNV == 2 ? MT : 1];
+            if constexpr (LNV == 2) {      // (summed over the producer's slabs by row_stats_prologue before the next tile's DMA was issued)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) st[mt] = *reinterpret_cast<const float2 *>(srow + 2 * (wm * (16 * MT) + mt * 16 + fr));
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int64_t m = cm + wm * (16 * MT) + mt * 16 + fr;
                 if (m >= g.M) continue;
+                if constexpr (LNV == 2) {
+                    const float mean = st[mt].x * g.ln_inv_k, rstd = rsqrtf(fmaxf(st[mt].y * g.ln_inv_k - mean * mean, 0.f) + g.ln_eps);
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) {
+                        acc[nt][mt][0] = rstd * (acc[nt][mt][0] - mean * csm[nt].x); acc[nt][mt][1] = rstd * (acc[nt][mt][1] - mean * csm[nt].y);
+                        acc[nt][mt][2] = rstd * (acc[nt][mt][2] - mean * csm[nt].z); acc[nt][mt][3] = rstd * (acc[nt][mt][3] - mean * csm[nt].w);
+                    }
+                }
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt) {
                     const int64_t n = n_lane + nt * 16;
@@ -1369,14 +1443,14 @@ __global__ __launch_bounds__(512, 1) void k_gemm8p(const GemmArgs g)
     }
 }
 
-template <class T, int NTW, int MT>
+template <class T, int NTW, int MT, int LNV = 0>
 void launch8p(const GemmArgs &g, int nwg, hipStream_t s)
 {
-    constexpr size_t lds = 3 * (64 * MT * 128 + 32 * NTW * 128);
+    constexpr size_t lds = 3 * (64 * MT * 128 + 32 * NTW * 128) + (LNV == 2 ? 64 * MT * 8 : 0);
     static_assert(lds <= 160 * 1024, "LDS ring");
     static gc::AttrOnce once;
-    gc::ensure_dynamic_lds(once, (const void *)k_gemm8p<T, NTW, MT>, (int)lds);
-    hipLaunchKernelGGL((k_gemm8p<T, NTW, MT>), dim3(nwg), dim3(512), lds, s, g);
+    gc::ensure_dynamic_lds(once, (const void *)k_gemm8p<T, NTW, MT, LNV>, (int)lds);
+    hipLaunchKernelGGL((k_gemm8p<T, NTW, MT, LNV>), dim3(nwg), dim3(512), lds, s, g);
 }
 
 // =====================================================================================================================
@@ -1967,15 +2041,46 @@ void launch4(const GemmArgs &g, dim3 grid, hipStream_t s)
     hipLaunchKernelGGL((k_gemm<T, MODE, NTW, FUSE>), grid, dim3(NT), lds, s, g);
 }
 
-template <class T, int MODE, int NTW, int MT, bool FUSE, bool CS = false, bool LEAN = false>
+template <class T, int MODE, int NTW, int MT, bool FUSE, bool CS = false, bool LEAN = false, int LNV = 0>
 void launch8(const GemmArgs &g, dim3 grid, hipStream_t s)
 {
-    // FUSE: + the row-sum array of row_stats_prologue; CS: + the [2][BN][2] channel-sum table
-    constexpr size_t lds = 3 * (64 * MT * 128 + 32 * NTW * 128) + (FUSE ? 64 * MT * 8 : 0) + (CS ? 32 * NTW * 16 : 0);
+    // FUSE / LNV 2: + the row-sum array of row_stats_prologue; CS: + the [2][BN][2] channel-sum table
+    constexpr size_t lds = 3 * (64 * MT * 128 + 32 * NTW * 128) + ((FUSE || LNV == 2) ? 64 * MT * 8 : 0) + (CS ? 32 * NTW * 16 : 0);
     static_assert(lds <= 160 * 1024, "LDS ring");
     static gc::AttrOnce once;
-    gc::ensure_dynamic_lds(once, (const void *)k_gemm8<T, MODE, NTW, MT, FUSE, CS, LEAN>, (int)lds);
-    hipLaunchKernelGGL((k_gemm8<T, MODE, NTW, MT, FUSE, CS, LEAN>), grid, dim3(512), lds, s, g);
+    gc::ensure_dynamic_lds(once, (const void *)k_gemm8<T, MODE, NTW, MT, FUSE, CS, LEAN, LNV>, (int)lds);
+    hipLaunchKernelGGL((k_gemm8<T, MODE, NTW, MT, FUSE, CS, LEAN, LNV>), grid, dim3(512), lds, s, g);
+}
+
+// ---- lean LayerNorm fold (round 5; dn_gemm_ln.hip).  Producer (lnv 1): lean epilogue + row partials.  Consumer (lnv 2): lean or plain epilogue
+// with the rstd / mean correction.  K % 64 == 0 linears (MODE 3) only; NTW 4 | 5; MT 1 (two workgroups per CU) .. 4.
+inline bool ln_lean_producer_of(const GemmArgs &g, int mode, int splits)
+{
+    return g.out_row_stats && !g.row_stats && !g.out_group_stats && !g.chan_parts && splits == 1 && mode == 0 && g.K % 64 == 0 && !g.geglu &&
+           g.act == 0 && !g.out_f32 && !g.out_t && g.out && g.N >= 4 && (!g.rowvec || g.rows_per_batch >= 256);
+}
+inline bool ln_lean_consumer_of(const GemmArgs &g, int mode, int splits)
+{
+    return g.row_stats && !g.out_row_stats && !g.out_group_stats && !g.chan_parts && splits == 1 && mode == 0 && g.K % 64 == 0 && g.N >= 4;
+}
+template <class T, int NTW, int MT>
+void dispatch8ln_m(const GemmArgs &g, int lnv, bool lean, dim3 grid, hipStream_t s)
+{
+    if (lnv == 1) launch8<T, 3, NTW, MT, false, false, true, 1>(g, grid, s);
+    else if (lean) launch8<T, 3, NTW, MT, false, false, true, 2>(g, grid, s);
+    else launch8<T, 3, NTW, MT, false, false, false, 2>(g, grid, s);
+}
+template <class T>
+void dispatch8ln(const GemmArgs &g, int lnv, bool lean, int ntw, int mt, dim3 grid, hipStream_t s)
+{
+    if (lnv == 2 && g.persist > 0 && ntw == 4 && mt == 4) { launch8p<T, 4, 4, 2>(g, g.persist, s); return; }
+    if (mt == 1 && ntw == 4) { dispatch8ln_m<T, 4, 1>(g, lnv, lean, grid, s); return; }
+    if (mt < 2) mt = 2;
+    if (ntw == 5) {
+        if (mt == 4) dispatch8ln_m<T, 5, 4>(g, lnv, lean, grid, s); else if (mt == 3) dispatch8ln_m<T, 5, 3>(g, lnv, lean, grid, s); else dispatch8ln_m<T, 5, 2>(g, lnv, lean, grid, s);
+    } else {
+        if (mt == 4) dispatch8ln_m<T, 4, 4>(g, lnv, lean, grid, s); else if (mt == 3) dispatch8ln_m<T, 4, 3>(g, lnv, lean, grid, s); else dispatch8ln_m<T, 4, 2>(g, lnv, lean, grid, s);
+    }
 }
 
 // lean epilogue (no GEGLU / activation / fp32 / transposed output): fast conv, upsample-fused conv, K % 64 == 0 linear
@@ -2074,3 +2179,4 @@ void dn_gemm_launch_splitk_epilogue(const GemmArgs &g, int dtype, hipStream_t s)
 void dn_gemm_launch_cs(const GemmArgs &g, int dtype, int mode, int ntw, int mt8, dim3 grid, hipStream_t s);     // 8-wave kernel + channel partials
 void dn_gemm_launch_splitk_epilogue_cs(const GemmArgs &g, int dtype, hipStream_t s);
 void dn_gemm_launch_lean(const GemmArgs &g, int dtype, int mode, int ntw, int mt8, dim3 grid, hipStream_t s);   // 8-wave kernel, lean epilogue
+void dn_gemm_launch_ln(const GemmArgs &g, int dtype, int lnv, bool lean, int ntw, int mt8, dim3 grid, hipStream_t s);   // lean LayerNorm fold (producer 1 / consumer 2)

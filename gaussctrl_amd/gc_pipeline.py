@@ -81,6 +81,9 @@ class GaussCtrlPipelineConfig(_PipelineConfigBase):
                                        # parameters (the reference's 500 single-view iterations, gc_trainer.py:186-201; no gradient collective:
                                        # replicas stay bit-identical), "throughput" = each rank renders its own view of the step, the N x 59
                                        # gradients are averaged by one flat in-place RCCL all-reduce (dist.FlatGrads) -- an N-view batch per step
+    fold_layernorms: bool = True       # LayerNorms of the C = 640 / 1280 transformer blocks folded into their producer / consumer GEMM epilogues
+                                       # (weights.prepare(fold_ln=2): +2 % views/s, same latents to the storage type's rounding); ignored with
+                                       # fp8 >= 2, whose linears take e4m3 activations from the LayerNorm kernel
     synthetic_weights: bool = False    # True: seeded random SD1.5-shaped weights + hashed prompt embeddings (bench / tests; there
                                        # are no checkpoints on the build machines).  False: checkpoints are REQUIRED -- no silent fallback.
 
@@ -147,7 +150,7 @@ class GaussCtrlPipeline(_PipelineBase):
             sdops.configure(batch_invariant=bool(config.batch_invariant))
         def prepared(name, shapes, seed):
             sd = get(name, shapes, seed)
-            out = prepare(sd, self.dtype, dev, heads=8)
+            out = prepare(sd, self.dtype, dev, heads=8, fold_ln=2 if (config.fold_layernorms and config.fp8 < 2) else False)
             if config.fp8 >= 1:
                 from .sd.weights import add_fp8_convs, add_fp8_linears
                 add_fp8_convs(out, sd, dev)

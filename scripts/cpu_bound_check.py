@@ -3,11 +3,12 @@
 import sys, time
 import torch
 sys.argv = [sys.argv[0], "--no-cpu-baseline", "--no-secondary"]
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from gaussctrl_amd import _lib
 
 args = bench.parse()
-args.views = 40
+args.views = 40; args.chunk_size = args.chunk_size or 3
 dev = torch.device("cuda", 0)
 B = bench.Bench(args, "bf16", 0, 1, dev, None, None)
 B.run(1, 1)                                    # setup + warm

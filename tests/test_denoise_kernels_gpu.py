@@ -347,17 +347,28 @@ def test_conv_output_group_statistics(dt, B, H, W, Cin, Cout, stride):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("variant", [0, 0x800])
 @pytest.mark.parametrize("M,N,K,geglu", [(512, 960, 320, False), (24576, 960, 320, False), (300, 1280, 1280, False), (1024, 2560, 320, True),
-                                         (384, 10240, 1280, True)])
-def test_linear_layernorm_folded(dt, M, N, K, geglu):
+                                         (384, 10240, 1280, True), (6144, 5120, 640, True), (1536, 10240, 1280, True), (1536, 1280, 1280, False),
+                                         (6144, 640, 640, False)])
+def test_linear_layernorm_folded(dt, M, N, K, geglu, variant, monkeypatch):
     """consumer side: y = LN(x) W^T + b computed as rstd (x W'^T - mean colsum) + b' from the row sums the PRODUCER of x left
-    (here: an identity-free producer GEMM x = x0 W0^T so that the slab layout is the real one); reference = torch layer_norm +
-    matmul in fp64 on the same rounded x and the UNfolded weights."""
+    (here: an identity-free producer GEMM x = x0 W0^T + residual so that the slab layout is the real one); reference = torch layer_norm +
+    matmul in fp64 on the same rounded x and the UNfolded weights.  variant 0: the LEAN fold of round 5 (k_gemm8<.., LNV = 1 | 2>, the
+    persistent k_gemm8p<.., 2> for the multi-round GEGLU shapes, the 64-row two-workgroups-per-CU tile for the K = N = C shapes); 0x800: the
+    round-2 everything-epilogue (FUSE), kept as the fallback of split-K / statistics-carrying problems."""
     from gaussctrl_amd.sd import ops
     from gaussctrl_amd.sd.weights import _fold_ln, geglu_permute
+    monkeypatch.setitem(ops.KERNEL_VARIANT, "gemm", ops.KERNEL_VARIANT["gemm"] | variant)
     x0 = _rand((M, 256), dt, 1.0, 1); w0 = _rand((K, 256), dt, 256 ** -0.5 * 1.7, 5); b0 = torch.full((K,), 0.4, device=DEV)
+    res = _rand((M, K), dt, 0.7, 9)
     rs = ops.RowStats()
-    x = ops.linear(x0, w0, b0, row_stats=rs)                                   # producer: leaves the row sums of x
+    x = ops.linear(x0, w0, b0, residual=res, row_stats=rs)                     # producer (bias + residual): leaves the row sums of x
+    assert torch.equal(x, ops.linear(x0, w0, b0, residual=res))                # ... and the same values as without the statistics
+    # the partial sums themselves: summed over the slots = (sum, sum^2) of the row as stored
+    tot = rs.buf.double().sum(0)
+    assert float((tot[:, 0] - x.double().sum(1)).abs().max()) <= 1e-4 * float(x.double().abs().sum(1).max())
+    assert float((tot[:, 1] - (x.double() ** 2).sum(1)).abs().max()) <= 1e-4 * float((x.double() ** 2).sum(1).max())
     w32 = torch.randn(N, K, generator=torch.Generator().manual_seed(2)).to(DEV) * K ** -0.5
     b = torch.randn(N, device=DEV); gamma = 1 + 0.2 * torch.randn(K, device=DEV); beta = 0.3 * torch.randn(K, device=DEV)
     o = {}
@@ -376,6 +387,33 @@ def test_linear_layernorm_folded(dt, M, N, K, geglu):
     colsum = wf.float().sum(1).contiguous()
     got = ops.linear(x, wf, bf, geglu=geglu, ln=(rs, colsum, 1e-5))
     _close(got, ref, dt, extra=2.0)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("variant", [0, 0x800])
+@pytest.mark.parametrize("B,L,C", [(6, 1024, 640), (6, 256, 1280), (2, 64, 1280)])
+def test_qkv_transposed_v_with_layernorm_folded(dt, B, L, C, variant, monkeypatch):
+    """the fused Q | K | V^T projection (columns [0, 2C) -> qk, [2C, 3C) -> V^T [B, C, Lp]) as a LayerNorm-FOLDED consumer: norm1 of a C = 640 /
+    1280 transformer block (diffusers BasicTransformerBlock.norm1 -> attn1.to_q/k/v) inside the GEMM's plain epilogue, the row statistics from
+    the proj_in-like producer's lean epilogue"""
+    from gaussctrl_amd.sd import ops
+    from gaussctrl_amd.sd.weights import _fold_ln
+    monkeypatch.setitem(ops.KERNEL_VARIANT, "gemm", ops.KERNEL_VARIANT["gemm"] | variant)
+    x0 = _rand((B, L, C), dt, 1.0, 1); w0 = _rand((C, C), dt, C ** -0.5 * 1.5, 5); b0 = torch.full((C,), -0.2, device=DEV)
+    rs = ops.RowStats()
+    x = ops.linear(x0, w0, b0, row_stats=rs)
+    w32 = torch.randn(3 * C, C, generator=torch.Generator().manual_seed(2)).to(DEV) * C ** -0.5
+    gamma = 1 + 0.2 * torch.randn(C, device=DEV); beta = 0.3 * torch.randn(C, device=DEV)
+    o = {}
+    _fold_ln(o, "w", w32, None, gamma, beta, dt)
+    wf, bf = o["w.weight"], o["w.bias"]
+    colsum = wf.float().sum(1).contiguous()
+    ref = F.layer_norm(x.double(), (C,), None, None, 1e-5) @ wf.double().T + bf.double()
+    Lp = (L + 7) // 8 * 8
+    vt = torch.zeros(B, C, Lp, dtype=dt, device=DEV)
+    qk = ops.linear(x, wf, bf, rows_per_batch=L, out_t=vt, ldt=Lp, t_batch_stride=C * Lp, t_col0=2 * C, out_cols=2 * C, ln=(rs, colsum, 1e-5))
+    _close(qk, ref[..., :2 * C], dt, extra=2.0)
+    _close(vt[..., :L].transpose(1, 2), ref[..., 2 * C:], dt, extra=2.0)
 
 
 @pytest.mark.parametrize("dt", DTS)

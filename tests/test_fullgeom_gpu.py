@@ -93,6 +93,41 @@ def test_edit_f7_h64_all_20_steps(nets, dt):
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_edit_f7_h64_layernorm_folded(dt):
+    """The same trajectory with the LayerNorms of the C = 640 / 1280 transformer blocks FOLDED into their consumer GEMMs
+    (weights.prepare(fold_ln=2): norm1 -> Q | K | V^T, norm2 -> attn2.to_q, norm3 -> GEGLU; row statistics from the producers' lean epilogues;
+    the C = 320 blocks stay on the row-resident head / tail kernels): in-batch references and the cached-bank product path, all 20 DDIM steps,
+    same bars as the unfolded network and the same falsifiable form -- the distance to the fp32 oracle must sit on the storage type's own curve
+    (the fold removes one rounding of the normalised activations and rounds W diag(gamma) once instead: no visible change is expected)."""
+    from oracle import sd15_torch as sd
+    from gaussctrl_amd.sd.pipeline import DenoisePipeline
+    from gaussctrl_amd.sd.weights import prepare
+    z = np.load(os.path.join(GOLD, "fullgeom_edit_f7_h64.npz"))
+    ref = z["lat_steps"]
+    f, h, steps, seed = [int(v) for v in z["meta"][:4]]
+    lat, disp, cn, cp = _inputs(f, h, seed)
+    r = lambda w: {k: v.to(torch.bfloat16).float() for k, v in w.items()}
+    uw = prepare(r(sd.make_unet_weights(sd.SD15, 100)), dt, DEV, heads=8, fold_ln=2)
+    cw = prepare(r(sd.make_controlnet_weights(sd.SD15, 200)), dt, DEV, heads=8, fold_ln=2)
+    assert any(k.endswith("attn1.to_qkv.colsum") for k in uw) and any(k.endswith(".tail.a") for k in uw)
+    pipe = DenoisePipeline(uw, cw, None, 20, 5.0)
+    trace = []
+    pipe.edit_chunk(lat.to(DEV), disp.to(DEV), cn.to(DEV), cp.to(DEV), steps=steps, on_step=lambda i, l: trace.append(l.permute(0, 3, 1, 2).float().cpu()))
+    cur = _curve(trace, ref)
+    print(f"\nedit f=7 h=64 {dt}, LayerNorms of levels 1-3 folded: rel L2 per step (in-batch):\n  " + " ".join(f"{e:.2e}" for e in cur))
+    within("max(cur)", max(cur), BAR[dt])
+    emu = np.load(os.path.join(GOLD, "fullgeom_edit_f7_h64_actround.npz"))["rel_bf16" if dt == torch.bfloat16 else "rel_f16"]
+    within("max_i |cur[i] / predicted[i] - 1|, steps 1..6", max(abs(cur[i] / float(emu[i]) - 1.0) for i in range(len(emu))), 0.25)
+    bank = pipe.build_ref_bank(lat[:4].to(DEV), disp[:4].to(DEV), cn.to(DEV), cp.to(DEV))
+    trace_c = []
+    pipe.edit_chunk_cached(lat[4:].to(DEV), disp[4:].to(DEV), cn.to(DEV), cp.to(DEV), bank,
+                           on_step=lambda i, l: trace_c.append(l.permute(0, 3, 1, 2).float().cpu()))
+    cur_c = [_rel(t, torch.tensor(ref[i][4:])) for i, t in enumerate(trace_c)]
+    print("  cached-reference path: " + " ".join(f"{e:.2e}" for e in cur_c))
+    within("max(cur_c)", max(cur_c), BAR[dt])
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_invert_f3_h64_all_20_steps(nets, dt):
     """render_reverse's DDIM inversion (plain attention, no CFG, batched views; gc_pipeline.py:136-145) at full size."""
     from gaussctrl_amd.sd.pipeline import DenoisePipeline
