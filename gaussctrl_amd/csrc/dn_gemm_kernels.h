@@ -1106,8 +1106,9 @@ __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g
     #pragma unroll
                     for (int nt = 0; nt < NTW; ++nt) {
                         const uint2 pk = pks[mt][nt];
-                        const float t0 = wgt * T::to_f((unsigned short)(pk.x & 0xffff)), t1 = wgt * T::to_f((unsigned short)(pk.x >> 16));
-                        const float t2 = wgt * T::to_f((unsigned short)(pk.y & 0xffff)), t3 = wgt * T::to_f((unsigned short)(pk.y >> 16));
+                        // (select, not multiply: an inf / NaN in the neighbouring batch's rows must not reach this batch's sums through 0 * inf)
+                        const float t0 = wgt != 0.f ? T::to_f((unsigned short)(pk.x & 0xffff)) : 0.f, t1 = wgt != 0.f ? T::to_f((unsigned short)(pk.x >> 16)) : 0.f;
+                        const float t2 = wgt != 0.f ? T::to_f((unsigned short)(pk.y & 0xffff)) : 0.f, t3 = wgt != 0.f ? T::to_f((unsigned short)(pk.y >> 16)) : 0.f;
                         cs[nt][0] += t0; cq[nt][0] += t0 * t0; cs[nt][1] += t1; cq[nt][1] += t1 * t1;
                         cs[nt][2] += t2; cq[nt][2] += t2 * t2; cs[nt][3] += t3; cq[nt][3] += t3 * t3;
                     }
@@ -1761,8 +1762,9 @@ __global__ __launch_bounds__(512, 1) void k_gemm8q(const GemmArgs g)
     #pragma unroll
                     for (int nt = 0; nt < NTW; ++nt) {
                         const uint2 pk = pks[mt][nt];
-                        const float t0 = wgt * T::to_f((unsigned short)(pk.x & 0xffff)), t1 = wgt * T::to_f((unsigned short)(pk.x >> 16));
-                        const float t2 = wgt * T::to_f((unsigned short)(pk.y & 0xffff)), t3 = wgt * T::to_f((unsigned short)(pk.y >> 16));
+                        // (select, not multiply: an inf / NaN in the neighbouring batch's rows must not reach this batch's sums through 0 * inf)
+                        const float t0 = wgt != 0.f ? T::to_f((unsigned short)(pk.x & 0xffff)) : 0.f, t1 = wgt != 0.f ? T::to_f((unsigned short)(pk.x >> 16)) : 0.f;
+                        const float t2 = wgt != 0.f ? T::to_f((unsigned short)(pk.y & 0xffff)) : 0.f, t3 = wgt != 0.f ? T::to_f((unsigned short)(pk.y >> 16)) : 0.f;
                         cs[nt][0] += t0; cq[nt][0] += t0 * t0; cs[nt][1] += t1; cq[nt][1] += t1 * t1;
                         cs[nt][2] += t2; cq[nt][2] += t2 * t2; cs[nt][3] += t3; cq[nt][3] += t3 * t3;
                     }

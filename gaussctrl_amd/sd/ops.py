@@ -182,6 +182,10 @@ class RowStats:
         self.buf, self.slots = None, 0
 
 
+DEBUG_FILL = None      # tests only: value the statistics buffers (RowStats / ChanParts) are filled with BEFORE the producer runs -- they come from
+                       # torch.empty and the consumers trust the producers' slot layout: NaN here exposes any slot read but never written
+
+
 def _run_gemm(d, dev, what, row_stats=None, want_parts=False, gn_groups=32):
     """-> ChanParts of the output when want_parts and the kernel this problem selects can produce them, else None"""
     lib = L.lib()
@@ -198,6 +202,8 @@ def _run_gemm(d, dev, what, row_stats=None, want_parts=False, gn_groups=32):
     if row_stats is not None:                      # the slab count depends on the kernel the library picks for this problem
         row_stats.slots = int(lib.gc_dn_gemm_row_stat_slots(C.byref(d)))
         row_stats.buf = torch.empty(row_stats.slots, d.M, 2, dtype=torch.float32, device=dev)
+        if DEBUG_FILL is not None:
+            row_stats.buf.fill_(DEBUG_FILL)
         d.out_row_stats = row_stats.buf.data_ptr()
     parts = None
     if want_parts and d.rows_per_batch >= 256:
@@ -207,6 +213,8 @@ def _run_gemm(d, dev, what, row_stats=None, want_parts=False, gn_groups=32):
         if 0 < rows.value and ns.value <= 64:        # (more slabs -- the VAE's 256 x 256 / 512 x 512 maps -- would make the apply prologue the long pole)
             parts = ChanParts(torch.empty(d.M // d.rows_per_batch, ns.value, gn_groups, 2, 2, dtype=torch.float32, device=dev), rows.value, ns.value,
                               0, ct.value, gn_groups)
+            if DEBUG_FILL is not None:
+                parts.buf.fill_(DEBUG_FILL)
             d.out_chan_parts = parts.buf.data_ptr()
         else:
             d.gn_groups = 0
@@ -490,6 +498,8 @@ def concat_add(a, b, c=None, group_stats=None, chan_parts=False, gn_groups=32):
         if rows.value == 0:
             return concat_add(a, b, c), None
         parts = ChanParts(torch.empty(a.shape[0], ns.value, gn_groups, 2, 2, dtype=torch.float32, device=a.device), rows.value, ns.value, 1, ct.value, gn_groups)
+        if DEBUG_FILL is not None:
+            parts.buf.fill_(DEBUG_FILL)
         L.check(L.lib().gc_dn_concat_add_parts(_dt(a), _p(a), C1, _p(b), _p(c), C2, _p(out), C.c_int64(M), C.c_int64(rpb), gn_groups, _p(parts.buf), _stream()),
                 "gc_dn_concat_add_parts")
         return out, parts

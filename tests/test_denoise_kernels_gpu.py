@@ -346,6 +346,51 @@ def test_conv_output_group_statistics(dt, B, H, W, Cin, Cout, stride):
     _stats_close(gs, _group_sums(out.reshape(B, -1, Cout), 32))
 
 
+@pytest.mark.parametrize("kind,B,H,Cin,Cout", [("conv", 6, 64, 320, 320), ("conv", 3, 64, 640, 320), ("conv", 6, 16, 1280, 1280), ("down", 6, 64, 320, 320),
+                                               ("linear", 6, 32, 640, 640), ("concat", 6, 64, 320, 320), ("concat", 2, 16, 1280, 640), ("ln", 6, 32, 640, 640)])
+def test_statistics_buffers_nan_poisoned(kind, B, H, Cin, Cout, monkeypatch):
+    """The statistics buffers (ChanParts, RowStats) come from torch.empty and the consumers trust their own recomputation of which slab /
+    half-1 / slot entries the producer wrote (advisor finding, round 4).  Here every buffer is NaN-filled BEFORE the producer launch
+    (sd.ops.DEBUG_FILL): a consumer that reads one entry the producer does not write -- straddling row tiles (MT = 3 on 4096-row batches), groups
+    that straddle column tiles, split-K reduce, concat, the LayerNorm row partials -- returns NaN."""
+    from gaussctrl_amd.sd import ops
+    from gaussctrl_amd.sd.weights import conv3x3_weight
+    monkeypatch.setattr(ops, "DEBUG_FILL", float("nan"))
+    dt = torch.bfloat16
+    G = 32
+    if kind in ("conv", "down"):
+        x = _rand((B, H, H, Cin), dt, 1.0, 1); w = _rand((Cout, Cin, 3, 3), dt, (9 * Cin) ** -0.5, 2); b = torch.randn(Cout, device=DEV)
+        out, parts = ops.conv3x3(x, conv3x3_weight(w, dt), b, stride=2 if kind == "down" else 1, chan_parts=True)
+    elif kind == "linear":
+        x = _rand((B, H * H, Cin), dt, 1.0, 1); w = _rand((Cout, Cin), dt, Cin ** -0.5, 2)
+        out, parts = ops.linear(x, w, None, rows_per_batch=H * H, chan_parts=True)
+    elif kind == "concat":
+        a = _rand((B, H, H, Cin), dt, 1.0, 1); bb = _rand((B, H, H, Cout), dt, 1.0, 2); cc = _rand((B, H, H, Cout), dt, 1.0, 3)
+        out, parts = ops.concat_add(a, bb, cc, chan_parts=True)
+    else:                                               # LayerNorm fold: producer row partials -> folded consumer
+        x0 = _rand((B * H * H, Cin), dt, 1.0, 1); w0 = _rand((Cout, Cin), dt, Cin ** -0.5, 2)
+        rs = ops.RowStats()
+        x = ops.linear(x0, w0, None, row_stats=rs)
+        assert torch.isfinite(rs.buf).all(), "a row-partial slot the layout query announces was not written"
+        wf = _rand((Cout, Cout), dt, Cout ** -0.5, 3)
+        y = ops.linear(x, wf, torch.zeros(Cout, device=DEV), ln=(rs, wf.float().sum(1).contiguous(), 1e-5))
+        assert torch.isfinite(y.float()).all()
+        return
+    assert parts is not None
+    gamma = torch.randn(out.shape[-1], device=DEV); beta = torch.randn(out.shape[-1], device=DEV)
+    y = ops.groupnorm(out, gamma, beta, G, 1e-5, True, parts=parts)
+    assert torch.isfinite(y.float()).all(), "GroupNorm from the producer's partials read an entry nobody wrote"
+    monkeypatch.setattr(ops, "DEBUG_FILL", None)
+    y3 = ops.groupnorm(out, gamma, beta, G, 1e-5, True)
+    within(f"{kind}: poisoned-buffer GroupNorm vs the stand-alone kernels", ((y.double() - y3.double()).abs().max() / y3.double().abs().max()).item(), 2 * EPS[dt])
+    # ... and an inf in ONE batch's rows stays in that batch: a row tile that straddles two batches must not leak it through 0 * inf
+    if kind == "conv" and B >= 2 and H == 64:
+        x2 = x.clone(); x2[1] = float("inf")
+        out2, parts2 = ops.conv3x3(x2, conv3x3_weight(w, dt), b, chan_parts=True)
+        y2 = ops.groupnorm(out2, gamma, beta, G, 1e-5, True, parts=parts2)
+        assert torch.isfinite(y2[0].float()).all() and torch.isfinite(y2[2:].float()).all(), "another batch's inf leaked through a straddling tile"
+
+
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("variant", [0, 0x800])
 @pytest.mark.parametrize("M,N,K,geglu", [(512, 960, 320, False), (24576, 960, 320, False), (300, 1280, 1280, False), (1024, 2560, 320, True),
