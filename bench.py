@@ -38,6 +38,11 @@ import torch
 
 UNET_GFLOP_XVIEW = 1293.3      # per sample-forward, SURVEY.md Appendix B (analytic, 2*MAC)
 CN_GFLOP_XVIEW = 430.0         # ControlNet with the weight-0 self term skipped
+# CFG-shared prefix (sd.unet.AttnCtx.share, round 5): conv_in, the first resnet and the first transformer block up to its cross-view self-attention
+# are computed for ONE of the two identical CFG halves.  GFLOP of that prefix per sample: UNet = 5 K/V sets x 4 L^2 C (107.4) + 2 convs 64^2
+# 320 -> 320 (15.1) + GroupNorm/proj_in/Q|K|V (3.4) + conv_in (0.2); ControlNet = 4 sets (85.9) + the same rest.  `mfma_util_step` counts the
+# FLOP EXECUTED: a CFG pair costs 2 x per_sample - prefix.
+UNET_PREFIX_GFLOP, CN_PREFIX_GFLOP = 126.1, 104.6
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "fp8": 2500.0}      # fp8 run: the dominant kernel (attention) still computes in bf16
 
 
@@ -660,7 +665,8 @@ def main():
             t3, v3, _ = B3.run(1, n3)
             r8, _ = denoise_roofline(args, "fp8", B3.pipe, sdops, B3.z0, B3.ctx_neg, B3.ctx_pos, B3.state["bank"], dev, fp8_class=True)
             per_s = (UNET_GFLOP_XVIEW + CN_GFLOP_XVIEW) * 1e9
-            fl8 = v3 * (nsteps * 2 * per_s + VAE_DECODE_GFLOP * 1e9) + (n3 / B3.cps) * nsteps * 8 * per_s
+            pair8 = 2 * per_s - ((UNET_PREFIX_GFLOP + CN_PREFIX_GFLOP) * 1e9 if sdops.OPTIONS.cfg_share else 0.0)
+            fl8 = v3 * (nsteps * pair8 + VAE_DECODE_GFLOP * 1e9) + (n3 / B3.cps) * nsteps * 4 * pair8
             secondary_fp8 = {"dtype": "fp8", "value": round(v3 / t3, 4), "unit": "views/s", "steps": n3, "warmup": 1,
                              "roofline": r8,
                              "mfma_util_step_mixed_peak": round(fl8 / t3 / (r8["mixed_peak_tflops"] * 1e12), 4),
@@ -684,9 +690,13 @@ def main():
             # algorithmic FLOP of the timed region, as executed (reference K/V cached): CFG doubles every chunk frame; the reference
             # trajectory (4 views x 2) is computed once per scene by ONE rank (or by every rank with --ref-mode replicate)
             per_sample = (UNET_GFLOP_XVIEW + CN_GFLOP_XVIEW) * 1e9
+            # executed FLOP of a CFG pair: the shared prefix runs once (not on a sample-sharded reference trajectory, which holds other subsets)
+            shared = (UNET_PREFIX_GFLOP + CN_PREFIX_GFLOP) * 1e9 if sdops.OPTIONS.cfg_share else 0.0
+            pair = 2 * per_sample - shared
+            pair_ref = 2 * per_sample - (0.0 if (world > 1 and args.ref_mode == "allgather") else shared)
             scenes = args.steps / chunks_per_scene
             ref_copies = world if args.ref_mode == "replicate" and world > 1 else 1
-            flop = views_done * (nsteps * 2 * per_sample + VAE_DECODE_GFLOP * 1e9) + scenes * ref_copies * nsteps * 8 * per_sample
+            flop = views_done * (nsteps * pair + VAE_DECODE_GFLOP * 1e9) + scenes * ref_copies * nsteps * 4 * pair_ref
             mfma_util = flop / dt_s / (world * PEAK_TFLOPS[args.dtype] * 1e12)
             par = (f"views of one scene sharded x{world}" + (" (load balanced: the bank owner edits ~4 views fewer)" if world > 1 and args.ref_mode in ("rotate", "owner0") else " (v % N)") +
                    "; reference bank: " +
@@ -708,6 +718,8 @@ def main():
                           "views_per_step": round(views_done / args.steps, 3), "chunks_per_scene_per_rank": chunks_per_scene, "parallelism": par,
                           "mean_intersections_M": int(np.mean(stats["M"])) if stats["M"] else 0,
                           "ref_trajectory_in_timed_region": bool(args.workload == "edit"),
+                          "cfg_shared_prefix": bool(sdops.OPTIONS.cfg_share) if args.workload == "edit" else None,
+                          "layernorm_fold_levels_1_3": (os.environ.get("GC_DN_FOLD_LN", "0" if (args.dtype == "fp8" and args.fp8_linears) else "2") != "0") if args.workload == "edit" else None,
                           "level0_transformer_blocks": ("one-launch head + tail" if sdops.OPTIONS.fused_head and sdops.OPTIONS.fused_tail
                                                         else f"fused_head={sdops.OPTIONS.fused_head} fused_tail={sdops.OPTIONS.fused_tail}") if args.workload == "edit" else None,
                           "ref_trajectory_share_per_step": f"{nsteps}/{chunks_per_scene} DDIM steps of the next scene's 4 reference views" if args.workload == "edit" else None},

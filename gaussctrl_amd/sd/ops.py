@@ -61,6 +61,8 @@ class KernelOptions:
     two_streams: bool = True         # ControlNet || UNet encoder on two HIP streams inside a denoise step
     gn_parts: bool = True            # GroupNorm statistics from the producer's epilogue (per-channel partials, plain stores): the
                                      # stand-alone statistics + finalize launches disappear (1 launch per GroupNorm instead of 3)
+    cfg_share: bool = True           # CFG-shared prefix (sd.unet.AttnCtx.share): conv_in .. the first transformer block's self-attention computed for
+                                     # ONE of the two identical CFG halves (bench: GC_CFG_SHARE=0 restores the duplicated computation)
     fp8_min_hw: int = 256            # fp8 path (weights.add_fp8_convs): smallest map, in pixels, whose resnet convolutions run on e4m3 -- 16 x 16 maps
                                      # run k-sliced; the 8 x 8 maps measure slower in e4m3 than on the split-K bf16 kernels
     ablate: frozenset = frozenset()  # TIMING ablations (results wrong by construction; scripts/ablate_classes.sh): op classes whose
@@ -103,7 +105,7 @@ def options_from_env(env=None) -> KernelOptions:
     a = (1 if on("GC_ATTN_SAFE", "0") else 0) | (2 if on("GC_ATTN_16", "0") else 0) | (int(e.get("GC_ATTN_V", "0")) << 2)
     return KernelOptions(gemm_variant=g, attn_variant=a, batch_invariant=on("GC_BATCH_INVARIANT", "0"),
                          fused_head=on("GC_FUSED_HEAD", "1"), fused_tail=on("GC_FUSED_TAIL", "1"), two_streams=on("GC_DN_STREAMS", "1"),
-                         gn_parts=on("GC_GN_PARTS", "1"),
+                         gn_parts=on("GC_GN_PARTS", "1"), cfg_share=on("GC_CFG_SHARE", "1"),
                          ablate=frozenset(x for x in e.get("GC_ABLATE", "").split(",") if x))
 
 

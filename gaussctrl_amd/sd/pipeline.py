@@ -131,6 +131,10 @@ class DenoisePipeline:
             tkv = st.get("text_kv", self.text_kv)          # (a sharded trajectory on ONE CFG half keeps its own one-row text K / V^T cache)
             a_cn = AttnCtx(st["mode"], st["cc"], st["fph"], tkv, bank, "controlnet")
             a_un = AttnCtx(st["mode"], st["cu"], st["fph"], tkv, bank, "unet")
+            # CFG-shared prefix (AttnCtx.share): both halves of the batch are copies of the same latents (rep = 2) -- not on a sharded
+            # reference trajectory (its ranks hold other sample subsets) and not with the group-statistics experiment paths
+            a_cn.share = a_un.share = bool(ops.OPTIONS.cfg_share and st["cfg"] and st["rep"] == 2 and st["mode"] == "xview" and
+                                           (bank is None or getattr(bank, "shard", None) is None))
             if self.two_streams:
                 # The ControlNet and the UNet encoder + mid block only share their input: run them on two HIP streams so that
                 # the part-filled grids of the 16x16 / 8x8 layers and every kernel's fill / epilogue phase overlap with the

@@ -94,6 +94,17 @@ class AttnCtx:
         self.text_kv = text_kv              # layer prefix -> (K [2,77,C], Vt [2,C,80]) cache
         self.bank = bank
         self.net = net
+        # CFG-shared prefix (round 5): with classifier-free guidance the network batch is [unconditional ; conditional] copies of the SAME
+        # latents (cat([latents] * 2), gc_pipeline.py:209-219 through the diffusers pipeline): everything before the first text cross-attention
+        # -- conv_in, the first resnet, and the first transformer block up to its (cross-view) self-attention -- is identical in the two
+        # halves, so it is computed for the first half only and duplicated where the halves diverge.  Exact in real arithmetic; in floating
+        # point equal up to the accumulation-order noise a different batch size already causes (bit-identical in batch-invariant mode).
+        self.share = False
+
+
+def dup2(t):
+    """[f, ...] -> [2 f, ...]: the two CFG halves of a tensor computed once (one device copy)"""
+    return torch.cat([t, t], 0)
 
 
 class SDNet:
@@ -229,7 +240,7 @@ class SDNet:
             return ops.conv3x3(h, w[p + ".conv2.weight"], w[p + ".conv2.bias"], residual=sc, chan_parts=True)
         return ops.conv3x3(h, w[p + ".conv2.weight"], w[p + ".conv2.bias"], residual=sc, group_stats=os_), os_
 
-    def _self_attention(self, p, n, actx: AttnCtx, ln=None, dt=None):
+    def _self_attention(self, p, n, actx: AttnCtx, ln=None, dt=None, dup=False):
         """n: LayerNorm-ed tokens, or the raw tokens with ln = (row sums, colsum, eps) when norm1 is folded into the Q|K|V GEMM, or (dt given)
         the e4m3 bytes of the LayerNorm-ed tokens for the fp8 projection (weights.add_fp8_linears)"""
         w = self.w
@@ -245,9 +256,9 @@ class SDNet:
         else:
             qk = ops.linear(n, w[p + ".to_qkv.weight"], w.get(p + ".to_qkv.bias") if ln is not None else None, rows_per_batch=L, out_t=vt,
                             ldt=Lp, t_batch_stride=Cc * Lp, t_col0=2 * Cc, out_cols=2 * Cc, ln=ln)
-        return self._attend(p, qk[..., :Cc], qk[..., Cc:], vt, actx)
+        return self._attend(p, qk[..., :Cc], qk[..., Cc:], vt, actx, dup)
 
-    def _attend(self, p, q, k, vt, actx: AttnCtx):
+    def _attend(self, p, q, k, vt, actx: AttnCtx, dup=False):
         """the attention processor proper on projected Q / K / V^T (utils.py:60-117)"""
         heads = self.cfg["heads"]
         L = q.shape[1]
@@ -264,7 +275,15 @@ class SDNet:
             h0 = bank.shard.half_base                    # first reference row of the half the local batch starts with
             return ops.attention(q, k, vt, heads, sets, actx.f, Lk=L, kref=kr[h0:], vtref=vtr[h0:], ref_fph=4, q_prescaled=self.qpre)
         if bank is not None and bank.mode == "record":
-            bank.store[bank.key((actx.net, p))] = (k, vt)            # the batch IS the reference batch [2*4]
+            if dup:     # CFG-shared prefix: K / V^T of the first half serve both halves; the bank keeps its [2 * 4] layout (K with the Q|K row stride)
+                Bk, Lk_, Ck = k.shape
+                ld = k.stride(1)
+                buf = torch.empty(2 * Bk, Lk_, ld, dtype=k.dtype, device=k.device)
+                k2 = buf[..., ld - Ck:]
+                k2[:Bk].copy_(k); k2[Bk:].copy_(k)
+                bank.store[bank.key((actx.net, p))] = (k2, dup2(vt))
+            else:
+                bank.store[bank.key((actx.net, p))] = (k, vt)            # the batch IS the reference batch [2*4]
         if bank is not None and bank.mode == "use":
             kr, vtr = bank.store[bank.key((actx.net, p))]
             return ops.attention(q, k, vt, heads, sets, actx.f, Lk=L, kref=kr, vtref=vtr, ref_fph=kr.shape[0] // 2, q_prescaled=self.qpre)
@@ -296,12 +315,17 @@ class SDNet:
         return bool(self.fused_tail and (p + ".tail.a") in self.w and (p + ".transformer_blocks.0.attn1.to_qkv.colsum") not in self.w and not self.fuse_stats
                     and ctx.shape[1] <= 96 and ctx.shape[0] <= 2)
 
-    def transformer(self, p, x, xs, ctx, actx: AttnCtx):
+    def transformer(self, p, x, xs, ctx, actx: AttnCtx, expand=False):
         """Transformer2DModel on (x, xs) -> (out, channel sums of out).  With folded LayerNorms (weights.prepare(fold_ln=True)) the
         three LayerNorm launches disappear: each producer GEMM leaves the row sums of its output, the consumer GEMM (whose weights
         carry gamma / beta) normalises in its epilogue -- 11 launches per block instead of 16."""
+        # expand (CFG-shared prefix, AttnCtx.share): x holds the first CFG half only; GroupNorm, proj_in, norm1, Q | K | V and the self-attention
+        # run on it, then (attention output, residual stream, block input) are duplicated and the text-dependent rest runs on both halves
         w = self.w
         B, H, W_, Cc = x.shape
+        B0 = B
+        if expand:
+            B = 2 * B0
         t = p + ".transformer_blocks.0"
         fold = self.ln_folded and (t + ".attn1.to_qkv.colsum") in w          # (prepare(fold_ln=2) folds only the blocks without a fused tail)
         # (the tail kernel reads one text block per CFG half: ctx rows <= 2 and an equal number of frames per row; anything else -- e.g. a
@@ -312,22 +336,24 @@ class SDNet:
         # down projection is 30 tiles of 40 k-steps -- stay on the split-K bf16 kernels, as the small-map convolutions do)
         q8 = self.fp8_lin if (not fold and not tail and (t + ".ff.net.0.proj.w8") in w and B * H * W_ >= 1024) else 0
         if self.fused_head and (p + ".head.w") in w and not fold and (xs is None or isinstance(xs, ops.ChanParts)) and (H * W_) % 128 == 0:
-            x3 = x.view(B, H * W_, Cc)
+            x3 = x.view(B0, H * W_, Cc)
             coef = ops.groupnorm_coef(x3, w[p + ".norm.weight"], w[p + ".norm.bias"], self.cfg["groups"], 1e-6, parts=xs)
             hfr = tail                       # h goes from one fused kernel to the other: stored as MFMA fragments
             h, qk, vt = ops.transformer_head(x3, coef, w[p + ".head.w"], w[p + ".head.params"], h_frags=hfr)
-            o = self._attend(t + ".attn1", qk[..., :Cc], qk[..., Cc:], vt, actx)
+            o = self._attend(t + ".attn1", qk[..., :Cc], qk[..., Cc:], vt, actx, expand)
         else:
             h = self.gn(x, xs, p + ".norm", 1e-6, False)
             rs = ops.RowStats() if fold else None
-            h = ops.linear(h.view(B, H * W_, Cc), w[p + ".proj_in.weight"], w[p + ".proj_in.bias"], row_stats=rs)
+            h = ops.linear(h.view(B0, H * W_, Cc), w[p + ".proj_in.weight"], w[p + ".proj_in.bias"], row_stats=rs)
             if fold:
-                o = self._self_attention(t + ".attn1", h, actx, ln=(rs, w[t + ".attn1.to_qkv.colsum"], 1e-5))
+                o = self._self_attention(t + ".attn1", h, actx, ln=(rs, w[t + ".attn1.to_qkv.colsum"], 1e-5), dup=expand)
             elif q8 & 4:
                 o = self._self_attention(t + ".attn1", ops.layernorm_fp8(h, w[t + ".norm1.weight"], w[t + ".norm1.bias"], a_scale=self.fp8_ln_scale),
-                                         actx, dt=h.dtype)
+                                         actx, dt=h.dtype, dup=expand)
             else:
-                o = self._self_attention(t + ".attn1", ops.layernorm(h, w[t + ".norm1.weight"], w[t + ".norm1.bias"]), actx)
+                o = self._self_attention(t + ".attn1", ops.layernorm(h, w[t + ".norm1.weight"], w[t + ".norm1.bias"]), actx, dup=expand)
+        if expand:                           # the halves diverge at the text cross-attention: both get the shared result
+            o, h, x = dup2(o), dup2(h), dup2(x)
         if tail:
             kv = self._text_stream(t + ".attn2", ctx, actx)
             out = ops.transformer_tail(o, h, x.view(B, H * W_, Cc), w[p + ".tail.a"], kv, w[p + ".tail.b"], w[p + ".tail.params"],
@@ -371,16 +397,21 @@ class SDNet:
                          group_stats=os_)
         return out.view(B, H, W_, Cc), os_
 
-    def encoder(self, x, xs, temb_act, ctx, actx):
-        """(x, xs = channel sums of x) -> (mid-block output, its channel sums, skip tensors)"""
+    def shares_prefix(self, xin, actx: AttnCtx) -> bool:
+        """CFG-shared prefix applies: two identical halves in the batch and a transformer block right after the first resnet"""
+        return bool(actx.share and xin.shape[0] == 2 * actx.f and self.cfg["attn_levels"][0])
+
+    def encoder(self, x, xs, temb_act, ctx, actx, share=False):
+        """(x, xs = channel sums of x) -> (mid-block output, its channel sums, skip tensors).  share: x is the first CFG half only
+        (AttnCtx.share); the first transformer block expands it to the full batch."""
         cfg = self.cfg
-        skips = [x]
+        skips = [dup2(x) if share else x]
         n = len(cfg["block_out_channels"])
         for i in range(n):
             for j in range(cfg["layers_per_block"]):
                 x, xs = self.resnet(f"down_blocks.{i}.resnets.{j}", x, xs, temb_act)
                 if cfg["attn_levels"][i]:
-                    x, xs = self.transformer(f"down_blocks.{i}.attentions.{j}", x, xs, ctx, actx)
+                    x, xs = self.transformer(f"down_blocks.{i}.attentions.{j}", x, xs, ctx, actx, expand=share and i == 0 and j == 0)
                 skips.append(x)
             if i < n - 1:
                 p = f"down_blocks.{i}.downsamplers.0.conv"
@@ -412,12 +443,15 @@ class ControlNet(SDNet):
         w = self.w
         self.begin_forward(xin.device)
         temb_act = self.time_embed(t, xin.device)
+        share = self.shares_prefix(xin, actx)
+        if share:
+            xin, cond_emb = xin[:actx.f], cond_emb[:actx.f]
         xs = self._cs(xin.shape[0], w["conv_in.weight"].shape[0], xin.shape[1] * xin.shape[2])
         if self.gn_parts and xs is None:
             x, xs = ops.conv3x3(xin, w["conv_in.weight"], w["conv_in.bias"], residual=cond_emb, chan_parts=True)
         else:
             x = ops.conv3x3(xin, w["conv_in.weight"], w["conv_in.bias"], residual=cond_emb, group_stats=xs)
-        x, _, skips = self.encoder(x, xs, temb_act, ctx, actx)
+        x, _, skips = self.encoder(x, xs, temb_act, ctx, actx, share)
         down = []
         for n, s in enumerate(skips):
             B, H, W_, Cc = s.shape
@@ -436,12 +470,15 @@ class UNet(SDNet):
         w = self.w
         self.begin_forward(xin.device)
         temb_act = self.time_embed(t, xin.device)
+        share = self.shares_prefix(xin, actx)
+        if share:
+            xin = xin[:actx.f]
         xs = self._cs(xin.shape[0], w["conv_in.weight"].shape[0], xin.shape[1] * xin.shape[2])
         if self.gn_parts and xs is None:
             x, xs = ops.conv3x3(xin, w["conv_in.weight"], w["conv_in.bias"], chan_parts=True)
         else:
             x = ops.conv3x3(xin, w["conv_in.weight"], w["conv_in.bias"], group_stats=xs)
-        x, _, skips = self.encoder(x, xs, temb_act, ctx, actx)
+        x, _, skips = self.encoder(x, xs, temb_act, ctx, actx, share)
         return x, skips, temb_act
 
     def decode(self, x, skips, temb_act, ctx, down_res, mid_res, actx: AttnCtx):
