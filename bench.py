@@ -129,8 +129,8 @@ class GemmProfiler:
             out = prof._lin(x, w, *a, **k)
             e.record()
             K = x.shape[-1]
-            N = w.shape[0]
-            ntw = 5 if (N % 160 == 0 and N % 128 != 0 and not k.get("geglu", False)) else 4      # mirrors plan() in dn_gemm.hip
+            N = w.shape[-2]                                                                   # ([S, N, K] weight sets: the text-attention fold)
+            ntw = 5 if ((N % 160 == 0 and N % 128 != 0 and not k.get("geglu", False)) or k.get("softmax_keys", 0)) else 4      # mirrors plan() in dn_gemm.hip
             prof.rec.append((f"gemm<{prof.dt},linear,BN={32 * ntw}>", 2.0 * (x.numel() // K) * N * K, s, e))
             return out
 

@@ -38,11 +38,12 @@ void plan(const gc_gemm_desc *d, int *ntw, int *splits, int *tps)
 {
     // GEGLU pairs tiles (nt, nt+1) inside a wave: needs an even number of n-tiles per wave
     *ntw = (d->N % 160 == 0 && d->N % 128 != 0 && !d->geglu) ? 5 : 4;
+    if (d->softmax_keys > 0) *ntw = 5;                                    // softmax-heads epilogue: one 80-column head block per wave column
     const int bn = 32 * *ntw;
     const int64_t Msel = d->plan_rows > 0 ? d->plan_rows : d->M;         // batch-invariant planning: the rows of one frame
     const int64_t blocks = ((Msel + BM - 1) / BM) * ((d->N + bn - 1) / bn);
     const int nk = (int)((d->K + BK - 1) / BK);
-    *splits = d->geglu ? 1 : choose_splits(blocks, nk);
+    *splits = (d->geglu || d->w_set_rows > 0 || d->softmax_keys > 0) ? 1 : choose_splits(blocks, nk);
     *tps = (nk + *splits - 1) / *splits;
     *splits = (nk + *tps - 1) / *tps;
 }
@@ -101,7 +102,7 @@ int ln_lean_kind(const gc_gemm_desc *d)
     if ((d->kernel_variant & 0x800) || d->fp8 || d->mode != 0 || d->K % 64 != 0 || d->out_group_stats || d->out_chan_parts || d->N < 4) return 0;
     if (d->out_row_stats && !d->ln_row_stats)
         return (!d->geglu && d->act == 0 && !d->out_f32 && !d->out_t && d->out && (!d->rowvec || d->rows_per_batch >= 256)) ? 1 : 0;
-    if (d->ln_row_stats && !d->out_row_stats) return 2;
+    if (d->ln_row_stats && !d->out_row_stats) return d->softmax_keys > 0 ? 3 : 2;
     return 0;
 }
 // kernel choice of one problem (shared by the launcher and the row-statistics layout query)
@@ -142,7 +143,13 @@ int select(const gc_gemm_desc *d, Sel *o, bool want_parts)
             const int64_t t1 = ((d->M + 63) / 64) * nbn, t2 = ((d->M + 127) / 128) * nbn;
             if (mt == 2 && t2 <= 256 && t1 <= 512 && t1 > 128 && nk_host <= 24) mt = 1;      // (same accumulation order as MT 2)
         }
-        const bool want_split = !force_mt && use8 != 2 && !d->geglu && d->workspace && tiles8 <= 128 && (mode == 0 ? (!small || nk_host >= 24) : (convsplit >= (small ? 2 : 1)));
+        if (d->w_set_rows > 0 && mt) {       // weight sets: the row tile must divide the rows of a set (a tile never straddles two sets)
+            int pick = 0;
+            const int cand[5] = {mt, 4, 3, 2, (ntw == 4 && d->softmax_keys == 0) ? 1 : 2};
+            for (int c = 0; c < 5 && !pick; ++c) if (d->w_set_rows % (64 * cand[c]) == 0) pick = cand[c];
+            mt = pick ? pick : mt;
+        }
+        const bool want_split = !force_mt && use8 != 2 && !d->geglu && d->w_set_rows == 0 && d->softmax_keys == 0 && d->workspace && tiles8 <= 128 && (mode == 0 ? (!small || nk_host >= 24) : (convsplit >= (small ? 2 : 1)));
         int s8 = 1, tps8 = nk_host;
         if (want_split) {
             s8 = (int)std::min<int64_t>(small ? (256 + tiles8 - 1) / tiles8 : 256 / tiles8, nk_host / 12);
@@ -248,6 +255,10 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
                                !d->out_group_stats && d->ldc % 4 == 0),
                "out_fp8: an fp8 linear with a plain output (no fp32 / transposed output, no statistics, no LayerNorm fold), ldc % 4 == 0");
     g.dbg = (d->kernel_variant >> 8) & 0xff;
+    g.w_set_rows = d->w_set_rows; g.w_set_stride = d->w_set_stride; g.sm_keys = d->softmax_keys;
+    GC_REQUIRE(d->w_set_rows >= 0 && d->softmax_keys >= 0 && d->softmax_keys <= 80, "bad weight-set / softmax arguments");
+    GC_REQUIRE(!d->softmax_keys || (d->ln_row_stats && d->N % 80 == 0 && d->out && !d->out_f32 && !d->out_t && !d->geglu && !d->residual && d->act == 0),
+               "softmax_keys: a LayerNorm-folded linear with N % 80 == 0 and a plain 2-byte output");
     GC_REQUIRE((d->ln_row_stats == nullptr) == (d->ln_colsum == nullptr), "ln_row_stats and ln_colsum must be given together");
     GC_REQUIRE(!d->ln_row_stats || d->mode == 0, "LayerNorm folding applies to linear GEMMs");
     GC_REQUIRE(!(d->out_row_stats || d->out_group_stats) || (!d->geglu && !d->out_t && d->out), "output statistics need a plain (non-GEGLU, non-transposed) output");
@@ -302,6 +313,10 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
     const int64_t nbn = (d->N + bn - 1) / bn;
     g.persist = 0;
     const int lnk = (sel.mt8 && sel.splits == 1) ? ln_lean_kind(d) : 0;
+    if (d->w_set_rows > 0 || d->softmax_keys > 0) {
+        GC_REQUIRE(lnk != 0, "weight sets / softmax_keys need a lean LayerNorm-fold problem (K % 64 == 0 linear with ln_row_stats or out_row_stats, no forced variant)");
+        GC_REQUIRE(d->w_set_rows == 0 || (d->w_set_rows % (64 * sel.mt8) == 0 && d->M % d->w_set_rows == 0), "w_set_rows must be a multiple of the row tile and divide M");
+    }
     if (sel.mt8 == 4 && sel.ntw == 4 && sel.mode == 0 && sel.splits == 1 && d->K % 64 == 0 && d->K <= 64 * 24 && (!fuse_of(g) || lnk == 2) && !g.chan_parts &&
         !g.rowvec && !g.out_t && !g.out_f32 && g.out && g.act != 2 && !(d->kernel_variant & 0x200)) {
         // multi-round short-K linear (the GEGLU FF-up projections): persistent workgroups, next tile's fill under this tile's epilogue

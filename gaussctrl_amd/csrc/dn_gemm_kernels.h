@@ -62,6 +62,11 @@ struct GemmArgs {
     // width: at most two).  PLAIN stores: no atomics (round 2's per-(batch, group) float atomics cost 26 ms per chunk in same-line
     // contention), no zero-init; gc_dn_groupnorm_apply_parts adds them up in its prologue.
     float *chan_parts; int cp_nslab; int cp_rows;
+    // lean LayerNorm-fold kernels only (LNV != 0): weight SETS selected by the row tile -- rows [s w_set_rows, (s + 1) w_set_rows) multiply weight
+    // matrix s (W + s w_set_stride elements; bias / colsum + s N): the text cross-attention folded into two GEMMs has one matrix pair per CFG half
+    // (the text differs).  0: one set.  sm_keys (LNV 3): valid score columns per 80-column head block of the softmax-heads epilogue.
+    int64_t w_set_rows, w_set_stride;
+    int sm_keys;
 };
 }  // namespace dng
 
@@ -723,6 +728,11 @@ __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g
     static_assert(!(FUSE && CS), "one statistics epilogue at a time");
     static_assert(LNV == 0 || (!FUSE && !CS && MODE == 3), "lean LayerNorm fold: K % 64 == 0 linears on the non-FUSE epilogues");
     static_assert(LNV != 1 || LEAN_, "row partials come from the lean epilogue");
+    static_assert(LNV != 3 || (NTW == 5 && !LEAN_), "softmax-heads epilogue: one 80-column head block per wave column");
+    // LNV 3 (text cross-attention folded into GEMMs): LayerNorm-folded consumer whose N columns are attention SCORES against the
+    // <= 80 text keys of each head (W = K_text Wq: one 80-row block per head) -- the epilogue takes the softmax over each head block (= this
+    // wave's 80 columns of the row: 20 values per lane, 4 lanes per row) and stores the probabilities.
+    constexpr bool LNIN = LNV >= 2;
     constexpr bool LEAN = LEAN_ || CS;
     constexpr int BM = 64 * MT;
     constexpr bool CONVF = MODE == 2 || MODE == 4, UPS = MODE == 4;   // MODE 4 = MODE 2 + fused nearest-x2 upsample
@@ -808,7 +818,8 @@ __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g
             a_vm[i] = vm;
         }
     }
-    const unsigned char *Ab = (const unsigned char *)g.A, *Wb = (const unsigned char *)g.W;
+    const int64_t wset = (LNV != 0 && g.w_set_rows > 0) ? m_base / g.w_set_rows : 0;          // weight set of this row tile (never straddles: host check)
+    const unsigned char *Ab = (const unsigned char *)g.A, *Wb = (const unsigned char *)g.W + (LNV != 0 ? wset * g.w_set_stride * 2 : 0);
     const unsigned char *Zp = (const unsigned char *)g.zeros;
     int ld_tap = 0, ld_ci = 0;
     if (CONVF && kt0 > 0) { ld_tap = (kt0 * BK) / g.Cin; ld_ci = kt0 * BK - ld_tap * g.Cin; }
@@ -946,7 +957,7 @@ __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g
         if (nk > 2) issue(2, 2);
         // lean LayerNorm-folded consumer: the rows' statistics are summed over the producer's slabs HERE, under the first k-tiles' flight (the
         // prologue ends in vmcnt(0): it waits for those tiles too, which the loop would do next anyway)
-        if constexpr (LNV == 2) row_stats_prologue<BM>(g, m_base, srow);
+        if constexpr (LNIN) row_stats_prologue<BM>(g, m_base, srow);
         if (nk > 2) wait_tiles(std::integral_constant<int, 2>{}); else if (nk > 1) wait_tiles(std::integral_constant<int, 1>{}); else wait_tiles(std::integral_constant<int, 0>{});
         __builtin_amdgcn_s_barrier();
         load_frag(f0, 0, 0);
@@ -999,6 +1010,52 @@ __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g
         }
         return;
     }
+    if constexpr (LNV == 3) {
+        // ---- softmax-heads epilogue (LayerNorm-folded scores -> probabilities)
+        const float *biasp = g.bias + wset * g.N, *csp = g.colsum + wset * g.N;
+        float4 bia[NTW], csm[NTW];
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int64_t n = n_lane + nt * 16, nc = n < g.N ? n : g.N - 4;
+            bia[nt] = *reinterpret_cast<const float4 *>(biasp + nc);
+            csm[nt] = *reinterpret_cast<const float4 *>(csp + nc);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int64_t m = m_base + wm * (16 * MT) + mt * 16 + fr;
+            const float2 st = *reinterpret_cast<const float2 *>(srow + 2 * (wm * (16 * MT) + mt * 16 + fr));
+            const float mean = st.x * g.ln_inv_k, rstd = rsqrtf(fmaxf(st.y * g.ln_inv_k - mean * mean, 0.f) + g.ln_eps);
+            float v[NTW][4];
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                v[nt][0] = rstd * (acc[nt][mt][0] - mean * csm[nt].x) + bia[nt].x; v[nt][1] = rstd * (acc[nt][mt][1] - mean * csm[nt].y) + bia[nt].y;
+                v[nt][2] = rstd * (acc[nt][mt][2] - mean * csm[nt].z) + bia[nt].z; v[nt][3] = rstd * (acc[nt][mt][3] - mean * csm[nt].w) + bia[nt].w;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool key = nt * 16 + fc * 4 + r < g.sm_keys;          // column inside the head block = text key index
+                    v[nt][r] = key ? v[nt][r] : -3.0e38f;
+                    mx = fmaxf(mx, v[nt][r]);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[nt][r] = exp2f(v[nt][r] - mx); sum += v[nt][r]; }     // (the scores carry log2(e) / sqrt(D): folded into Wq)
+            sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.f / sum;
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int64_t n = n_lane + nt * 16;
+                if (m < g.M && n < g.N)
+                    *reinterpret_cast<uint2 *>((unsigned char *)g.out + (m * g.ldc + n) * 2) =
+                        make_uint2(pack2<T>(v[nt][0] * inv, v[nt][1] * inv), pack2<T>(v[nt][2] * inv, v[nt][3] * inv));
+            }
+        }
+        return;
+    }
     if constexpr (LEAN) {
         // ---- lean epilogue.  EVERY operand load is issued first, branch-free (rows / columns past the edge re-read a valid element,
         // absent operands read the zero page), then the tile is computed and stored.  The generic epilogue loads bias / row-vector /
@@ -1006,7 +1063,7 @@ __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g
         // gfx9 that counter also holds the STORES in flight -- MT x NTW serialised store round trips per wave (seen in the ISA).
         const unsigned char *zp = (const unsigned char *)g.zeros;
         const bool has_b = g.bias != nullptr, has_rv = g.rowvec != nullptr, has_res = g.residual != nullptr;
-        const float *biasp = has_b ? g.bias : reinterpret_cast<const float *>(zp);
+        const float *biasp = has_b ? g.bias + (LNV != 0 ? wset * g.N : 0) : reinterpret_cast<const float *>(zp);
         const float *rvp = has_rv ? g.rowvec : reinterpret_cast<const float *>(zp);
         const unsigned char *resp = has_res ? (const unsigned char *)g.residual : zp;
         // the row vector is per batch: a tile holds rows of at most two batches (rows_per_batch >= BM, checked by the launcher)
@@ -1036,7 +1093,7 @@ __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
                 const int64_t n = n_lane + nt * 16, nc = n < g.N ? n : g.N - 4;
-                csm[nt] = *reinterpret_cast<const float4 *>(g.colsum + nc);
+                csm[nt] = *reinterpret_cast<const float4 *>(g.colsum + wset * g.N + nc);
             }
         }
         uint2 pks[CS ? MT : 1][CS ? NTW : 1];
@@ -2047,7 +2104,7 @@ template <class T, int MODE, int NTW, int MT, bool FUSE, bool CS = false, bool L
 void launch8(const GemmArgs &g, dim3 grid, hipStream_t s)
 {
     // FUSE / LNV 2: + the row-sum array of row_stats_prologue; CS: + the [2][BN][2] channel-sum table
-    constexpr size_t lds = 3 * (64 * MT * 128 + 32 * NTW * 128) + ((FUSE || LNV == 2) ? 64 * MT * 8 : 0) + (CS ? 32 * NTW * 16 : 0);
+    constexpr size_t lds = 3 * (64 * MT * 128 + 32 * NTW * 128) + ((FUSE || LNV >= 2) ? 64 * MT * 8 : 0) + (CS ? 32 * NTW * 16 : 0);
     static_assert(lds <= 160 * 1024, "LDS ring");
     static gc::AttrOnce once;
     gc::ensure_dynamic_lds(once, (const void *)k_gemm8<T, MODE, NTW, MT, FUSE, CS, LEAN, LNV>, (int)lds);
@@ -2068,6 +2125,7 @@ inline bool ln_lean_consumer_of(const GemmArgs &g, int mode, int splits)
 template <class T, int NTW, int MT>
 void dispatch8ln_m(const GemmArgs &g, int lnv, bool lean, dim3 grid, hipStream_t s)
 {
+    if (lnv == 3) { if constexpr (NTW == 5) launch8<T, 3, 5, MT, false, false, false, 3>(g, grid, s); return; }
     if (lnv == 1) launch8<T, 3, NTW, MT, false, false, true, 1>(g, grid, s);
     else if (lean) launch8<T, 3, NTW, MT, false, false, true, 2>(g, grid, s);
     else launch8<T, 3, NTW, MT, false, false, false, 2>(g, grid, s);

@@ -28,7 +28,8 @@ class GemmDesc(C.Structure):
                 ("ln_row_stats", C.c_void_p), ("ln_row_stat_slots", C.c_int), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float),
                 ("out_row_stats", C.c_void_p), ("out_group_stats", C.c_void_p), ("gn_groups", C.c_int),
                 ("fp8", C.c_int), ("w_scale", C.c_void_p), ("a_scale", C.c_int),
-                ("kernel_variant", C.c_int), ("out_chan_parts", C.c_void_p), ("plan_rows", C.c_int64), ("out_fp8", C.c_int)]
+                ("kernel_variant", C.c_int), ("out_chan_parts", C.c_void_p), ("plan_rows", C.c_int64), ("out_fp8", C.c_int),
+                ("w_set_rows", C.c_int64), ("w_set_stride", C.c_int64), ("softmax_keys", C.c_int)]
 
 
 class AttnDesc(C.Structure):
@@ -61,6 +62,7 @@ class KernelOptions:
     two_streams: bool = True         # ControlNet || UNet encoder on two HIP streams inside a denoise step
     gn_parts: bool = True            # GroupNorm statistics from the producer's epilogue (per-channel partials, plain stores): the
                                      # stand-alone statistics + finalize launches disappear (1 launch per GroupNorm instead of 3)
+    text_fold: bool = True           # LayerNorm-folded blocks: attn2.to_q -> text attention -> attn2.to_out as two GEMMs (SDNet._text_fold; GC_TEXT_FOLD=0)
     cfg_share: bool = True           # CFG-shared prefix (sd.unet.AttnCtx.share): conv_in .. the first transformer block's self-attention computed for
                                      # ONE of the two identical CFG halves (bench: GC_CFG_SHARE=0 restores the duplicated computation)
     fp8_min_hw: int = 256            # fp8 path (weights.add_fp8_convs): smallest map, in pixels, whose resnet convolutions run on e4m3 -- 16 x 16 maps
@@ -105,7 +107,7 @@ def options_from_env(env=None) -> KernelOptions:
     a = (1 if on("GC_ATTN_SAFE", "0") else 0) | (2 if on("GC_ATTN_16", "0") else 0) | (int(e.get("GC_ATTN_V", "0")) << 2)
     return KernelOptions(gemm_variant=g, attn_variant=a, batch_invariant=on("GC_BATCH_INVARIANT", "0"),
                          fused_head=on("GC_FUSED_HEAD", "1"), fused_tail=on("GC_FUSED_TAIL", "1"), two_streams=on("GC_DN_STREAMS", "1"),
-                         gn_parts=on("GC_GN_PARTS", "1"), cfg_share=on("GC_CFG_SHARE", "1"),
+                         gn_parts=on("GC_GN_PARTS", "1"), cfg_share=on("GC_CFG_SHARE", "1"), text_fold=on("GC_TEXT_FOLD", "1"),
                          ablate=frozenset(x for x in e.get("GC_ABLATE", "").split(",") if x))
 
 
@@ -233,8 +235,10 @@ def _stats_args(d, ln, group_stats):
 
 def linear(x, w, bias=None, residual=None, act=0, geglu=False, out_f32=False, scale=1.0, rowvec=None, rows_per_batch=0,
            ld_rowvec=None, out=None, want_out=True, out_t=None, ldt=0, t_batch_stride=0, t_col0=0, out_cols=None,
-           ln=None, row_stats=None, group_stats=None, chan_parts=False, gn_groups=32):
+           ln=None, row_stats=None, group_stats=None, chan_parts=False, gn_groups=32, w_set_rows=0, softmax_keys=0):
     """x [..., K] (last dim contiguous, rows strided by x.stride(-2)) @ w[N,K]^T with fused epilogue.
+    w_set_rows > 0: w is [S, N, K] (bias / colsum [S, N]): rows [s w_set_rows, (s + 1) w_set_rows) use matrix s (lean LayerNorm-fold problems only);
+    softmax_keys > 0 (with ln): every 80-column block of a row is one head's scores, the output is their softmax over the first softmax_keys columns.
     chan_parts=True: returns (out, ChanParts | None) -- the per-channel partial sums of the output for a following GroupNorm (needs rows_per_batch);
     ln=(RowStats of x, colsum [N], eps): LayerNorm folded in (w carries gamma, bias carries W beta);
     row_stats: a RowStats() that receives the per-row (sum, sum^2) partials of the stored output;
@@ -242,12 +246,16 @@ def linear(x, w, bias=None, residual=None, act=0, geglu=False, out_f32=False, sc
     _gpu(x, w)
     K = x.shape[-1]
     M = x.numel() // K
-    N = w.shape[0]
+    N = w.shape[-2]
     lda = x.stride(-2) if x.dim() > 1 else K
     d = GemmDesc()
     d.dtype = _dt(x); d.mode = 0; d.M, d.N, d.K = M, N, K
     d.A = x.data_ptr(); d.lda = lda; d.W = w.data_ptr()
     d.bias = None if bias is None else bias.data_ptr()
+    if w_set_rows:
+        assert w.dim() == 3 and w.is_contiguous() and (bias is None or bias.shape == (w.shape[0], N)) and M == w.shape[0] * w_set_rows
+        d.w_set_rows = int(w_set_rows); d.w_set_stride = N * K
+    d.softmax_keys = int(softmax_keys)
     if rowvec is not None:
         d.rowvec = rowvec.data_ptr(); d.ld_rowvec = rowvec.stride(0) if ld_rowvec is None else ld_rowvec
     d.rows_per_batch = rows_per_batch

@@ -137,6 +137,8 @@ class SDNet:
         self.fused_head = ops.OPTIONS.fused_head
         # GroupNorm statistics as per-channel partials from the producing conv / linear / concat (ops.ChanParts travel in the `xs` slot)
         self.gn_parts = ops.OPTIONS.gn_parts
+        # text cross-attention of the LayerNorm-folded blocks as two GEMMs (SDNet._text_fold)
+        self.text_fold = ops.OPTIONS.text_fold
         self._arenas = {}
         self.arena = None
 
@@ -310,6 +312,45 @@ class SDNet:
             actx.text_kv[key] = weights_mod.tail_text_stream(k, vt, Lt, self.cfg["heads"])
         return actx.text_kv[key]
 
+    def _text_fold(self, t, ctx, actx: AttnCtx):
+        """The text cross-attention of transformer block `t` folded into two GEMM weight sets per CFG half g:
+             scores[m, (h, j)] = LN2(x)[m] . A_g[(h, j)],   A_g[(h, j)] = sum_d K_g[j, h D + d] Wq'[h D + d, :]      (Wq' carries gamma2 and log2(e) / sqrt(D))
+             out[m]            = softmax_h(scores)[m] . Bm_g^T + b_o + x[m],   Bm_g[n, (h, j)] = sum_d Wo[n, h D + d] V_g[j, h D + d]
+        i.e. attn2.to_q -> attention over the 77 text keys -> attn2.to_out is  GEMM (softmax-heads epilogue) -> GEMM: the attention launch is
+        gone and for C = 1280 both GEMMs shrink (640 score columns instead of 1 280 channels).  The text K / V^T are fixed per prompt, so the
+        products are formed ONCE per (prompt pair, block) -- by this library's GEMM with an fp32 output -- and rounded to the activation type.
+        Returns (A [2, 640, C], a [2, 640] fp32, colsum [2, 640] fp32, Bm [2, C, 640], b_o [2, C] fp32), or None when the block is not eligible."""
+        key = (actx.net, t, "fold")
+        if key in actx.text_kv:
+            return actx.text_kv[key]
+        w = self.w
+        heads = self.cfg["heads"]
+        k, vt, Lt = self._text_kv(t + ".attn2", ctx, actx)          # [2, Lt, C], [2, C, Lp]
+        res = None
+        if k.shape[0] == 2 and Lt <= 80 and heads == 8 and (t + ".attn2.to_q.colsum") in w and vt.shape[-1] >= 80:
+            Cc = k.shape[-1]
+            D = Cc // heads
+            wq, bq = w[t + ".attn2.to_q.weight"], w[t + ".attn2.to_q.bias"]
+            wo, bo = w[t + ".attn2.to_out.0.weight"], w[t + ".attn2.to_out.0.bias"]
+            dt, dev = k.dtype, k.device
+            A = torch.zeros(2, heads, 80, Cc, dtype=torch.float32, device=dev)
+            Bm = torch.zeros(2, Cc, heads, 80, dtype=torch.float32, device=dev)
+            for h in range(heads):
+                wqT = wq[h * D:(h + 1) * D, :].t().contiguous()                   # [C, D]: W operand of  K_h (Wq'_h)  (layout only)
+                woh = wo[:, h * D:(h + 1) * D]                                    # [C, D] view, row stride C
+                for g in range(2):
+                    A[g, h, :Lt] = ops.linear(k[g, :, h * D:(h + 1) * D], wqT, out_f32=True)                      # [Lt, C]
+                    vh = vt[g, h * D:(h + 1) * D, :80].t().contiguous()           # [80, D] (rows >= Lt are the V^T buffer's zero padding)
+                    Bm[g, :, h] = ops.linear(woh, vh, out_f32=True)                                              # [C, 80]
+            A = A.reshape(2, heads * 80, Cc).to(dt).contiguous()
+            Bm = Bm.reshape(2, Cc, heads * 80).to(dt).contiguous()
+            a = torch.zeros(2, heads, 80, dtype=torch.float32, device=dev)
+            a[:, :, :Lt] = (k.float() * bq).view(2, Lt, heads, D).sum(-1).transpose(1, 2)            # K_g b'  (b' = Wq beta2, prescaled)
+            res = (A, a.reshape(2, heads * 80).contiguous(), A.float().sum(-1).contiguous(), Bm,
+                   torch.stack([bo, bo]).float().contiguous(), Lt)
+        actx.text_kv[key] = res
+        return res
+
     def tail_eligible(self, p, ctx) -> bool:
         """static part of the fused-tail predicate for transformer block `p` (the shape part is checked per call)"""
         return bool(self.fused_tail and (p + ".tail.a") in self.w and (p + ".transformer_blocks.0.attn1.to_qkv.colsum") not in self.w and not self.fuse_stats
@@ -361,18 +402,31 @@ class SDNet:
             return out.view(B, H, W_, Cc), None
         rs = ops.RowStats() if fold else None
         h = ops.linear(o, w[t + ".attn1.to_out.0.weight"], w[t + ".attn1.to_out.0.bias"], residual=h, row_stats=rs)
-        if fold:
+        tf = None
+        if fold and self.text_fold and not ops.BATCH_INVARIANT:
+            Mh = (B // 2) * H * W_
+            if B % 2 == 0 and any(Mh % (64 * mt) == 0 for mt in (2, 3, 4)):
+                tf = self._text_fold(t, ctx, actx)
+        if tf is not None:
+            # text cross-attention as two GEMMs (weight set per CFG half): scores + softmax per head in the first one's epilogue (norm2 folded in),
+            # probabilities x (Wo V^T) + bias + residual in the second, which also leaves the row partials of norm3
+            A, a, acs, Bm, bo2, Lt = tf
+            pr = ops.linear(h, A, a, ln=(rs, acs, 1e-5), w_set_rows=Mh, softmax_keys=Lt)
+            rs = ops.RowStats()
+            h = ops.linear(pr, Bm, bo2, residual=h, row_stats=rs, w_set_rows=Mh)
+        elif fold:
             q = ops.linear(h, w[t + ".attn2.to_q.weight"], w[t + ".attn2.to_q.bias"], ln=(rs, w[t + ".attn2.to_q.colsum"], 1e-5))
         elif q8 & 2:
             q = ops.linear_fp8(ops.layernorm_fp8(h, w[t + ".norm2.weight"], w[t + ".norm2.bias"], a_scale=self.fp8_ln_scale),
                                w[t + ".attn2.to_q.w8"], w[t + ".attn2.to_q.w8_scale"], h.dtype, a_scale=self.fp8_ln_scale)
         else:
             q = ops.linear(ops.layernorm(h, w[t + ".norm2.weight"], w[t + ".norm2.bias"]), w[t + ".attn2.to_q.weight"])
-        k, vt, Lt = self._text_kv(t + ".attn2", ctx, actx)
-        # ctx holds one text row per CFG half ([negative || positive]); frame b reads row b // f (kind -2)
-        o = ops.attention(q, k, vt, self.cfg["heads"], [(-2, 1.0)], B // k.shape[0], Lk=Lt, q_prescaled=self.qpre)
-        rs = ops.RowStats() if fold else None
-        h = ops.linear(o, w[t + ".attn2.to_out.0.weight"], w[t + ".attn2.to_out.0.bias"], residual=h, row_stats=rs)
+        if tf is None:
+            k, vt, Lt = self._text_kv(t + ".attn2", ctx, actx)
+            # ctx holds one text row per CFG half ([negative || positive]); frame b reads row b // f (kind -2)
+            o = ops.attention(q, k, vt, self.cfg["heads"], [(-2, 1.0)], B // k.shape[0], Lk=Lt, q_prescaled=self.qpre)
+            rs = ops.RowStats() if fold else None
+            h = ops.linear(o, w[t + ".attn2.to_out.0.weight"], w[t + ".attn2.to_out.0.bias"], residual=h, row_stats=rs)
         if fold:
             ff = ops.linear(h, w[t + ".ff.net.0.proj.weight"], w[t + ".ff.net.0.proj.bias"], geglu=True,
                             ln=(rs, w[t + ".ff.net.0.proj.colsum"], 1e-5))

@@ -356,6 +356,15 @@ typedef struct gc_gemm_desc {
     int out_fp8;               /* fp8 linears only: 0 = output in `dtype`; else an E8M0 byte: `out` receives e4m3 BYTES [M][ldc] of value * 2^(127 - out_fp8), */
                                /* saturated to +-448 -- the activation operand of a following fp8 GEMM with a_scale = out_fp8 (GEGLU hidden ->    */
                                /* FF down projection: the feed-forward of /root/reference/gaussctrl/utils.py:121-131's blocks stays in e4m3)       */
+    /* Weight SETS and the softmax-heads epilogue (round 5: the text cross-attention of a transformer block folded into two GEMMs -- scores =
+     * LN(h) (K_text Wq)^T -> softmax per head -> P (Wo V_text^T)^T + b + h; diffusers BasicTransformerBlock.attn2 behind
+     * /root/reference/gaussctrl/gc_pipeline.py:209-219).  w_set_rows > 0: rows [s w_set_rows, (s + 1) w_set_rows) use weight matrix s = W + s w_set_stride
+     * elements, bias + s N, ln_colsum + s N (one set per CFG half: the text differs); only on the lean LayerNorm-fold kernels (a K % 64 == 0 linear with
+     * ln_row_stats or out_row_stats), w_set_rows a multiple of 64, 128, 192 or 256 (the library picks a row tile that divides it).
+     * softmax_keys > 0 (with ln_row_stats; N % 80 == 0): every 80-column block of a row is one head's scores against <= 80 keys, of which the first
+     * softmax_keys are real; `out` receives softmax over them (scores pre-scaled by log2(e) / sqrt(D)), zeros in the padding columns. */
+    int64_t w_set_rows, w_set_stride;
+    int softmax_keys;
 } gc_gemm_desc;
 size_t gc_dn_gemm_workspace_bytes(const gc_gemm_desc *desc);
 int gc_dn_gemm_row_stat_slots(const gc_gemm_desc *desc);   /* column slabs per row this problem writes to out_row_stats (with desc->workspace set) */

@@ -91,12 +91,12 @@ def test_descriptor_structs_match_the_header(tmp_path):
     from gaussctrl_amd.sd import ops
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "gaussctrl_hip.h"\n'
-                   'int main(void) { printf("%zu %zu %zu %zu\\n", sizeof(gc_gemm_desc), offsetof(gc_gemm_desc, out_fp8), sizeof(gc_attn_desc),'
+                   'int main(void) { printf("%zu %zu %zu %zu\\n", sizeof(gc_gemm_desc), offsetof(gc_gemm_desc, softmax_keys), sizeof(gc_attn_desc),'
                    ' offsetof(gc_attn_desc, workspace_bytes)); return 0; }\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
-    assert got == [ctypes.sizeof(ops.GemmDesc), ops.GemmDesc.out_fp8.offset, ctypes.sizeof(ops.AttnDesc), ops.AttnDesc.workspace_bytes.offset]
+    assert got == [ctypes.sizeof(ops.GemmDesc), ops.GemmDesc.softmax_keys.offset, ctypes.sizeof(ops.AttnDesc), ops.AttnDesc.workspace_bytes.offset]
 
 
 def test_fp8_linear_copies_of_transformer_weights():

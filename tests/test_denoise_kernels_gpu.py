@@ -462,6 +462,64 @@ def test_qkv_transposed_v_with_layernorm_folded(dt, B, L, C, variant, monkeypatc
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("B,L,C", [(6, 1024, 640), (6, 256, 1280), (6, 64, 1280), (8, 256, 1280), (2, 1024, 640)])
+def test_text_cross_attention_folded_into_two_gemms(dt, B, L, C):
+    """attn2 of a LayerNorm-folded transformer block -- norm2 -> to_q -> softmax(q K_text^T / sqrt(D)) V_text -> to_out + bias + residual (diffusers
+    BasicTransformerBlock.attn2 behind /root/reference/gaussctrl/gc_pipeline.py:209-219; one text row per CFG half) -- as TWO GEMMs with one weight
+    set per half (SDNet._text_fold): scores = LN(x) (K Wq)^T with the per-head softmax in the epilogue (k_gemm8<.., LNV = 3>), then P (Wo V^T)^T +
+    b + x.  Reference: the unfolded chain in float64 on the same rounded x, text K / V^T and weights.  The fold replaces the bf16 rounding of q and
+    of the attention output by ONE rounding of the folded matrices and of P: bar = 4 output roundings (as the attention kernels' tests)."""
+    import math
+    from gaussctrl_amd.sd import ops
+    from gaussctrl_amd.sd.unet import AttnCtx, SDNet
+    from gaussctrl_amd.sd.weights import LOG2E, _fold_ln
+    heads, Lt, Dc = 8, 77, 768
+    D = C // heads
+    t = "blk"
+    g = torch.Generator().manual_seed(4)
+    r = lambda *shp, sc=1.0: (torch.randn(*shp, generator=g) * sc).to(DEV)
+    wq32, wk, wv, wo = r(C, C, sc=C ** -0.5), r(C, Dc, sc=Dc ** -0.5).to(dt), r(C, Dc, sc=Dc ** -0.5).to(dt), r(C, C, sc=C ** -0.5).to(dt)
+    bo = r(C, sc=0.2); gamma = 1 + 0.2 * r(C); beta = 0.3 * r(C)
+    w = {}
+    _fold_ln(w, t + ".attn2.to_q", wq32 * (D ** -0.5 * LOG2E), None, gamma, beta, dt)          # W' = Wq diag(gamma) (prescaled), b' = Wq beta, colsum
+    w.update({t + ".attn2.to_k.weight": wk, t + ".attn2.to_v.weight": wv, t + ".attn2.to_out.0.weight": wo, t + ".attn2.to_out.0.bias": bo})
+    net = object.__new__(SDNet)
+    net.w, net.cfg = w, {"heads": heads}
+    ctx = r(2, Lt, Dc).to(dt)
+    actx = AttnCtx("xview", 0.6, B // 2, {}, None, "unet")
+    tf = net._text_fold(t, ctx, actx)
+    assert tf is not None
+    A, a, acs, Bm, bo2, lt = tf
+    assert A.shape == (2, 640, C) and Bm.shape == (2, C, 640) and lt == Lt
+    # producer of x: a GEMM + residual that leaves the row partials, as attn1.to_out does
+    x0 = _rand((B, L, 256), dt, 1.0, 1); w0 = _rand((C, 256), dt, 256 ** -0.5 * 1.5, 5); res = _rand((B, L, C), dt, 0.8, 9)
+    rs = ops.RowStats()
+    x = ops.linear(x0, w0, torch.full((C,), 0.3, device=DEV), residual=res, row_stats=rs)
+    Mh = (B // 2) * L
+    pr = ops.linear(x, A, a, ln=(rs, acs, 1e-5), w_set_rows=Mh, softmax_keys=Lt)
+    rs3 = ops.RowStats()
+    out = ops.linear(pr, Bm, bo2, residual=x, row_stats=rs3, w_set_rows=Mh)
+    # float64 reference of the unfolded chain
+    k, vt, _ = net._text_kv(t + ".attn2", ctx, actx)                       # the rounded text K [2, Lt, C] / V^T [2, C, Lp] the product uses
+    z = F.layer_norm(x.double(), (C,), None, None, 1e-5)
+    q = z @ w[t + ".attn2.to_q.weight"].double().T + w[t + ".attn2.to_q.bias"].double()            # carries log2(e) / sqrt(D)
+    q = q.view(2, B // 2, L, heads, D)
+    kk = k.double().view(2, Lt, heads, D); vv = vt.double()[:, :, :Lt].transpose(1, 2).reshape(2, Lt, heads, D)
+    sc = torch.einsum("gblhd,gjhd->gblhj", q, kk) * math.log(2.0)          # natural-log scores
+    p = torch.softmax(sc, -1)
+    o = torch.einsum("gblhj,gjhd->gblhd", p, vv).reshape(B, L, C)
+    ref = o @ wo.double().T + bo.double() + x.double()
+    # the probabilities themselves: rows sum to one over the 77 keys, zero in the padding columns
+    prd = pr.double().view(B, L, heads, 80)
+    assert float(prd[..., Lt:].abs().max()) == 0.0
+    within("softmax rows sum to 1", float((prd[..., :Lt].sum(-1) - 1).abs().max()), 4 * EPS[dt])
+    within("probabilities vs float64", float((prd[..., :Lt] - p.reshape(B, L, heads, Lt)).abs().max()), 3 * EPS[dt])
+    _close(out, ref, dt, extra=4.0)
+    tot = rs3.buf.double().sum(0)
+    assert float((tot[:, 0] - out.double().reshape(-1, C).sum(1)).abs().max()) <= 1e-4 * float(out.double().abs().reshape(-1, C).sum(1).max())
+
+
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("B,HW,C,G", [(2, 256, 320, 32), (3, 64, 1280, 32), (2, 112, 2560, 32), (6, 4096, 320, 32), (2, 36, 960, 32), (1, 16, 1920, 32)])
 def test_groupnorm_apply_from_statistics(dt, B, HW, C, G):
     from gaussctrl_amd.sd import ops

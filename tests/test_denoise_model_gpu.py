@@ -101,3 +101,40 @@ def test_vae_decode_matches_oracle():
     err = float((got.cpu() - ref).abs().max())
     print(f"vae decode max abs err {err:.3e}")
     within("err", err, 1.0 / 255.0)  # images in [0,1]; f16 activations through 30 convs
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_cfg_shared_prefix_equals_duplicated_computation(sd15, dt, monkeypatch):
+    """KernelOptions.cfg_share (sd.unet.AttnCtx.share, default on): conv_in .. the first transformer block's cross-view self-attention run for ONE
+    of the two identical CFG halves ([uncond ; cond] copies of the same latents: cat([latents] * 2) in the diffusers pipeline the reference
+    calls, /root/reference/gaussctrl/gc_pipeline.py:209-219).  Against the duplicated computation (cfg_share = False): BIT-identical latents and
+    BIT-identical reference bank in batch-invariant mode (full SD1.5 widths, 16 x 16 latents, 2 steps, in-batch references AND bank + chunk);
+    in the default planning the two differ by accumulation-order noise only (inside the dtype's bar)."""
+    import dataclasses
+    sd, uw, cw = sd15
+    from gaussctrl_amd.sd import ops
+    from gaussctrl_amd.sd.pipeline import DenoisePipeline
+    from gaussctrl_amd.sd.weights import prepare
+    lat, disp, cn, cp = _inputs(6, 16)
+    to = lambda t: t.to(DEV)
+    pipe = DenoisePipeline(prepare(uw, dt, DEV, heads=8, fold_ln=2), prepare(cw, dt, DEV, heads=8, fold_ln=2), None, 20, 5.0)
+    keep = ops.OPTIONS
+
+    def run(share, invariant):
+        monkeypatch.setattr(ops, "OPTIONS", dataclasses.replace(keep, cfg_share=share))
+        monkeypatch.setattr(ops, "BATCH_INVARIANT", invariant)
+        a = pipe.edit_chunk(to(lat), to(disp), to(cn), to(cp), steps=2)
+        bank = pipe.build_ref_bank(to(lat[:4]), to(disp[:4]), to(cn), to(cp), steps=2)
+        b = pipe.edit_chunk_cached(to(lat[4:]), to(disp[4:]), to(cn), to(cp), bank, steps=2)
+        return a, b, bank
+    a1, b1, k1 = run(True, True)
+    a0, b0, k0 = run(False, True)
+    assert torch.equal(a1, a0) and torch.equal(b1, b0)
+    assert set(k1.store) == set(k0.store)
+    for key in k0.store:
+        assert k1.store[key][0].shape == k0.store[key][0].shape and k1.store[key][0].stride(1) == k0.store[key][0].stride(1), key
+        assert torch.equal(k1.store[key][0], k0.store[key][0]) and torch.equal(k1.store[key][1], k0.store[key][1]), key
+    a1, b1, _ = run(True, False)
+    a0, b0, _ = run(False, False)
+    within("shared vs duplicated, in-batch (default planning)", _rel(a1, a0), TOL[dt])
+    within("shared vs duplicated, bank + chunk (default planning)", _rel(b1, b0), TOL[dt])
