@@ -62,6 +62,8 @@ class KernelOptions:
     two_streams: bool = True         # ControlNet || UNet encoder on two HIP streams inside a denoise step
     gn_parts: bool = True            # GroupNorm statistics from the producer's epilogue (per-channel partials, plain stores): the
                                      # stand-alone statistics + finalize launches disappear (1 launch per GroupNorm instead of 3)
+    q_only: bool = True              # ControlNet blocks against a cached bank (self weight 0): project Q only, not Q | K | V (GC_Q_ONLY=0)
+    ffout_merge: bool = True         # LayerNorm-folded blocks: feed-forward down projection + proj_out as ONE GEMM over [ff | h] (GC_FFOUT_MERGE=0)
     text_fold: bool = True           # LayerNorm-folded blocks: attn2.to_q -> text attention -> attn2.to_out as two GEMMs (SDNet._text_fold; GC_TEXT_FOLD=0)
     cfg_share: bool = True           # CFG-shared prefix (sd.unet.AttnCtx.share): conv_in .. the first transformer block's self-attention computed for
                                      # ONE of the two identical CFG halves (bench: GC_CFG_SHARE=0 restores the duplicated computation)
@@ -107,7 +109,7 @@ def options_from_env(env=None) -> KernelOptions:
     a = (1 if on("GC_ATTN_SAFE", "0") else 0) | (2 if on("GC_ATTN_16", "0") else 0) | (int(e.get("GC_ATTN_V", "0")) << 2)
     return KernelOptions(gemm_variant=g, attn_variant=a, batch_invariant=on("GC_BATCH_INVARIANT", "0"),
                          fused_head=on("GC_FUSED_HEAD", "1"), fused_tail=on("GC_FUSED_TAIL", "1"), two_streams=on("GC_DN_STREAMS", "1"),
-                         gn_parts=on("GC_GN_PARTS", "1"), cfg_share=on("GC_CFG_SHARE", "1"), text_fold=on("GC_TEXT_FOLD", "1"),
+                         gn_parts=on("GC_GN_PARTS", "1"), cfg_share=on("GC_CFG_SHARE", "1"), text_fold=on("GC_TEXT_FOLD", "1"), ffout_merge=on("GC_FFOUT_MERGE", "1"), q_only=on("GC_Q_ONLY", "1"),
                          ablate=frozenset(x for x in e.get("GC_ABLATE", "").split(",") if x))
 
 

@@ -139,6 +139,7 @@ class SDNet:
         self.gn_parts = ops.OPTIONS.gn_parts
         # text cross-attention of the LayerNorm-folded blocks as two GEMMs (SDNet._text_fold)
         self.text_fold = ops.OPTIONS.text_fold
+        self.ffout_merge = ops.OPTIONS.ffout_merge     # ... and FF-down + proj_out as one GEMM over [ff | h]
         self._arenas = {}
         self.arena = None
 
@@ -250,6 +251,19 @@ class SDNet:
         B, L, Cc = n.shape
         Lp = (L + 7) // 8 * 8
         adt = dt or n.dtype
+        bank = actx.bank
+        if (dt is None and actx.mode == "xview" and actx.coeff == 0.0 and bank is not None and bank.mode == "use" and
+                getattr(bank, "shard", None) is None and ops.OPTIONS.q_only):
+            # ControlNet (self_attn_coeff = 0, utils.py:95-102: the self term has weight 0) against a cached reference bank: the frame's own K / V^T
+            # are never read -- project Q only (the first C rows of the fused Q | K | V weight), a third of the GEMM
+            kr, vtr = bank.store[bank.key((actx.net, p))]
+            wq = w[p + ".to_qkv.weight"][:Cc]
+            if ln is not None:
+                q = ops.linear(n, wq, w[p + ".to_qkv.bias"][:Cc], ln=(ln[0], ln[1][:Cc], ln[2]))
+            else:
+                q = ops.linear(n, wq)
+            sets = [(r, 1.0 / 4.0) for r in range(4)]
+            return ops.attention(q, kr, vtr, heads, sets, actx.f, Lk=L, kref=kr, vtref=vtr, ref_fph=kr.shape[0] // 2, q_prescaled=self.qpre)
         vt = torch.zeros(B, Cc, Lp, dtype=adt, device=n.device) if Lp != L else torch.empty(B, Cc, Lp, dtype=adt, device=n.device)
         # one GEMM for Q | K | V: columns [0,2C) -> qk [B,L,2C], columns [2C,3C) -> V^T [B,C,Lp]
         if dt is not None:
@@ -402,6 +416,12 @@ class SDNet:
             return out.view(B, H, W_, Cc), None
         rs = ops.RowStats() if fold else None
         h = ops.linear(o, w[t + ".attn1.to_out.0.weight"], w[t + ".attn1.to_out.0.bias"], residual=h, row_stats=rs)
+        # feed-forward down projection + proj_out as ONE GEMM over [ff | h] (weights.prepare: ffout.weight = [Wp Wd | Wp]): the residual stream after
+        # attn2 and the GEGLU hidden are written side by side into one [M, 5 C] buffer (ldc = lda = 5 C), proj_out's launch disappears
+        fb = None
+        if fold and self.ffout_merge and (t + ".ffout.weight") in w and not q8:
+            fb = torch.empty(B, H * W_, 5 * Cc, dtype=h.dtype, device=h.device)
+        h_out = None if fb is None else fb[..., 4 * Cc:]
         tf = None
         if fold and self.text_fold and not ops.BATCH_INVARIANT:
             Mh = (B // 2) * H * W_
@@ -413,7 +433,7 @@ class SDNet:
             A, a, acs, Bm, bo2, Lt = tf
             pr = ops.linear(h, A, a, ln=(rs, acs, 1e-5), w_set_rows=Mh, softmax_keys=Lt)
             rs = ops.RowStats()
-            h = ops.linear(pr, Bm, bo2, residual=h, row_stats=rs, w_set_rows=Mh)
+            h = ops.linear(pr, Bm, bo2, residual=h, row_stats=rs, w_set_rows=Mh, out=h_out)
         elif fold:
             q = ops.linear(h, w[t + ".attn2.to_q.weight"], w[t + ".attn2.to_q.bias"], ln=(rs, w[t + ".attn2.to_q.colsum"], 1e-5))
         elif q8 & 2:
@@ -426,7 +446,18 @@ class SDNet:
             # ctx holds one text row per CFG half ([negative || positive]); frame b reads row b // f (kind -2)
             o = ops.attention(q, k, vt, self.cfg["heads"], [(-2, 1.0)], B // k.shape[0], Lk=Lt, q_prescaled=self.qpre)
             rs = ops.RowStats() if fold else None
-            h = ops.linear(o, w[t + ".attn2.to_out.0.weight"], w[t + ".attn2.to_out.0.bias"], residual=h, row_stats=rs)
+            h = ops.linear(o, w[t + ".attn2.to_out.0.weight"], w[t + ".attn2.to_out.0.bias"], residual=h, row_stats=rs, out=h_out)
+        if fb is not None:
+            ops.linear(h, w[t + ".ff.net.0.proj.weight"], w[t + ".ff.net.0.proj.bias"], geglu=True,
+                       ln=(rs, w[t + ".ff.net.0.proj.colsum"], 1e-5), out=fb[..., :4 * Cc])
+            os_ = self._cs(B, Cc, H * W_)
+            if self.gn_parts and os_ is None:
+                out, os_ = ops.linear(fb, w[t + ".ffout.weight"], w[t + ".ffout.bias"], residual=x.view(B, H * W_, Cc), rows_per_batch=H * W_,
+                                      chan_parts=True)
+                return out.view(B, H, W_, Cc), os_
+            out = ops.linear(fb, w[t + ".ffout.weight"], w[t + ".ffout.bias"], residual=x.view(B, H * W_, Cc), rows_per_batch=H * W_,
+                             group_stats=os_)
+            return out.view(B, H, W_, Cc), os_
         if fold:
             ff = ops.linear(h, w[t + ".ff.net.0.proj.weight"], w[t + ".ff.net.0.proj.bias"], geglu=True,
                             ln=(rs, w[t + ".ff.net.0.proj.colsum"], 1e-5))

@@ -185,6 +185,15 @@ def prepare(sd: dict, dtype, device, heads=None, fold_ln=False) -> dict:
                 _fold_ln(out, t + "attn2.to_q", q2, None, out[t + "norm2.weight"], out[t + "norm2.bias"], dtype)
                 ff = sd[t + "ff.net.0.proj.weight"].to(device).float()
                 _fold_ln(out, t + "ff.net.0.proj", ff, out[t + "ff.net.0.proj.bias"], out[t + "norm3.weight"], out[t + "norm3.bias"], dtype)
+                # feed-forward down projection and the block's proj_out as ONE GEMM over [ff | h] (K = 5 C):
+                #   out = (ff Wd^T + bd + h) Wp^T + bp + x  =  [ff | h] [Wp Wd | Wp]^T + (Wp bd + bp) + x
+                # (constant folding of the checkpoint's weights, in fp32 from the fp32 masters, ONE rounding to the activation type)
+                pfx = t[:-len("transformer_blocks.0.")]
+                wp = sd[pfx + "proj_out.weight"].to(device).float()
+                wp = wp.reshape(wp.shape[0], wp.shape[1])
+                wd = sd[t + "ff.net.2.weight"].to(device).float()
+                out[t + "ffout.weight"] = torch.cat([wp @ wd, wp], 1).to(dtype).contiguous()                    # [C, 5 C]
+                out[t + "ffout.bias"] = (wp @ sd[t + "ff.net.2.bias"].to(device).float() + sd[pfx + "proj_out.bias"].to(device).float()).contiguous()
             else:
                 out[a + "to_qkv.weight"] = torch.cat([out[a + "to_q.weight"], out[a + "to_k.weight"], out[a + "to_v.weight"]], 0).contiguous()
     names = sorted(k[:-len(".time_emb_proj.weight")] for k in out if k.endswith(".time_emb_proj.weight"))
