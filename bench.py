@@ -75,8 +75,13 @@ class GemmProfiler:
 
     def __init__(self, dt="BF16"):
         self.rec = []
+        self.shapes = []            # (op, M, N, K, flags, start, end) of every linear / conv launch (GC_BENCH_SHAPES=1: per-shape table on stderr)
         self.dt = dt
         self.true_cin = {}          # e4m3 conv weight pointer -> un-padded input channels (the fp8 convs pad Cin to 128)
+
+    @staticmethod
+    def _given(v):
+        return v is not None and v is not False and not (isinstance(v, (int, float)) and v == 0)
 
     def wrap(self, ops):
         self._lin, self._conv, self._att = ops.linear, ops.conv3x3, ops.attention
@@ -132,6 +137,7 @@ class GemmProfiler:
             N = w.shape[-2]                                                                   # ([S, N, K] weight sets: the text-attention fold)
             ntw = 5 if ((N % 160 == 0 and N % 128 != 0 and not k.get("geglu", False)) or k.get("softmax_keys", 0)) else 4      # mirrors plan() in dn_gemm.hip
             prof.rec.append((f"gemm<{prof.dt},linear,BN={32 * ntw}>", 2.0 * (x.numel() // K) * N * K, s, e))
+            prof.shapes.append(("linear", x.numel() // K, N, K, "+".join(f for f in ("geglu", "ln", "residual", "out_t", "softmax_keys", "chan_parts") if prof._given(k.get(f))), s, e))
             return out
 
         def conv(x, w, *a, **k):
@@ -144,6 +150,7 @@ class GemmProfiler:
             mode = 2 if x.shape[-1] % 64 == 0 else 1
             o = out[0] if isinstance(out, tuple) else out              # (out, ChanParts) when the producer statistics were asked for
             prof.rec.append((f"gemm<{prof.dt},conv3x3{'' if mode == 2 else ' generic'},BN={32 * ntw}>", 2.0 * (o.numel() // o.shape[-1]) * N * w.shape[1], s, e))
+            prof.shapes.append(("conv3x3", o.numel() // o.shape[-1], N, w.shape[1], f"hw={o.shape[1]}x{o.shape[2]}" if o.dim() == 4 else "", s, e))
             return out
 
         def tail(o, h, x, *a, **k):      # level-0 block after the attention, one launch: 2 * rows * 1.6896 M weights (incl. the 77-key text attention)
@@ -769,6 +776,12 @@ def denoise_roofline(args, dtype_name, pipe, sdops, z0, ctx_neg, ctx_pos, bank, 
         prof.unwrap(sdops)
         pipe.two_streams = two
     sm = prof.summary()
+    if os.environ.get("GC_BENCH_SHAPES"):
+        tab = {}
+        for op, M, N, K, fl, s_, e_ in prof.shapes:
+            t = tab.setdefault((op, M, N, K, fl), [0, 0.0]); t[0] += 1; t[1] += s_.elapsed_time(e_)
+        for (op, M, N, K, fl), (n, ms) in sorted(tab.items(), key=lambda kv: -kv[1][1]):
+            print(f"# shape {op:8s} M={M:6d} N={N:5d} K={K:5d} {fl:40s} x{n:4d} {ms:8.2f} ms {ms / n * 1e3:7.1f} us {2.0 * M * N * K * n / ms / 1e9:7.1f} TF/s", file=sys.stderr)
     is8 = lambda k: k.startswith("gemm8q<e4m3")
     peak_of = lambda k: PEAK_E4M3_TFLOPS if is8(k) else PEAK_TFLOPS[dtype_name]
     cand = {k: v for k, v in sm.items() if is8(k)} if fp8_class else sm

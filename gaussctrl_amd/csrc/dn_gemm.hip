@@ -34,6 +34,35 @@ int choose_mt(int64_t M, int64_t N, int ntw, bool forced)
     return best;
 }
 
+// Column-panel width of the tile order (tile_coords in dn_gemm_kernels.h).  The `conc` workgroups an XCD runs together execute a contiguous run of
+// logical tiles = a patch of rows x cols tiles; over the fabric the XCD fetches rows A panels (bm rows x the k range; a 3 x 3 conv's im2col panel is
+// 9 x its real bytes, the rest are L2 hits) and cols W panels (bn rows x the k range).  Pick the width with the fewest bytes; ties keep whole rows.
+int choose_pw(int64_t nbm, int64_t nbn, int64_t total_wgs, int conc, int64_t bm, int64_t bn, bool conv)
+{
+    int64_t r = total_wgs / 8 < 1 ? 1 : total_wgs / 8;
+    if (r > conc) r = conc;
+    const int64_t tiles = nbm * nbn;
+    if (r >= tiles) return 0;                                   // an XCD covers a whole slice anyway
+    const int64_t ca = conv ? bm : 9 * bm, cw = 9 * bn;         // panel bytes up to a common factor (x 9: integers)
+    int best = 0;
+    int64_t best_cost = -1;
+    for (int64_t pw = nbn; pw >= 1; --pw) {
+        const int64_t per = nbm * pw;
+        const int64_t cols = std::min<int64_t>(nbn, pw * ((r + per - 1) / per)), rows = std::min<int64_t>(nbm, (r + pw - 1) / pw);
+        const int64_t cost = rows * ca + cols * cw;
+        if (best_cost < 0 || cost < best_cost) { best = pw == nbn ? 0 : (int)pw; best_cost = cost; }
+    }
+    return best;
+}
+
+// kernel_variant bits 16..23: n + 1 forces panel width n (0 = whole rows) -- experiments / the bit-identity test
+int pw_of(const gc_gemm_desc *d, int64_t nbm, int64_t nbn, int64_t total_wgs, int conc, int64_t bm, int64_t bn)
+{
+    const int f = (d->kernel_variant >> 16) & 0xff;
+    if (f) return f - 1;
+    return choose_pw(nbm, nbn, total_wgs, conc, bm, bn, d->mode == 1);
+}
+
 void plan(const gc_gemm_desc *d, int *ntw, int *splits, int *tps)
 {
     // GEGLU pairs tiles (nt, nt+1) inside a wave: needs an even number of n-tiles per wave
@@ -123,7 +152,7 @@ int select(const gc_gemm_desc *d, Sel *o, bool want_parts)
     const int kv = d->kernel_variant;
     const int force_mt = kv & 7;                                   // 2 | 3 | 4: force the 8-wave kernel's m-tiles per wave
     const int use8 = (kv & 0x10) ? 0 : ((kv & 0x20) ? 2 : 1);      // 0x10: 4-wave kernel only; 0x20: force the 8-wave kernel
-    const int convsplit = (kv & 0x40) ? 0 : ((kv & 0x80) ? 2 : 1); // 0x40: no k-slices for 16x16-map convs; 0x80: also slice the 8x8-map convs
+    const int convsplit = (kv & 0x40) ? 0 : ((kv & 0x80) ? 1 : 2); // 0x40: no k-slices for part-filled conv grids; 0x80: not for the small ones (8x8 maps, stride-2 convs: 4-wave split-K kernel, the round-2..4 choice)
     o->mode = mode; o->ntw = ntw; o->splits = splits; o->tps = tps; o->mt8 = 0;
     // 8-wave LDS-DMA kernel (one workgroup per CU, software-pipelined): workgroup tile (64 MT) x (32 NTW).
     if (use8 && d->zeros) {
@@ -134,7 +163,8 @@ int select(const gc_gemm_desc *d, Sel *o, bool want_parts)
         if (mt && !force_mt && Msel != d->M) mt = choose_mt(d->M, d->N, ntw, true);
         const int64_t tiles8 = ((Msel + 127) / 128) * nbn;
         // long-K problems with a part-filled grid (16x16-map convs, the 5120 -> 1280 FF projection): k-slices of >= 12 k-tiles
-        // fill the CUs; variant 0x40 sends such convs back to the 4-wave split-K kernel, 0x80 also takes the 8x8-map convs
+        // fill the CUs, the small grids too (M = 384: 30 tiles x 8 slices, every XCD owns one slice -- round 5: 34.4 -> 25.3 us per 8 x 8-map conv,
+        // profiles/r05_conv8x8_slices_ab.txt); variant 0x40 sends such convs back to the 4-wave split-K kernel, 0x80 only the small ones
         const bool small = tiles8 < 96;
         if (!mt && mode == 0 && !force_mt) mt = 2;       // small linears: the 8-wave kernel's fill + epilogue is the shorter one (12.6 vs 20.9 us at M = 384)
         // part-filled single-round grids of short-K linears: 64-row tiles, two workgroups per CU (all resident when <= 512 tiles)
@@ -152,9 +182,12 @@ int select(const gc_gemm_desc *d, Sel *o, bool want_parts)
         const bool want_split = !force_mt && use8 != 2 && !d->geglu && d->w_set_rows == 0 && d->softmax_keys == 0 && d->workspace && tiles8 <= 128 && (mode == 0 ? (!small || nk_host >= 24) : (convsplit >= (small ? 2 : 1)));
         int s8 = 1, tps8 = nk_host;
         if (want_split) {
-            s8 = (int)std::min<int64_t>(small ? (256 + tiles8 - 1) / tiles8 : 256 / tiles8, nk_host / 12);
+            const int smt = (kv >> 24) & 7;                                  // experiments: m-tiles per wave of the k-sliced problems (default 2)
+            const int mts = (smt >= 2 && smt <= 4) ? smt : 2;
+            const int64_t tiles_s = ((Msel + 64 * mts - 1) / (64 * mts)) * nbn;
+            s8 = (int)std::min<int64_t>(std::max<int64_t>(256 / tiles_s, 2), nk_host / 12);         // one round: tiles x slices <= 256 workgroups
             if (s8 >= 2 && d->workspace_bytes >= sizeof(float) * (size_t)s8 * (size_t)d->M * (size_t)d->N) {
-                mt = 2; tps8 = (nk_host + s8 - 1) / s8; s8 = (nk_host + tps8 - 1) / tps8;
+                mt = mts; tps8 = (nk_host + s8 - 1) / s8; s8 = (nk_host + tps8 - 1) / tps8;
             } else s8 = 1;
         }
         if (splits > 1 && s8 == 1 && !force_mt && use8 != 2) mt = 0;      // otherwise: 4-wave split-K kernel as planned
@@ -304,6 +337,7 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
         GC_REQUIRE(!d->out_chan_parts || q.splits > 1 || (d->mode == 1 && !fuse_of(g)), "fp8: channel partials come from k-sliced problems and fast convs");
         const int64_t nbn_q = (d->N + 32 * ntw - 1) / (32 * ntw), nbm_q = (d->M + 64 * mt - 1) / (64 * mt);
         const dim3 gq((unsigned)(nbm_q * nbn_q), (unsigned)q.splits);
+        g.pw = pw_of(d, nbm_q, nbn_q, nbm_q * nbn_q * q.splits, 32, 64 * mt, 32 * ntw);
         dn_gemm_launch_fp8(g, d->dtype, d->mode == 1 ? 2 : 3, ntw, mt, gq, s);
         if (q.splits > 1) { if (g.chan_parts) dn_gemm_launch_splitk_epilogue_cs(g, d->dtype, s); else dn_gemm_launch_splitk_epilogue(g, d->dtype, s); }
         return gc::check_launch("gc_dn_gemm(fp8)");
@@ -326,6 +360,7 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
     if (sel.mt8) {
         const int64_t nbm8 = (d->M + 64 * sel.mt8 - 1) / (64 * sel.mt8);
         const dim3 grid8((unsigned)(nbm8 * nbn), (unsigned)sel.splits);
+        g.pw = pw_of(d, nbm8, nbn, g.persist ? 8 * 32 : nbm8 * nbn * sel.splits, sel.mt8 == 1 ? 64 : 32, 64 * sel.mt8, bn);
         if (lnk) dn_gemm_launch_ln(g, d->dtype, lnk, lean_of(g, sel.mode) && g.persist == 0, sel.ntw, sel.mt8, grid8, s);
         else if (fuse_of(g)) dn_gemm_launch_fuse(g, d->dtype, sel.mode, sel.ntw, sel.mt8 < 2 ? 2 : sel.mt8, grid8, s);
         else if (g.chan_parts && sel.splits == 1) dn_gemm_launch_cs(g, d->dtype, sel.mode, sel.ntw, sel.mt8, grid8, s);
@@ -334,6 +369,7 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
     } else {
         const int64_t nbm = (d->M + BM - 1) / BM;
         const dim3 grid((unsigned)(nbm * nbn), (unsigned)sel.splits);
+        g.pw = pw_of(d, nbm, nbn, nbm * nbn * sel.splits, 64, BM, bn);
         if (fuse_of(g)) dn_gemm_launch_fuse(g, d->dtype, sel.mode, sel.ntw, 0, grid, s); else dn_gemm_launch_plain(g, d->dtype, sel.mode, sel.ntw, 0, grid, s);
     }
     if (sel.splits > 1) { if (g.chan_parts) dn_gemm_launch_splitk_epilogue_cs(g, d->dtype, s); else dn_gemm_launch_splitk_epilogue(g, d->dtype, s); }

@@ -66,8 +66,34 @@ struct GemmArgs {
     // matrix s (W + s w_set_stride elements; bias / colsum + s N): the text cross-attention folded into two GEMMs has one matrix pair per CFG half
     // (the text differs).  0: one set.  sm_keys (LNV 3): valid score columns per 80-column head block of the softmax-heads epilogue.
     int64_t w_set_rows, w_set_stride;
+    int pw;                             // column-panel width of the tile order (tile_coords below); 0 = m-major
     int sm_keys;
 };
+
+// (blockIdx.x, blockIdx.y) of a (tiles, k-slices) launch grid -> (m block, n block, k-slice) of this workgroup.
+// Workgroups go to the 8 XCDs round-robin in linear dispatch order (XCD = (x + gridDim.x * y) % 8) and every XCD has its own L2, so each XCD is
+// given a CONTIGUOUS run of the logical order [k-slice][column panel][m block][n block inside the panel]:
+//  * with k-slices an XCD owns whole slices (or a run inside one): every weight / activation k-range is fetched over the fabric by one XCD
+//    instead of by all eight (the 8 x 8-map convolutions: 30 tiles x 15 slices);
+//  * inside a slice the run is a compact patch of the tile grid, `pw` n blocks wide (0 = whole rows, the m-major order): the workgroups that
+//    run together on an XCD share rows AND columns.  The host picks pw from the panel bytes (gc_dn_gemm: small-M / wide-N problems take narrow
+//    panels -- their weight panels are what the fabric moves; the 64 x 64-map convolutions keep whole rows -- their activations are).
+// The assignment does not change what any (tile, slice) computes: results are bit-identical for every pw.
+__device__ __forceinline__ void tile_coords(int64_t bid, int nbm, int nbn, int pw, int64_t &mblk, int64_t &nblk)
+{
+    if (pw <= 0 || pw >= nbn) { mblk = bid / nbn; nblk = bid % nbn; return; }
+    const int64_t per = (int64_t)nbm * pw, p = bid / per, within = bid - p * per;
+    const int64_t w = (nbn - p * pw) < pw ? (nbn - p * pw) : pw;              // the last panel may be narrower
+    mblk = within / w; nblk = p * pw + within % w;
+}
+__device__ __forceinline__ void wg_tile(const GemmArgs &g, int nbm, int nbn, int64_t &mblk, int64_t &nblk, int &slice)
+{
+    const int64_t tiles = gridDim.x, total = tiles * gridDim.y, lin = blockIdx.x + tiles * blockIdx.y;
+    const int64_t xcd = lin & 7, qq = total >> 3, rr = total & 7;
+    const int64_t L = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (lin >> 3);
+    slice = (int)(L / tiles);
+    tile_coords(L - (int64_t)slice * tiles, nbm, nbn, g.pw, mblk, nblk);
+}
 }  // namespace dng
 
 namespace {
@@ -202,11 +228,11 @@ __device__ __forceinline__ void row_stats_prologue(const GemmArgs &g, int64_t m_
 // before the first one is consumed: the naive per-accumulator load -> use chain costs ~1 us of latency per m-tile on every launch.
 template <class T, int NTW, int MT, int NTHREADS>
 __device__ __forceinline__ void wave_epilogue(const GemmArgs &g, f32x4 (&acc)[NTW][MT], int64_t m_base, int64_t m_wave, int64_t n_wave, int lane,
-                                              unsigned char *smem, const float *srow = nullptr)
+                                              unsigned char *smem, const float *srow = nullptr, int slice = 0)
 {
     const int fr = lane & 15, fc = lane >> 4;
     const int64_t n_lane = n_wave + fc * 4;
-    if (g.splits > 1) {   // partial sums of this k-slice: plain 16-byte stores into slab blockIdx.y
+    if (g.splits > 1) {   // partial sums of this k-slice: plain 16-byte stores into slab `slice`
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int64_t m = m_wave + mt * 16 + fr;
@@ -215,7 +241,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs &g, f32x4 (&acc)[NT
             for (int nt = 0; nt < NTW; ++nt) {
                 const int64_t n = n_lane + nt * 16;
                 if (n < g.N)
-                    *reinterpret_cast<float4 *>(g.ws + ((int64_t)blockIdx.y * g.M + m) * g.N + n) =
+                    *reinterpret_cast<float4 *>(g.ws + ((int64_t)slice * g.M + m) * g.N + n) =
                         make_float4(acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]);
             }
         }
@@ -417,12 +443,12 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmArgs g)
     const int nbn = (int)((g.N + BN - 1) / BN);
     // workgroup b runs on XCD b % 8: give each XCD a contiguous run of logical tiles (bijective remap) so the
     // workgroups that share an activation panel share an L2
-    const int64_t nwg = gridDim.x, xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
-    const int64_t bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
-    const int64_t mblk = bid / nbn, nblk = bid % nbn;
+    int64_t mblk, nblk;
+    int slice;
+    wg_tile(g, (int)((g.M + BM - 1) / BM), nbn, mblk, nblk, slice);
     const int64_t m_base = mblk * BM, n_base = nblk * BN;
     const int nk = (int)((g.K + BK - 1) / BK);
-    const int kt0 = blockIdx.y * g.tiles_per_split, kt1 = min(nk, kt0 + g.tiles_per_split);
+    const int kt0 = slice * g.tiles_per_split, kt1 = min(nk, kt0 + g.tiles_per_split);
     if (kt0 >= kt1) return;
 
     // ---- per-lane staging coordinates: 4 Act chunks + WCH W chunks per k-tile.  All per-lane address arithmetic is
@@ -589,14 +615,14 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmArgs g)
     }
 
     if constexpr (FUSE) {
-        wave_epilogue<T, NTW, 4, NT>(g, acc, m_base, m_base + wm * 64, n_base + wn * (16 * NTW), lane, smem);
+        wave_epilogue<T, NTW, 4, NT>(g, acc, m_base, m_base + wm * 64, n_base + wn * (16 * NTW), lane, smem, nullptr, slice);
         return;
     }
     // ---- epilogue: lane holds out[m = m0 + (lane&15)][n = n0 + 4*(lane>>4) + r], r = 0..3.
     // All operand loads of a row (bias once per lane; row-vector + residual per m-tile) are issued together BEFORE they are
     // used: the naive per-accumulator load->use chain cost ~1 us of latency x 20 accumulators on every launch.
     const int64_t n_lane = n_base + wn * (16 * NTW) + fc * 4;
-    if (g.splits > 1) {   // partial sums of this k-slice: plain 16-byte stores into slab blockIdx.y
+    if (g.splits > 1) {   // partial sums of this k-slice: plain 16-byte stores into slab `slice`
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const int64_t m = m_base + wm * 64 + mt * 16 + fr;
@@ -605,7 +631,7 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmArgs g)
             for (int nt = 0; nt < NTW; ++nt) {
                 const int64_t n = n_lane + nt * 16;
                 if (n < g.N)
-                    *reinterpret_cast<float4 *>(g.ws + ((int64_t)blockIdx.y * g.M + m) * g.N + n) =
+                    *reinterpret_cast<float4 *>(g.ws + ((int64_t)slice * g.M + m) * g.N + n) =
                         make_float4(acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]);
             }
         }
@@ -746,12 +772,12 @@ __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 1, wn = wid & 1;
     const int nbn = (int)((g.N + BN - 1) / BN);
-    const int64_t nwg = gridDim.x, xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
-    const int64_t bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
-    const int64_t mblk = bid / nbn, nblk = bid % nbn;
+    int64_t mblk, nblk;
+    int slice;
+    wg_tile(g, (int)((g.M + BM - 1) / BM), nbn, mblk, nblk, slice);
     const int64_t m_base = mblk * BM, n_base = nblk * BN;
     const int nk_all = (int)((g.K + BK - 1) / BK);
-    const int kt0 = blockIdx.y * g.tiles_per_split;                      // split-K: this workgroup's k-tiles [kt0, kt0 + nk)
+    const int kt0 = slice * g.tiles_per_split;                           // split-K: this workgroup's k-tiles [kt0, kt0 + nk)
     const int nk = min(nk_all, kt0 + g.tiles_per_split) - kt0;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
     float *srow = reinterpret_cast<float *>(smem + NS * STAGE);          // FUSE: [BM][2] row sums of the LayerNorm-folded consumer
@@ -990,12 +1016,12 @@ __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g
 
     if constexpr (FUSE) {
         wave_epilogue<T, NTW, MT, 512>(g, acc, m_base, m_base + wm * (16 * MT), n_base + wn * (16 * NTW), lane, smem,
-                                       (g.row_stats && g.splits == 1) ? srow : nullptr);
+                                       (g.row_stats && g.splits == 1) ? srow : nullptr, slice);
         return;
     }
     // ---- epilogue (same math as k_gemm; MT m-tiles per wave)
     const int64_t n_lane = n_base + wn * (16 * NTW) + fc * 4;
-    if (g.splits > 1) {   // partial sums of this k-slice: plain 16-byte stores into slab blockIdx.y
+    if (g.splits > 1) {   // partial sums of this k-slice: plain 16-byte stores into slab `slice`
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int64_t m = m_base + wm * (16 * MT) + mt * 16 + fr;
@@ -1004,7 +1030,7 @@ __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g
             for (int nt = 0; nt < NTW; ++nt) {
                 const int64_t n = n_lane + nt * 16;
                 if (n < g.N)
-                    *reinterpret_cast<float4 *>(g.ws + ((int64_t)blockIdx.y * g.M + m) * g.N + n) =
+                    *reinterpret_cast<float4 *>(g.ws + ((int64_t)slice * g.M + m) * g.N + n) =
                         make_float4(acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]);
             }
         }
@@ -1309,7 +1335,9 @@ __global__ __launch_bounds__(512, 1) void k_gemm8p(const GemmArgs g)
     auto tile_of = [&](int64_t d, int64_t &m_base, int64_t &n_base) __attribute__((always_inline)) {
         const int64_t xcd = d & 7, qq = ntiles >> 3, rr = ntiles & 7;
         const int64_t bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (d >> 3);
-        m_base = (bid / nbn) * BM; n_base = (bid % nbn) * BN;
+        int64_t mblk, nblk;
+        dng::tile_coords(bid, (int)((g.M + BM - 1) / BM), nbn, g.pw, mblk, nblk);
+        m_base = mblk * BM; n_base = nblk * BN;
     };
     int a_off[AI], w_off[WI];
     auto set_offsets = [&](int64_t m_base, int64_t n_base) __attribute__((always_inline)) {
@@ -1535,14 +1563,14 @@ __global__ __launch_bounds__(512, 1) void k_gemm8q(const GemmArgs g)
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 1, wn = wid & 1;
     const int nbn = (int)((g.N + BN - 1) / BN);
-    const int64_t nwg = gridDim.x, xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
-    const int64_t bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
-    const int64_t mblk = bid / nbn, nblk = bid % nbn;
+    int64_t mblk, nblk;
+    int slice;
+    wg_tile(g, (int)((g.M + BM - 1) / BM), nbn, mblk, nblk, slice);
     const int64_t m_base = mblk * BM, n_base = nblk * BN;
-    // k-slices (long-K problems on part-filled grids: the 16 x 16-map convolutions): slice blockIdx.y covers k-tiles [k0, k0 + nk) and leaves an
+    // k-slices (long-K problems on part-filled grids: the 16 x 16-map convolutions): slice `slice` covers k-tiles [k0, k0 + nk) and leaves an
     // fp32 partial slab for the split-K reduce kernels, exactly as k_gemm8 does
     const int nk_all = (int)(g.K / BKB);
-    const int k0 = g.splits > 1 ? (int)blockIdx.y * g.tiles_per_split : 0;
+    const int k0 = g.splits > 1 ? slice * g.tiles_per_split : 0;
     const int nk = g.splits > 1 ? (nk_all - k0 < g.tiles_per_split ? nk_all - k0 : g.tiles_per_split) : nk_all;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
     float *srow = reinterpret_cast<float *>(smem + NS * STAGE);
@@ -1724,12 +1752,12 @@ __global__ __launch_bounds__(512, 1) void k_gemm8q(const GemmArgs g)
     };
     if (w3) run(std::true_type{}); else run(std::false_type{});
     if constexpr (FUSE) {
-        wave_epilogue<T, NTW, MT, 512>(g, acc, m_base, m_base + wm * (16 * MT), n_base + wn * (16 * NTW), lane, smem, g.row_stats ? srow : nullptr);
+        wave_epilogue<T, NTW, MT, 512>(g, acc, m_base, m_base + wm * (16 * MT), n_base + wn * (16 * NTW), lane, smem, g.row_stats ? srow : nullptr, slice);
         return;
     }
     // ---- epilogue (same math as k_gemm; MT m-tiles per wave)
     const int64_t n_lane = n_base + wn * (16 * NTW) + fc * 4;
-    if (g.splits > 1) {   // partial sums of this k-slice: plain 16-byte stores into slab blockIdx.y
+    if (g.splits > 1) {   // partial sums of this k-slice: plain 16-byte stores into slab `slice`
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int64_t m = m_base + wm * (16 * MT) + mt * 16 + fr;
@@ -1738,7 +1766,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm8q(const GemmArgs g)
             for (int nt = 0; nt < NTW; ++nt) {
                 const int64_t n = n_lane + nt * 16;
                 if (n < g.N)
-                    *reinterpret_cast<float4 *>(g.ws + ((int64_t)blockIdx.y * g.M + m) * g.N + n) =
+                    *reinterpret_cast<float4 *>(g.ws + ((int64_t)slice * g.M + m) * g.N + n) =
                         make_float4(acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]);
             }
         }
@@ -1930,6 +1958,10 @@ __global__ __launch_bounds__(512, 1) void k_gemm8q(const GemmArgs g)
     }
 }
 
+// The split-K reduce kernels add the slabs in slab order (the result does not depend on the slice -> workgroup assignment), ZC slabs per
+// round trip: the loads of a chunk are all issued before the first add.  (Round 1..4: one slab per iteration = `splits` dependent round trips
+// to the fabric, 11 us for the 15 slabs of an 8 x 8-map convolution.)
+constexpr int ZC = 8;
 // epilogue of a split-K problem: ws fp32 [M][N] -> out (same epilogue as the fused path; no GEGLU)
 template <class T>
 __global__ __launch_bounds__(256) void k_splitk_epilogue_plain(const GemmArgs g)
@@ -1938,9 +1970,14 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue_plain(const GemmArgs g)
     for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < g.M * nq; q += (int64_t)gridDim.x * 256) {
         const int64_t m = q / nq, n = (q - m * nq) * 4;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int z = 0; z < g.splits; ++z) {
-            const float4 a = *reinterpret_cast<const float4 *>(g.ws + ((int64_t)z * g.M + m) * g.N + n);
-            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+        for (int z0 = 0; z0 < g.splits; z0 += ZC) {          // ZC slab loads in flight, added in slab order (see ZC)
+            float4 a[ZC];
+#pragma unroll
+            for (int u = 0; u < ZC; ++u)
+                if (z0 + u < g.splits) a[u] = *reinterpret_cast<const float4 *>(g.ws + ((int64_t)(z0 + u) * g.M + m) * g.N + n);
+#pragma unroll
+            for (int u = 0; u < ZC; ++u)
+                if (z0 + u < g.splits) { v[0] += a[u].x; v[1] += a[u].y; v[2] += a[u].z; v[3] += a[u].w; }
         }
         float gate[4] = {0.f, 0.f, 0.f, 0.f};
         epilogue_store<T>(g, m, n, n, v, gate);
@@ -1969,15 +2006,22 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const GemmArgs g)
 #pragma unroll
     for (int i = 0; i < 4; ++i) { v[i][0] = 0.f; v[i][1] = 0.f; v[i][2] = 0.f; v[i][3] = 0.f; }
     if (okc) {
-        for (int z = 0; z < g.splits; ++z) {
+        for (int z0 = 0; z0 < g.splits; z0 += ZC / 2) {           // 4 rows x ZC / 2 slabs: 16-byte loads in flight together, added in slab order
+            float4 a[ZC / 2][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {           // 4 independent 16-byte loads in flight per slab
-                const int64_t m = m0 + rl + 4 * i;
-                if (m < g.M) {
-                    const float4 a = *reinterpret_cast<const float4 *>(g.ws + ((int64_t)z * g.M + m) * g.N + n);
-                    v[i][0] += a.x; v[i][1] += a.y; v[i][2] += a.z; v[i][3] += a.w;
+            for (int u = 0; u < ZC / 2; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int64_t m = m0 + rl + 4 * i;
+                    if (z0 + u < g.splits && m < g.M) a[u][i] = *reinterpret_cast<const float4 *>(g.ws + ((int64_t)(z0 + u) * g.M + m) * g.N + n);
                 }
-            }
+#pragma unroll
+            for (int u = 0; u < ZC / 2; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int64_t m = m0 + rl + 4 * i;
+                    if (z0 + u < g.splits && m < g.M) { v[i][0] += a[u][i].x; v[i][1] += a[u][i].y; v[i][2] += a[u][i].z; v[i][3] += a[u][i].w; }
+                }
         }
     }
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -2038,15 +2082,22 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue_cs(const GemmArgs g)
 #pragma unroll
     for (int i = 0; i < RPT; ++i) { v[i][0] = 0.f; v[i][1] = 0.f; v[i][2] = 0.f; v[i][3] = 0.f; }
     if (okc) {
-        for (int z = 0; z < g.splits; ++z) {
+        for (int z0 = 0; z0 < g.splits; z0 += ZC) {            // RPT rows x ZC slabs in flight together, added in slab order
+            float4 a[ZC][RPT];
 #pragma unroll
-            for (int i = 0; i < RPT; ++i) {
-                const int64_t m = m0 + rl + 16 * i;
-                if (m < g.M) {
-                    const float4 a = *reinterpret_cast<const float4 *>(g.ws + ((int64_t)z * g.M + m) * g.N + n);
-                    v[i][0] += a.x; v[i][1] += a.y; v[i][2] += a.z; v[i][3] += a.w;
+            for (int u = 0; u < ZC; ++u)
+#pragma unroll
+                for (int i = 0; i < RPT; ++i) {
+                    const int64_t m = m0 + rl + 16 * i;
+                    if (z0 + u < g.splits && m < g.M) a[u][i] = *reinterpret_cast<const float4 *>(g.ws + ((int64_t)(z0 + u) * g.M + m) * g.N + n);
                 }
-            }
+#pragma unroll
+            for (int u = 0; u < ZC; ++u)
+#pragma unroll
+                for (int i = 0; i < RPT; ++i) {
+                    const int64_t m = m0 + rl + 16 * i;
+                    if (z0 + u < g.splits && m < g.M) { v[i][0] += a[u][i].x; v[i][1] += a[u][i].y; v[i][2] += a[u][i].z; v[i][3] += a[u][i].w; }
+                }
         }
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {

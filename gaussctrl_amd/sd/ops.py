@@ -90,7 +90,7 @@ def configure(options: KernelOptions | None = None, **kw) -> KernelOptions:
 
 def options_from_env(env=None) -> KernelOptions:
     """The experiment switches of bench.py / scripts / the spawned ranks of the tests, decoded from GC_* variables (NOT called on
-    import and never by the plugin path):  GC_GEMM_MT / GC_GEMM8 / GC_GEMM_CONVSPLIT / GC_GEMM_DBG -> gemm_variant;  GC_ATTN_SAFE /
+    import and never by the plugin path):  GC_GEMM_MT / GC_GEMM8 / GC_GEMM_CONVSPLIT / GC_GEMM_DBG / GC_GEMM_PW -> gemm_variant;  GC_ATTN_SAFE /
     GC_ATTN_16 / GC_ATTN_V -> attn_variant;  GC_BATCH_INVARIANT, GC_FUSED_HEAD, GC_FUSED_TAIL, GC_DN_STREAMS, GC_GN_PARTS, GC_ABLATE=a,b,c."""
     e = os.environ if env is None else env
     on = lambda k, d: e.get(k, d) not in ("", "0")
@@ -103,9 +103,12 @@ def options_from_env(env=None) -> KernelOptions:
     cs = e.get("GC_GEMM_CONVSPLIT")
     if cs == "0":
         g |= 0x40
-    elif cs == "2":
+    elif cs == "1":            # (2 = default: also the small grids -- 8 x 8 maps, stride-2 convs -- on the k-sliced 8-wave kernel)
         g |= 0x80
     g |= (int(e.get("GC_GEMM_DBG", "0")) & 0xff) << 8
+    g |= (int(e.get("GC_GEMM_SPLIT_MT", "0")) & 7) << 24                  # m-tiles per wave of the k-sliced 8-wave problems (default 2)
+    if e.get("GC_GEMM_PW", "") != "":            # forced column-panel width of the GEMM tile order (0 = whole rows, the round-1..4 order)
+        g |= ((int(e["GC_GEMM_PW"]) + 1) & 0xff) << 16
     a = (1 if on("GC_ATTN_SAFE", "0") else 0) | (2 if on("GC_ATTN_16", "0") else 0) | (int(e.get("GC_ATTN_V", "0")) << 2)
     return KernelOptions(gemm_variant=g, attn_variant=a, batch_invariant=on("GC_BATCH_INVARIANT", "0"),
                          fused_head=on("GC_FUSED_HEAD", "1"), fused_tail=on("GC_FUSED_TAIL", "1"), two_streams=on("GC_DN_STREAMS", "1"),

@@ -4,6 +4,7 @@ import sys, torch
 sys.path.insert(0, '.')
 from gaussctrl_amd.sd import ops
 from gaussctrl_amd.sd.weights import conv3x3_weight, geglu_permute
+ops.configure(ops.options_from_env())       # GC_GEMM_MT / GC_GEMM_PW / ... experiment switches
 DEV = 'cuda:0'
 what = sys.argv[1] if len(sys.argv) > 1 else 'all'
 if __name__ != '__main__': what = 'none'
