@@ -182,8 +182,8 @@ int select(const gc_gemm_desc *d, Sel *o, bool want_parts)
         const bool want_split = !force_mt && use8 != 2 && !d->geglu && d->w_set_rows == 0 && d->softmax_keys == 0 && d->workspace && tiles8 <= 128 && (mode == 0 ? (!small || nk_host >= 24) : (convsplit >= (small ? 2 : 1)));
         int s8 = 1, tps8 = nk_host;
         if (want_split) {
-            const int smt = (kv >> 24) & 7;                                  // experiments: m-tiles per wave of the k-sliced problems (default 2)
-            const int mts = (smt >= 2 && smt <= 4) ? smt : 2;
+            const int smt = (kv >> 24) & 7;                                  // experiments: forced m-tiles per wave of the k-sliced problems
+            const int mts = (smt >= 2 && smt <= 4) ? smt : ((mode != 0 && !small) ? 3 : 2);    // 16 x 16-map convs: 192-row tiles x 3 slices (60.4 vs 63.7 us); the small grids and the linears: 128 rows
             const int64_t tiles_s = ((Msel + 64 * mts - 1) / (64 * mts)) * nbn;
             s8 = (int)std::min<int64_t>(std::max<int64_t>(256 / tiles_s, 2), nk_host / 12);         // one round: tiles x slices <= 256 workgroups
             if (s8 >= 2 && d->workspace_bytes >= sizeof(float) * (size_t)s8 * (size_t)d->M * (size_t)d->N) {
@@ -271,6 +271,7 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
     GC_REQUIRE(d->N % 4 == 0, "N must be a multiple of 4 (pad output channels on the host)");
     GC_REQUIRE(d->dtype == DT_BF16 || d->dtype == DT_F16, "dtype must be 0 (bf16) or 1 (f16)");
     GemmArgs g;
+    g.pw = 0;
     g.M = d->M; g.N = d->N; g.K = d->K; g.A = d->A; g.lda = d->lda;
     g.B = d->B; g.Hi = d->Hi; g.Wi = d->Wi; g.Cin = d->Cin; g.Ho = d->Ho; g.Wo = d->Wo; g.stride = d->stride; g.ups = d->upsample; g.pad = d->pad_lo;
     g.W = d->W; g.bias = d->bias; g.rowvec = d->rowvec; g.ld_rowvec = d->ld_rowvec;
