@@ -214,6 +214,7 @@ def _ref_attn(q, k, v, heads, scale):
 
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("f,L,heads,D,coeff", [(5, 256, 8, 40, 0.6), (7, 100, 8, 80, 0.6), (5, 64, 8, 160, 0.0), (6, 4, 8, 160, 0.6),
+                                               (3, 256, 8, 160, 0.6), (3, 128, 8, 160, 0.0), (5, 64, 8, 160, 0.6), (3, 192, 8, 160, 0.6),
                                                (5, 1024, 2, 40, 0.6), (5, 70, 2, 8, 0.6), (5, 200, 3, 40, 0.6), (5, 64, 2, 40, 0.0),
                                                (5, 136, 2, 80, 0.6)])
 def test_cross_view_attention(dt, f, L, heads, D, coeff):
