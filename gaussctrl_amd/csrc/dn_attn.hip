@@ -32,6 +32,19 @@ __global__ __launch_bounds__(256, 2) void k_attn(const AttnArgs a)
     attn_safe_body<T, D, QT>(a, qblk, h, b, sK, sV);
 }
 
+// The set-split form with ALL queries of a (frame, head) in one workgroup (head size 160 at L = 256: 8 waves x 32 queries): the K / V^T of a set
+// cross the L2 -> LDS path once per (frame, head, set) instead of once per 64-query block (154 -> 38 MB per launch, the measured bound of the
+// 64-query form: profiles/r05_attn160_prefetch_ab.txt), and every LDS fragment feeds two MFMAs.
+template <class T, int D, int QT, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void k_attn_wide(const AttnArgs a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char sK[SafeLds<D>::KBYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char sV[SafeLds<D>::VBYTES];
+    int qblk, h, b;
+    block_coords(a, QT, qblk, h, b);
+    attn_safe_body<T, D, QT, NW, true>(a, qblk, h, b, sK, sV);
+}
+
 // out = round(sum_s part[s]) in a fixed order: the second launch of a set-split attention (below)
 template <class T>
 __global__ __launch_bounds__(256) void k_attn_combine(const float *__restrict__ part, int nsets, int64_t n4, int64_t set_stride4, unsigned short *__restrict__ O,
@@ -802,6 +815,16 @@ int launch_attn(const AttnArgs &a, int D, int B, bool fast, int variant, hipStre
     }
     // Few workgroups and several K/V sets (D = 160 at 16x16 / 8x8: 192 / 48 workgroups of one wave per SIMD, nobody to hide the
     // S -> max -> exp -> P V dependency chain): one workgroup per (query block, set) + a fixed-order fp32 combine
+    if (D == 160 && a.part && a.nsets > 1 && (a.Lq & 255) == 0 && !(variant & 128)) {      // kernel_variant bit 7: the 64-query form (A/B, tests)
+        AttnArgs aa = a;
+        aa.nqb = a.Lq / 256;
+        const unsigned nwg = (unsigned)(aa.nqb * a.H * B);
+        hipLaunchKernelGGL((k_attn_wide<T, 160, 2, 8>), dim3(nwg, (unsigned)a.nsets), dim3(512), 0, s, aa);
+        const int64_t n4 = (int64_t)B * a.Lq * (a.H * 160) / 4;
+        hipLaunchKernelGGL((k_attn_combine<T>), dim3((unsigned)std::min<int64_t>((n4 + 255) / 256, 2048)), dim3(256), 0, s, a.part, a.nsets,
+                           n4, n4, a.O, a.ldo, a.o_bs, (int64_t)(a.H * 160) / 4, (int64_t)a.Lq);
+        return GC_OK;
+    }
 #define GC_ATT(DD, QQ)                                                                                  \
     do {                                                                                                \
         AttnArgs aa = a;                                                                                \

@@ -49,7 +49,9 @@ template <int D> struct SafeLds {
 
 // The "safe" form: online softmax with a running row maximum (no assumption on the logits).  It is the whole kernel for the
 // head sizes without spare contraction columns and the in-kernel fallback of k_attn3.
-template <class T, int D, int QT, int NW = 4>
+// SPLIT_ONLY: the kernel is only launched in the set-split form (gridDim.y = nsets): the set loop is ONE iteration at compile time and the weighted
+// total does not live beside the set's accumulator (k_attn_wide: 32 queries per wave at head size 160 would not fit otherwise).
+template <class T, int D, int QT, int NW = 4, bool SPLIT_ONLY = false>
 __device__ __forceinline__ void attn_safe_body(const AttnArgs &a, int qblk, int h, int b, unsigned char *sK, unsigned char *sV)
 {
     constexpr int NT = NW * 64;                 // threads of the workgroup
@@ -123,9 +125,9 @@ __device__ __forceinline__ void attn_safe_body(const AttnArgs &a, int qblk, int 
     const float c2 = a.scale_log2e;
     // set-split launch: this workgroup handles K/V set blockIdx.y only and leaves its weighted output in a.part (the sets are independent
     // attentions, out = sum_s w_s O_s: k_attn_combine adds them in a fixed order)
-    const bool split = gridDim.y > 1;
+    const bool split = SPLIT_ONLY || gridDim.y > 1;
     const int s_begin = split ? (int)blockIdx.y : 0, s_end = split ? s_begin + 1 : a.nsets;
-    for (int s = s_begin; s < s_end; ++s) {
+    for (int s = s_begin; SPLIT_ONLY ? s == s_begin : s < s_end; ++s) {
         const int kind = a.set_kind[s];
         const unsigned short *Kb, *Vb;
         if (kind >= 0) {

@@ -214,7 +214,7 @@ def _ref_attn(q, k, v, heads, scale):
 
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("f,L,heads,D,coeff", [(5, 256, 8, 40, 0.6), (7, 100, 8, 80, 0.6), (5, 64, 8, 160, 0.0), (6, 4, 8, 160, 0.6),
-                                               (3, 256, 8, 160, 0.6), (3, 128, 8, 160, 0.0), (5, 64, 8, 160, 0.6), (3, 192, 8, 160, 0.6),
+                                               (5, 256, 8, 160, 0.6), (4, 256, 8, 160, 0.0), (4, 128, 8, 160, 0.0), (5, 64, 8, 160, 0.6), (4, 192, 8, 160, 0.6),
                                                (5, 1024, 2, 40, 0.6), (5, 70, 2, 8, 0.6), (5, 200, 3, 40, 0.6), (5, 64, 2, 40, 0.0),
                                                (5, 136, 2, 80, 0.6)])
 def test_cross_view_attention(dt, f, L, heads, D, coeff):
@@ -823,3 +823,20 @@ def test_tile_order_does_not_change_results(dt, monkeypatch):
         for name, fn in cases():
             o = fn(); o = o[0] if isinstance(o, tuple) else o
             assert torch.equal(o, base[name]), (name, pw)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_attention_head160_wide_form_matches_64_query_form(dt, monkeypatch):
+    """k_attn_wide (head size 160, set-split: all 256 queries of a (frame, head) in one 8-wave workgroup, 32 queries per wave) runs the same body as
+    the 64-query form (kernel_variant bit 7): per set the same keys in the same tile order -> bit-identical partial outputs and result."""
+    from gaussctrl_amd.sd import ops
+    f, L, heads, D = 5, 256, 8, 160
+    B, C = 2 * f, heads * D
+    q = _rand((B, L, C), dt, 1.0, 1); k = _rand((B, L, C), dt, 1.0, 2); v = _rand((B, L, C), dt, 1.0, 3)
+    k[:, 37, :] = k[:, 37, :] * 5.0                       # a spiked key: the running maximum jumps inside the first tile
+    vt = v.transpose(1, 2).contiguous()
+    sets = [(-1, 0.6)] + [(r, 0.1) for r in range(4)]
+    wide = ops.attention(q, k, vt, heads, sets, f, Lk=L)
+    monkeypatch.setitem(ops.KERNEL_VARIANT, "attn", 128)
+    narrow = ops.attention(q, k, vt, heads, sets, f, Lk=L)
+    assert torch.equal(wide, narrow)
