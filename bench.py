@@ -58,7 +58,9 @@ def parse():
     ap.add_argument("--denoise-steps", type=int, default=20)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "fp8"])     # fp8: e4m3 resnet convs + C = 640 / 1280 transformer linears on the block-scaled MFMA, bf16 elsewhere
     ap.add_argument("--fp8-min-hw", type=int, default=256)   # with --dtype fp8: smallest map (pixels) whose resnet convs run on e4m3 (256: 16 x 16 maps, k-sliced; 1024: round-3 behaviour)
-    ap.add_argument("--fp8-linears", type=int, default=7)     # with --dtype fp8: bit mask of the C = 640 / 1280 transformer linears that also run on e4m3 (weights.add_fp8_linears; 0: convolutions only)
+    ap.add_argument("--fp8-linears", type=int, default=0)     # with --dtype fp8: bit mask of the C = 640 / 1280 transformer linears that also run on e4m3 (weights.add_fp8_linears).
+                                                              # Default 0 since round 5: e4m3 convolutions + the bf16 transformer blocks WITH the LayerNorm fold and the graph
+                                                              # merges beat e4m3 linears without them (9.83 vs 9.66 views/s same box, profiles/r05_fp8_hybrid_ab.txt); 7 = round 4
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="edit", choices=["edit", "raster", "full"])   # full: SURVEY.md 8d's optional whole-pipeline number (N = 1)
     ap.add_argument("--train-iters", type=int, default=500)     # --workload full: Adam iterations after the edit (gc_trainer.py:186-201)
