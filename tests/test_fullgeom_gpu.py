@@ -230,7 +230,8 @@ def test_vae_encode_h512(dt):
 def _config4_run(nets, dt, fp8, cached=False):
     """BASELINE configs[3] end to end against the oracle fixture: f = 4 references + chunk_size 8, ALL 20 DDIM steps, VAE decode of the 8
     chunk frames, composite through the synthetic elliptical object mask (gc_pipeline.py:209-234).
-    fp8: False | "convs" (e4m3 resnet convolutions) | "all" (what `bench.py --dtype fp8` runs: convolutions + add_fp8_linears(.., 7)).
+    fp8: False | "convs" (e4m3 resnet convolutions) | "all" (`bench.py --dtype fp8 --fp8-linears 7`: convolutions + add_fp8_linears(.., 7)) |
+    "hybrid" (`bench.py --dtype fp8` since round 5: e4m3 convolutions + the folded / merged bf16 transformer blocks).
     cached: False = in-batch references (CFG batch 24); True = the product path, reference bank + the 8 chunk frames (CFG batch 16: the
     grids `bench.py --dtype fp8 --chunk-size 8 --mask` launches -- k_gemm8q picks tiles and k-slices from M, so B = 16 is its own plan)."""
     from oracle import sd15_torch as sd
@@ -246,8 +247,15 @@ def _config4_run(nets, dt, fp8, cached=False):
     f, h, steps, seed, _, _, vseed, stride = [int(v) for v in z["meta"]]
     which = [int(v) for v in z["which_steps"]]
     lat, disp, cn, cp = _inputs(f, h, seed)
-    uw, cw = nets(dt)
-    if fp8:
+    if fp8 == "hybrid":       # e4m3 convolutions + the round-5 bf16 transformer blocks (LayerNorm fold, text fold, FF merge, Q-only): `bench.py --dtype fp8` since round 5
+        from gaussctrl_amd.sd.weights import prepare
+        rr = lambda w: {k: v.to(torch.bfloat16).float() for k, v in w.items()}
+        usd, csd = rr(sd.make_unet_weights(sd.SD15, 100)), rr(sd.make_controlnet_weights(sd.SD15, 200))
+        uw = prepare(usd, dt, DEV, heads=8, fold_ln=2); cw = prepare(csd, dt, DEV, heads=8, fold_ln=2)
+        add_fp8_convs(uw, usd, DEV); add_fp8_convs(cw, csd, DEV)
+    else:
+        uw, cw = nets(dt)
+    if fp8 and fp8 != "hybrid":
         uw, cw = dict(uw), dict(cw)
         r = lambda w: {k: v.to(torch.bfloat16).float() for k, v in w.items() if k.endswith((".conv1.weight", ".conv2.weight"))}
         add_fp8_convs(uw, r(sd.make_unet_weights(sd.SD15, 100)), DEV)
@@ -256,7 +264,7 @@ def _config4_run(nets, dt, fp8, cached=False):
             add_fp8_linears(uw, 7); add_fp8_linears(cw, 7)
     vw = {k: v.to(torch.bfloat16).float().to(DEV) for k, v in sd.make_vae_decoder_weights(sd.VAE_SD, vseed).items()}
     pipe = DenoisePipeline(uw, cw, prepare_vae_weights(vw, dt, DEV), 20, 5.0)
-    assert pipe.unet.fp8 == bool(fp8) and pipe.controlnet.fp8 == bool(fp8)
+    assert bool(pipe.unet.fp8) == bool(fp8) and bool(pipe.controlnet.fp8) == bool(fp8)
     if fp8 == "all":
         assert pipe.unet.fp8_lin == 7 and pipe.controlnet.fp8_lin == 7
     trace = []
@@ -281,7 +289,7 @@ def _config4_run(nets, dt, fp8, cached=False):
         comp = sdops.mask_composite(imgs[j].contiguous(), unedited, mask)[::stride, ::stride].cpu()
         errs.append((comp - torch.tensor(z["composite"][j])).abs())
     e = torch.stack(errs)
-    tag = {False: "", "convs": " + e4m3 convs", "all": " + e4m3 convs and linears"}[fp8] + (", cached bank B=16" if cached else ", in-batch B=24")
+    tag = {False: "", "convs": " + e4m3 convs", "all": " + e4m3 convs and linears", "hybrid": " + e4m3 convs, folded / merged bf16 blocks"}[fp8] + (", cached bank B=16" if cached else ", in-batch B=24")
     print(f"\nconfig 4 ({dt}{tag}): latent rel L2 at steps {which}: " + " ".join(f"{c:.2e}" for c in cur) +
           f"; composited images: mean abs {float(e.mean()):.3e} max abs {float(e.max()):.3e}")
     return cur, float(e.mean()), float(e.max())
@@ -310,6 +318,19 @@ def test_config4_f12_fp8_convs(nets):
     cur, mean_e, max_e = _config4_run(nets, torch.bfloat16, "convs")
     within("max(cur)", max(cur), 6e-2)
     within("mean_e", mean_e, 2.0 / 255.0)
+
+
+@pytest.mark.parametrize("cached", [False, True])
+def test_config4_f12_fp8_convs_with_folded_linears(nets, cached):
+    """configs[3] on the configuration `bench.py --dtype fp8 --chunk-size 8 --mask` launches since round 5: e4m3 resnet convolutions beside the
+    round-5 bf16 transformer blocks (LayerNorm fold, text attention as two GEMMs, FF-down + proj_out merged, Q-only ControlNet projections, CFG-shared
+    prefix).  f = 4 + 8 frames in-batch (CFG batch 24) and the cached bank with the 8 chunk frames (CFG batch 16), all 20 DDIM steps, VAE decode, mask
+    composite; the e4m3 bars and the falsifiable saturated-curve bar of test_config4_f12_fp8_convs_and_linears."""
+    cur, mean_e, max_e = _config4_run(nets, torch.bfloat16, "hybrid", cached)
+    within("max(cur)", max(cur), 6e-2)
+    within("mean_e", mean_e, 2.0 / 255.0)
+    pred = _e4m3_predicted()[-1]
+    within("|cur[-1] / predicted - 1|", abs(cur[-1] / pred - 1.0), 0.25)
 
 
 @pytest.mark.parametrize("cached", [False, True])
