@@ -304,10 +304,11 @@ class FlatGrads:
     `reduce_async()` posts it (c10d orders it after the work queued on the current stream); `wait()` makes the current stream wait for
     it -- call it before the buffer is read (optimizer) or overwritten (the next-but-one batch when two FlatGrads alternate)."""
 
-    def __init__(self, params: dict, group=None):
+    def __init__(self, params: dict, group=None, pad_to: int = 1):
         n = sum(int(v.numel()) for v in params.values())
         any_p = next(iter(params.values()))
-        self.flat = torch.zeros(n, dtype=torch.float32, device=any_p.device)
+        self.n = n
+        self.flat = torch.zeros((n + pad_to - 1) // pad_to * pad_to, dtype=torch.float32, device=any_p.device)    # (pad_to: equal shards for ShardedAdam)
         self.views, o = {}, 0
         for k, v in params.items():
             self.views[k] = self.flat[o:o + v.numel()].view(v.shape)
@@ -324,3 +325,88 @@ class FlatGrads:
         if self.work is not None:
             self.work.wait()
             self.work = None
+
+
+class FlatParams:
+    """The leaf parameters re-homed as views of ONE flat fp32 buffer with FlatGrads' layout (same order, same offsets), padded so that `world`
+    equal shards of a multiple of 4 elements tile it: what ShardedAdam updates slice by slice and all-gathers in place.  The nn.Parameter objects
+    stay the same (their `.data` becomes the view), so modules, optimizers' references and checkpoints are untouched."""
+
+    def __init__(self, params: dict, world: int):
+        n = sum(int(v.numel()) for v in params.values())
+        any_p = next(iter(params.values()))
+        self.n = n
+        self.shard = ((n + world - 1) // world + 3) // 4 * 4
+        self.flat = torch.zeros(self.shard * world, dtype=torch.float32, device=any_p.device)
+        self.spans, o = {}, 0
+        with torch.no_grad():
+            for k, v in params.items():
+                view = self.flat[o:o + v.numel()].view(v.shape)
+                view.copy_(v.data)
+                v.data = view
+                self.spans[k] = (o, o + v.numel())
+                o += v.numel()
+
+    def matches(self, params: dict) -> bool:
+        return all(k in self.spans and self.spans[k][1] - self.spans[k][0] == v.numel() and v.data_ptr() == self.flat.data_ptr() + 4 * self.spans[k][0]
+                   for k, v in params.items())
+
+
+def _hip_adam(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
+    """torch.optim.Adam's update on one contiguous fp32 slice through the fused HIP kernel (gc_adam_step); raises on CPU tensors -- no fallback."""
+    from . import _lib as L
+    if not param.is_cuda:
+        raise L.GaussCtrlHipError("ShardedAdam: the fused Adam kernel needs GPU tensors")
+    L.check(L.lib().gc_adam_step(L.ptr(param), L.ptr(grad), L.ptr(exp_avg), L.ptr(exp_avg_sq), L.i64(param.numel()), L.f32(lr), L.f32(beta1), L.f32(beta2),
+                                 L.f32(eps), L.i32(step), L.stream_ptr()), "gc_adam_step")
+
+
+class ShardedAdam:
+    """SURVEY.md 8e collective 2, second form: reduce-scatter of the flat gradient buffer -> every rank runs Adam on ITS 1 / world slice of the flat
+    parameter buffer (the two moment buffers exist only for that slice: optimizer state 1 / world per rank) -> all-gather of the updated slices in
+    place.  Same result as an all-reduce followed by the replicated per-group Adam (torch.optim.Adam semantics, /root/reference/gaussctrl/
+    gc_config.py:58-87: per-group lr / eps), element for element: Adam is element-wise, and the reduce-scatter sums the same values.  Per step
+    2 (G - 1) / G x 236 B x N cross the links either way; what changes is 8 bytes of moments and ~28 bytes of optimizer traffic per element / G.
+    `adam` is the slice update (default: the fused HIP kernel); the gloo tests pass a reference implementation -- the product never does.
+    Backends without reduce_scatter_tensor (gloo, the CPU / one-GPU tests) take all_reduce + slice."""
+
+    def __init__(self, fparams: FlatParams, fgrads: FlatGrads, world: int, rank: int, group=None, betas=(0.9, 0.999), adam=None):
+        assert fgrads.flat.numel() == fparams.flat.numel(), "FlatGrads must be built with pad_to = world * FlatParams.shard"
+        self.fp, self.fg, self.world, self.rank, self.group, self.betas = fparams, fgrads, world, rank, group, betas
+        self.lo, self.hi = rank * fparams.shard, (rank + 1) * fparams.shard
+        self.exp_avg = torch.zeros(fparams.shard, dtype=torch.float32, device=fparams.flat.device)
+        self.exp_avg_sq = torch.zeros_like(self.exp_avg)
+        self.gshard = torch.zeros_like(self.exp_avg)
+        self.steps = 0
+        self.adam = adam or _hip_adam
+
+    @torch.no_grad()
+    def step(self, hyper: dict):
+        """hyper: parameter name -> (lr, eps) of this step (the trainer's schedulers own the learning rates)."""
+        import torch.distributed as dist
+        fp = self.fp
+        if self.world > 1:
+            if dist.get_backend(self.group) == "nccl":
+                dist.reduce_scatter_tensor(self.gshard, self.fg.flat, group=self.group)
+            else:
+                if self.fg.flat.is_cuda:
+                    torch.cuda.current_stream().synchronize()
+                dist.all_reduce(self.fg.flat, group=self.group)
+                self.gshard.copy_(self.fg.flat[self.lo:self.hi])
+        else:
+            self.gshard.copy_(self.fg.flat[self.lo:self.hi])
+        self.steps += 1
+        for name, (a, b) in fp.spans.items():
+            x, y = max(a, self.lo), min(b, self.hi)
+            if x >= y:
+                continue
+            lr, eps = hyper[name]
+            self.adam(fp.flat[x:y], self.gshard[x - self.lo:y - self.lo], self.exp_avg[x - self.lo:y - self.lo], self.exp_avg_sq[x - self.lo:y - self.lo],
+                      float(lr), self.betas[0], self.betas[1], float(eps), self.steps)
+        if self.world > 1:
+            if dist.get_backend(self.group) == "nccl":
+                dist.all_gather_into_tensor(fp.flat, fp.flat[self.lo:self.hi], group=self.group)          # in place: the input is this rank's slice of the output
+            else:
+                if fp.flat.is_cuda:
+                    torch.cuda.current_stream().synchronize()
+                dist.all_gather_into_tensor(fp.flat, fp.flat[self.lo:self.hi].clone(), group=self.group)

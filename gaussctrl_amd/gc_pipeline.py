@@ -80,7 +80,9 @@ class GaussCtrlPipelineConfig(_PipelineConfigBase):
     train_mode: str = "parity"         # world_size > 1: "parity" = every rank takes the SAME single-view step on replicated
                                        # parameters (the reference's 500 single-view iterations, gc_trainer.py:186-201; no gradient collective:
                                        # replicas stay bit-identical), "throughput" = each rank renders its own view of the step, the N x 59
-                                       # gradients are averaged by one flat in-place RCCL all-reduce (dist.FlatGrads) -- an N-view batch per step
+                                       # gradients are averaged by one flat in-place RCCL all-reduce (dist.FlatGrads) -- an N-view batch per step;
+                                       # "sharded" = the same batch with reduce-scatter -> Adam on each rank's 1 / N slice of ONE flat parameter
+                                       # buffer (optimizer state 1 / N per rank) -> in-place all-gather (dist.ShardedAdam)
     fold_layernorms: bool = True       # LayerNorms of the C = 640 / 1280 transformer blocks folded into their producer / consumer GEMM epilogues
                                        # (weights.prepare(fold_ln=2): +2 % views/s, same latents to the storage type's rounding); ignored with
                                        # fp8 >= 2, whose linears take e4m3 activations from the LayerNorm kernel
@@ -392,9 +394,23 @@ class GaussCtrlPipeline(_PipelineBase):
         from .dist import FlatGrads
         m = self.model
         fg = getattr(self, "_fg", None)
-        if fg is None or fg.views["means"].shape != m.means.shape or fg.flat.device != m.means.device:
+        if fg is None or fg.views["means"].shape != m.means.shape or fg.flat.device != m.means.device or fg.flat.numel() != fg.n:
             fg = self._fg = FlatGrads({k: getattr(m, k) for k in self._GRAD_KEYS})
         return fg
+
+    _GROUP_OF = {"xyz": "means", "scaling": "scales", "rotation": "quats", "opacity": "opacities", "features_dc": "features_dc", "features_rest": "features_rest"}
+
+    def _sharded_adam(self):
+        """dist.ShardedAdam over the flat parameter / gradient buffers of the six leaf tensors (rebuilt when densification changes their size)"""
+        from .dist import FlatGrads, FlatParams, ShardedAdam
+        m = self.model
+        params = {k: getattr(m, k) for k in self._GRAD_KEYS}
+        sa = getattr(self, "_sa", None)
+        if sa is None or not sa.fp.matches(params):
+            fp = FlatParams(params, self.world_size)
+            self._fg = FlatGrads(params, pad_to=fp.flat.numel())
+            sa = self._sa = ShardedAdam(fp, self._fg, self.world_size, self.local_rank)
+        return sa
 
     def _sync_view(self, draw):
         """train_mode "parity": every rank trains on the view rank 0 drew (a 1-int control-path broadcast; no data-path collective)"""
@@ -416,6 +432,13 @@ class GaussCtrlPipeline(_PipelineBase):
         for opt in optimizers.values():
             opt.zero_grad(set_to_none=True)
         loss, loss_dict, metrics_dict = self.train_forward_backward(step)
+        if self.world_size > 1 and self.config.train_mode == "sharded":
+            # train_mode "sharded" -- "throughput" with SURVEY.md 8e's second form of collective 2: reduce-scatter of the flat gradient buffer, every
+            # rank runs the fused Adam on its 1 / N slice of the flat parameter buffer (moment state 1 / N per rank), all-gather of the slices in
+            # place (dist.ShardedAdam); the optimizers passed in only supply this step's lr / eps per group (their schedulers keep working)
+            hyper = {key: (optimizers[g].param_groups[0]["lr"], optimizers[g].param_groups[0]["eps"]) for g, key in self._GROUP_OF.items() if g in optimizers}
+            self._sharded_adam().step(hyper)
+            return loss, loss_dict, metrics_dict
         for opt in optimizers.values():
             opt.step()
         return loss, loss_dict, metrics_dict
@@ -426,11 +449,16 @@ class GaussCtrlPipeline(_PipelineBase):
         > 1): the autograd .grad path with a flat all-reduce of the accumulated tensors is used instead of the write-once flat buffer."""
         multi = self.world_size > 1
         mode = self.config.train_mode if multi else "single"
-        if mode not in ("single", "parity", "throughput"):
-            raise ValueError(f"train_mode must be 'parity' or 'throughput', not {mode!r}")
+        if mode not in ("single", "parity", "throughput", "sharded"):
+            raise ValueError(f"train_mode must be 'parity', 'throughput' or 'sharded', not {mode!r}")
+        if mode == "sharded" and accumulating:
+            raise ValueError("train_mode 'sharded' writes the flat gradient buffer once per step: no gradient accumulation")
         m = self.model
         fg = None
-        if mode == "throughput" and not accumulating:
+        if mode == "sharded":
+            fg = self._sharded_adam().fg
+            m.grad_into = fg.views
+        elif mode == "throughput" and not accumulating:
             fg = self._flat_grads()
             m.grad_into = fg.views
         self.datamanager.view_sync = self._sync_view if mode == "parity" else None
@@ -443,6 +471,8 @@ class GaussCtrlPipeline(_PipelineBase):
             (loss / self.world_size).backward()
             if getattr(m, "_aux", None) is None or m._aux.xys_grad is None:
                 fg.flat.zero_()                          # this rank's view rendered nothing (gc_model.py:155-156): it contributes zeros
+            if mode == "sharded":
+                return loss.detach(), loss_dict, metrics_dict          # ShardedAdam.step reduce-scatters the buffer (train_iteration)
             fg.reduce_async(self.world_size)
             fg.wait()
             for k in self._GRAD_KEYS:

@@ -149,11 +149,17 @@ else:
                 loss.backward()
                 self.pipeline.reduce_gradients()
                 loss = loss.detach()
+            sharded = getattr(self.pipeline, "world_size", 1) > 1 and getattr(getattr(self.pipeline, "config", None), "train_mode", "") == "sharded"
             for g, opt in self.optimizers.items():                       # optimizer_scaler_step_some
                 if step % acc(g) == acc(g) - 1:
                     for pg in opt.param_groups:
                         pg["lr"] = self.lr_at(g, step)                   # scheduler value for this step (scheduler_step_all, :294-298)
-                    opt.step()
+                    if not sharded:
+                        opt.step()
+            if sharded:        # reduce-scatter -> Adam on this rank's slice of the flat parameter buffer -> all-gather (dist.ShardedAdam), this step's lr / eps
+                p = self.pipeline
+                p._sharded_adam().step({key: (self.optimizers[g].param_groups[0]["lr"], self.optimizers[g].param_groups[0]["eps"])
+                                        for g, key in p._GROUP_OF.items() if g in self.optimizers})
             return loss, loss_dict, metrics_dict
 
 

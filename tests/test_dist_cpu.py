@@ -264,3 +264,137 @@ def test_train_modes_world2(mode):
             assert torch.allclose(g0["means"], 2 * p0["means"] * ((v0 + 1) + (v1 + 1)) / 2)
     if mode == "throughput":
         assert any(a[1] != b[1] for a, b in zip(o0, o1)), "the ranks drew the same views: the test would not tell mean from single"
+
+
+# ---------------------------------------------------------------------------------------------------------------- sharded optimizer (8e, collective 2)
+_HYPER = {"means": (1.6e-2, 1e-15), "scales": (5e-3, 1e-15), "quats": (1e-3, 1e-15), "opacities": (5e-2, 1e-15), "features_dc": (2.5e-3, 1e-15),
+          "features_rest": (1.25e-4, 1e-15)}
+_SHAPES = dict(means=(7, 3), scales=(7, 3), quats=(7, 4), opacities=(7, 1), features_dc=(7, 3), features_rest=(7, 15, 3))      # 413 elements: not a multiple of 2 x 4
+
+
+def _ref_adam(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
+    """torch.optim.Adam (no weight decay / amsgrad) on one slice, in place -- the CPU stand-in of gc_adam_step for the gloo tests only."""
+    exp_avg.mul_(beta1).add_(grad, alpha=1 - beta1)
+    exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+    bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
+    param.addcdiv_(exp_avg, (exp_avg_sq.sqrt() / (bc2 ** 0.5)).add_(eps), value=-lr / bc1)
+
+
+def _init_params():
+    g = torch.Generator().manual_seed(0)
+    return {k: torch.nn.Parameter(torch.randn(*s, generator=g)) for k, s in _SHAPES.items()}
+
+
+def _rank_grad(k, rank, step):
+    g = torch.Generator().manual_seed(1000 * step + 10 * rank + sorted(_SHAPES).index(k))
+    return torch.randn(*_SHAPES[k], generator=g)
+
+
+def _sharded_adam_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gaussctrl_amd.dist import FlatGrads, FlatParams, ShardedAdam
+        params = _init_params()
+        fp = FlatParams(params, world)
+        fg = FlatGrads(params, pad_to=fp.flat.numel())
+        sa = ShardedAdam(fp, fg, world, rank, adam=_ref_adam)
+        assert fp.matches(params) and all(p.data_ptr() == fp.flat.data_ptr() + 4 * fp.spans[k][0] for k, p in params.items())
+        for step in range(3):
+            for k in params:
+                fg.views[k].copy_(_rank_grad(k, rank, step))
+            sa.step(_HYPER)
+        ret[rank] = ({k: p.detach().clone() for k, p in params.items()}, sa.exp_avg.numel(), fp.shard, fp.flat.numel())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_adam_world2_equals_replicated_adam():
+    """dist.ShardedAdam (reduce-scatter of the flat gradient buffer -> Adam on each rank's slice of the flat parameter buffer -> all-gather) at
+    world 2 over gloo: after 3 steps both ranks hold the parameters a single process gets from Adam on the SUMMED gradients with the per-group
+    lr / eps, bit for bit; a rank keeps moments for its slice only; parameter tensors whose elements straddle the slice boundary are handled."""
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_sharded_adam_worker, args=(2, 29500 + os.getpid() % 150, ret), nprocs=2, join=True)
+    (p0, nstate, shard, padded), (p1, _, _, _) = ret[0], ret[1]
+    assert nstate == shard and padded == 2 * shard and shard % 4 == 0 and shard < sum(int(torch.tensor(s).prod()) for s in _SHAPES.values())
+    ref = _init_params()
+    st = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in ref.items()}
+    with torch.no_grad():
+        for step in range(3):
+            for k, v in ref.items():
+                g = _rank_grad(k, 0, step) + _rank_grad(k, 1, step)
+                _ref_adam(v.data, g, st[k][0], st[k][1], _HYPER[k][0], 0.9, 0.999, _HYPER[k][1], step + 1)
+    for k in ref:
+        assert torch.equal(p0[k], p1[k]), k
+        assert torch.equal(p0[k], ref[k].detach()), k
+
+
+def _sharded_mode_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import random
+        import types
+        import gaussctrl_amd.dist as gdist
+        from gaussctrl_amd.gc_datamanager import _NextTrainMixin
+        from gaussctrl_amd.gc_pipeline import GaussCtrlPipeline
+        gdist._hip_adam = _ref_adam                     # (CPU test only: the product's slice update is the HIP kernel and raises on CPU tensors)
+
+        class Model(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                for k, v in _init_params().items():
+                    setattr(self, k, v)
+                self.grad_into = None
+                self._aux = None
+
+            def forward(self, view):
+                self._aux = type("Aux", (), {"xys_grad": None})()
+                ps = [getattr(self, k) for k in GaussCtrlPipeline._GRAD_KEYS]
+                return {"loss": _FusedFake.apply(float(view + 1), self.grad_into, self._aux, *ps)}
+
+            def get_metrics_dict(self, out, batch): return {}
+            def get_loss_dict(self, out, batch, metrics=None): return {"main_loss": out["loss"]}
+
+        class DM(_NextTrainMixin):
+            def __init__(self):
+                self.train_data = list(range(6)); self._init_sampling(6); self.seen = []
+
+            def next_train(self, step):
+                i = self._pop_view(); self.seen.append(i)
+                return i, {}
+
+        random.seed(100 + rank)
+        pipe = object.__new__(GaussCtrlPipeline)
+        torch.nn.Module.__init__(pipe)
+        pipe.world_size, pipe.local_rank = world, rank
+        pipe.config = type("C", (), {"train_mode": "sharded"})()
+        pipe.datamanager, pipe._model = DM(), Model()
+        opts = {g: types.SimpleNamespace(param_groups=[{"lr": _HYPER[key][0], "eps": _HYPER[key][1]}], zero_grad=lambda set_to_none=True: None,
+                                         step=lambda: (_ for _ in ()).throw(AssertionError("train_mode 'sharded' must not call the per-group optimizers")))
+                for g, key in GaussCtrlPipeline._GROUP_OF.items()}
+        for step in range(3):
+            pipe.train_iteration(opts, step)
+        ret[rank] = ({k: getattr(pipe._model, k).detach().clone() for k in GaussCtrlPipeline._GRAD_KEYS}, list(pipe.datamanager.seen))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_train_mode_sharded_world2():
+    """GaussCtrlPipeline.train_iteration with train_mode "sharded" at world 2 over gloo: each rank renders its own view into the flat gradient buffer
+    (loss carries 1 / N), dist.ShardedAdam reduce-scatters it, updates its slice of the flat PARAMETER buffer with the groups' lr / eps and all-gathers:
+    both ranks end with the parameters of Adam on the mean gradient of the two views, bit for bit; the per-group optimizers are never stepped."""
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_sharded_mode_worker, args=(2, 29650 + os.getpid() % 150, ret), nprocs=2, join=True)
+    (p0, seen0), (p1, seen1) = ret[0], ret[1]
+    ref = _init_params()
+    st = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in ref.items()}
+    with torch.no_grad():
+        for step in range(3):
+            grads = {k: (2 * v.data * float(seen0[step] + 1)) / 2 + (2 * v.data * float(seen1[step] + 1)) / 2 for k, v in ref.items()}
+            for k, v in ref.items():
+                _ref_adam(v.data, grads[k], st[k][0], st[k][1], _HYPER[k][0], 0.9, 0.999, _HYPER[k][1], step + 1)
+    assert seen0 != seen1
+    for k in ref:
+        assert torch.equal(p0[k], p1[k]), k
+        assert torch.allclose(p0[k], ref[k].detach(), rtol=1e-6, atol=1e-7), k

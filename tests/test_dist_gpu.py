@@ -213,3 +213,34 @@ def test_ref_shard_world4_and_8_end_to_end(world, monkeypatch):
         bad = [k for k in ref if bank[k] != ref[k]]
         assert not bad, (r, len(bad), bad[:3])
         assert np.array_equal(out, ref_out), (r, float(np.abs(out - ref_out).max()))
+
+
+def test_sharded_adam_slice_update_is_the_fused_adam_kernel():
+    """dist.ShardedAdam's product slice update (gc_adam_step on views of the flat parameter / gradient / moment buffers) against train_ops.FusedAdam on
+    separate tensors with the same gradients and per-group lr / eps: bit-identical parameters after 3 steps (world 1: the collectives are the gloo
+    world-2 tests' business, tests/test_dist_cpu.py); on CPU tensors the slice update raises instead of falling back."""
+    from gaussctrl_amd.dist import FlatGrads, FlatParams, ShardedAdam
+    from gaussctrl_amd.train_ops import FusedAdam
+    dev = "cuda:0"
+    shapes = dict(means=(1001, 3), scales=(1001, 3), quats=(1001, 4), opacities=(1001, 1), features_dc=(1001, 3), features_rest=(1001, 15, 3))
+    hyper = {"means": (1.6e-4, 1e-15), "scales": (5e-3, 1e-15), "quats": (1e-3, 1e-15), "opacities": (5e-2, 1e-15), "features_dc": (2.5e-3, 1e-15),
+             "features_rest": (1.25e-4, 1e-15)}
+    g = torch.Generator().manual_seed(0)
+    init = {k: torch.randn(*s, generator=g) for k, s in shapes.items()}
+    a = {k: torch.nn.Parameter(v.clone().to(dev)) for k, v in init.items()}
+    b = {k: torch.nn.Parameter(v.clone().to(dev)) for k, v in init.items()}
+    fp = FlatParams(a, 1); fg = FlatGrads(a, pad_to=fp.flat.numel()); sa = ShardedAdam(fp, fg, 1, 0)
+    opts = {k: FusedAdam([b[k]], lr=hyper[k][0], eps=hyper[k][1]) for k in b}
+    for step in range(3):
+        for k in a:
+            gk = torch.randn(*shapes[k], generator=g).to(dev)
+            fg.views[k].copy_(gk); b[k].grad = gk.clone()
+        sa.step(hyper)
+        for o in opts.values():
+            o.step()
+    for k in a:
+        assert torch.equal(a[k].detach(), b[k].detach()), k
+    cpu = {k: torch.nn.Parameter(v.clone()) for k, v in init.items()}
+    fpc = FlatParams(cpu, 1)
+    with pytest.raises(Exception):
+        ShardedAdam(fpc, FlatGrads(cpu, pad_to=fpc.flat.numel()), 1, 0).step(hyper)
