@@ -663,9 +663,9 @@ def main():
                      "note": "same workload with f16 activations (latents within 1e-3 rel of the fp32 oracle, tests/test_fullgeom_gpu.py)"}
         del B2
         torch.cuda.empty_cache()
-    # ... and BASELINE configs[3]'s "fp8 MFMA UNet path" on the same workload: e4m3 resnet convolutions (>= 16 x 16 maps) and transformer
-    # linears of the C = 640 / 1280 levels on the block-scaled MFMA, bf16 elsewhere (latents 2.7e-2 from the fp32 oracle: a reported
-    # variant, never `value`).  A failure here must not cost the headline line.
+    # ... and BASELINE configs[3]'s "fp8 MFMA UNet path" on the same workload: e4m3 resnet convolutions (>= 16 x 16 maps) on the block-scaled MFMA
+    # (+ with --fp8-linears 7 the transformer linears of the C = 640 / 1280 levels), bf16 elsewhere (latents 2.7e-2 from the fp32 oracle: a
+    # reported variant, never `value`).  A failure here must not cost the headline line.
     secondary_fp8 = None
     if rank == 0 and world == 1 and args.workload == "edit" and args.dtype == "bf16" and not args.no_secondary:
         try:
@@ -680,8 +680,13 @@ def main():
                              "roofline": r8,
                              "mfma_util_step_mixed_peak": round(fl8 / t3 / (r8["mixed_peak_tflops"] * 1e12), 4),
                              "mfma_util_step_vs_bf16_peak": round(fl8 / t3 / (PEAK_TFLOPS["bf16"] * 1e12), 4),
-                             "note": "same workload, --dtype fp8: e4m3 convolutions + C = 640 / 1280 transformer linears, bf16 elsewhere (latents within "
-                                     "6e-2 rel of the fp32 oracle at every step, measured 2.7e-2: tests/test_fullgeom_gpu.py::test_edit_f7_h64_fp8_convs_and_linears)"}
+                             "config": {"fp8_linears_mask": args.fp8_linears, "fp8_min_hw": args.fp8_min_hw,
+                                        "layernorm_fold_and_graph_merges": not args.fp8_linears},
+                             "note": ("same workload, --dtype fp8: e4m3 resnet convolutions beside the bf16 transformer blocks with the LayerNorm fold and the "
+                                      "round-5 graph merges (latents within 6e-2 rel of the fp32 oracle at every step, measured 2.7e-2 on the predicted curve: "
+                                      "tests/test_fullgeom_gpu.py::test_edit_f7_h64_fp8_convs_with_folded_linears)") if not args.fp8_linears else
+                                     ("same workload, --dtype fp8 --fp8-linears %d: e4m3 convolutions + C = 640 / 1280 transformer linears, bf16 elsewhere "
+                                      "(tests/test_fullgeom_gpu.py::test_edit_f7_h64_fp8_convs_and_linears)" % args.fp8_linears)}
             del B3
         except Exception as ex:                    # noqa: BLE001 -- reported, not raised
             secondary_fp8 = {"dtype": "fp8", "error": f"{type(ex).__name__}: {ex}"[:300]}
