@@ -45,6 +45,7 @@ struct TailArgs {
     const unsigned char *wa, *wkv, *wb;    // stream segments; wkv: [2 halves][BLK_KV KB]
     const float *params;                   // [P_TOTAL]
     int M, rows_per_frame, f, Lt, h_frags;
+    int in_rows;                           // > 0: the three inputs hold rows [0, in_rows) only; output row m reads input row m % in_rows (CFG-shared prefix)
     float eps;
     int stop;                              // tests: 0 = whole tail; 1..5 = write the intermediate after that many stages to `out` and leave
 };
@@ -130,12 +131,13 @@ __global__ __launch_bounds__(256, 1) void k_ttail(const TailArgs a)
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
         return l;
     };
-    auto row_off = [&]() __attribute__((always_inline)) -> int64_t {      // element offset of this lane's 4-channel group 0 in a [M][320] tensor
+    const int64_t row0_in = a.in_rows > 0 ? row0 % a.in_rows : row0;     // (in_rows % 128 == 0: a workgroup's rows never straddle the wrap)
+    auto row_off = [&](int64_t base = -1) __attribute__((always_inline)) -> int64_t {      // element offset of this lane's 4-channel group 0 in a [M][320] tensor
         const unsigned l = fresh_lane();
-        return (row0 + wid * 32 + (l & 31)) * TC + 4 * (l >> 5);
+        return ((base < 0 ? row0 : base) + wid * 32 + (l & 31)) * TC + 4 * (l >> 5);
     };
     auto load_rows = [&](const unsigned short *p, uint4 *dst) __attribute__((always_inline)) {
-        const unsigned short *r = p + row_off();
+        const unsigned short *r = p + row_off(row0_in);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const uint2 lo = *reinterpret_cast<const uint2 *>(r + 16 * ks), hi = *reinterpret_cast<const uint2 *>(r + 16 * ks + 8);
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256, 1) void k_ttail(const TailArgs a)
     f32x16 acc[NB];
     load_rows(a.o1, xf);
     if (a.h_frags) {                       // written by the head kernel as the fragments themselves: 1 KB per load instruction
-        const uint4 *r = reinterpret_cast<const uint4 *>(a.h) + ((row0 >> 5) + wid) * (KS * 64) + fresh_lane();
+        const uint4 *r = reinterpret_cast<const uint4 *>(a.h) + ((row0_in >> 5) + wid) * (KS * 64) + fresh_lane();
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) hres[ks] = r[ks * 64];
     } else load_rows(a.h, hres);
@@ -471,6 +473,8 @@ extern "C" int gc_dn_transformer_tail(const gc_ttail_desc *d, void *stream)
     a.wa = (const unsigned char *)d->w_a; a.wkv = (const unsigned char *)d->w_kv; a.wb = (const unsigned char *)d->w_b;
     a.params = d->params; a.M = (int)d->M; a.rows_per_frame = (int)d->rows_per_frame; a.f = d->frames_per_half; a.Lt = d->text_len;
     a.eps = d->ln_eps; a.stop = d->stop_after & 7; a.h_frags = d->resid_fragment_layout;
+    GC_REQUIRE(d->in_rows >= 0 && (d->in_rows == 0 || (d->in_rows % 128 == 0 && d->M % d->in_rows == 0)), "in_rows must be 0 or a multiple of 128 dividing M");
+    a.in_rows = (int)d->in_rows;
 #ifdef TTAIL_ABLATIONS
     if (d->dtype == DT_BF16 && (d->stop_after & 7)) {
         switch (d->stop_after & 7) {

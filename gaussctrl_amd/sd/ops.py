@@ -62,6 +62,7 @@ class KernelOptions:
     two_streams: bool = True         # ControlNet || UNet encoder on two HIP streams inside a denoise step
     gn_parts: bool = True            # GroupNorm statistics from the producer's epilogue (per-channel partials, plain stores): the
                                      # stand-alone statistics + finalize launches disappear (1 launch per GroupNorm instead of 3)
+    tail_in_rows: bool = True        # CFG-shared prefix: the level-0 tail kernel reads the shared rows for both halves (gc_ttail_desc.in_rows); False: 3 duplicate copies
     q_only: bool = True              # ControlNet blocks against a cached bank (self weight 0): project Q only, not Q | K | V (GC_Q_ONLY=0)
     ffout_merge: bool = True         # LayerNorm-folded blocks: feed-forward down projection + proj_out as ONE GEMM over [ff | h] (GC_FFOUT_MERGE=0)
     text_fold: bool = True           # LayerNorm-folded blocks: attn2.to_q -> text attention -> attn2.to_out as two GEMMs (SDNet._text_fold; GC_TEXT_FOLD=0)
@@ -112,7 +113,7 @@ def options_from_env(env=None) -> KernelOptions:
     a = (1 if on("GC_ATTN_SAFE", "0") else 0) | (2 if on("GC_ATTN_16", "0") else 0) | (int(e.get("GC_ATTN_V", "0")) << 2)
     return KernelOptions(gemm_variant=g, attn_variant=a, batch_invariant=on("GC_BATCH_INVARIANT", "0"),
                          fused_head=on("GC_FUSED_HEAD", "1"), fused_tail=on("GC_FUSED_TAIL", "1"), two_streams=on("GC_DN_STREAMS", "1"),
-                         gn_parts=on("GC_GN_PARTS", "1"), cfg_share=on("GC_CFG_SHARE", "1"), text_fold=on("GC_TEXT_FOLD", "1"), ffout_merge=on("GC_FFOUT_MERGE", "1"), q_only=on("GC_Q_ONLY", "1"),
+                         gn_parts=on("GC_GN_PARTS", "1"), cfg_share=on("GC_CFG_SHARE", "1"), text_fold=on("GC_TEXT_FOLD", "1"), ffout_merge=on("GC_FFOUT_MERGE", "1"), q_only=on("GC_Q_ONLY", "1"), tail_in_rows=on("GC_TAIL_INROWS", "1"),
                          ablate=frozenset(x for x in e.get("GC_ABLATE", "").split(",") if x))
 
 
@@ -587,10 +588,11 @@ class TailDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("channels", C.c_int), ("heads", C.c_int), ("M", C.c_int64), ("rows_per_frame", C.c_int64),
                 ("frames_per_half", C.c_int), ("text_len", C.c_int), ("ln_eps", C.c_float), ("attn_out", C.c_void_p), ("resid", C.c_void_p),
                 ("x_in", C.c_void_p), ("out", C.c_void_p), ("w_a", C.c_void_p), ("w_kv", C.c_void_p), ("w_b", C.c_void_p),
-                ("params", C.c_void_p), ("stop_after", C.c_int), ("resid_fragment_layout", C.c_int)]
+                ("params", C.c_void_p), ("stop_after", C.c_int), ("resid_fragment_layout", C.c_int), ("in_rows", C.c_int64)]
 
 
-def transformer_tail(attn_out, resid, x_in, seg_a, seg_kv, seg_b, params, heads, frames_per_half, text_len, eps=1e-5, stop_after=0, resid_frags=False):
+def transformer_tail(attn_out, resid, x_in, seg_a, seg_kv, seg_b, params, heads, frames_per_half, text_len, eps=1e-5, stop_after=0, resid_frags=False,
+                     halves=1):
     """Everything of a level-0 transformer block after the self-attention, one launch (gc_dn_transformer_tail): attn_out / resid / x_in
     [B, HW, 320]; seg_* / params from weights.tail_streams / weights.tail_text_stream."""
     _gpu(attn_out, resid, x_in, seg_a, seg_kv, seg_b, params)
@@ -600,9 +602,11 @@ def transformer_tail(attn_out, resid, x_in, seg_a, seg_kv, seg_b, params, heads,
         z = _ablated("tail", attn_out.shape, attn_out.dtype, attn_out.device)
         if z is not None:
             return z
-    out = torch.empty_like(attn_out)
+    # halves = 2 (CFG-shared prefix): the inputs hold ONE CFG half; the output has both, each continuing from the shared rows (no duplicate copies)
+    out = torch.empty((halves * B, HW, Cc), dtype=attn_out.dtype, device=attn_out.device)
     d = TailDesc()
-    d.dtype = _dt(attn_out); d.channels = Cc; d.heads = heads; d.M = B * HW; d.rows_per_frame = HW
+    d.dtype = _dt(attn_out); d.channels = Cc; d.heads = heads; d.M = halves * B * HW; d.rows_per_frame = HW
+    d.in_rows = B * HW if halves > 1 else 0
     d.frames_per_half = frames_per_half; d.text_len = text_len; d.ln_eps = eps
     d.attn_out = attn_out.data_ptr(); d.resid = resid.data_ptr(); d.x_in = x_in.data_ptr(); d.out = out.data_ptr()
     d.w_a = seg_a.data_ptr(); d.w_kv = seg_kv.data_ptr(); d.w_b = seg_b.data_ptr(); d.params = params.data_ptr(); d.stop_after = stop_after

@@ -407,13 +407,15 @@ class SDNet:
                                          actx, dt=h.dtype, dup=expand)
             else:
                 o = self._self_attention(t + ".attn1", ops.layernorm(h, w[t + ".norm1.weight"], w[t + ".norm1.bias"]), actx, dup=expand)
+        if tail and expand and not ops.OPTIONS.tail_in_rows:      # (A/B: duplicate the three inputs instead of gc_ttail_desc.in_rows)
+            o, h, x, B0, expand = dup2(o), dup2(h), dup2(x), B, False
+        if tail:                             # (expand: the tail reads the shared rows for both CFG halves -- gc_ttail_desc.in_rows -- no duplicate copies)
+            kv = self._text_stream(t + ".attn2", ctx, actx)
+            out = ops.transformer_tail(o, h, x.view(B0, H * W_, Cc), w[p + ".tail.a"], kv, w[p + ".tail.b"], w[p + ".tail.params"],
+                                       self.cfg["heads"], B // kv.shape[0], ctx.shape[1], resid_frags=hfr, halves=2 if expand else 1)
+            return out.view(B, H, W_, Cc), None
         if expand:                           # the halves diverge at the text cross-attention: both get the shared result
             o, h, x = dup2(o), dup2(h), dup2(x)
-        if tail:
-            kv = self._text_stream(t + ".attn2", ctx, actx)
-            out = ops.transformer_tail(o, h, x.view(B, H * W_, Cc), w[p + ".tail.a"], kv, w[p + ".tail.b"], w[p + ".tail.params"],
-                                       self.cfg["heads"], B // kv.shape[0], ctx.shape[1], resid_frags=hfr)
-            return out.view(B, H, W_, Cc), None
         rs = ops.RowStats() if fold else None
         h = ops.linear(o, w[t + ".attn1.to_out.0.weight"], w[t + ".attn1.to_out.0.bias"], residual=h, row_stats=rs)
         # feed-forward down projection + proj_out as ONE GEMM over [ff | h] (weights.prepare: ffout.weight = [Wp Wd | Wp]): the residual stream after

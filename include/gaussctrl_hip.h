@@ -435,6 +435,8 @@ typedef struct gc_ttail_desc {
     const float *params;             /* biases / LayerNorm affine in lane order */
     int stop_after;                  /* 0; tests: 1..5 = `out` receives the intermediate after that stage */
     int resid_fragment_layout;       /* 1: `resid` was written by gc_dn_transformer_head with h_fragment_layout = 1 */
+    int64_t in_rows;                 /* > 0: attn_out / resid / x_in hold rows [0, in_rows) only and output row m reads input row m % in_rows -- the
+                                      * CFG-shared prefix: both CFG halves continue from ONE copy of the shared rows (in_rows % 128 == 0, M % in_rows == 0) */
 } gc_ttail_desc;
 int gc_dn_transformer_tail(const gc_ttail_desc *desc, void *stream);
 void gc_dn_transformer_tail_layout(int64_t *blocks_a, int64_t *blocks_kv, int64_t *blocks_b, int64_t *param_floats);
