@@ -130,8 +130,8 @@ __device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + ((c ^ ((
 // epilogue of one lane's 4 consecutive output channels (n .. n+3) of row m; v = raw accumulators (+ gate for GEGLU)
 // (split-K reduce kernel) epilogue of 4 consecutive output channels of one row; on return v holds the values as stored
 template <class T>
-__device__ __forceinline__ void epilogue_store(const GemmArgs &g, int64_t m, int64_t n, int64_t on, float *v, const float *gate)
-{
+__device__ __forceinline__ void epilogue_store(const GemmArgs &g, int64_t m, int64_t n, int64_t on, float *v, const float *gate, const uint2 *res_pre = nullptr)
+{       // res_pre: the residual words of (m, on .. on + 3), loaded by the caller ahead of its own loads (split-K reduce kernels)
     const int64_t bidx = g.rowvec ? m / g.rows_per_batch : 0;
     if (g.row_stats) {
         float2 rs = make_float2(0.f, 0.f);
@@ -166,7 +166,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs &g, int64_t m, int
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] *= g.out_scale;
     if (g.residual) {
-        const uint2 rr = *reinterpret_cast<const uint2 *>((const unsigned char *)g.residual + (m * g.ldr + on) * 2);
+        const uint2 rr = res_pre ? *res_pre : *reinterpret_cast<const uint2 *>((const unsigned char *)g.residual + (m * g.ldr + on) * 2);
         v[0] += T::to_f((unsigned short)(rr.x & 0xffff)); v[1] += T::to_f((unsigned short)(rr.x >> 16));
         v[2] += T::to_f((unsigned short)(rr.y & 0xffff)); v[3] += T::to_f((unsigned short)(rr.y >> 16));
     }
@@ -1970,6 +1970,8 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue_plain(const GemmArgs g)
     for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < g.M * nq; q += (int64_t)gridDim.x * 256) {
         const int64_t m = q / nq, n = (q - m * nq) * 4;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
+        // (the residual is fetched with the slabs, not after them: one fabric round trip less per launch)
+        const uint2 rpre = g.residual ? *reinterpret_cast<const uint2 *>((const unsigned char *)g.residual + (m * g.ldr + n) * 2) : make_uint2(0u, 0u);
         for (int z0 = 0; z0 < g.splits; z0 += ZC) {          // ZC slab loads in flight, added in slab order (see ZC)
             float4 a[ZC];
 #pragma unroll
@@ -1980,7 +1982,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue_plain(const GemmArgs g)
                 if (z0 + u < g.splits) { v[0] += a[u].x; v[1] += a[u].y; v[2] += a[u].z; v[3] += a[u].w; }
         }
         float gate[4] = {0.f, 0.f, 0.f, 0.f};
-        epilogue_store<T>(g, m, n, n, v, gate);
+        epilogue_store<T>(g, m, n, n, v, gate, &rpre);
     }
 }
 
@@ -2082,6 +2084,12 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue_cs(const GemmArgs g)
 #pragma unroll
     for (int i = 0; i < RPT; ++i) { v[i][0] = 0.f; v[i][1] = 0.f; v[i][2] = 0.f; v[i][3] = 0.f; }
     if (okc) {
+        uint2 rpre[RPT];                                       // the residual rows travel with the slabs
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int64_t m = m0 + rl + 16 * i;
+            rpre[i] = (g.residual && m < g.M) ? *reinterpret_cast<const uint2 *>((const unsigned char *)g.residual + (m * g.ldr + n) * 2) : make_uint2(0u, 0u);
+        }
         for (int z0 = 0; z0 < g.splits; z0 += ZC) {            // RPT rows x ZC slabs in flight together, added in slab order
             float4 a[ZC][RPT];
 #pragma unroll
@@ -2104,7 +2112,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue_cs(const GemmArgs g)
             const int64_t m = m0 + rl + 16 * i;
             if (m >= g.M) break;
             float gate[4] = {0.f, 0.f, 0.f, 0.f};
-            epilogue_store<T>(g, m, n, n, v[i], gate);      // on return v holds the values as stored
+            epilogue_store<T>(g, m, n, n, v[i], gate, &rpre[i]);      // on return v holds the values as stored
 #pragma unroll
             for (int r = 0; r < 4; ++r) { cs[2 * r] += v[i][r]; cs[2 * r + 1] += v[i][r] * v[i][r]; }
         }
