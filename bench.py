@@ -570,15 +570,54 @@ def run_full_pipeline(args):
         "edited_views_per_s_edit_phase": round(V / edit, 3), "train_iterations_per_s": round(args.train_iters / train, 1)}), flush=True)
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run with N ranks on this node."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on these hosts
+    env.setdefault("OMP_NUM_THREADS", "8")
+    rc = subprocess.call(cmd, env=env)
+    if rc:
+        raise SystemExit(rc)
+
+
+def dry_run(rank, world):
+    """GC_BENCH_DRY=1 (tests/test_bench_launch.py, no GPU): the launch + rendez-vous path only -- init_process_group on GC_BENCH_BACKEND
+    (gloo), one all-reduce, one JSON line from rank 0.  No measurement."""
+    import datetime
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(os.environ.get("GC_BENCH_BACKEND", "gloo"), rank=rank, world_size=world, timeout=datetime.timedelta(minutes=2))
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "world": world, "sum_of_rank_plus_1": float(t.item())}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.workload == "full":
         assert args.gpus == 1, "--workload full is a single-GPU measurement"
         return run_full_pipeline(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # a bare `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU under torch.distributed.run, rendez-vous on
+        # 127.0.0.1 and a free port) -- the form `python -m torch.distributed.run ... bench.py --gpus N` keeps working unchanged
+        return self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks (use --nproc-per-node {args.gpus})")
+    if os.environ.get("GC_BENCH_DRY", "0") == "1":
+        return dry_run(rank, world)
     # GC_BENCH_ONE_GPU=1 + GC_BENCH_BACKEND=gloo: every rank on cuda:0 over gloo -- exercises the N > 1 code path on a 1-GPU box
     # (a functional check only; its number means nothing).  The driver's multi-GPU runs use neither.
     if os.environ.get("GC_BENCH_ONE_GPU", "0") == "1":

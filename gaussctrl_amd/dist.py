@@ -65,7 +65,9 @@ def split_chunks(views: list, n_chunks: int, chunk_size: int) -> list[list]:
 
 
 def allreduce_gradients(params, world_size: int, average: bool = True) -> None:
-    """Flat all-reduce of every .grad in `params` (in place)."""
+    """Flat all-reduce of every .grad in `params` (in place; a gather copy + a blocking collective + a copy back).  NOT the path of a normal
+    training step (that is FlatGrads: the backward writes the buffer RCCL reduces in place); it serves the cases where autograd owns the
+    .grad tensors: gradient accumulation over several steps, a crop box during training, parameters outside the six leaf tensors."""
     if world_size <= 1:
         return
     import torch.distributed as dist
@@ -379,6 +381,64 @@ class ShardedAdam:
         self.gshard = torch.zeros_like(self.exp_avg)
         self.steps = 0
         self.adam = adam or _hip_adam
+
+    # ---- optimizer state that survives a change of the parameter set (culling) and a checkpoint
+    def _gather_full(self, shard: torch.Tensor) -> torch.Tensor:
+        """this rank's 1 / world slice of a moment buffer -> the whole flat buffer (FlatParams layout) on every rank"""
+        if self.world <= 1:
+            return shard.clone()
+        import torch.distributed as dist
+        out = torch.empty(self.world * shard.numel(), dtype=shard.dtype, device=shard.device)
+        if shard.is_cuda and dist.get_backend(self.group) != "nccl":
+            torch.cuda.current_stream().synchronize()
+        dist.all_gather_into_tensor(out, shard.contiguous(), group=self.group)
+        return out
+
+    @torch.no_grad()
+    def adopt(self, old: "ShardedAdam", keep: torch.Tensor) -> None:
+        """Carry the Adam state of `old` (the optimizer of the parameter set BEFORE a cull) over to this one: `keep` is the boolean row mask
+        the cull applied to every leaf tensor (gc_trainer.CullCallback / SplatfactoModel.cull_gaussians prune parameters and moments with the
+        same mask in the replicated path).  The old moment shards are all-gathered, masked per tensor and re-sliced to the new shard
+        boundaries; the step count (bias correction) continues.  A collective when world > 1: every rank culls at the same step."""
+        n_old = int(keep.numel())
+        ea, es = old._gather_full(old.exp_avg), old._gather_full(old.exp_avg_sq)
+        new_a = torch.zeros(self.fp.flat.numel(), dtype=torch.float32, device=ea.device)
+        new_s = torch.zeros_like(new_a)
+        keep = keep.to(ea.device)
+        for name, (a, b) in old.fp.spans.items():
+            a2, b2 = self.fp.spans[name]
+            w = (b - a) // n_old
+            assert w * n_old == b - a and (b2 - a2) % w == 0, (name, a, b, a2, b2, n_old)
+            new_a[a2:b2] = ea[a:b].view(n_old, w)[keep].reshape(-1)
+            new_s[a2:b2] = es[a:b].view(n_old, w)[keep].reshape(-1)
+        self.exp_avg.copy_(new_a[self.lo:self.hi])
+        self.exp_avg_sq.copy_(new_s[self.lo:self.hi])
+        self.steps = old.steps
+
+    def state_dict(self, full: bool = True) -> dict:
+        """full=True (a collective when world > 1): the moments of ALL parameters in FlatParams order, so that a checkpoint written at one world
+        size restores at another; full=False: this rank's slice only."""
+        if full:
+            n = self.fp.n
+            return {"layout": {k: list(v) for k, v in self.fp.spans.items()}, "steps": self.steps, "full": True,
+                    "exp_avg": self._gather_full(self.exp_avg)[:n].clone(), "exp_avg_sq": self._gather_full(self.exp_avg_sq)[:n].clone()}
+        return {"layout": {k: list(v) for k, v in self.fp.spans.items()}, "steps": self.steps, "full": False, "rank": self.rank, "world": self.world,
+                "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone()}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd: dict) -> None:
+        if {k: list(v) for k, v in self.fp.spans.items()} != {k: list(v) for k, v in sd["layout"].items()}:
+            raise ValueError("ShardedAdam.load_state_dict: the checkpoint's parameter layout differs from this model's")
+        if sd.get("full", True):
+            pad = self.fp.flat.numel() - self.fp.n
+            for name, dst in (("exp_avg", self.exp_avg), ("exp_avg_sq", self.exp_avg_sq)):
+                src = torch.cat([sd[name].to(dst.device, torch.float32), torch.zeros(pad, device=dst.device)])
+                dst.copy_(src[self.lo:self.hi])
+        else:
+            if sd["rank"] != self.rank or sd["world"] != self.world:
+                raise ValueError("a per-rank ShardedAdam state restores only on the same rank / world size (save with full=True otherwise)")
+            self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.steps = int(sd["steps"])
 
     @torch.no_grad()
     def step(self, hyper: dict):

@@ -119,6 +119,8 @@ class GaussCtrlModel(_ModelBase):
             bc = self.config.background_color
             background = (torch.rand(3, device=dev) if bc == "random" else torch.ones(3, device=dev) if bc == "white"
                           else torch.zeros(3, device=dev) if bc == "black" else self.background_color.to(dev))
+            if bc == "random" and getattr(self, "background_override", None) is not None:
+                background = self.background_override.to(dev)       # multi-GPU train_mode "parity": the colour rank 0 drew (GaussCtrlPipeline._sync_view)
         else:
             background = self.background_color.to(dev)
         W, H = int(camera.width.reshape(-1)[0]), int(camera.height.reshape(-1)[0])
@@ -147,6 +149,15 @@ class GaussCtrlModel(_ModelBase):
         return {"rgb": rgb, "depth": depth_im, "accumulation": alpha[..., None]}
 
     forward = get_outputs
+
+    if HAVE_NERFSTUDIO:
+        def cull_gaussians(self, *args, **kwargs):
+            """SplatfactoModel.cull_gaussians + a record of the row mask it applied: train_mode "sharded" prunes its 1 / N optimizer-state
+            slices with it (GaussCtrlPipeline._sharded_adam), as splatfacto's own remove_from_all_optim does for the replicated Adam."""
+            culls = super().cull_gaussians(*args, **kwargs)
+            if torch.is_tensor(culls):
+                self._cull_keep = ~culls
+            return culls
 
     @property
     def xys_grad(self):

@@ -172,6 +172,7 @@ class GaussCtrlPipeline(_PipelineBase):
         self.text_encoder = text_encoder                           # CLIP text tower: outside the hot path
         self.mask_fn = mask_fn                                     # LangSAM stand-in: image[H,W,3] -> mask[H,W] (out of scope)
         self.bank_hook = None                                      # optional callable(RefBank | None), called once inside edit_images (tests)
+        self._spread_calls = 0                                     # training steps taken in train_mode "throughput" / "sharded" (view schedule)
         print("[gaussctrl_amd] diffusion weights: " + ", ".join(f"{k} <- {v}" for k, v in sorted(self.weights_source.items())))
 
     if not HAVE_NERFSTUDIO:
@@ -205,20 +206,25 @@ class GaussCtrlPipeline(_PipelineBase):
         td = self.datamanager.train_data
         rb = max(1, int(self.config.render_batch))
         batched = rb > 1 and hasattr(self.model, "get_outputs_for_cameras")
-        outs = {}
-        for s0 in range(0, len(views), rb) if batched else ():
-            grp = views[s0:s0 + rb]
-            for cam_idx, out in zip(grp, self.model.get_outputs_for_cameras([self.datamanager.cameras[i] for i in grp])):
-                outs[cam_idx] = out
-        for cam_idx in views:
-            out = outs[cam_idx] if batched else self._model.get_outputs_for_camera(self.datamanager.cameras[cam_idx])      # (views may repeat: ref_indices)
+        def keep(cam_idx, out):
+            if "depth" not in out:          # gc_model.py:155-156: a view that meets no Gaussian returns only {"rgb": background}
+                raise RuntimeError(f"render_reverse: view {cam_idx} intersects no Gaussian (no depth to condition the ControlNet on); "
+                                   "the reference fails here too (gc_pipeline.py:131 reads rendered_image['depth'])")
             rgb, depth = out["rgb"], out["depth"][..., 0]
             if self.config.round_like_reference:                              # :132-133 `.to(torch.float16)` (values kept in fp32 storage)
                 rgb, depth = rgb.to(torch.float16).float(), depth.to(torch.float16).float()
-            td[cam_idx]["unedited_image"] = rgb                               # [H,W,3] fp32, stays on the GPU
-            td[cam_idx]["depth_image"] = depth                                # [H,W]
+            td[cam_idx]["unedited_image"] = rgb.clone() if batched else rgb   # [H,W,3] fp32, stays on the GPU (clone: drop the batch's other planes)
+            td[cam_idx]["depth_image"] = depth.clone() if batched else depth  # [H,W]
             if self.config.langsam_obj != "" and self.mask_fn is not None:
                 td[cam_idx]["mask_image"] = self.mask_fn(rgb, self.config.langsam_obj)
+        if batched:                       # each group is consumed right after its launch set: only one batch of outputs is alive at a time
+            for s0 in range(0, len(views), rb):
+                grp = views[s0:s0 + rb]
+                for cam_idx, out in zip(grp, self.model.get_outputs_for_cameras([self.datamanager.cameras[i] for i in grp])):
+                    keep(cam_idx, out)
+        else:
+            for cam_idx in views:         # (views may repeat: ref_indices)
+                keep(cam_idx, self._model.get_outputs_for_camera(self.datamanager.cameras[cam_idx]))
         ctx = self._encode(self.positive_reverse_prompt)
         for s in range(0, len(views), max(self.chunk_size, 1)):
             chunk = views[s:s + max(self.chunk_size, 1)]
@@ -407,17 +413,56 @@ class GaussCtrlPipeline(_PipelineBase):
         params = {k: getattr(m, k) for k in self._GRAD_KEYS}
         sa = getattr(self, "_sa", None)
         if sa is None or not sa.fp.matches(params):
+            old = sa
             fp = FlatParams(params, self.world_size)
             self._fg = FlatGrads(params, pad_to=fp.flat.numel())
             sa = self._sa = ShardedAdam(fp, self._fg, self.world_size, self.local_rank)
+            if old is not None:
+                # the parameter set changed under us: a cull (gc_trainer.CullCallback / SplatfactoModel.cull_gaussians) pruned every leaf tensor
+                # with one row mask.  The replicated path prunes Adam's moments with the same mask; so do we (ShardedAdam.adopt) -- otherwise
+                # the bias correction would restart and every surviving Gaussian take an lr * sign(g) step.
+                keep = getattr(m, "_cull_keep", None)
+                n_old = old.fp.spans["means"][1] // 3 - old.fp.spans["means"][0] // 3
+                if keep is not None and keep.numel() == n_old and int(keep.sum()) == m.means.shape[0]:
+                    sa.adopt(old, keep)
+                else:
+                    import warnings
+                    warnings.warn("train_mode 'sharded': the Gaussian set changed without a cull mask (densification?); Adam moments restart at zero")
+            m._cull_keep = None
         return sa
 
+    def sharded_adam_state(self) -> Optional[dict]:
+        """train_mode "sharded": the optimizer state for a checkpoint (moments of all parameters in flat order + step count; a collective when
+        world_size > 1 -- call it on every rank, save on one).  None before the first sharded step."""
+        sa = getattr(self, "_sa", None)
+        return None if sa is None else sa.state_dict(full=True)
+
+    def load_sharded_adam_state(self, sd: dict) -> None:
+        self._sharded_adam().load_state_dict(sd)
+
     def _sync_view(self, draw):
-        """train_mode "parity": every rank trains on the view rank 0 drew (a 1-int control-path broadcast; no data-path collective)"""
+        """train_mode "parity": every rank trains on the view rank 0 drew, against the background rank 0 drew (background_color "random" is
+        torch.rand(3) of each rank's OWN generator: replicas would diverge from the first step) -- one small control-path broadcast, no
+        data-path collective.  The replicas' Gaussian counts travel along and must agree (a diverged replica culls differently)."""
         import torch.distributed as dist
-        box = [draw() if self.local_rank == 0 else None]
+        m = self.model
+        box = [(draw(), [random.random() for _ in range(3)], int(m.num_points)) if self.local_rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
-        return int(box[0])
+        view, bg, n0 = box[0]
+        if int(m.num_points) != n0:
+            raise RuntimeError(f"train_mode 'parity': rank {self.local_rank} holds {int(m.num_points)} Gaussians, rank 0 {n0} -- the replicas diverged")
+        m.background_override = torch.tensor(bg, dtype=torch.float32, device=m.device)
+        return int(view)
+
+    def _spread_view(self, draw):
+        """train_modes "throughput" / "sharded": the N ranks of a step render N DISTINCT views.  Every rank derives the same per-epoch
+        permutation of the views from a private generator (never the global `random`, which every rank seeds identically in __init__ and in
+        the datamanager) and rank r takes element step * N + r of it: no collective, no duplicated gradient."""
+        n = len(self.datamanager.train_data)
+        k = self._spread_calls * self.world_size + self.local_rank
+        self._spread_calls += 1
+        epoch, pos = divmod(k, n)
+        return random.Random(0x5EED ^ (epoch * 7919)).sample(range(n), n)[pos]
 
     def train_iteration(self, optimizers: dict, step: int):
         """One splat-optimisation iteration as GaussCtrlTrainer.train_iteration runs it (gc_trainer.py:257-301): zero grads,
@@ -438,6 +483,9 @@ class GaussCtrlPipeline(_PipelineBase):
             # place (dist.ShardedAdam); the optimizers passed in only supply this step's lr / eps per group (their schedulers keep working)
             hyper = {key: (optimizers[g].param_groups[0]["lr"], optimizers[g].param_groups[0]["eps"]) for g, key in self._GROUP_OF.items() if g in optimizers}
             self._sharded_adam().step(hyper)
+            for g, opt in optimizers.items():            # groups outside the six leaf tensors (e.g. camera_opt) keep their own optimizer
+                if g not in self._GROUP_OF:
+                    opt.step()
             return loss, loss_dict, metrics_dict
         for opt in optimizers.values():
             opt.step()
@@ -461,15 +509,26 @@ class GaussCtrlPipeline(_PipelineBase):
         elif mode == "throughput" and not accumulating:
             fg = self._flat_grads()
             m.grad_into = fg.views
-        self.datamanager.view_sync = self._sync_view if mode == "parity" else None
+        self.datamanager.view_sync = self._sync_view if mode == "parity" else self._spread_view if mode in ("throughput", "sharded") else None
         try:
             _, loss_dict, metrics_dict = self.get_train_loss_dict(step)
         finally:
             m.grad_into = None
+            m.background_override = None
         loss = sum(loss_dict.values())
         if fg is not None:
+            aux = getattr(m, "_aux", None)
+            honoured = aux is not None and aux.grad_into is not None       # the model only takes grad_into without a crop box (gc_model.get_outputs)
             (loss / self.world_size).backward()
-            if getattr(m, "_aux", None) is None or m._aux.xys_grad is None:
+            if not honoured:
+                # autograd owns this step's gradients (crop box during training, or nothing rendered): move them into the flat buffer so that the
+                # collective below sees this step's values, never stale buffer contents
+                fg.flat.zero_()
+                for k in self._GRAD_KEYS:
+                    g = getattr(m, k).grad
+                    if g is not None:
+                        fg.views[k].copy_(g)
+            elif aux.xys_grad is None:
                 fg.flat.zero_()                          # this rank's view rendered nothing (gc_model.py:155-156): it contributes zeros
             if mode == "sharded":
                 return loss.detach(), loss_dict, metrics_dict          # ShardedAdam.step reduce-scatters the buffer (train_iteration)

@@ -154,7 +154,7 @@ else:
                 if step % acc(g) == acc(g) - 1:
                     for pg in opt.param_groups:
                         pg["lr"] = self.lr_at(g, step)                   # scheduler value for this step (scheduler_step_all, :294-298)
-                    if not sharded:
+                    if not sharded or g not in getattr(self.pipeline, "_GROUP_OF", {}):      # (groups outside the six leaf tensors keep their optimizer)
                         opt.step()
             if sharded:        # reduce-scatter -> Adam on this rank's slice of the flat parameter buffer -> all-gather (dist.ShardedAdam), this step's lr / eps
                 p = self.pipeline
@@ -207,6 +207,7 @@ class CullCallback(_Callback):
         if not bool(culls.any()):
             return
         keep = ~culls
+        m._cull_keep = keep              # train_mode "sharded" prunes its optimizer-state slices with the same mask (GaussCtrlPipeline._sharded_adam)
         self.n_culled += int(culls.sum())
         groups = m.get_param_groups()
         for gname, params in groups.items():

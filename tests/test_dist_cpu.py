@@ -212,9 +212,15 @@ def _train_mode_worker(rank, world, port, mode, ret):
                 self._aux = None
 
             def forward(self, view):
-                self._aux = type("Aux", (), {"xys_grad": None})()
+                into = None if getattr(self, "ignore_grad_into", False) else self.grad_into      # (a crop box makes the real model ignore it)
+                self._aux = type("Aux", (), {"xys_grad": None, "grad_into": into})()
                 ps = [getattr(self, k) for k in GaussCtrlPipeline._GRAD_KEYS]
-                return {"loss": _FusedFake.apply(float(view + 1), self.grad_into, self._aux, *ps)}
+                self.backgrounds.append(getattr(self, "background_override", None))
+                return {"loss": _FusedFake.apply(float(view + 1), into, self._aux, *ps)}
+
+            num_points = property(lambda self: self.means.shape[0])
+            device = property(lambda self: self.means.device)
+            backgrounds = []
 
             def get_metrics_dict(self, out, batch): return {}
             def get_loss_dict(self, out, batch, metrics=None): return {"main_loss": out["loss"]}
@@ -227,32 +233,41 @@ def _train_mode_worker(rank, world, port, mode, ret):
                 i = self._pop_view(); self.seen.append(i)
                 return i, {}
 
-        random.seed(100 + rank)                                          # ranks draw DIFFERENT views unless the mode syncs them
+        random.seed(13789)                   # the SAME global seed on every rank, as GaussCtrlPipeline.__init__ / the datamanager leave it
         pipe = object.__new__(GaussCtrlPipeline)
         torch.nn.Module.__init__(pipe)
-        pipe.world_size, pipe.local_rank = world, rank
+        pipe.world_size, pipe.local_rank, pipe._spread_calls = world, rank, 0
+        mode, no_into = (mode[:-len("+cropbox")], True) if mode.endswith("+cropbox") else (mode, False)
         pipe.config = type("C", (), {"train_mode": mode})()
         pipe.datamanager, pipe._model = DM(), Model()
+        pipe._model.ignore_grad_into = no_into
         opts = {"all": torch.optim.SGD(pipe._model.parameters(), lr=0.0)}
         out = []
         for step in range(4):
             loss, _, _ = pipe.train_iteration(opts, step)
             out.append((float(loss), pipe.datamanager.seen[-1], {k: getattr(pipe._model, k).grad.clone() for k in GaussCtrlPipeline._GRAD_KEYS},
                         pipe._model.means.grad.data_ptr() == pipe._fg.views["means"].data_ptr() if mode == "throughput" else None))
-        ret[rank] = (out, {k: getattr(pipe._model, k).detach().clone() for k in GaussCtrlPipeline._GRAD_KEYS})
+        ret[rank] = (out, {k: getattr(pipe._model, k).detach().clone() for k in GaussCtrlPipeline._GRAD_KEYS},
+                     [None if b is None else b.clone() for b in pipe._model.backgrounds])
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["parity", "throughput"])
+@pytest.mark.parametrize("mode", ["parity", "throughput", "throughput+cropbox"])
 def test_train_modes_world2(mode):
-    """GaussCtrlPipeline.train_iteration at world_size 2 over gloo with a stand-in model that honours the grad_into contract:
-    parity     -- both ranks train on the view rank 0 drew (control-path broadcast), gradients equal the single-view gradient, no reduction;
-    throughput -- each rank its own view, the loss carries 1 / N, the flat buffer is all-reduced in place: every rank ends with the MEAN of
-                  the two views' gradients, and the optimizers read views of that one buffer (no autograd .grad tensors, no gather copy)."""
+    """GaussCtrlPipeline.train_iteration at world_size 2 over gloo with a stand-in model that honours the grad_into contract; every rank's global
+    `random` is seeded identically, as in the product:
+    parity     -- both ranks train on the view rank 0 drew against the background rank 0 drew (control-path broadcast), gradients equal the
+                  single-view gradient, no reduction;
+    throughput -- the ranks take DISTINCT views of one per-epoch permutation (no collective), the loss carries 1 / N, the flat buffer is
+                  all-reduced in place: every rank ends with the MEAN of the two views' gradients, and the optimizers read views of that one
+                  buffer (no autograd .grad tensors, no gather copy);
+    +cropbox   -- the model does not honour grad_into (a crop box during training): autograd's gradients are moved into the flat buffer first,
+                  the reduction never sees stale buffer contents."""
     mgr = mp.Manager(); ret = mgr.dict()
-    mp.spawn(_train_mode_worker, args=(2, 29800 + os.getpid() % 150 + (0 if mode == "parity" else 1), mode, ret), nprocs=2, join=True)
-    (o0, p0), (o1, p1) = ret[0], ret[1]
+    mp.spawn(_train_mode_worker, args=(2, 29800 + os.getpid() % 150 + ["parity", "throughput", "throughput+cropbox"].index(mode), mode, ret), nprocs=2, join=True)
+    (o0, p0, b0), (o1, p1, b1) = ret[0], ret[1]
+    seen = []
     for (l0, v0, g0, f0), (l1, v1, g1, f1) in zip(o0, o1):
         for k in g0:
             assert torch.equal(g0[k], g1[k]), (mode, k)                  # replicas stay in lock step in both modes
@@ -260,10 +275,15 @@ def test_train_modes_world2(mode):
             assert v0 == v1 and l0 == l1
             assert torch.allclose(g0["means"], 2 * p0["means"] * (v0 + 1))
         else:
-            assert f0 and f1
+            assert v0 != v1, "two ranks rendered the same view in one step: the all-reduce would average copies of one gradient"
+            assert (f0 and f1) if mode == "throughput" else True
             assert torch.allclose(g0["means"], 2 * p0["means"] * ((v0 + 1) + (v1 + 1)) / 2)
-    if mode == "throughput":
-        assert any(a[1] != b[1] for a, b in zip(o0, o1)), "the ranks drew the same views: the test would not tell mean from single"
+            seen += [v0, v1]
+    if mode == "parity":
+        assert all(a is not None and torch.equal(a, b) for a, b in zip(b0, b1)), "parity replicas must render against the same background"
+        assert len({tuple(a.tolist()) for a in b0}) == len(b0), "a fresh background per step"
+    else:
+        assert sorted(seen[:6]) == list(range(6)), "one epoch of the view schedule covers every view once across the ranks"
 
 
 # ---------------------------------------------------------------------------------------------------------------- sharded optimizer (8e, collective 2)
@@ -329,7 +349,7 @@ def test_sharded_adam_world2_equals_replicated_adam():
         assert torch.equal(p0[k], ref[k].detach()), k
 
 
-def _sharded_mode_worker(rank, world, port, ret):
+def _sharded_mode_worker(rank, world, port, cull, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -349,9 +369,12 @@ def _sharded_mode_worker(rank, world, port, ret):
                 self._aux = None
 
             def forward(self, view):
-                self._aux = type("Aux", (), {"xys_grad": None})()
+                self._aux = type("Aux", (), {"xys_grad": None, "grad_into": self.grad_into})()
                 ps = [getattr(self, k) for k in GaussCtrlPipeline._GRAD_KEYS]
                 return {"loss": _FusedFake.apply(float(view + 1), self.grad_into, self._aux, *ps)}
+
+            num_points = property(lambda self: self.means.shape[0])
+            device = property(lambda self: self.means.device)
 
             def get_metrics_dict(self, out, batch): return {}
             def get_loss_dict(self, out, batch, metrics=None): return {"main_loss": out["loss"]}
@@ -364,37 +387,71 @@ def _sharded_mode_worker(rank, world, port, ret):
                 i = self._pop_view(); self.seen.append(i)
                 return i, {}
 
-        random.seed(100 + rank)
+        random.seed(13789)                  # the same global seed on every rank, as in the product
         pipe = object.__new__(GaussCtrlPipeline)
         torch.nn.Module.__init__(pipe)
-        pipe.world_size, pipe.local_rank = world, rank
+        pipe.world_size, pipe.local_rank, pipe._spread_calls = world, rank, 0
         pipe.config = type("C", (), {"train_mode": "sharded"})()
         pipe.datamanager, pipe._model = DM(), Model()
+        stepped = []
         opts = {g: types.SimpleNamespace(param_groups=[{"lr": _HYPER[key][0], "eps": _HYPER[key][1]}], zero_grad=lambda set_to_none=True: None,
                                          step=lambda: (_ for _ in ()).throw(AssertionError("train_mode 'sharded' must not call the per-group optimizers")))
                 for g, key in GaussCtrlPipeline._GROUP_OF.items()}
-        for step in range(3):
+        opts["camera_opt"] = types.SimpleNamespace(param_groups=[{"lr": 1e-3, "eps": 1e-15}], zero_grad=lambda set_to_none=True: None,
+                                                   step=lambda: stepped.append(1))      # a group outside the six leaf tensors keeps its optimizer
+        extra = {}
+        for step in range(5 if cull else 3):
             pipe.train_iteration(opts, step)
-        ret[rank] = ({k: getattr(pipe._model, k).detach().clone() for k in GaussCtrlPipeline._GRAD_KEYS}, list(pipe.datamanager.seen))
+            if cull and step == 1:          # what gc_trainer.CullCallback / SplatfactoModel.cull_gaussians do: one row mask over every leaf tensor
+                keep = torch.tensor(_KEEP)
+                m = pipe._model
+                with torch.no_grad():
+                    for k in GaussCtrlPipeline._GRAD_KEYS:
+                        getattr(m, k).data = getattr(m, k).data[keep].contiguous()
+                m._cull_keep = keep
+            if cull and step == 3:          # checkpoint round trip (a collective: every rank calls it), restored into a FRESH ShardedAdam
+                sd = pipe.sharded_adam_state()
+                extra = {"steps": sd["steps"], "n": int(sd["exp_avg"].numel())}
+                pipe._sa = None
+                pipe.load_sharded_adam_state(sd)
+        assert len(stepped) == (5 if cull else 3)
+        ret[rank] = ({k: getattr(pipe._model, k).detach().clone() for k in GaussCtrlPipeline._GRAD_KEYS}, list(pipe.datamanager.seen), extra)
     finally:
         dist.destroy_process_group()
 
 
-def test_train_mode_sharded_world2():
-    """GaussCtrlPipeline.train_iteration with train_mode "sharded" at world 2 over gloo: each rank renders its own view into the flat gradient buffer
-    (loss carries 1 / N), dist.ShardedAdam reduce-scatters it, updates its slice of the flat PARAMETER buffer with the groups' lr / eps and all-gathers:
-    both ranks end with the parameters of Adam on the mean gradient of the two views, bit for bit; the per-group optimizers are never stepped."""
+_KEEP = [True, False, True, True, False, True, True]          # the cull of the mid-run test: rows 1 and 4 of the 7 Gaussians go
+
+
+@pytest.mark.parametrize("cull", [False, True])
+def test_train_mode_sharded_world2(cull):
+    """GaussCtrlPipeline.train_iteration with train_mode "sharded" at world 2 over gloo: each rank renders its own (distinct) view into the flat
+    gradient buffer (loss carries 1 / N), dist.ShardedAdam reduce-scatters it, updates its slice of the flat PARAMETER buffer with the groups' lr / eps
+    and all-gathers: both ranks end with the parameters of Adam on the mean gradient of the two views; the per-group optimizers of the six leaf
+    tensors are never stepped, a group outside them is.
+    cull=True: after step 1 every leaf tensor loses rows 1 and 4 (CullCallback's mask).  The replicated path prunes Adam's moments with the
+    same mask and keeps counting steps (gc_trainer.py CullCallback); the sharded state must do the same (ShardedAdam.adopt) -- compared against
+    exactly that replicated computation.  After step 3 the state goes through sharded_adam_state() / load_sharded_adam_state() into a fresh
+    ShardedAdam: step 4 must not notice."""
     mgr = mp.Manager(); ret = mgr.dict()
-    mp.spawn(_sharded_mode_worker, args=(2, 29650 + os.getpid() % 150, ret), nprocs=2, join=True)
-    (p0, seen0), (p1, seen1) = ret[0], ret[1]
+    mp.spawn(_sharded_mode_worker, args=(2, 29650 + os.getpid() % 150 + int(cull), cull, ret), nprocs=2, join=True)
+    (p0, seen0, ex0), (p1, seen1, _) = ret[0], ret[1]
     ref = _init_params()
-    st = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in ref.items()}
+    st = {k: [torch.zeros_like(v), torch.zeros_like(v)] for k, v in ref.items()}
     with torch.no_grad():
-        for step in range(3):
+        for step in range(5 if cull else 3):
             grads = {k: (2 * v.data * float(seen0[step] + 1)) / 2 + (2 * v.data * float(seen1[step] + 1)) / 2 for k, v in ref.items()}
             for k, v in ref.items():
                 _ref_adam(v.data, grads[k], st[k][0], st[k][1], _HYPER[k][0], 0.9, 0.999, _HYPER[k][1], step + 1)
-    assert seen0 != seen1
+            if cull and step == 1:
+                keep = torch.tensor(_KEEP)
+                for k, v in ref.items():
+                    v.data = v.data[keep].contiguous()
+                    st[k] = [st[k][0][keep].contiguous(), st[k][1][keep].contiguous()]
+    assert all(a != b for a, b in zip(seen0, seen1)), "the ranks of a step must render distinct views"
+    if cull:
+        assert ex0 == {"steps": 4, "n": sum(int(v.numel()) for v in ref.values())}
     for k in ref:
         assert torch.equal(p0[k], p1[k]), k
+        assert p0[k].shape == ref[k].shape
         assert torch.allclose(p0[k], ref[k].detach(), rtol=1e-6, atol=1e-7), k
