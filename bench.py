@@ -66,7 +66,11 @@ def parse():
     ap.add_argument("--train-iters", type=int, default=500)     # --workload full: Adam iterations after the edit (gc_trainer.py:186-201)
     ap.add_argument("--ref-mode", default="rotate", choices=["rotate", "owner0", "replicate", "allgather"])    # N > 1: who computes the reference bank
     # (allgather: the reference trajectory sharded by sample, K / V^T all-gathered per attention layer; N in {2, 4, 8})
-    ap.add_argument("--inflight", type=int, default=2)         # chunks in flight on independent HIP stream pairs (1: strictly one after the other)
+    ap.add_argument("--inflight", type=int, default=2)         # launch sets in flight on independent HIP stream pairs (1: strictly one after the other)
+    ap.add_argument("--cobatch", type=int, default=2)          # consecutive chunks of a scene that share ONE launch set (GaussCtrlPipelineConfig.chunks_per_launch): against
+                                                              # the cached reference bank a view's result does not depend on what shares its network batch, so two chunks of
+                                                              # chunk_size views run as one batch of 2 x chunk_size -- every GEMM sees twice the rows (the 384-row level-3
+                                                              # problems fill a round).  A step stays ONE chunk of chunk_size views; 1 = one chunk per launch set (rounds 1-5)
     ap.add_argument("--no-secondary", action="store_true")     # skip the short f16 secondary measurement (default workload, N = 1)
     ap.add_argument("--mask", action="store_true")   # BASELINE configs[3]: edits composited through a (synthetic elliptical) mask, gc_pipeline.py:226-234
     return ap.parse_args()
@@ -289,6 +293,8 @@ class Bench:
         # so the part-filled grids and the fill / drain phases of one chunk's kernels are covered by the other's; the next scene's
         # reference trajectory has a stream of its own
         self.inflight = max(1, args.inflight) if self.edit else 1
+        self.cobatch = max(1, args.cobatch) if self.edit else 1
+        self.sets_done = 0
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.inflight)] if self.inflight > 1 else [None]
         self.ref_stream = torch.cuda.Stream(device=dev) if self.inflight > 1 else None
         self.bank_ready = None          # event on ref_stream: the bank the chunks are about to use is complete
@@ -364,20 +370,39 @@ class Bench:
         self.bank_layers = tr.layers
         return tr.finish() if done else None
 
-    def step(self, s):
-        st_ = self.streams[s % len(self.streams)]
-        if st_ is None:
-            return self._step(s)
-        with torch.cuda.stream(st_):
-            return self._step(s)
+    def groups(self, g0, n):
+        """the n steps (chunks) g0 .. g0 + n - 1 as launch sets: up to `cobatch` consecutive chunks of ONE scene share a set"""
+        out, s, end = [], g0, g0 + n
+        while s < end:
+            k = 1
+            # (sets are aligned to multiples of `cobatch` inside a scene, wherever the timed region starts: the short last chunk of a scene
+            # always shares its set with the chunk before it)
+            while k < self.cobatch and s + k < end and (s + k) // self.cps == s // self.cps and ((s + k) % self.cps) % self.cobatch != 0:
+                k += 1
+            out.append(list(range(s, s + k)))
+            s += k
+        return out
 
-    def _step(self, s):
-        """Chunk s of an endless stream of scenes (cps chunks per scene on every rank).  A scene's reference trajectory (4 views x 20
-        DDIM steps, shared by its chunks) is computed while the PREVIOUS scene is edited, 20 / cps DDIM steps per chunk, so every
-        step carries exactly its share of the reference work whatever K is."""
+    def step(self, s):
+        """one launch set: chunk s, or the list of co-batched chunks"""
+        ss = [s] if isinstance(s, int) else list(s)
+        st_ = self.streams[self.sets_done % len(self.streams)]
+        self.sets_done += 1
+        if st_ is None:
+            return self._step(ss)
+        with torch.cuda.stream(st_):
+            return self._step(ss)
+
+    def _step(self, ss):
+        """Chunks ss (consecutive, one scene) of an endless stream of scenes (cps chunks per scene on every rank) as ONE launch set.  A scene's
+        reference trajectory (4 views x 20 DDIM steps, shared by its chunks) is computed while the PREVIOUS scene is edited, 20 / cps DDIM
+        steps per chunk, so every step carries exactly its share of the reference work whatever K is."""
         st, c, cps, nsteps, p = self.state, self.c, self.cps, self.nsteps, self.params
+        s = ss[0]
         scene, j = divmod(s, cps)
-        views = self.chunks_of(scene)[j]
+        j1 = j + len(ss) - 1                       # last chunk of the set (same scene)
+        assert (ss[-1]) // cps == scene
+        views = [v for jj in range(j, j1 + 1) for v in self.chunks_of(scene)[jj]]
         st["views_done"] += len(views)
         ev = None
         if self.record_halves:
@@ -392,7 +417,7 @@ class Bench:
                     self.bank_ready = torch.cuda.Event(); self.bank_ready.record()
                 if st["next"] is None:                # the following scene's references start with this scene
                     st["next"] = self.begin_bank(scene + 1)
-                quota = (nsteps * (j + 1)) // cps - (nsteps * j) // cps
+                quota = (nsteps * (j1 + 1)) // cps - (nsteps * j) // cps          # the reference share of every chunk of the set
                 done = self.advance_bank(st["next"], quota)          # owner: compute + post sends; others: post receives (they arrive under (b))
             if self.bank_ready is not None:
                 cur.wait_event(self.bank_ready)       # (no-op on the stream that recorded it)
@@ -401,7 +426,7 @@ class Bench:
                 disp = torch.stack([self.disparity_of(e[1]) for e in evals])
                 lat = self.pipe.edit_chunk_cached(self.z0[views], disp, self.ctx_neg, self.ctx_pos, st["bank"])   # (b)
                 edited = self.pipe.decode(lat)                                                              # (c)
-            if j == cps - 1:
+            if j1 == cps - 1:
                 assert done is not None
                 st["prev_bank"] = st["bank"]          # chunks still in flight on other streams read it: keep it alive for one more scene
                 st["bank"], st["next"] = done, None
@@ -412,7 +437,7 @@ class Bench:
             edited = [None] * len(views)
         if ev:
             ev[1].record()
-        fg = self.grads[s % len(self.grads)]            # (same index -> same stream when chunks are in flight on several streams)
+        fg = self.grads[(self.sets_done - 1) % len(self.grads)]            # (same index -> same stream when sets are in flight on several streams)
         fg.wait()                                 # the all-reduce posted two chunks ago (N > 1) has finished before its buffer is rewritten
         if self.view_batch and len(views) >= 2:                                                             # (d), batched: one launch set
             aux = self.new_aux()
@@ -471,17 +496,17 @@ class Bench:
         state), `warmup` untimed steps, then EXACTLY `steps` timed steps between barriers; returns (seconds = max over ranks,
         views edited by this rank in the timed region, training renders in it)"""
         g = 0
-        for i in range(2 + warmup):
-            self.step(g); g += 1
+        for i, grp in enumerate(self.groups(0, 2 * self.cobatch) + self.groups(2 * self.cobatch, warmup)):
+            self.step(grp); g += len(grp)
             if i < 2:
-                torch.cuda.synchronize()      # the priming chunks also fill the per-prompt / per-timestep caches every stream reads later
+                torch.cuda.synchronize()      # the priming sets also fill the per-prompt / per-timestep caches every stream reads later
         self.finish()
         self.barrier()
         v0, r0 = self.state["views_done"], self.state["renders_done"]
         self.record_halves = True
         t0 = time.perf_counter()
-        for _ in range(steps):
-            self.step(g); g += 1
+        for grp in self.groups(g, steps):          # EXACTLY `steps` chunks, `cobatch` of them per launch set
+            self.step(grp); g += len(grp)
         self.finish()
         self.barrier()
         dt_s = time.perf_counter() - t0
@@ -568,6 +593,25 @@ def run_full_pipeline(args):
         "phases_s": {"render_reverse (render + VAE encode + inversion)": round(inv, 3), "edit_images": round(edit, 3),
                      f"train_iteration x {args.train_iters}": round(train, 3)},
         "edited_views_per_s_edit_phase": round(V / edit, 3), "train_iterations_per_s": round(args.train_iters / train, 1)}), flush=True)
+
+
+_BENCH_ENV_DEFAULTS = {"GC_DN_FOLD_LN": None, "GC_DN_FUSE_GN": "0", "GC_DN_GN2": "0", "GC_BENCH_SYNCFREE": "1", "GC_BENCH_ONE_GPU": "0", "GC_BENCH_BACKEND": "nccl"}
+
+
+def effective_options(sdops, args):
+    """{switch: value} this run used -- every sd.ops.KernelOptions field plus the bench-level environment toggles; (None, None) returns
+    the product defaults in the same shape, so `is_product_default` is a plain equality."""
+    import dataclasses
+    from gaussctrl_amd.sd import ops as _ops
+    o = dataclasses.asdict(_ops.KernelOptions() if sdops is None else sdops.OPTIONS)
+    o["ablate"] = sorted(o["ablate"])
+    for k, d in _BENCH_ENV_DEFAULTS.items():
+        v = d if sdops is None else os.environ.get(k, d)
+        if k == "GC_DN_FOLD_LN":            # default depends on the run: fold level 2 except with e4m3 linears (they take e4m3 from the LayerNorm kernel)
+            dflt = "2" if (args is None or not (args.dtype == "fp8" and args.fp8_linears)) else "0"
+            v = dflt if (sdops is None or v is None) else v
+        o[k] = v
+    return o
 
 
 def self_launch(args):
@@ -683,12 +727,13 @@ def main():
             rr = raster_roofline(args, B, g, stats, H * W)          # the rasterizer half of the same run: chain roofline at this N
             # headline fraction = priced on the (tile, Gaussian) pairs the kernels really move (tight boxes); `frac_reference_lists` prices
             # the same time against gsplat's longer lists (what the reference would have to move)
-            roof_raster = {"bound": "hbm", "unit": "GB/s", "peak": 8000.0, "achieved": round(rr["chain"]["frac_processed_pairs"] * 8000.0, 1),
-                           "frac": rr["chain"]["frac_processed_pairs"], "frac_reference_lists": rr["chain"]["frac"],
-                           "kernel_us_per_view": rr["chain"]["kernel_us_per_view"], "algorithmic_MB_per_view": rr["chain"]["algorithmic_MB_per_view"],
-                           "traffic_ratio": rr["chain"].get("traffic_ratio"), "N": rr["chain"]["N"], "M_mean": rr["chain"]["M_mean"],
-                           "M_processed_mean": rr["chain"]["M_processed_mean"], "frac_processed_pairs": rr["chain"]["frac_processed_pairs"],
-                           "formula": rr["chain"]["formula"], "dominant_stage": rr["kernel"], "dominant_stage_frac": rr["frac"]}
+            ch = rr["chain"]
+            roof_raster = {"bound": "hbm", "unit": "GB/s", "peak": 8000.0, "achieved": round(ch["frac"] * 8000.0, 1),
+                           "frac": ch["frac"], "frac_counters": ch["frac_counters"], "frac_8d_unbatched": ch["frac_8d_unbatched"],
+                           "kernel_us_per_view": ch["kernel_us_per_view"], "algorithmic_MB_per_view": ch["algorithmic_MB_per_view"],
+                           "traffic_MB_per_view": ch["traffic_MB_per_view"], "traffic_ratio": ch.get("traffic_ratio"), "N": ch["N"],
+                           "views_per_launch_set": ch["views_per_launch_set"], "M_mean": ch["M_mean"], "M_processed_mean": ch["M_processed_mean"],
+                           "formula": ch["formula"], "dominant_stage": rr["kernel"], "dominant_stage_frac": rr["frac"]}
 
     # ---------------------------------------------------------------- secondary: the f16 activation path (the dtype that meets north_star's 1e-3)
     secondary = None
@@ -756,7 +801,8 @@ def main():
                    ({"rotate": "owner rotates per scene, per-DDIM-step async RCCL broadcast", "owner0": "rank 0 owns, per-DDIM-step async RCCL broadcast",
                      "replicate": "replicated on every rank (no collective)",
                      "allgather": "trajectory sharded by sample, per-layer RCCL all-gather of K / V^T"}[args.ref_mode] if world > 1 else "local") +
-                   f"; flat async gradient all-reduce; {B0_inflight} chunk(s) in flight on independent stream pairs; ControlNet || UNet encoder on 2 HIP streams")
+                   f"; flat async gradient all-reduce; {args.cobatch} chunk(s) per launch set (one network batch), {B0_inflight} launch set(s) in flight on independent "
+                   "stream pairs; ControlNet || UNet encoder on 2 HIP streams")
         else:
             flop, mfma_util = None, None
             par = f"every rank renders its own {V} cameras (x{world}); flat async gradient all-reduce"
@@ -769,13 +815,18 @@ def main():
                                       f"{args.gaussians} Gaussians, 512x512" if args.workload == "edit" else
                                       f"raster-only fwd+bwd (+ fused L1+SSIM loss), {args.gaussians} Gaussians, {V} random cameras/GPU, 512x512, fx=fy=540",
                           "views_per_step": round(views_done / args.steps, 3), "chunks_per_scene_per_rank": chunks_per_scene, "parallelism": par,
+                          "chunks_per_launch_set": args.cobatch if args.workload == "edit" else 1,
                           "mean_intersections_M": int(np.mean(stats["M"])) if stats["M"] else 0,
                           "ref_trajectory_in_timed_region": bool(args.workload == "edit"),
                           "cfg_shared_prefix": bool(sdops.OPTIONS.cfg_share) if args.workload == "edit" else None,
                           "layernorm_fold_levels_1_3": (os.environ.get("GC_DN_FOLD_LN", "0" if (args.dtype == "fp8" and args.fp8_linears) else "2") != "0") if args.workload == "edit" else None,
                           "level0_transformer_blocks": ("one-launch head + tail" if sdops.OPTIONS.fused_head and sdops.OPTIONS.fused_tail
                                                         else f"fused_head={sdops.OPTIONS.fused_head} fused_tail={sdops.OPTIONS.fused_tail}") if args.workload == "edit" else None,
-                          "ref_trajectory_share_per_step": f"{nsteps}/{chunks_per_scene} DDIM steps of the next scene's 4 reference views" if args.workload == "edit" else None},
+                          "ref_trajectory_share_per_step": f"{nsteps}/{chunks_per_scene} DDIM steps of the next scene's 4 reference views" if args.workload == "edit" else None,
+                          # the EFFECTIVE switches of this run (defaults = the product configuration; any GC_* experiment variable that changed
+                          # one shows up here, so a headline line is provably the default build): sd.ops.KernelOptions + the bench-level toggles
+                          "kernel_options": effective_options(sdops, args),
+                          "is_product_default": effective_options(sdops, args) == effective_options(None, None)},
                # the two halves separately (GPU time of rank 0's launch stream between HIP events in the timed steps)
                # (the wall time of the timed region is apportioned to the halves by their share of the per-chunk GPU spans: with one
                # chunk in flight that is the measured span itself, with several the spans overlap but their ratio stands)
@@ -806,7 +857,7 @@ def denoise_roofline(args, dtype_name, pipe, sdops, z0, ctx_neg, ctx_pos, bank, 
     Returns (roofline dict, per-class summary).  fp8_class=False: the dominant kernel class of the chunk against the dense 2-byte MFMA peak.
     fp8_class=True (`--dtype fp8` runs): the dominant e4m3 GEMM class against the dense e4m3 peak (5 PF) -- the chunk's dominant kernel stays
     the bf16 attention, reported under `other` with its own fraction of 2.5 PF."""
-    c, H, W = args.chunk_size, 512, 512
+    c, H, W = args.chunk_size * max(1, args.cobatch), 512, 512          # the instrumented launch set = what the timed steps launch (cobatch chunks)
     prof = GemmProfiler("F16" if dtype_name == "f16" else "BF16")
     for net in (pipe.unet, pipe.controlnet):             # un-padded input channels of the e4m3 convolutions (weights pad Cin to 128)
         for k, v in net.w.items():
@@ -894,18 +945,32 @@ class LibTimer:
 # algorithmic HBM bytes of one training render (forward + backward) per stage: coefficients of (N Gaussians, M tile
 # intersections, HW pixels) from SURVEY.md 8(d), which add up to N*868 + M*124 + HW*44 -- except k_project_sh_bwd: since round 2 it takes
 # the forward colours instead of re-reading the 192-byte SH record (reads 108 B, writes 236 B per Gaussian: 344 instead of 552), so the
-# chain total is N*660 + M*124 + HW*44
+# chain total is N*660 + M*124 + HW*44 for ONE camera per launch set.
+# A batch of C cameras (round 5) reads / writes the camera-independent part of a Gaussian's record once per BATCH: projection
+# forward 236 + C * 60 bytes per Gaussian (C * 296 unbatched; the 8d row's 280 + the 16 bytes of depth-sort pair and opacity it writes since
+# round 5), projection backward 56 + C * 64 read + 236 written (C * 344 unbatched... 8d: 344).  `raster_stage_bytes` returns the bytes ONE view
+# is charged: the batch-aware count is what a launch really has to move, the 8d count what C unbatched renders would.
 RASTER_STAGES = {
-    "gc_project_sh_fwd": ("k_project_sh_fwd", 280, 0, 0),
-    "gc_raster_depth_order": ("binning: depth keys + 4 radix passes + scan (raster_sort.hip)", 0, 0, 0),      # counted with the next row
-    "gc_raster_bin_tiles_dev": ("binning: emit + 2 tile radix passes + bins (raster_sort.hip)", 0, 44, 0),
-    "gc_raster_bin_tiles": ("binning: emit + 2 tile radix passes + bins (raster_sort.hip)", 0, 44, 0),
-    "gc_rasterize_fwd": ("k_rasterize_fwd", 0, 40, 20),
-    "gc_raster_finalize": ("k_raster_finalize", 0, 0, 0),
-    "gc_l1_ssim_fwd_bwd": ("k_ssim_stats + k_ssim_grad (loss, not in the 8d byte count)", 0, 0, 0),
-    "gc_rasterize_bwd": ("k_rasterize_bwd", 36, 40, 24),
-    "gc_project_sh_bwd": ("k_project_sh_bwd", 344, 0, 0),
+    # name: (label, per-Gaussian bytes per view [8d], per-Gaussian bytes per BATCH, per-Gaussian bytes per view inside a batch, per pair, per pixel)
+    "gc_project_sh_fwd": ("k_project_sh_fwd", 280, 236, 60, 0, 0),
+    "gc_raster_depth_order": ("binning: depth keys + 4 radix passes + scan (raster_sort.hip)", 0, 0, 0, 0, 0),      # counted with the next row
+    "gc_raster_bin_tiles_dev": ("binning: emit + 2 tile radix passes + bins (raster_sort.hip)", 0, 0, 0, 44, 0),
+    "gc_raster_bin_tiles": ("binning: emit + 2 tile radix passes + bins (raster_sort.hip)", 0, 0, 0, 44, 0),
+    "gc_rasterize_fwd": ("k_rasterize_fwd", 0, 0, 0, 40, 20),
+    "gc_raster_finalize": ("k_raster_finalize", 0, 0, 0, 0, 0),
+    "gc_l1_ssim_fwd_bwd": ("k_ssim_stats + k_ssim_grad (loss, not in the 8d byte count)", 0, 0, 0, 0, 0),
+    "gc_rasterize_bwd": ("k_rasterize_bwd", 36, 0, 36, 40, 24),
+    "gc_project_sh_bwd": ("k_project_sh_bwd", 344, 56 + 236, 64, 0, 0),
 }
+
+
+def raster_stage_bytes(name, N, M, HW, C=1):
+    """(bytes per view by the SURVEY 8d formula, bytes per view when C cameras share a launch set)"""
+    _, n8d, n_batch, n_view, cm, chw = RASTER_STAGES[name]
+    b8d = n8d * N + cm * M + chw * HW
+    if C <= 1:
+        return b8d, b8d
+    return b8d, (n_batch / C + n_view) * N + cm * M + chw * HW
 
 
 def raster_roofline(args, B, g, stats, HW):
@@ -964,36 +1029,51 @@ def raster_roofline(args, B, g, stats, HW):
     traffic = None
     # PMC traffic of the configuration that ran: the batched-views passes (round 5, 8 views per launch set) or the one-camera-per-launch ones
     batched = B.view_batch and min(args.chunk_size, nviews) >= 2
-    for tname in (("r05_raster_traffic_views8.json",) if batched else ("r03_raster_traffic.json", "r02_raster_traffic.json")):
+    Cb = min(args.chunk_size, nviews) if batched else 1
+    for tname in ((f"r06_raster_traffic_views{Cb}.json", f"r05_raster_traffic_views{Cb}.json") if batched else ("r03_raster_traffic.json", "r02_raster_traffic.json")):
         tpath = os.path.join(ROOT, "profiles", tname)
         if traffic is None and os.path.exists(tpath):
             traffic = json.load(open(tpath)).get(str(N))
-    stages, tot_b, tot_s = {}, 0.0, 0.0
-    for name, (label, cn, cm, chw) in RASTER_STAGES.items():
+    C = min(args.chunk_size, nviews) if batched else 1               # cameras per launch set of the instrumented step
+    stages, tot_8d, tot_b, tot_s = {}, 0.0, 0.0, 0.0
+    for name in RASTER_STAGES:
         if name not in per:
             continue
+        label = RASTER_STAGES[name][0]
         secs = float(np.mean(per[name]))
-        b = cn * N + cm * M + chw * HW
-        tot_b += b; tot_s += secs
+        b8d, b = raster_stage_bytes(name, N, M_proc, HW, C)           # priced on the pairs the kernels really bin (tight boxes)
+        b8d_ref = raster_stage_bytes(name, N, M, HW, 1)[0]            # ... and the 8d formula on gsplat's longer lists (what the reference would move)
+        tot_8d += b8d_ref; tot_b += b; tot_s += secs
+        tr = None if not traffic or name not in traffic else traffic[name]
         stages[name] = {"kernel": label, "avg_us": round(secs * 1e6, 1), "algorithmic_MB": round(b / 1e6, 1),
-                        "GBps": round(b / secs / 1e9, 1) if b else None,
-                        "traffic_MB": None if not traffic or name not in traffic else traffic[name]}
-    traffic_ratio = None
-    if traffic:                   # counters of the committed PMC passes at this N over the algorithmic bytes of the same stages
-        tb = sum(v for k, v in traffic.items() if k in stages or k == "loss+finalize")
-        traffic_ratio = round(tb * 1e6 / tot_b, 3)
+                        "GBps": round(b / secs / 1e9, 1) if b else None, "algorithmic_MB_8d_unbatched": round(b8d_ref / 1e6, 1),
+                        "traffic_MB": tr, "traffic_GBps": None if tr is None else round(tr * 1e6 / secs / 1e9, 1)}
+    traffic_ratio = traffic_MB = frac_counters = None
+    if traffic:                   # counters of the committed PMC passes at this N: what the chain really moved, over the same stages
+        traffic_MB = sum(v for k, v in traffic.items() if k in stages or k == "loss+finalize")
+        traffic_ratio = round(traffic_MB * 1e6 / tot_b, 3)
+        frac_counters = round(traffic_MB * 1e6 / tot_s / 8e12, 4)
     dom = max((k for k in stages if stages[k]["GBps"]), key=lambda k: stages[k]["avg_us"])
     d = stages[dom]
     ach = d["algorithmic_MB"] * 1e6 / (d["avg_us"] * 1e-6) / 1e9
+    assert all(v["GBps"] is None or v["GBps"] <= 8000.0 for v in stages.values()), "a stage priced above the HBM peak: its byte count is wrong"
     return {"bound": "hbm", "kernel": f"{d['kernel']} ({dom}, dominant stage of the render fwd+bwd chain)", "achieved": round(ach, 1),
             "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": d["traffic_MB"] and d["traffic_MB"] * 1e6,
             "avg_launch_us": d["avg_us"], "algorithmic_bytes_per_launch": d["algorithmic_MB"] * 1e6,
             "chain": {"algorithmic_MB_per_view": round(tot_b / 1e6, 1), "kernel_us_per_view": round(tot_s * 1e6, 1),
-                      "GBps": round(tot_b / tot_s / 1e9, 1), "frac": round(tot_b / tot_s / 8e12, 4), "views_in_sample": nviews,
-                      "views_per_launch_set": (min(args.chunk_size, nviews) if B.view_batch else 1),
+                      "GBps": round(tot_b / tot_s / 1e9, 1),
+                      # three readings of the same time, most conservative first:
+                      #   frac                -- batch-aware algorithmic bytes on the pairs really binned (what one launch set has to move) / time
+                      #   frac_counters       -- HBM bytes the PMC counters saw (committed passes at this N and batch) / time
+                      #   frac_8d_unbatched   -- SURVEY 8d's per-view formula on gsplat's lists (what C unbatched reference renders would move) / time
+                      "frac": round(tot_b / tot_s / 8e12, 4), "frac_counters": frac_counters, "frac_8d_unbatched": round(tot_8d / tot_s / 8e12, 4),
+                      "traffic_MB_per_view": None if traffic_MB is None else round(traffic_MB, 1),
+                      "views_in_sample": nviews, "views_per_launch_set": C,
                       "N": N, "M_mean": int(M), "M_processed_mean": int(M_proc),
-                      "frac_processed_pairs": round((tot_b - 124.0 * (M - M_proc)) / tot_s / 8e12, 4),
-                      "traffic_ratio": traffic_ratio, "formula": "N*660 + M*124 + HW*44 bytes per view (SURVEY.md 8d with the SH record no longer re-read in the backward); M = intersections of gsplat's boxes (the reference's lists), M_processed = pairs binned on the tight boxes"},
+                      "traffic_ratio": traffic_ratio,
+                      "formula": ("per view of a C-camera launch set: N*((236+56+236)/C + 60+36+64) + M*124 + HW*44 bytes (DESIGN.md 3.1; C = 1 gives SURVEY.md 8d's "
+                                  "N*660 + M*124 + HW*44 plus the 32 bytes of sort pair / opacity written since round 5); M = pairs binned on the tight boxes "
+                                  "(M_processed_mean); M_mean = intersections of gsplat's boxes, used only by frac_8d_unbatched")},
             "stages": stages}
 
 

@@ -70,6 +70,11 @@ class GaussCtrlPipelineConfig(_PipelineConfigBase):
                                        # layer all-gathers K / V^T (dist.RefShard) -- no owner, no extra work on any rank; wins over ref_bank_owner
     inflight_chunks: int = 2           # chunks of edit_images in flight on independent HIP stream pairs (consecutive chunks only share the
                                        # read-only reference bank; 1 = strictly one after the other, as the reference runs them)
+    chunks_per_launch: int = 2         # with the reference K / V^T cached a view's result does not depend on which views share its network batch
+                                       # (each view attends to itself and to the 4 references, utils.py:95-102), so `chunks_per_launch` consecutive
+                                       # chunks of `chunk_size` views run as ONE batch: every GEMM sees that many times the rows (the levels-1..3
+                                       # linears of a 3-view chunk are launch-granularity bound).  1 = one chunk per network batch, as the reference
+                                       # runs them; ignored (= 1) without cache_reference_kv, where the references ride in every batch
     round_like_reference: bool = False  # True: round the rendered rgb / depth to fp16 before inversion, disparity and the mask composite,
                                        # exactly where the reference does (gc_pipeline.py:132-133,155); False keeps the fp32 renders
     batch_invariant: Optional[bool] = None    # kernel planning that makes a view's result independent of its chunk / rank count
@@ -284,8 +289,9 @@ class GaussCtrlPipeline(_PipelineBase):
             # received by broadcast nothing has touched the pipeline's lazily filled caches yet (text K / V^T, time-embedding rows).
             self.pipe.warm_caches(cn, cp)
             ready.record(main)
-        for ci, s in enumerate(range(0, len(views), self.chunk_size)):
-            chunk = views[s:s + self.chunk_size]
+        per_launch = self.chunk_size * (max(1, int(self.config.chunks_per_launch)) if bank is not None else 1)
+        for ci, s in enumerate(range(0, len(views), per_launch)):
+            chunk = views[s:s + per_launch]
             stream = self._chunk_streams[ci % n_fly] if n_fly > 1 else main
             if n_fly > 1:
                 stream.wait_event(ready)          # bank, z_0 and depth images were produced on the caller's stream

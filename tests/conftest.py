@@ -1,6 +1,12 @@
 import os
 import sys
 
+# CPU threads of the checkers.  The GPU boxes have 256 logical cores; fp32 torch on all of them runs the oracle's small problems several times
+# SLOWER than on a few dozen (bench.py measured 289 s vs 30 s for one denoise step), and the tests that spawn 2-8 ranks or child pytest
+# processes multiply that.  Set before torch is imported; children inherit it.
+os.environ.setdefault("OMP_NUM_THREADS", str(min(32, os.cpu_count() or 1)))
+os.environ.setdefault("MKL_NUM_THREADS", os.environ["OMP_NUM_THREADS"])
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -22,8 +22,10 @@ def _rel(a, b):
 @pytest.fixture(scope="module")
 def sd15():
     from oracle import sd15_torch as sd
+    import _nets
     torch.manual_seed(0)
-    return sd, sd.make_unet_weights(sd.SD15, 100), sd.make_controlnet_weights(sd.SD15, 200)
+    uw, cw = _nets.raw_sd15(rounded=False)          # (the seeded generators' tensors, shared with the full-geometry tests)
+    return sd, uw, cw
 
 
 def _inputs(f, h, seed=2):

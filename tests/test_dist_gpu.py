@@ -73,6 +73,7 @@ def _run(pipe, model):
 
 
 def _worker(rank, world, port, owner, ret, gather=False):
+    torch.set_num_threads(4)                       # several ranks share the host cores
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from gaussctrl_amd.sd import ops as sdops
@@ -150,6 +151,7 @@ def test_two_ranks_one_gpu_match_single_rank(owner, invariant, monkeypatch):
 
 # ------------------------------------------------------------------------------------------------ RefShard at world 4 / 8, end to end
 def _shard_worker(rank, world, port, ret):
+    torch.set_num_threads(4)                       # up to 8 ranks share the host cores
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:

@@ -35,19 +35,10 @@ def _inputs(f, h, seed):
 
 @pytest.fixture(scope="module")
 def nets():
-    """fp32 weights of the fixture (seeded CPU generators), rounded to bf16 like the generator did; prepared per dtype on demand."""
-    from oracle import sd15_torch as sd
-    from gaussctrl_amd.sd.weights import prepare
-    r = lambda w: {k: v.to(torch.bfloat16).float() for k, v in w.items()}
-    uw, cw = r(sd.make_unet_weights(sd.SD15, 100)), r(sd.make_controlnet_weights(sd.SD15, 200))
-    cache = {}
-
-    def get(dt):
-        if dt not in cache:
-            cache.clear()
-            cache[dt] = (prepare(uw, dt, DEV, heads=8), prepare(cw, dt, DEV, heads=8))
-        return cache[dt]
-    return get
+    """the fixture's weights (seeded CPU generators, rounded to bf16 like the generator did) prepared per dtype on demand (tests/_nets.py:
+    shared with every other test of the session that wants them)"""
+    import _nets
+    return lambda dt: _nets.prepared(dt, False)
 
 
 def _curve(trace, ref, sl=slice(None)):
@@ -106,9 +97,8 @@ def test_edit_f7_h64_layernorm_folded(dt):
     ref = z["lat_steps"]
     f, h, steps, seed = [int(v) for v in z["meta"][:4]]
     lat, disp, cn, cp = _inputs(f, h, seed)
-    r = lambda w: {k: v.to(torch.bfloat16).float() for k, v in w.items()}
-    uw = prepare(r(sd.make_unet_weights(sd.SD15, 100)), dt, DEV, heads=8, fold_ln=2)
-    cw = prepare(r(sd.make_controlnet_weights(sd.SD15, 200)), dt, DEV, heads=8, fold_ln=2)
+    import _nets
+    uw, cw = _nets.prepared(dt, 2)
     assert any(k.endswith("attn1.to_qkv.colsum") for k in uw) and any(k.endswith(".tail.a") for k in uw)
     pipe = DenoisePipeline(uw, cw, None, 20, 5.0)
     trace = []
@@ -248,18 +238,16 @@ def _config4_run(nets, dt, fp8, cached=False):
     which = [int(v) for v in z["which_steps"]]
     lat, disp, cn, cp = _inputs(f, h, seed)
     if fp8 == "hybrid":       # e4m3 convolutions + the round-5 bf16 transformer blocks (LayerNorm fold, text fold, FF merge, Q-only): `bench.py --dtype fp8` since round 5
-        from gaussctrl_amd.sd.weights import prepare
-        rr = lambda w: {k: v.to(torch.bfloat16).float() for k, v in w.items()}
-        usd, csd = rr(sd.make_unet_weights(sd.SD15, 100)), rr(sd.make_controlnet_weights(sd.SD15, 200))
-        uw = prepare(usd, dt, DEV, heads=8, fold_ln=2); cw = prepare(csd, dt, DEV, heads=8, fold_ln=2)
-        add_fp8_convs(uw, usd, DEV); add_fp8_convs(cw, csd, DEV)
+        import _nets
+        uw, cw = (dict(w) for w in _nets.prepared(dt, 2))
+        add_fp8_convs(uw, _nets.conv_weights()[0], DEV); add_fp8_convs(cw, _nets.conv_weights()[1], DEV)
     else:
         uw, cw = nets(dt)
     if fp8 and fp8 != "hybrid":
+        import _nets
         uw, cw = dict(uw), dict(cw)
-        r = lambda w: {k: v.to(torch.bfloat16).float() for k, v in w.items() if k.endswith((".conv1.weight", ".conv2.weight"))}
-        add_fp8_convs(uw, r(sd.make_unet_weights(sd.SD15, 100)), DEV)
-        add_fp8_convs(cw, r(sd.make_controlnet_weights(sd.SD15, 200)), DEV)
+        add_fp8_convs(uw, _nets.conv_weights()[0], DEV)
+        add_fp8_convs(cw, _nets.conv_weights()[1], DEV)
         if fp8 == "all":
             add_fp8_linears(uw, 7); add_fp8_linears(cw, 7)
     vw = {k: v.to(torch.bfloat16).float().to(DEV) for k, v in sd.make_vae_decoder_weights(sd.VAE_SD, vseed).items()}
@@ -398,9 +386,9 @@ def test_edit_f7_h64_fp8_convs(nets):
     dt = torch.bfloat16
     uw, cw = nets(dt)
     uw, cw = dict(uw), dict(cw)
-    r = lambda w: {k: v.to(torch.bfloat16).float() for k, v in w.items() if k.endswith((".conv1.weight", ".conv2.weight"))}
-    add_fp8_convs(uw, r(sd.make_unet_weights(sd.SD15, 100)), DEV)
-    add_fp8_convs(cw, r(sd.make_controlnet_weights(sd.SD15, 200)), DEV)
+    import _nets
+    add_fp8_convs(uw, _nets.conv_weights()[0], DEV)
+    add_fp8_convs(cw, _nets.conv_weights()[1], DEV)
     pipe = DenoisePipeline(uw, cw, None, 20, 5.0)
     assert pipe.unet.fp8 and pipe.controlnet.fp8
     trace = []
@@ -426,10 +414,9 @@ def test_edit_f7_h64_fp8_convs_with_folded_linears():
     f, h, steps, seed = [int(v) for v in z["meta"][:4]]
     lat, disp, cn, cp = _inputs(f, h, seed)
     dt = torch.bfloat16
-    r = lambda w: {k: v.to(torch.bfloat16).float() for k, v in w.items()}
-    usd, csd = r(sd.make_unet_weights(sd.SD15, 100)), r(sd.make_controlnet_weights(sd.SD15, 200))
-    uw = prepare(usd, dt, DEV, heads=8, fold_ln=2); cw = prepare(csd, dt, DEV, heads=8, fold_ln=2)
-    add_fp8_convs(uw, usd, DEV); add_fp8_convs(cw, csd, DEV)
+    import _nets
+    uw, cw = (dict(w) for w in _nets.prepared(dt, 2))
+    add_fp8_convs(uw, _nets.conv_weights()[0], DEV); add_fp8_convs(cw, _nets.conv_weights()[1], DEV)
     pipe = DenoisePipeline(uw, cw, None, 20, 5.0)
     assert pipe.unet.fp8 and pipe.controlnet.fp8 and not pipe.unet.fp8_lin and any(k.endswith("ffout.weight") for k in uw)
     trace = []
@@ -465,9 +452,9 @@ def test_edit_f7_h64_fp8_convs_and_linears(nets, which):
     dt = torch.bfloat16
     uw, cw = nets(dt)
     uw, cw = dict(uw), dict(cw)
-    r = lambda w: {k: v.to(torch.bfloat16).float() for k, v in w.items() if k.endswith((".conv1.weight", ".conv2.weight"))}
-    add_fp8_convs(uw, r(sd.make_unet_weights(sd.SD15, 100)), DEV)
-    add_fp8_convs(cw, r(sd.make_controlnet_weights(sd.SD15, 200)), DEV)
+    import _nets
+    add_fp8_convs(uw, _nets.conv_weights()[0], DEV)
+    add_fp8_convs(cw, _nets.conv_weights()[1], DEV)
     add_fp8_linears(uw, which); add_fp8_linears(cw, which)
     pipe = DenoisePipeline(uw, cw, None, 20, 5.0)
     assert pipe.unet.fp8 and pipe.controlnet.fp8 and pipe.unet.fp8_lin == which and pipe.controlnet.fp8_lin == which

@@ -262,12 +262,11 @@ def test_psnr_vs_oracle_full_size(oracle_c):
     from gaussctrl_amd import gsplat_ops as ops
     from gaussctrl_amd.camera import camera_to_gsplat
     N, W, H = 1000000, 512, 512
-    P = syn.make_gaussians(N, seed=0)
-    c2w = syn.make_cameras(1, seed=1)[0]
+    c2w = full_cams(1, 1)[0]
     K = syn.ROUND_INTRINSICS
-    o = oracle_c.render(P, c2w, K["fx"], K["fy"], K["cx"], K["cy"], W, H, BG, training=False)
+    o = oracle_full(oracle_c, N, (1, 1), 0, "round", False)
     cam = camera_to_gsplat(c2w, K["fx"], K["fy"], K["cx"], K["cy"], W, H)
-    tp = {k: _t(v) for k, v in P.items()}
+    tp = full_scene_gpu(N)
     rgb, alpha, depth = ops.render_view(tp["means"], tp["scales"], tp["quats"], tp["opacities"], tp["features_dc"],
                                         tp["features_rest"], cam, _t(BG), True, 3, None)
     mse = float(((rgb.cpu().numpy().astype(np.float64) - o["rgb"]) ** 2).mean())
@@ -293,16 +292,59 @@ def test_empty_and_all_culled():
 
 
 # ---------------------------------------------------------------------------------------- BASELINE configs 3 and 5
-def _full_parity(oracle_c, P, c2w, K, training, seed=5):
+# Full-size scenes and their oracle renders are shared by every test that needs them (this file and test_raster_views_gpu.py): building
+# 4 M Gaussians takes 10 s and one serial oracle render 5-15 s, and the same (scene, camera, mode) is wanted by several tests.
+_SCENES, _SCENES_GPU, _CAMS, _ORACLE = {}, {}, {}, {}
+INTRINSICS = {"bear": syn.BEAR_INTRINSICS, "garden": syn.GARDEN_INTRINSICS, "round": syn.ROUND_INTRINSICS}
+
+
+def full_scene(N, seed=0):
+    if (N, seed) not in _SCENES:
+        _SCENES[(N, seed)] = syn.make_gaussians(N, seed=seed)
+    return _SCENES[(N, seed)]
+
+
+def full_scene_gpu(N, seed=0):
+    """the scene's six tensors on the GPU (no grad; tests that differentiate make their own leaves with .clone().requires_grad_())"""
+    if (N, seed) not in _SCENES_GPU:
+        _SCENES_GPU[(N, seed)] = {k: _t(v) for k, v in full_scene(N, seed).items()}
+    return _SCENES_GPU[(N, seed)]
+
+
+def full_cams(n, seed):
+    if (n, seed) not in _CAMS:
+        _CAMS[(n, seed)] = syn.make_cameras(n, seed=seed)
+    return _CAMS[(n, seed)]
+
+
+def upstream(H, W, seed=5):
+    g = np.random.default_rng(seed)
+    return g.normal(size=(H, W, 3)).astype(np.float32), g.normal(size=(H, W)).astype(np.float32)
+
+
+def oracle_full(oracle_c, N, cams, ci, kname, training):
+    """oracle_c.render of camera `ci` of full_cams(*cams) on full_scene(N) with background BG and the upstream gradients of upstream();
+    memoised for the session"""
+    key = (N, cams, ci, kname, training)
+    if key not in _ORACLE:
+        K = INTRINSICS[kname]
+        v_rgb, v_a = upstream(K["H"], K["W"])
+        _ORACLE[key] = oracle_c.render(full_scene(N), full_cams(*cams)[ci], K["fx"], K["fy"], K["cx"], K["cy"], K["W"], K["H"], BG,
+                                       training=training, v_rgb=v_rgb, v_alpha=v_a)
+    return _ORACLE[key]
+
+
+def _full_parity(oracle_c, N, cams, ci, kname, training):
     """fused product render (fwd [+ depth] + bwd to the six leaf tensors) vs the C oracle at full size."""
     from gaussctrl_amd import gsplat_ops as ops
     from gaussctrl_amd.camera import camera_to_gsplat
+    K = INTRINSICS[kname]
     W, H = K["W"], K["H"]
-    g = np.random.default_rng(seed)
-    v_rgb = g.normal(size=(H, W, 3)).astype(np.float32); v_a = g.normal(size=(H, W)).astype(np.float32)
-    o = oracle_c.render(P, c2w, K["fx"], K["fy"], K["cx"], K["cy"], W, H, BG, training=training, v_rgb=v_rgb, v_alpha=v_a)
-    cam = camera_to_gsplat(c2w, K["fx"], K["fy"], K["cx"], K["cy"], W, H)
-    tp = {k: _t(v).requires_grad_(True) for k, v in P.items()}
+    P = full_scene(N)
+    v_rgb, v_a = upstream(H, W)
+    o = oracle_full(oracle_c, N, cams, ci, kname, training)
+    cam = camera_to_gsplat(full_cams(*cams)[ci], K["fx"], K["fy"], K["cx"], K["cy"], W, H)
+    tp = {k: v.clone().requires_grad_(True) for k, v in full_scene_gpu(N).items()}
     aux = ops.RenderAux()
     rgb, alpha, depth = ops.render_view(tp["means"], tp["scales"], tp["quats"], tp["opacities"], tp["features_dc"],
                                         tp["features_rest"], cam, _t(BG), not training, 3, aux)
@@ -328,9 +370,7 @@ def _full_parity(oracle_c, P, c2w, K, training, seed=5):
 @pytest.mark.parametrize("training", [False, True])
 def test_config3_garden_2m(oracle_c, training):
     """BASELINE configs[2]: garden intrinsics (/root/reference/data/garden/transforms.json), ~2 M Gaussians."""
-    P = syn.make_gaussians(2_000_000, seed=0)
-    c2w = syn.make_cameras(3, seed=11)[2]
-    M = _full_parity(oracle_c, P, c2w, syn.GARDEN_INTRINSICS, training)
+    M = _full_parity(oracle_c, 2_000_000, (3, 11), 2, "garden", training)
     print(f"config 3: M = {M}")
 
 
@@ -339,9 +379,7 @@ def test_config2_bear_1m(oracle_c, training):
     """BASELINE configs[1] exactly as bench.py renders it: 1 M Gaussians, the bear intrinsics of
     /root/reference/data/bear/transforms.json (fx 539.05, fy 538.17, cx 258.74, cy 239.35: non-square focal, off-centre
     principal point), eval (rgb + depth) and training render with backward, against the C oracle."""
-    P = syn.make_gaussians(1_000_000, seed=0)
-    c2w = syn.make_cameras(40, seed=1)[7]
-    M = _full_parity(oracle_c, P, c2w, syn.BEAR_INTRINSICS, training)
+    M = _full_parity(oracle_c, 1_000_000, (40, 1), 7, "bear", training)
     print(f"config 2 (bear intrinsics, 1 M): M = {M}")
 
 
@@ -352,12 +390,11 @@ def test_config5_raster_4m(oracle_c):
     from gaussctrl_amd import gsplat_ops as ops
     from gaussctrl_amd.camera import camera_to_gsplat
     N = 4_000_000
-    P = syn.make_gaussians(N, seed=0)
-    cams = syn.make_cameras(256, seed=1)
+    cams = full_cams(256, 1)
     K = syn.ROUND_INTRINSICS
-    M = _full_parity(oracle_c, P, cams[17], K, True)
+    M = _full_parity(oracle_c, N, (256, 1), 17, "round", True)
     print(f"config 5: M = {M}")
-    tp = {k: _t(v) for k, v in P.items()}
+    tp = full_scene_gpu(N)
     W, H = K["W"], K["H"]
     tb = ((W + 15) // 16, (H + 15) // 16, 1)
     T = tb[0] * tb[1]

@@ -256,3 +256,87 @@ def test_depth_order_views_with_and_without_pairs():
             assert torch.equal(order[c], o1) and torch.equal(cum[c], c1) and int(cnt[c]) == int(n1)
         assert torch.equal(o1, ref)
         assert torch.equal(c1.to(torch.int64), torch.cumsum(nth[c][ref.long()].to(torch.int64), 0))
+
+
+# ---------------------------------------------------------------------------------------- the batched path AT THE SIZES bench.py times it
+@pytest.mark.parametrize("N,kname,cams,views", [(1_000_000, "bear", (40, 1), (7, 19, 33)),                              # configs[1]: chunk_size 3
+                                                  (4_000_000, "round", (256, 1), (17, 0, 100, 255, 3, 64, 128, 200))])    # configs[4]: 8 cameras per launch set
+def test_render_views_full_size(oracle_c, N, kname, cams, views):
+    """bench.py renders every view through gsplat_ops.render_views in sync-free capacity mode (RenderAux.m_cap: device-side counts, no host
+    round trip) -- the eval renders (rgb + depth + alpha) and the training renders with the fused backward writing the batch's gradient SUM into
+    one flat buffer (RenderAux.grad_into / dist.FlatGrads) -- at N = 1 M, C = 3 (BASELINE configs[1], the bear intrinsics) and, with
+    `--workload raster`, N = 4 M, C = 8 (configs[4]).  Here exactly those calls, at exactly those sizes, against the C oracle:
+      * the FIRST and the LAST view of the batch (per-view workspace offsets, blockIdx.y / z view indexing, the second group of camera
+        arguments) vs oracle_c.render: rgb / alpha / depth at the 1e-4 bars of test_raster_gpu._img_close, PSNR >= 45 dB;
+      * every OTHER view bit-identical to the single-view entry on its camera (which test_raster_gpu.py checks against the oracle at full size);
+      * leaf gradients of the summed loss of the first and last view (the other views get a zero upstream gradient, so their launches run but
+        add nothing) vs the sum of the two oracle gradients, 1e-3 of max, read from the flat buffer; no .grad tensors are created;
+      * no capacity overflow with the margin bench.py uses (1.3 x the largest count + 1 024)."""
+    import math
+    from gaussctrl_amd import gsplat_ops as ops
+    from gaussctrl_amd.camera import camera_to_gsplat
+    from gaussctrl_amd.dist import FlatGrads
+    from test_raster_gpu import INTRINSICS, full_cams, full_scene, full_scene_gpu, oracle_full, upstream
+    K = INTRINSICS[kname]
+    W, H = K["W"], K["H"]
+    C = len(views)
+    c2ws = full_cams(*cams)
+    gcams = [camera_to_gsplat(c2ws[i], K["fx"], K["fy"], K["cx"], K["cy"], W, H) for i in views]
+    P = full_scene(N)
+    tp = {k: v.clone().requires_grad_(True) for k, v in full_scene_gpu(N).items()}
+    args = (tp["means"], tp["scales"], tp["quats"], tp["opacities"], tp["features_dc"], tp["features_rest"])
+    ends = (0, C - 1)
+    # sizing pass (what bench.py's first frames do: counts read back once), then the sync-free calls proper
+    a0 = ops.RenderAux()
+    with torch.no_grad():
+        ops.render_views(*args, gcams, _t(BG), True, 3, a0)
+    cap = int(int(a0.M[0].max()) * 1.3) + 1024
+    # ---- eval batch: rgb + depth + alpha, sync-free
+    ae = ops.RenderAux(); ae.m_cap = cap
+    with torch.no_grad():
+        rgb, alpha, depth = ops.render_views(*args, gcams, _t(BG), True, 3, ae)
+    assert int(ae.M[1].max()) == 0, "capacity overflow with bench.py's margin"
+    assert torch.equal(ae.M[0], a0.M[0])
+    for c in range(C):
+        if c in ends:
+            o = oracle_full(oracle_c, N, cams, views[c], kname, False)
+            _img_close(rgb[c].cpu().numpy(), o["rgb"])
+            _img_close(alpha[c].cpu().numpy(), o["accumulation"][..., 0])
+            mse = float(((rgb[c].cpu().numpy().astype(np.float64) - o["rgb"]) ** 2).mean())
+            assert 10 * math.log10(1.0 / max(mse, 1e-20)) >= 45.0
+            d = depth[c].cpu().numpy(); od = o["depth"][..., 0]
+            far = (od == 1000.0)
+            assert np.array_equal(far, d == 1000.0)
+            _img_close(np.where(far, 0, d), np.where(far, 0, od))
+            assert int(ae.M[0][c]) <= o["M"] + 4
+        else:
+            a1 = ops.RenderAux()
+            with torch.no_grad():
+                r1, al1, d1 = ops.render_view(*args, gcams[c], _t(BG), True, 3, a1)
+            assert torch.equal(rgb[c], r1) and torch.equal(alpha[c], al1) and torch.equal(depth[c], d1), c
+            assert int(ae.M[0][c]) == a1.M
+    del rgb, alpha, depth
+    # ---- training batch: sync-free, fused backward into ONE flat buffer (pre-filled with NaN: the first batch must overwrite every element)
+    fg = FlatGrads({k: v for k, v in tp.items()})
+    fg.flat.fill_(float("nan"))
+    at = ops.RenderAux(); at.m_cap = cap
+    at.grad_into, at.grad_accumulate = fg.views, False
+    rgb, alpha, _ = ops.render_views(*args, gcams, _t(BG), False, 3, at)
+    v_rgb, v_a = upstream(H, W)
+    up_rgb = torch.zeros(C, H, W, 3, device=DEV); up_a = torch.zeros(C, H, W, device=DEV)
+    for c in ends:
+        up_rgb[c] = _t(v_rgb); up_a[c] = _t(v_a)
+    ((rgb * up_rgb).sum() + (alpha * up_a).sum()).backward()
+    assert int(at.M[1].max()) == 0
+    assert all(p.grad is None for p in tp.values()), "grad_into: autograd must not materialise .grad tensors"
+    assert bool(torch.isfinite(fg.flat).all())
+    ref_g = {k: np.zeros(v.shape, np.float64) for k, v in P.items()}
+    for c in ends:
+        o = oracle_full(oracle_c, N, cams, views[c], kname, True)
+        _img_close(rgb[c].detach().cpu().numpy(), o["rgb"])
+        _img_close(alpha[c].detach().cpu().numpy(), o["accumulation"][..., 0])
+        for k in P:
+            ref_g[k] += o["grads"][k]
+    scale = max(np.abs(v).max() for v in ref_g.values())
+    for k in P:
+        _grad_close(fg.views[k].cpu().numpy(), ref_g[k], scale)
