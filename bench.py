@@ -283,6 +283,7 @@ class Bench:
         self.stats = {"M": [], "dev": []}
         self.state = {"bank": None, "next": None, "cap": None, "views_done": 0, "renders_done": 0}
         self.syncfree = os.environ.get("GC_BENCH_SYNCFREE", "1") != "0"
+        self.sorted_boxes = os.environ.get("GC_RASTER_SORTED_BOXES", "1") != "0"      # 0: the round-5 depth-order chain (pairs + two gathers), A/B
         self.raster_target = torch.rand(H, W, 3, device=dev, generator=g)     # raster-only workload: a fixed synthetic target image
         self.edit_mask = torch.tensor(syn.elliptical_mask(H, W, soft=True), device=dev, dtype=torch.float32) if args.mask else None
         # the chunk's summed leaf gradients: six views of ONE flat buffer that the backward kernel writes into and RCCL reduces in
@@ -305,6 +306,7 @@ class Bench:
     # ------------------------------------------------------------------------------------------------ pieces of a step
     def new_aux(self):
         aux = self.gops.RenderAux()
+        aux.sorted_boxes = self.sorted_boxes
         if self.syncfree and self.state["cap"]:
             aux.m_cap = self.state["cap"]          # device-side intersection count + capacity: no host round trip in the frame
         return aux
@@ -595,7 +597,8 @@ def run_full_pipeline(args):
         "edited_views_per_s_edit_phase": round(V / edit, 3), "train_iterations_per_s": round(args.train_iters / train, 1)}), flush=True)
 
 
-_BENCH_ENV_DEFAULTS = {"GC_DN_FOLD_LN": None, "GC_DN_FUSE_GN": "0", "GC_DN_GN2": "0", "GC_BENCH_SYNCFREE": "1", "GC_BENCH_ONE_GPU": "0", "GC_BENCH_BACKEND": "nccl"}
+_BENCH_ENV_DEFAULTS = {"GC_DN_FOLD_LN": None, "GC_DN_FUSE_GN": "0", "GC_DN_GN2": "0", "GC_BENCH_SYNCFREE": "1", "GC_RASTER_SORTED_BOXES": "1", "GC_BENCH_ONE_GPU": "0",
+                       "GC_BENCH_BACKEND": "nccl"}
 
 
 def effective_options(sdops, args):
@@ -990,7 +993,7 @@ def raster_roofline(args, B, g, stats, HW):
         else:                      # default workload: only the training renders of one chunk (fwd + loss + bwd), no denoise
             keep, B.edit = B.edit, False
             try:
-                B.step(0)
+                B.step(B.groups(0, B.cobatch)[0])          # one launch set, as the timed steps run them (cobatch chunks)
             finally:
                 B.edit = keep
         torch.cuda.synchronize()
@@ -1020,7 +1023,9 @@ def raster_roofline(args, B, g, stats, HW):
              "gc_project_sh_fwd_views": "gc_project_sh_fwd", "gc_raster_depth_order_views": "gc_raster_depth_order",
              "gc_raster_bin_tiles_views": "gc_raster_bin_tiles_dev", "gc_rasterize_fwd_views": "gc_rasterize_fwd",
              "gc_rasterize_bwd_views": "gc_rasterize_bwd", "gc_project_sh_bwd_views": "gc_project_sh_bwd",
-             "gc_l1_ssim_fwd_bwd_views": "gc_l1_ssim_fwd_bwd"}
+             "gc_l1_ssim_fwd_bwd_views": "gc_l1_ssim_fwd_bwd",
+             # round 6: the gather-free chain
+             "gc_raster_order_boxes_views": "gc_raster_depth_order", "gc_raster_bin_sorted_views": "gc_raster_bin_tiles_dev"}
     tot_stage = {}
     for name, s, e in timer.rec:
         k = alias.get(name, name)
@@ -1028,13 +1033,15 @@ def raster_roofline(args, B, g, stats, HW):
     per = {k: [v / nviews] for k, v in tot_stage.items()}            # seconds per training view and stage
     traffic = None
     # PMC traffic of the configuration that ran: the batched-views passes (round 5, 8 views per launch set) or the one-camera-per-launch ones
-    batched = B.view_batch and min(args.chunk_size, nviews) >= 2
-    Cb = min(args.chunk_size, nviews) if batched else 1
-    for tname in ((f"r06_raster_traffic_views{Cb}.json", f"r05_raster_traffic_views{Cb}.json") if batched else ("r03_raster_traffic.json", "r02_raster_traffic.json")):
+    batched = B.view_batch and nviews >= 2
+    Cb = nviews if batched else 1                   # every view of the instrumented launch set goes through ONE batched call
+    # (the round-5 passes were taken on the pair chain: they describe this run only with GC_RASTER_SORTED_BOXES=0)
+    names = ((f"r06_raster_traffic_views{Cb}.json",) + (() if B.sorted_boxes else (f"r05_raster_traffic_views{Cb}.json",))) if batched else ("r03_raster_traffic.json", "r02_raster_traffic.json")
+    for tname in names:
         tpath = os.path.join(ROOT, "profiles", tname)
         if traffic is None and os.path.exists(tpath):
             traffic = json.load(open(tpath)).get(str(N))
-    C = min(args.chunk_size, nviews) if batched else 1               # cameras per launch set of the instrumented step
+    C = Cb                                                           # cameras per launch set of the instrumented step
     stages, tot_8d, tot_b, tot_s = {}, 0.0, 0.0, 0.0
     for name in RASTER_STAGES:
         if name not in per:

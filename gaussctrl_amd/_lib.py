@@ -26,6 +26,8 @@ SYMBOLS = [
     "gc_project_sh_fwd_views", "gc_project_sh_bwd_views", "gc_raster_scan_tiles_views", "gc_raster_depth_order_views_workspace_bytes",
     "gc_raster_depth_order_views", "gc_raster_bin_views_workspace_bytes", "gc_raster_bin_tiles_views", "gc_rasterize_fwd_views",
     "gc_rasterize_bwd_views", "gc_l1_ssim_views_workspace_bytes", "gc_l1_ssim_fwd_bwd_views",
+    # gather-free depth order (round 6)
+    "gc_raster_order_boxes_views_workspace_bytes", "gc_raster_order_boxes_views", "gc_raster_bin_sorted_views",
     "gc_dn_gemm", "gc_dn_gemm_workspace_bytes", "gc_dn_gemm_row_stat_slots", "gc_dn_gemm_chan_parts_layout", "gc_dn_groupnorm_apply_parts", "gc_dn_groupnorm_apply_parts_fp8", "gc_dn_groupnorm_coef_parts", "gc_dn_concat_parts_layout", "gc_dn_concat_add_parts", "gc_dn_attention", "gc_dn_groupnorm", "gc_dn_groupnorm_workspace_bytes", "gc_dn_groupnorm_apply", "gc_dn_groupnorm_apply_fp8", "gc_dn_group_stats", "gc_dn_layernorm", "gc_dn_layernorm_fp8", "gc_dn_concat_add", "gc_dn_axpby",
     "gc_dn_cast_f32", "gc_dn_softmax_rows", "gc_dn_attention_workspace_bytes", "gc_dn_transformer_tail", "gc_dn_transformer_tail_layout", "gc_dn_transformer_head", "gc_dn_groupnorm_coef", "gc_dn_cfg_ddim_step", "gc_dn_depth_to_disparity", "gc_dn_mask_composite",
 ]

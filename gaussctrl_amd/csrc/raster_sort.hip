@@ -324,7 +324,9 @@ __global__ __launch_bounds__(256) void k_emit_sorted(int64_t N, int64_t M_cap, c
                                                      const int32_t *__restrict__ cum_sorted, int tiles_x, int tiles_y,
                                                      uint32_t *__restrict__ tile_keys, uint32_t *__restrict__ gids,
                                                      unsigned dmask, int nblocks, int32_t *__restrict__ hist /* [digits][nblocks], zeroed */, VS vs,
-                                                     int idb /* > 0: packed pairs, (tile << idb) | id in tile_keys, gids unused */)
+                                                     int idb /* > 0: packed pairs, (tile << idb) | id in tile_keys, gids unused */,
+                                                     const int32_t *__restrict__ nvis_dev /* != NULL: tile_box is in DEPTH ORDER (box of order[j] at j) and
+                                                                                            only the first nvis_dev[view] entries of order / tile_box exist */)
 {
     {
         const int64_t o = (int64_t)blockIdx.y * vs.ws, e = (int64_t)blockIdx.y * vs.src;
@@ -332,6 +334,7 @@ __global__ __launch_bounds__(256) void k_emit_sorted(int64_t N, int64_t M_cap, c
         if (tile_box) tile_box += e;
         if (xys) { xys += 2 * e; radii += e; }
     }
+    const int64_t n_live = nvis_dev ? (int64_t)nvis_dev[blockIdx.y] : N;
     __shared__ uint32_t sT[EW], sG[EW];
     __shared__ int64_t sRange[2];
     __shared__ int sH[2 * 64];                    // first tile pass's digit counts of the (at most two) 4096-blocks a window touches
@@ -345,10 +348,10 @@ __global__ __launch_bounds__(256) void k_emit_sorted(int64_t N, int64_t M_cap, c
     uint32_t g = 0;
     int minx = 0, w = 0, miny = 0;
     int64_t lo = 0, hi = 0;                       // this Gaussian's output range
-    if (j < N) {
+    if (j < n_live) {
         g = order[j];
-        if (tile_box) {            // tight boxes written by gc_project_sh_fwd_boxes (0 = no tile)
-            const uint32_t bx = tile_box[g];
+        if (tile_box) {            // tight boxes written by gc_project_sh_fwd_boxes (0 = no tile); nvis_dev: read in order, no gather
+            const uint32_t bx = tile_box[nvis_dev ? (uint32_t)j : g];
             minx = (int)(bx & 255u); miny = (int)((bx >> 16) & 255u);
             w = (int)((bx >> 8) & 255u) - minx;
             const int hgt = (int)(bx >> 24) - miny;
@@ -408,7 +411,7 @@ __global__ __launch_bounds__(256) void k_tile_bins32(int64_t M, const int32_t *_
 {
     {
         const int64_t o = (int64_t)blockIdx.y * vs.ws;
-        tkeys += o; bins += (int64_t)blockIdx.y * 2 * num_tiles; depths += blockIdx.y * vs.src;
+        tkeys += o; bins += (int64_t)blockIdx.y * 2 * num_tiles; if (depths) depths += blockIdx.y * vs.src;
         gids += (int64_t)blockIdx.y * vs.ext;             // (the last radix pass wrote the ids into the external [C][M_cap] array)
         if (keys64) keys64 += (int64_t)blockIdx.y * vs.ext;
         if (m_dev) { m_dev += blockIdx.y * vs.nd; overflow += blockIdx.y * vs.nd; }
@@ -576,7 +579,7 @@ int bin_tiles_impl(int64_t N, int C, int64_t M, const int32_t *m_dev, int32_t *o
                    const int32_t *cum_sorted, const float *xys, const float *depths, const int32_t *radii, const uint32_t *tile_boxes,
                    int tiles_x, int tiles_y,
                    int32_t *gaussian_ids_sorted, int32_t *tile_bins, int64_t *isect_ids_sorted, void *workspace,
-                   size_t workspace_bytes, void *stream, const char *what)
+                   size_t workspace_bytes, void *stream, const char *what, const int32_t *visible_dev = nullptr)
 {
     const int num_tiles = tiles_x * tiles_y;
     hipStream_t s = gc::S(stream);
@@ -584,7 +587,7 @@ int bin_tiles_impl(int64_t N, int C, int64_t M, const int32_t *m_dev, int32_t *o
     if (overflow_dev && hipMemsetAsync(overflow_dev, 0, 4 * (size_t)C, s) != hipSuccess) return GC_ELAUNCH;
     if (M == 0 || N == 0) return GC_OK;
     if (num_tiles > 65536) { gc::set_error("%s: at most 65536 tiles", what); return GC_EINVAL; }
-    if (!(depth_order && cum_sorted && ((xys && radii) || tile_boxes) && depths && gaussian_ids_sorted && workspace)) { gc::set_error("%s: null pointer", what); return GC_EINVAL; }
+    if (!(depth_order && cum_sorted && ((xys && radii) || tile_boxes) && (depths || !isect_ids_sorted) && gaussian_ids_sorted && workspace)) { gc::set_error("%s: null pointer", what); return GC_EINVAL; }
     const Plan p = make_plan(M);
     if (workspace_bytes < p.total * (size_t)C) { gc::set_error("%s: workspace too small", what); return GC_ENOSPC; }
     set_attr();
@@ -611,7 +614,7 @@ int bin_tiles_impl(int64_t N, int C, int64_t M, const int32_t *m_dev, int32_t *o
     if (!(dbits <= 6 && passes * dbits + idb <= 32)) idb = 0;
     hipLaunchKernelGGL(k_emit_sorted, dim3(gc::cdiv(N, 256), (unsigned)C), dim3(256), 0, s, N, M, (const uint32_t *)depth_order, xys, radii,
                        tile_boxes, cum_sorted, tiles_x, tiles_y, k0, v0, fused_hist ? (1u << dbits) - 1u : 0u, fused_hist ? p.nb : 0,
-                       (int32_t *)(w + p.off_hist), vs, idb);
+                       (int32_t *)(w + p.off_hist), vs, idb, visible_dev);
     uint32_t *ks = k0, *vsrc = v0;
     for (int pass = 0; pass < passes; ++pass) {
         const bool last = pass == passes - 1;
@@ -680,6 +683,237 @@ int gc_raster_bin_tiles_views(int64_t N, int C, int64_t M_cap, const int32_t *co
     GC_REQUIRE(tiles_x <= 255 && tiles_y <= 255, "packed boxes hold at most 255 x 255 tiles");
     return bin_tiles_impl(N, C, M_cap, count_dev, overflow_dev, depth_order, cum_sorted, nullptr, depths, nullptr, tile_boxes, tiles_x, tiles_y,
                           gaussian_ids_sorted, tile_bins, isect_ids_sorted, workspace, workspace_bytes, stream, "gc_raster_bin_tiles_views");
+}
+
+}  // extern "C"
+
+
+// ================================================================================================================================
+// Round 6: depth order WITHOUT the per-Gaussian gathers.  gc_raster_depth_order_views sorts (depth bits, id) pairs; afterwards the scan reads
+// num_tiles_hit[order[j]] and the emission tile_boxes[order[j]] -- two random 4-byte reads per Gaussian, i.e. two 128-byte line fetches:
+// by the counters (profiles/r05_raster_traffic_views8.json) 2/3 of everything the depth order fetched.  Here the packed tight box rides through
+// the radix passes as a third word of the item (12-byte (key, id, box) triples), so the scan (count = box area) and the emission read their
+// inputs sequentially; and the Gaussians the projection culled (key 0xFFFFFFFF) are dropped by the FIRST pass instead of travelling through
+// all four (its rank only counts visible items; the later passes run on visible_dev[view] items).
+// The order is the same stable LSD sort by (depth bits, id) over the same visible set: gaussian_ids_sorted / tile_bins are bit-identical.
+namespace {
+
+struct __attribute__((packed, aligned(4))) Tri { uint32_t k, id, box; };
+
+// P0: the items are the projection's external (key, id) pairs [C][N] + tile boxes [C][N], culled items (key 0xFFFFFFFF) do not count
+template <bool P0>
+__global__ __launch_bounds__(RT) void k_tri_hist(const void *__restrict__ items, int64_t n, const int32_t *__restrict__ n_dev, int shift,
+                                                 int nblocks, int32_t *__restrict__ hist, int32_t *__restrict__ visible_dev, VS vs)
+{
+    hist += (int64_t)blockIdx.y * vs.ws;
+    const uint32_t *keys;
+    if (P0) keys = (const uint32_t *)items + (int64_t)blockIdx.y * 2 * vs.ext;
+    else { keys = (const uint32_t *)items + (int64_t)blockIdx.y * vs.ws; n = (int64_t)n_dev[blockIdx.y] < n ? (int64_t)n_dev[blockIdx.y] : n; }
+    __shared__ int h[256];
+    __shared__ int vis;
+    h[threadIdx.x] = 0;
+    if (threadIdx.x == 0) vis = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RB;
+    int mine = 0;
+#pragma unroll
+    for (int j = 0; j < RI; ++j) {
+        const int64_t i = base + j * RT + threadIdx.x;
+        if (i < n) {
+            const uint32_t k = keys[(P0 ? 2 : 3) * i];
+            if (!P0 || k != 0xFFFFFFFFu) { atomicAdd(&h[(k >> shift) & 255], 1); ++mine; }
+        }
+    }
+    if (P0 && mine) atomicAdd(&vis, mine);
+    __syncthreads();
+    hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+    if (P0 && threadIdx.x == 0 && vis) atomicAdd(&visible_dev[blockIdx.y], vis);
+}
+
+// LAST: the sorted ids and boxes go to the external [C][N] arrays (the keys are not needed any more).
+// Stable rank with 8 KB of LDS (the pair kernel above keeps a 64 KB (round, wave) x digit table: two workgroups per CU, and by the counters
+// its passes run at a quarter of the HBM rate although they move few bytes -- occupancy, not traffic, bounds them).  Here wave w owns the
+// CONTIGUOUS items [1024 w, 1024 w + 1024) of the workgroup's 4096 and walks them in 16 rounds of 64: the order of an item is (wave, round,
+// lane), so a per-wave running digit counter (cnt[w][d], read and advanced by the leader lane of every digit group of a round, the old value
+// broadcast to the group with ds_bpermute) gives the rank among the wave's earlier items, the ballots the rank inside the round, and one
+// prefix over the four waves per digit (thread d) the rest.  8+ workgroups per CU hide the round-to-round LDS dependency.
+template <bool P0, bool LAST>
+__global__ __launch_bounds__(RT) void k_tri_scatter(const void *__restrict__ items, const uint32_t *__restrict__ boxes_in, Tri *__restrict__ out,
+                                                    uint32_t *__restrict__ ids_out, uint32_t *__restrict__ boxes_out, int64_t n,
+                                                    const int32_t *__restrict__ n_dev, int shift, int nblocks, const int32_t *__restrict__ hist,
+                                                    const int32_t *__restrict__ offs, const int32_t *__restrict__ sums, VS vs)
+{
+    {
+        const int64_t o = (int64_t)blockIdx.y * vs.ws;
+        hist += o; offs += o; sums += o;
+        if (!LAST) out = (Tri *)((uint32_t *)out + o);
+        else { ids_out += (int64_t)blockIdx.y * vs.ext; boxes_out += (int64_t)blockIdx.y * vs.ext; }
+        if (P0) boxes_in += (int64_t)blockIdx.y * vs.ext;
+    }
+    const uint32_t *src = P0 ? (const uint32_t *)items + (int64_t)blockIdx.y * 2 * vs.ext : (const uint32_t *)items + (int64_t)blockIdx.y * vs.ws;
+    if (!P0) n = (int64_t)n_dev[blockIdx.y] < n ? (int64_t)n_dev[blockIdx.y] : n;
+    const int64_t base = (int64_t)blockIdx.x * RB;
+    if (base >= n) return;
+    __shared__ int cnt[4 * 256];      // running count of digit d among the items wave w has walked
+    __shared__ int wbase[4 * 256];    // output position of wave w's first item with digit d
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int i = tid; i < 4 * 256; i += RT) cnt[i] = 0;
+    __syncthreads();
+    uint32_t k[RI], v[RI], bx[RI];
+    int pre[RI];                      // rank among the wave's items with the same digit (-1: no item)
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    int *my = cnt + wid * 256;
+#pragma unroll
+    for (int j = 0; j < RI; ++j) {
+        const int64_t i = base + wid * (RI * 64) + j * 64 + lane;
+        bool ok = i < n;
+        k[j] = 0xFFFFFFFFu; v[j] = 0u; bx[j] = 0u;
+        if (ok) {
+            if (P0) {
+                const uint2 kv = reinterpret_cast<const uint2 *>(src)[i];
+                k[j] = kv.x; v[j] = kv.y;
+                ok = kv.x != 0xFFFFFFFFu;
+                if (ok) bx[j] = boxes_in[i];
+            } else {
+                const Tri t = reinterpret_cast<const Tri *>(src)[i];
+                k[j] = t.k; v[j] = t.id; bx[j] = t.box;
+            }
+        }
+        const unsigned d = (k[j] >> shift) & 255;
+        unsigned long long m = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long bal = __ballot((d >> b) & 1);
+            m &= ((d >> b) & 1) ? bal : ~bal;
+        }
+        const bool leader = ok && (m & lt) == 0;
+        int old = 0;
+        if (leader) { old = my[d]; my[d] = old + __popcll(m); }        // (LDS operations of one wave execute in program order: round j + 1 sees this)
+        const int lead_lane = ok ? __builtin_ctzll(m) : lane;
+        old = __shfl(old, lead_lane, 64);
+        pre[j] = ok ? old + __popcll(m & lt) : -1;
+    }
+    __syncthreads();
+    {   // thread d: where each wave's items of digit d start (global offset of (d, this workgroup) + the earlier waves' totals)
+        const int d = tid;
+        const int64_t e = (int64_t)d * nblocks + blockIdx.x;
+        int run = offs[e] + sums[e / TS_CHUNK] - hist[e];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { wbase[w * 256 + d] = run; run += cnt[w * 256 + d]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RI; ++j) {
+        if (pre[j] >= 0) {
+            const unsigned d = (k[j] >> shift) & 255;
+            const int pos = wbase[wid * 256 + d] + pre[j];
+            if (LAST) { ids_out[pos] = v[j]; boxes_out[pos] = bx[j]; }
+            else { Tri t; t.k = k[j]; t.id = v[j]; t.box = bx[j]; out[pos] = t; }
+        }
+    }
+}
+
+// tile count of the box at depth position j (0 past the visible ones), written where the in-place scan turns it into cum_sorted
+__global__ __launch_bounds__(256) void k_box_counts(int64_t N, const uint32_t *__restrict__ boxes_sorted, const int32_t *__restrict__ visible_dev,
+                                                    int32_t *__restrict__ cnt)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    boxes_sorted += blockIdx.y * N; cnt += blockIdx.y * N;
+    int c = 0;
+    if (i < (int64_t)visible_dev[blockIdx.y]) {
+        const uint32_t bx = boxes_sorted[i];
+        const int w = (int)((bx >> 8) & 255u) - (int)(bx & 255u), h = (int)(bx >> 24) - (int)((bx >> 16) & 255u);
+        c = (w > 0 && h > 0) ? w * h : 0;
+    }
+    cnt[i] = c;
+}
+
+// per-view workspace of the triple sort: 2 ping-pong triple buffers + digit tables + scan scratch + ticket
+struct TriPlan { size_t off_buf[2], off_hist, off_offs, off_scan, scan_bytes, off_cnt, total; int nb; };
+TriPlan make_tri_plan(int64_t n)
+{
+    TriPlan p;
+    p.nb = (int)((n + RB - 1) / RB);
+    if (p.nb < 1) p.nb = 1;
+    size_t o = 0;
+    for (int i = 0; i < 2; ++i) { p.off_buf[i] = o; o += al(12 * (size_t)n + 16); }
+    p.off_hist = o; o += al(4 * 256 * (size_t)p.nb);
+    p.off_offs = o; o += al(4 * 256 * (size_t)p.nb);
+    const int64_t scan_n = 256 * (int64_t)p.nb > n ? 256 * (int64_t)p.nb : n;
+    p.scan_bytes = al(gc_raster_scan_workspace_bytes(scan_n));
+    p.off_scan = o; o += p.scan_bytes;
+    p.off_cnt = o; o += 256;
+    p.total = o;
+    return p;
+}
+
+void set_attr_tri() {}
+
+}  // namespace
+
+extern "C" {
+
+size_t gc_raster_order_boxes_views_workspace_bytes(int64_t N, int C) { return make_tri_plan(N > 0 ? N : 1).total * (size_t)(C > 0 ? C : 1); }
+
+/* Depth order of C views on the packed tight boxes (see the block comment above): depth_pairs [C][N][2] and tile_boxes [C][N] as
+ * gc_project_sh_fwd_views writes them -> depth_order [C][N] = ids of the VISIBLE Gaussians in (depth bits, id) order (entries past
+ * visible_dev[c] are unspecified), boxes_sorted [C][N] = their boxes in that order, cum_sorted [C][N] = inclusive scan of the boxes' tile counts
+ * (constant past the visible ones), count_dev [C] = M, visible_dev [C]. */
+int gc_raster_order_boxes_views(int64_t N, int C, const uint32_t *depth_pairs, const uint32_t *tile_boxes, int32_t *depth_order,
+                                uint32_t *boxes_sorted, int32_t *cum_sorted, int32_t *count_dev, int32_t *visible_dev, void *workspace,
+                                size_t workspace_bytes, void *stream)
+{
+    GC_REQUIRE(N >= 0 && C >= 1 && C <= 65535 && count_dev && visible_dev, "bad arguments");
+    hipStream_t s = gc::S(stream);
+    if (hipMemsetAsync(visible_dev, 0, 4 * (size_t)C, s) != hipSuccess) return GC_ELAUNCH;
+    if (N == 0) return hipMemsetAsync(count_dev, 0, 4 * (size_t)C, s) == hipSuccess ? GC_OK : GC_ELAUNCH;
+    GC_REQUIRE(depth_pairs && tile_boxes && depth_order && boxes_sorted && cum_sorted && workspace, "null pointer");
+    const TriPlan p = make_tri_plan(N);
+    if (workspace_bytes < p.total * (size_t)C) { gc::set_error("gc_raster_order_boxes_views: workspace too small"); return GC_ENOSPC; }
+    set_attr_tri();
+    unsigned char *w = (unsigned char *)workspace;
+    VS vs; vs.ws = (int64_t)(p.total / 4); vs.ext = N; vs.src = N; vs.nd = 1;
+    for (int c = 0; c < C; ++c)                                                            // tickets of k_table_scan
+        if (hipMemsetAsync(w + p.total * (size_t)c + p.off_cnt, 0, 4, s) != hipSuccess) return GC_ELAUNCH;
+    int32_t *hist = (int32_t *)(w + p.off_hist), *offs = (int32_t *)(w + p.off_offs), *tick = (int32_t *)(w + p.off_cnt), *sums = (int32_t *)(w + p.off_scan);
+    const dim3 g((unsigned)p.nb, (unsigned)C);
+    const int64_t ne = 256 * (int64_t)p.nb;
+    const dim3 gscan((unsigned)((ne + TS_CHUNK - 1) / TS_CHUNK), (unsigned)C);
+    const size_t lds = 0;
+    Tri *a = (Tri *)(w + p.off_buf[0]), *b = (Tri *)(w + p.off_buf[1]);
+    // pass 0: external pairs + boxes in, visible triples out
+    hipLaunchKernelGGL(k_tri_hist<true>, g, dim3(RT), 0, s, (const void *)depth_pairs, N, (const int32_t *)nullptr, 0, p.nb, hist, visible_dev, vs);
+    hipLaunchKernelGGL(k_table_scan, gscan, dim3(256), 0, s, ne, hist, offs, sums, tick, vs);
+    hipLaunchKernelGGL((k_tri_scatter<true, false>), g, dim3(RT), lds, s, (const void *)depth_pairs, tile_boxes, a, (uint32_t *)nullptr, (uint32_t *)nullptr, N,
+                       (const int32_t *)nullptr, 0, p.nb, hist, offs, sums, vs);
+    for (int pass = 1; pass < 4; ++pass) {   // visible depths are > 0: the float bit pattern is monotone
+        hipLaunchKernelGGL(k_tri_hist<false>, g, dim3(RT), 0, s, (const void *)a, N, (const int32_t *)visible_dev, 8 * pass, p.nb, hist, (int32_t *)nullptr, vs);
+        hipLaunchKernelGGL(k_table_scan, gscan, dim3(256), 0, s, ne, hist, offs, sums, tick, vs);
+        if (pass < 3)
+            hipLaunchKernelGGL((k_tri_scatter<false, false>), g, dim3(RT), lds, s, (const void *)a, (const uint32_t *)nullptr, b, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                               N, (const int32_t *)visible_dev, 8 * pass, p.nb, hist, offs, sums, vs);
+        else
+            hipLaunchKernelGGL((k_tri_scatter<false, true>), g, dim3(RT), lds, s, (const void *)a, (const uint32_t *)nullptr, (Tri *)nullptr, (uint32_t *)depth_order, boxes_sorted,
+                               N, (const int32_t *)visible_dev, 8 * pass, p.nb, hist, offs, sums, vs);
+        Tri *t = a; a = b; b = t;
+    }
+    hipLaunchKernelGGL(k_box_counts, dim3(gc::cdiv(N, 256), (unsigned)C), dim3(256), 0, s, N, (const uint32_t *)boxes_sorted, (const int32_t *)visible_dev, cum_sorted);
+    int rc = gc_raster_scan_tiles_views(N, C, cum_sorted, nullptr, cum_sorted, count_dev, w + p.off_scan, p.scan_bytes, (int64_t)p.total, (void *)s);
+    if (rc != GC_OK) return rc;
+    return gc::check_launch("gc_raster_order_boxes_views");
+}
+
+/* Phase 2 on the output of gc_raster_order_boxes_views (always sync-free): emission in depth order from the SORTED boxes (no gather), the tile
+ * radix passes, tile_bins.  workspace >= gc_raster_bin_views_workspace_bytes(M_cap, C). */
+int gc_raster_bin_sorted_views(int64_t N, int C, int64_t M_cap, const int32_t *count_dev, int32_t *overflow_dev, const int32_t *visible_dev,
+                               const int32_t *depth_order, const uint32_t *boxes_sorted, const int32_t *cum_sorted, int tiles_x, int tiles_y,
+                               int32_t *gaussian_ids_sorted, int32_t *tile_bins, void *workspace, size_t workspace_bytes, void *stream)
+{
+    GC_REQUIRE(N >= 0 && C >= 1 && C <= 65535 && M_cap >= 0 && tile_bins && boxes_sorted && count_dev && overflow_dev && visible_dev, "bad arguments");
+    GC_REQUIRE(tiles_x <= 255 && tiles_y <= 255, "packed boxes hold at most 255 x 255 tiles");
+    return bin_tiles_impl(N, C, M_cap, count_dev, overflow_dev, depth_order, cum_sorted, nullptr, nullptr, nullptr, boxes_sorted, tiles_x, tiles_y,
+                          gaussian_ids_sorted, tile_bins, nullptr, workspace, workspace_bytes, stream, "gc_raster_bin_sorted_views", visible_dev);
 }
 
 }  // extern "C"

@@ -315,6 +315,9 @@ class RenderAux:
     # tile_bins then describe the SHORTER lists; set False for the lists gsplat would build (the gsplat-shaped operators always do).
     tight_boxes = None            # None: module default TIGHT_BOXES
     tile_boxes = None
+    # render_views (round 6): True = the gather-free depth order (gc_raster_order_boxes_views + gc_raster_bin_sorted_views: the packed boxes ride
+    # through the radix passes, culled Gaussians drop out in the first pass); False = the round-5 chain (same lists bit for bit; A/B and cross-checks)
+    sorted_boxes = True
 
 
 class _RenderView(torch.autograd.Function):
@@ -464,10 +467,18 @@ class _RenderViews(torch.autograd.Function):
             CH, L.i32(H), L.i32(W), L.i32(tb[0]), L.i32(tb[1]), L.f32(0.01), L.ptr(xys), L.ptr(depths), L.ptr(radii), L.ptr(conics),
             L.ptr(nth), L.ptr(rgbs), L.ptr(opac), L.ptr(boxes), L.ptr(pairs), st), "gc_project_sh_fwd_views")
         order = torch.empty(C, N, **i32); cum = torch.empty(C, N, **i32); cnt = torch.empty(C, **i32)
-        wb = int(lib.gc_raster_depth_order_views_workspace_bytes(L.i64(N), L.i32(C)))
-        ws = torch.empty(wb, dtype=torch.uint8, device=dev)
-        L.check(lib.gc_raster_depth_order_views(L.i64(N), L.i32(C), None, None, L.ptr(pairs), L.ptr(nth), L.ptr(order), L.ptr(cum), L.ptr(cnt),
-                                                L.ptr(ws), L.C.c_size_t(wb), st), "gc_raster_depth_order_views")
+        sorted_boxes = bool(getattr(aux, "sorted_boxes", True)) if aux is not None else True
+        if sorted_boxes:      # round 6: the boxes ride through the depth sort, culled Gaussians drop out in its first pass -- no per-Gaussian gathers
+            bxs = torch.empty(C, N, **i32); nvis = torch.empty(C, **i32)
+            wb = int(lib.gc_raster_order_boxes_views_workspace_bytes(L.i64(N), L.i32(C)))
+            ws = torch.empty(wb, dtype=torch.uint8, device=dev)
+            L.check(lib.gc_raster_order_boxes_views(L.i64(N), L.i32(C), L.ptr(pairs), L.ptr(boxes), L.ptr(order), L.ptr(bxs), L.ptr(cum), L.ptr(cnt),
+                                                    L.ptr(nvis), L.ptr(ws), L.C.c_size_t(wb), st), "gc_raster_order_boxes_views")
+        else:                 # the round-5 chain (A/B, cross-check tests)
+            wb = int(lib.gc_raster_depth_order_views_workspace_bytes(L.i64(N), L.i32(C)))
+            ws = torch.empty(wb, dtype=torch.uint8, device=dev)
+            L.check(lib.gc_raster_depth_order_views(L.i64(N), L.i32(C), None, None, L.ptr(pairs), L.ptr(nth), L.ptr(order), L.ptr(cum), L.ptr(cnt),
+                                                    L.ptr(ws), L.C.c_size_t(wb), st), "gc_raster_depth_order_views")
         del pairs
         m_cap = None if aux is None else aux.m_cap
         if m_cap is None:                     # one readback of the C counts sizes the lists exactly (the sync-free form passes a capacity)
@@ -478,9 +489,15 @@ class _RenderViews(torch.autograd.Function):
         bb = int(lib.gc_raster_bin_views_workspace_bytes(L.i64(M_cap), L.i32(C)))
         del ws
         bws = torch.empty(bb, dtype=torch.uint8, device=dev)
-        L.check(lib.gc_raster_bin_tiles_views(L.i64(N), L.i32(C), L.i64(M_cap), L.ptr(cnt), L.ptr(ovf), L.ptr(order), L.ptr(cum), L.ptr(boxes),
-                                              L.ptr(depths), L.i32(tb[0]), L.i32(tb[1]), L.ptr(ids_s), L.ptr(bins), None, L.ptr(bws),
-                                              L.C.c_size_t(bb), st), "gc_raster_bin_tiles_views")
+        if sorted_boxes:
+            L.check(lib.gc_raster_bin_sorted_views(L.i64(N), L.i32(C), L.i64(M_cap), L.ptr(cnt), L.ptr(ovf), L.ptr(nvis), L.ptr(order), L.ptr(bxs),
+                                                   L.ptr(cum), L.i32(tb[0]), L.i32(tb[1]), L.ptr(ids_s), L.ptr(bins), L.ptr(bws), L.C.c_size_t(bb), st),
+                    "gc_raster_bin_sorted_views")
+            del bxs
+        else:
+            L.check(lib.gc_raster_bin_tiles_views(L.i64(N), L.i32(C), L.i64(M_cap), L.ptr(cnt), L.ptr(ovf), L.ptr(order), L.ptr(cum), L.ptr(boxes),
+                                                  L.ptr(depths), L.i32(tb[0]), L.i32(tb[1]), L.ptr(ids_s), L.ptr(bins), None, L.ptr(bws),
+                                                  L.C.c_size_t(bb), st), "gc_raster_bin_tiles_views")
         del bws
         bg = _c(backgrounds)
         shared_bg = 1 if bg.dim() == 1 else 0

@@ -269,6 +269,20 @@ int gc_raster_bin_tiles_views(int64_t N, int C, int64_t M_cap, const int32_t *co
                               const int32_t *depth_order, const int32_t *cum_sorted, const uint32_t *tile_boxes, const float *depths,
                               int tiles_x, int tiles_y, int32_t *gaussian_ids_sorted, int32_t *tile_bins, int64_t *isect_ids_sorted,
                               void *workspace, size_t workspace_bytes, void *stream);
+/* Round 6: the same two phases WITHOUT the per-Gaussian gathers (num_tiles_hit[order[j]] in the scan, tile_boxes[order[j]] in the emission: two
+ * 128-byte line fetches per Gaussian, 2/3 of the bytes the depth order fetched).  The packed tight box rides through the radix passes as a third
+ * word of the item, culled Gaussians are dropped by the first pass; the scan and the emission read sorted arrays sequentially.
+ * gc_raster_order_boxes_views: depth_pairs [C][N][2] + tile_boxes [C][N] (gc_project_sh_fwd_views) -> depth_order [C][N] = ids of the VISIBLE
+ * Gaussians in (depth bits, id) order (entries past visible_dev[c] unspecified), boxes_sorted [C][N], cum_sorted [C][N], count_dev [C] = M,
+ * visible_dev [C].  gc_raster_bin_sorted_views: phase 2 on those (workspace: gc_raster_bin_views_workspace_bytes).  gaussian_ids_sorted and
+ * tile_bins are bit-identical to gc_raster_depth_order_views + gc_raster_bin_tiles_views. */
+size_t gc_raster_order_boxes_views_workspace_bytes(int64_t N, int C);
+int gc_raster_order_boxes_views(int64_t N, int C, const uint32_t *depth_pairs, const uint32_t *tile_boxes, int32_t *depth_order,
+                                uint32_t *boxes_sorted, int32_t *cum_sorted, int32_t *count_dev, int32_t *visible_dev, void *workspace,
+                                size_t workspace_bytes, void *stream);
+int gc_raster_bin_sorted_views(int64_t N, int C, int64_t M_cap, const int32_t *count_dev, int32_t *overflow_dev, const int32_t *visible_dev,
+                               const int32_t *depth_order, const uint32_t *boxes_sorted, const int32_t *cum_sorted, int tiles_x, int tiles_y,
+                               int32_t *gaussian_ids_sorted, int32_t *tile_bins, void *workspace, size_t workspace_bytes, void *stream);
 /* compositing of C views in one launch.  opacities [N] (shared_opacities = 1) or [C][N]; background [3] (shared_background = 1) or [C][3]. */
 int gc_rasterize_fwd_views(int C, int64_t N, int64_t M_cap, int shared_opacities, int shared_background, int img_h, int img_w,
                            int tiles_x, int tiles_y, const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,

@@ -340,3 +340,68 @@ def test_render_views_full_size(oracle_c, N, kname, cams, views):
     scale = max(np.abs(v).max() for v in ref_g.values())
     for k in P:
         _grad_close(fg.views[k].cpu().numpy(), ref_g[k], scale)
+
+
+# ---------------------------------------------------------------------------------------- round 6: the gather-free depth order
+@pytest.mark.parametrize("N,W,H,fx,sm,C,behind", [(30000, 160, 112, 150.0, 0.03, 3, False), (200000, 512, 512, 540.0, 0.01, 5, False),
+                                                    (20000, 200, 136, 180.0, 0.03, 9, True), (7, 33, 17, 40.0, 0.3, 2, False),
+                                                    (4097, 64, 64, 70.0, 0.05, 1, True)])
+def test_sorted_boxes_chain_bit_identical_to_the_pair_chain(N, W, H, fx, sm, C, behind):
+    """gc_raster_order_boxes_views + gc_raster_bin_sorted_views (the packed tight box rides through the depth sort as a third word of the item, the
+    Gaussians the projection culled are dropped by the first radix pass, scan and emission read sorted arrays: RenderAux.sorted_boxes = True, the
+    default) against the round-5 chain gc_raster_depth_order_views + gc_raster_bin_tiles_views (pairs through four passes, then
+    num_tiles_hit[order[j]] and tile_boxes[order[j]] gathered): the same stable (depth bits, id) order over the same visible set, so every
+    per-view output -- counts, sorted id lists, tile bins, images, depth, final indices -- must be BIT-identical.  `behind`: the scene is moved so
+    that roughly half of the Gaussians are behind some of the cameras (culled: the items the first pass drops); N = 4097 crosses a radix block."""
+    from gaussctrl_amd import gsplat_ops as ops
+    P = syn.make_gaussians(N, seed=5, scale_mean=sm)
+    if behind:
+        P["means"][:, :] *= 3.0                                  # a cloud much larger than the camera orbit: many centres behind / outside
+    cams, _ = _cams(C, W, H, fx, seed=9)
+    tp = {k: _t(v) for k, v in P.items()}
+    bgs = torch.rand(C, 3, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    outs = {}
+    for mode in (True, False):
+        aux = ops.RenderAux(); aux.sorted_boxes = mode
+        with torch.no_grad():
+            rgb, alpha, depth = ops.render_views(tp["means"], tp["scales"], tp["quats"], tp["opacities"], tp["features_dc"], tp["features_rest"],
+                                                 cams, bgs, True, 3, aux)
+        outs[mode] = (rgb, alpha, depth, aux)
+    (r1, a1, d1, x1), (r0, a0, d0, x0) = outs[True], outs[False]
+    assert torch.equal(x1.M[0], x0.M[0]) and int(x1.M[1].max()) == 0 and int(x0.M[1].max()) == 0
+    if behind:
+        vis = (x1.radii > 0).float().mean(dim=1)
+        assert float(vis.min()) < 0.9, "the test scene should cull a good part of the Gaussians for some camera"
+    for c in range(C):
+        m = int(x1.M[0][c])
+        assert torch.equal(x1.gaussian_ids_sorted[c, :m], x0.gaussian_ids_sorted[c, :m]), c
+        assert torch.equal(x1.tile_bins[c], x0.tile_bins[c]) and torch.equal(x1.final_index[c], x0.final_index[c]), c
+    assert torch.equal(r1, r0) and torch.equal(a1, a0) and torch.equal(d1, d0)
+
+
+def test_sorted_boxes_chain_all_culled_and_capacity():
+    """every Gaussian behind the camera: zero intersections, background image; and the sync-free capacity / overflow protocol on the new chain"""
+    from gaussctrl_amd import gsplat_ops as ops
+    from gaussctrl_amd.camera import camera_to_gsplat
+    c2w = syn.look_at_c2w(np.array([0.0, -2.0, 0.0]), np.zeros(3))
+    cams = [camera_to_gsplat(c2w, 100.0, 100.0, 32.0, 32.0, 64, 64)] * 2
+    P = syn.make_gaussians(500, seed=1)
+    P["means"][:] = [0, -5, 0]
+    tp = {k: _t(v) for k, v in P.items()}
+    aux = ops.RenderAux()
+    with torch.no_grad():
+        rgb, alpha, depth = ops.render_views(tp["means"], tp["scales"], tp["quats"], tp["opacities"], tp["features_dc"], tp["features_rest"], cams,
+                                             _t(BG), True, 3, aux)
+    assert int(aux.M[0].max()) == 0 and float(alpha.abs().max()) == 0.0 and torch.allclose(rgb, _t(BG).expand(2, 64, 64, 3))
+    N, W, H, C = 30000, 160, 112, 3
+    P = syn.make_gaussians(N, seed=2, scale_mean=0.03)
+    cams, _ = _cams(C, W, H, 150.0)
+    tp = {k: _t(v) for k, v in P.items()}
+    a0 = ops.RenderAux()
+    with torch.no_grad():
+        ops.render_views(tp["means"], tp["scales"], tp["quats"], tp["opacities"], tp["features_dc"], tp["features_rest"], cams, _t(BG), False, 3, a0)
+        mmax = int(a0.M[0].max())
+        a2 = ops.RenderAux(); a2.m_cap = mmax // 2
+        ops.render_views(tp["means"], tp["scales"], tp["quats"], tp["opacities"], tp["features_dc"], tp["features_rest"], cams, _t(BG), False, 3, a2)
+    ovf = a2.M[1].cpu().numpy(); cnt = a2.M[0].cpu().numpy()
+    assert np.array_equal(ovf, (cnt > mmax // 2).astype(np.int32)) and ovf.max() == 1
