@@ -13,9 +13,10 @@
 //   4. tile bins from the sorted tile ids; the 64-bit keys are re-assembled only on request (tests / API compatibility).
 //
 // Radix pass = histogram kernel (256 LDS counters / workgroup) -> scan of the [digit][workgroup] table (the wave64 scan of
-// raster_bin.hip) -> scatter kernel with a STABLE in-workgroup rank: 4096 items / workgroup in 16 strided rounds; inside a wave the
-// rank among equal digits comes from 8 ballots (match-any) + popcount; the (round, wave) x digit count table lives in LDS (64 KiB),
-// is prefixed by 256 lanes (one digit each) and seeded with the global digit/workgroup offset.
+// raster_bin.hip) -> scatter kernel with a STABLE in-workgroup rank: 4096 items / workgroup, each wave walks its contiguous 1024 in 16
+// rounds of 64; the rank among equal digits = a per-wave running digit counter in LDS (advanced by the leader lane of each digit group,
+// 8 ballots (match-any) + popcount inside the round) + a prefix over the four waves per digit, seeded with the global digit / workgroup
+// offset (round 6: 8 KB of LDS; rounds 1-5 kept a 64 KiB (round, wave) x digit table and ran two workgroups per CU).
 #include "common.h"
 
 // raster_bin.hip (internal, not in the public header): scan of C views' tile counts, optionally gathered through `order` first;
@@ -144,17 +145,24 @@ __global__ __launch_bounds__(RT) void k_radix_scatter(const uint32_t *__restrict
         if (n_dev) n_dev += blockIdx.y * vs.nd;
     }
     n = live_count(n, n_dev);
-    extern __shared__ int tbl[];   // [RI*4][256]
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    for (int i = tid; i < RI * 4 * 256; i += RT) tbl[i] = 0;
-    __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * RB;
+    if (base >= n) return;
+    // Stable rank with 8 KB of LDS (round 6; rounds 1-5 kept a 64 KB (round, wave) x digit table: two workgroups per CU -- occupancy, not bytes,
+    // bounded the pass): wave w owns the CONTIGUOUS items [1024 w, 1024 w + 1024) of the workgroup's 4096 and walks them in 16 rounds of 64, so the
+    // order of an item is (wave, round, lane): a per-wave running digit counter, advanced by the leader lane of every digit group of a round
+    // (old value broadcast with ds_bpermute), + the ballot rank inside the round + one prefix over the four waves per digit.
+    __shared__ int cnt[4 * 256];
+    __shared__ int wbase[4 * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int i = tid; i < 4 * 256; i += RT) cnt[i] = 0;
+    __syncthreads();
     uint32_t k[RI], v[RI];
-    unsigned short rk[RI];        // rank inside the wave among equal digits
+    int pre[RI];
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    int *my = cnt + wid * 256;
 #pragma unroll
     for (int j = 0; j < RI; ++j) {
-        const int64_t i = base + j * RT + tid;
+        const int64_t i = base + wid * (RI * 64) + j * 64 + lane;
         const bool ok = i < n;
         if (PAIR) {
             const uint2 kv = ok ? reinterpret_cast<const uint2 *>(keys)[i] : make_uint2(0xFFFFFFFFu, 0u);
@@ -170,28 +178,26 @@ __global__ __launch_bounds__(RT) void k_radix_scatter(const uint32_t *__restrict
             const unsigned long long bal = __ballot((d >> b) & 1);
             m &= ((d >> b) & 1) ? bal : ~bal;
         }
-        rk[j] = (unsigned short)__popcll(m & lt);
-        if (ok && (m & lt) == 0) tbl[(j * 4 + wid) * 256 + d] = __popcll(m);     // leader of each digit group writes the count
+        const bool leader = ok && (m & lt) == 0;
+        int old = 0;
+        if (leader) { old = my[d]; my[d] = old + __popcll(m); }
+        old = __shfl(old, ok ? __builtin_ctzll(m) : lane, 64);
+        pre[j] = ok ? old + __popcll(m & lt) : -1;
     }
     __syncthreads();
-    {   // lane d: exclusive prefix over the 64 (round, wave) slots of digit d, seeded with the global offset
+    {
         const int d = tid;
         const int64_t e = (int64_t)d * nblocks + blockIdx.x;
         int run = offs[e] + sums[e / TS_CHUNK] - hist[e];
-#pragma unroll 8
-        for (int s = 0; s < RI * 4; ++s) {
-            const int c = tbl[s * 256 + d];
-            tbl[s * 256 + d] = run;
-            run += c;
-        }
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { wbase[w * 256 + d] = run; run += cnt[w * 256 + d]; }
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < RI; ++j) {
-        const int64_t i = base + j * RT + tid;
-        if (i < n) {
+        if (pre[j] >= 0) {
             const unsigned d = (k[j] >> shift) & 255;
-            const int pos = tbl[(j * 4 + wid) * 256 + d] + rk[j];
+            const int pos = wbase[wid * 256 + d] + pre[j];
             if (PAIR) {       // keys_out == NULL: last pass, only the values are still needed
                 if (keys_out) reinterpret_cast<uint2 *>(keys_out)[pos] = make_uint2(k[j], v[j]);
                 else vals_out[pos] = v[j];
@@ -459,13 +465,7 @@ Plan make_plan(int64_t n)
     return p;
 }
 
-void set_attr()
-{
-    static gc::AttrOnce once;
-    gc::ensure_dynamic_lds(once, (const void *)k_radix_scatter<false>, RI * 4 * 256 * 4);
-    static gc::AttrOnce once_p;
-    gc::ensure_dynamic_lds(once_p, (const void *)k_radix_scatter<true>, RI * 4 * 256 * 4);
-}
+void set_attr() {}
 
 // one stable radix pass of `dbits` bits (8: the direct scatter; 5 / 6: the LDS-staged scatter of the tile passes) over C views at once
 // (grid.y = view; per-view workspace regions of vs.ws words).  vals_ext: `vo` is the external [C][vs.ext] array, not a workspace buffer.
@@ -493,10 +493,10 @@ int radix_pass(const uint32_t *ki, const uint32_t *vi, uint32_t *ko, uint32_t *v
     else if (dbits == 6)
         hipLaunchKernelGGL((k_radix_scatter_staged<6, false>), g, dim3(RT), 0, s, ki, vi, ko, vo, n, n_dev, shift, p.nb, hist, offs, sums, vs, vals_ext, idmask);
     else if (pair)
-        hipLaunchKernelGGL(k_radix_scatter<true>, g, dim3(RT), (size_t)RI * 4 * 256 * sizeof(int), s, ki, vi, ko, vo, n, n_dev,
+        hipLaunchKernelGGL(k_radix_scatter<true>, g, dim3(RT), 0, s, ki, vi, ko, vo, n, n_dev,
                            shift, p.nb, hist, offs, sums, vs, vals_ext, keys_ext);
     else
-        hipLaunchKernelGGL(k_radix_scatter<false>, g, dim3(RT), (size_t)RI * 4 * 256 * sizeof(int), s, ki, vi, ko, vo, n, n_dev,
+        hipLaunchKernelGGL(k_radix_scatter<false>, g, dim3(RT), 0, s, ki, vi, ko, vo, n, n_dev,
                            shift, p.nb, hist, offs, sums, vs, vals_ext, 0);
     return GC_OK;
 }
