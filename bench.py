@@ -67,10 +67,10 @@ def parse():
     ap.add_argument("--ref-mode", default="rotate", choices=["rotate", "owner0", "replicate", "allgather"])    # N > 1: who computes the reference bank
     # (allgather: the reference trajectory sharded by sample, K / V^T all-gathered per attention layer; N in {2, 4, 8})
     ap.add_argument("--inflight", type=int, default=2)         # launch sets in flight on independent HIP stream pairs (1: strictly one after the other)
-    ap.add_argument("--cobatch", type=int, default=2)          # consecutive chunks of a scene that share ONE launch set (GaussCtrlPipelineConfig.chunks_per_launch): against
-                                                              # the cached reference bank a view's result does not depend on what shares its network batch, so two chunks of
-                                                              # chunk_size views run as one batch of 2 x chunk_size -- every GEMM sees twice the rows (the 384-row level-3
-                                                              # problems fill a round).  A step stays ONE chunk of chunk_size views; 1 = one chunk per launch set (rounds 1-5)
+    ap.add_argument("--cobatch", type=int, default=4)          # consecutive chunks of a scene that share ONE launch set (GaussCtrlPipelineConfig.chunks_per_launch): against
+                                                              # the cached reference bank a view's result does not depend on what shares its network batch, so `cobatch` chunks of
+                                                              # chunk_size views run as one batch of cobatch x chunk_size -- every GEMM sees that many times the rows (the 384-row level-3
+                                                              # problems fill a round; same box: 10.30 / 10.47 / 10.88 / 10.88 views/s at 2 / 3 / 4 / 7, profiles/r06_cobatch_sweep.txt).  A step stays ONE chunk; 1 = rounds 1-5
     ap.add_argument("--no-secondary", action="store_true")     # skip the short f16 secondary measurement (default workload, N = 1)
     ap.add_argument("--mask", action="store_true")   # BASELINE configs[3]: edits composited through a (synthetic elliptical) mask, gc_pipeline.py:226-234
     return ap.parse_args()
@@ -294,7 +294,7 @@ class Bench:
         # so the part-filled grids and the fill / drain phases of one chunk's kernels are covered by the other's; the next scene's
         # reference trajectory has a stream of its own
         self.inflight = max(1, args.inflight) if self.edit else 1
-        self.cobatch = max(1, args.cobatch) if self.edit else 1
+        self.cobatch = max(1, min(args.cobatch, max(1, 21 // max(1, args.chunk_size or 3)))) if self.edit else 1          # (a launch set is validated up to 21 views)
         self.sets_done = 0
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.inflight)] if self.inflight > 1 else [None]
         self.ref_stream = torch.cuda.Stream(device=dev) if self.inflight > 1 else None
@@ -498,7 +498,12 @@ class Bench:
         state), `warmup` untimed steps, then EXACTLY `steps` timed steps between barriers; returns (seconds = max over ranks,
         views edited by this rank in the timed region, training renders in it)"""
         g = 0
-        for i, grp in enumerate(self.groups(0, 2 * self.cobatch) + self.groups(2 * self.cobatch, warmup)):
+        prime = 2 * self.cobatch
+        # the timed region starts on a launch-set boundary of its scene (sets are aligned to multiples of `cobatch` inside a scene): a few more
+        # UNTIMED priming chunks when 2 cobatch + warmup does not end on one -- otherwise the first timed set is a torn one no pipeline run ever launches
+        while self.cobatch > 1 and ((prime + warmup) % self.cps) % self.cobatch != 0:
+            prime += 1
+        for i, grp in enumerate(self.groups(0, prime) + self.groups(prime, warmup)):
             self.step(grp); g += len(grp)
             if i < 2:
                 torch.cuda.synchronize()      # the priming sets also fill the per-prompt / per-timestep caches every stream reads later

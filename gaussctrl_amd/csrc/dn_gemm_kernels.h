@@ -68,6 +68,7 @@ struct GemmArgs {
     int64_t w_set_rows, w_set_stride;
     int pw;                             // column-panel width of the tile order (tile_coords below); 0 = m-major
     int sm_keys;
+    int conv_korder;                    // k_gemm8 fast convs: 1 = tap-inner k-tile sequence (default), 0 = tap-outer (kernel_variant 0x1000)
 };
 
 // (blockIdx.x, blockIdx.y) of a (tiles, k-slices) launch grid -> (m block, n block, k-slice) of this workgroup.
@@ -847,8 +848,19 @@ __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g
     const int64_t wset = (LNV != 0 && g.w_set_rows > 0) ? m_base / g.w_set_rows : 0;          // weight set of this row tile (never straddles: host check)
     const unsigned char *Ab = (const unsigned char *)g.A, *Wb = (const unsigned char *)g.W + (LNV != 0 ? wset * g.w_set_stride * 2 : 0);
     const unsigned char *Zp = (const unsigned char *)g.zeros;
+    // k order of the fast convs (round 6).  The K axis of W is (tap, ci); the k-tile SEQUENCE j = kt0 + kt may walk it in either order:
+    //   tap-inner (default, g.conv_korder = 1): j -> (ci slice j / 9, tap j % 9).  Nine consecutive k-tiles fetch the SAME 64-channel slice of
+    //     pixels shifted by one tap: the A lines of a k-tile are L1 / L2 hits of the previous ones (reuse distance one k-tile).
+    //   tap-outer (rounds 1-5, conv_korder = 0): j -> (tap j / (Cin / 64), ci slice j % (Cin / 64)): a line is touched again only after a sweep over
+    //     the workgroup's whole activation footprint (Cin / 64 k-tiles), per XCD a cyclic sweep over ~4 MB: the LRU worst case
+    //     (scripts/ubench/gemm_loop.hip, profiles/r06_gemm_loop_conv_order.txt: 644 -> 864 TF/s at Cin = 320 on the same loop).
+    // The products summed per output are the same set; only the summation order differs.
+    const bool tap_inner = CONVF && g.conv_korder != 0;
     int ld_tap = 0, ld_ci = 0;
-    if (CONVF && kt0 > 0) { ld_tap = (kt0 * BK) / g.Cin; ld_ci = kt0 * BK - ld_tap * g.Cin; }
+    if (CONVF && kt0 > 0) {
+        if (tap_inner) { ld_tap = kt0 % 9; ld_ci = (kt0 / 9) * BK; }
+        else { ld_tap = (kt0 * BK) / g.Cin; ld_ci = kt0 * BK - ld_tap * g.Cin; }
+    }
 
     // DMA of one k-tile, split into per-instruction pieces so that the main loop can place them between MFMAs.
     struct TileSrc { int kb, dy_u, dx_u, tap_off, tap; unsigned sbase; };
@@ -857,9 +869,11 @@ __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g
         t.kb = (kt0 + kt) * BK; t.dy_u = 0; t.dx_u = 0; t.tap_off = 0; t.tap = 0;
         if (CONVF) {
             t.tap = ld_tap;
+            t.kb = __builtin_amdgcn_readfirstlane(ld_tap * g.Cin + ld_ci);          // W column of this k-tile (= (kt0 + kt) * BK in the tap-outer order)
             t.dy_u = ld_tap / 3; t.dx_u = ld_tap - t.dy_u * 3;
             t.tap_off = UPS ? ld_ci : (t.dy_u * g.Wi + t.dx_u) * g.Cin + ld_ci;
-            ld_ci += BK; if (ld_ci >= g.Cin) { ld_ci -= g.Cin; ++ld_tap; }
+            if (tap_inner) { if (++ld_tap == 9) { ld_tap = 0; ld_ci += BK; } }
+            else { ld_ci += BK; if (ld_ci >= g.Cin) { ld_ci -= g.Cin; ++ld_tap; } }
         }
         t.sbase = lds0 + stage * STAGE;
         return t;

@@ -70,7 +70,7 @@ class GaussCtrlPipelineConfig(_PipelineConfigBase):
                                        # layer all-gathers K / V^T (dist.RefShard) -- no owner, no extra work on any rank; wins over ref_bank_owner
     inflight_chunks: int = 2           # chunks of edit_images in flight on independent HIP stream pairs (consecutive chunks only share the
                                        # read-only reference bank; 1 = strictly one after the other, as the reference runs them)
-    chunks_per_launch: int = 2         # with the reference K / V^T cached a view's result does not depend on which views share its network batch
+    chunks_per_launch: int = 4         # with the reference K / V^T cached a view's result does not depend on which views share its network batch
                                        # (each view attends to itself and to the 4 references, utils.py:95-102), so `chunks_per_launch` consecutive
                                        # chunks of `chunk_size` views run as ONE batch: every GEMM sees that many times the rows (the levels-1..3
                                        # linears of a 3-view chunk are launch-granularity bound).  1 = one chunk per network batch, as the reference
@@ -290,6 +290,10 @@ class GaussCtrlPipeline(_PipelineBase):
             self.pipe.warm_caches(cn, cp)
             ready.record(main)
         per_launch = self.chunk_size * (max(1, int(self.config.chunks_per_launch)) if bank is not None else 1)
+        if per_launch > self.chunk_size:
+            # one launch set = 2 CFG halves x per_launch views in one network batch; validated up to 21 views (42 frames: 7 chunks of 3,
+            # profiles/r06_cobatch_sweep.txt) -- whole chunks only, never fewer than one
+            per_launch = max(self.chunk_size, min(per_launch, (21 // self.chunk_size) * self.chunk_size))
         for ci, s in enumerate(range(0, len(views), per_launch)):
             chunk = views[s:s + per_launch]
             stream = self._chunk_streams[ci % n_fly] if n_fly > 1 else main

@@ -360,6 +360,7 @@ typedef struct gc_gemm_desc {
     int kernel_variant;        /* 0 = automatic.  Overrides for tests / experiments: bits 0-2 force the 8-wave kernel's m-tiles per wave (2,3,4); */
                                /* 0x10 4-wave kernel only; 0x20 force the 8-wave kernel; 0x40 no k-slices for part-filled conv grids; 0x80 slice 8x8-map convs too. */
                                /* fp8 problems (k_gemm8q) honour bits 0-2 (a forced tile height also disables their k-slices) and 0x40 */
+                               /* 0x1000: fast 3x3 convs walk K tap-outer (rounds 1-5) instead of tap-inner (round 6 default: same products, other summation order) */
     float *out_chan_parts;     /* NULL or [M / rows_per_batch][nslab][gn_groups][2][2]: partial (sum, sum of squares) of the stored output per row slab,  */
                                /* GroupNorm group (N / gn_groups channels) and half (1: rest of a group straddling two column tiles); layout:          */
                                /* gc_dn_gemm_chan_parts_layout.  PLAIN stores -- no atomics, no zero-init -> gc_dn_groupnorm_apply_parts /              */
