@@ -290,6 +290,7 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
                "out_fp8: an fp8 linear with a plain output (no fp32 / transposed output, no statistics, no LayerNorm fold), ldc % 4 == 0");
     g.dbg = (d->kernel_variant >> 8) & 0x0f;
     g.conv_korder = (d->kernel_variant & 0x1000) ? 0 : 1;
+    g.prio_half = (d->kernel_variant & 0x2000) ? 1 : 0;
     g.w_set_rows = d->w_set_rows; g.w_set_stride = d->w_set_stride; g.sm_keys = d->softmax_keys;
     GC_REQUIRE(d->w_set_rows >= 0 && d->softmax_keys >= 0 && d->softmax_keys <= 80, "bad weight-set / softmax arguments");
     GC_REQUIRE(!d->softmax_keys || (d->ln_row_stats && d->N % 80 == 0 && d->out && !d->out_f32 && !d->out_t && !d->geglu && !d->residual && d->act == 0),
@@ -306,6 +307,10 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
     } else {
         GC_REQUIRE(d->lda >= d->K && d->lda % 8 == 0, "linear: lda must be >= K and a multiple of 8");
     }
+    // the kernels index the operands with 32-bit element offsets (per-lane DMA offsets are one register): refuse what does not fit instead of faulting
+    // (a 42-view VAE decode batch at 512 x 512 x 256 channels is 2.8 G elements: split the batch on the host)
+    GC_REQUIRE((d->mode == 1 ? (int64_t)d->B * d->Hi * d->Wi * d->Cin : d->M * d->lda) < ((int64_t)1 << 31) && (int64_t)d->N * d->K < ((int64_t)1 << 31),
+               "operand too large for 32-bit element offsets: split the batch");
     if (d->geglu) GC_REQUIRE(d->N % 32 == 0 && !d->out_t, "geglu needs N % 32 == 0");
     const int force_mt = d->kernel_variant & 7;
     GC_REQUIRE(force_mt >= 0 && force_mt <= 4, "kernel_variant: MT must be 0 .. 4");

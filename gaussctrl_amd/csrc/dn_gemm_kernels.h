@@ -69,6 +69,7 @@ struct GemmArgs {
     int pw;                             // column-panel width of the tile order (tile_coords below); 0 = m-major
     int sm_keys;
     int conv_korder;                    // k_gemm8 fast convs: 1 = tap-inner k-tile sequence (default), 0 = tap-outer (kernel_variant 0x1000)
+    int prio_half;                      // experiment (kernel_variant 0x2000): waves 4..7 of k_gemm8 run the k loop at s_setprio 1
 };
 
 // (blockIdx.x, blockIdx.y) of a (tiles, k-slices) launch grid -> (m block, n block, k-slice) of this workgroup.
@@ -992,6 +993,7 @@ __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g
         auto wait_tiles = [&](auto n_) __attribute__((always_inline)) {        // n tiles may stay in flight
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(n_)::value * GRPW) : "memory");
         };
+        if (g.prio_half && wid >= 4) __builtin_amdgcn_s_setprio(1);
         issue(0, 0);
         if (nk > 1) issue(1, 1);
         if (nk > 2) issue(2, 2);
@@ -1631,16 +1633,24 @@ __global__ __launch_bounds__(512, 1) void k_gemm8q(const GemmArgs g)
         w_off[i] = (int)(n < g.N ? n : g.N - 1) * (int)g.K + (ls ^ ((row >> 1) & 7)) * 16;
     }
     const unsigned char *Ab = (const unsigned char *)g.A, *Wb = (const unsigned char *)g.W, *Zp = (const unsigned char *)g.zeros;
-    int ld_tap = MODE == 2 ? (k0 * BKB) / g.Cin : 0, ld_ci = MODE == 2 ? (k0 * BKB) % g.Cin : 0;
+    // (k order of the fast convs: tap-inner by default, as in k_gemm8 -- see the comment there; g.conv_korder = 0 restores tap-outer)
+    const bool tap_inner = MODE == 2 && g.conv_korder != 0;
+    int ld_tap = 0, ld_ci = 0;
+    if (MODE == 2) {
+        if (tap_inner) { ld_tap = k0 % 9; ld_ci = (k0 / 9) * BKB; }
+        else { ld_tap = (k0 * BKB) / g.Cin; ld_ci = (k0 * BKB) % g.Cin; }
+    }
     struct TileSrc { int kb, tap, tap_off; unsigned sbase; };
     auto issue_begin = [&](int kt, int stage) __attribute__((always_inline)) -> TileSrc {
         TileSrc t;
         t.kb = (k0 + kt) * BKB; t.tap = 0; t.tap_off = 0;
         if (MODE == 2) {
             t.tap = ld_tap;
+            t.kb = __builtin_amdgcn_readfirstlane(ld_tap * g.Cin + ld_ci);
             const int dy = ld_tap / 3, dx = ld_tap - dy * 3;
             t.tap_off = (dy * g.Wi + dx) * g.Cin + ld_ci;
-            ld_ci += BKB; if (ld_ci >= g.Cin) { ld_ci -= g.Cin; ++ld_tap; }
+            if (tap_inner) { if (++ld_tap == 9) { ld_tap = 0; ld_ci += BKB; } }
+            else { ld_ci += BKB; if (ld_ci >= g.Cin) { ld_ci -= g.Cin; ++ld_tap; } }
         }
         t.sbase = lds0 + stage * STAGE;
         return t;

@@ -72,6 +72,27 @@ __device__ __forceinline__ int block_incl_scan256(int v, int *total, int *wsum /
     return sc + off;
 }
 
+// Zero-initialisation of a launch set's counters in ONE launch (round 6): the per-view tickets / first-pass digit tables / tile_bins / overflow
+// flags were one hipMemsetAsync each -- 27 fills of ~5 us per launch set of 8 views, 4 % of the raster-only chain at 1 M Gaussians
+// (profiles/r06_raster_kernel_stats_1000000_before_clear.txt).  Up to four regions, region r of view c = base[r] + c * stride[r] bytes, words[r] ints.
+struct ClearJob { unsigned char *base[4]; size_t stride[4]; int64_t words[4]; };
+__global__ __launch_bounds__(256) void k_clear_views(ClearJob j)
+{
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (!j.base[r]) continue;
+        int32_t *q = reinterpret_cast<int32_t *>(j.base[r] + j.stride[r] * blockIdx.y);
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < j.words[r]; i += (int64_t)gridDim.x * 256) q[i] = 0;
+    }
+}
+void clear_views(hipStream_t s, int C, const ClearJob &j)
+{
+    int64_t mx = 1;
+    for (int r = 0; r < 4; ++r) if (j.base[r] && j.words[r] > mx) mx = j.words[r];
+    const unsigned gx = (unsigned)std::min<int64_t>((mx + 1023) / 1024, 256);
+    hipLaunchKernelGGL(k_clear_views, dim3(gx, (unsigned)C), dim3(256), 0, s, j);
+}
+
 __global__ __launch_bounds__(256) void k_table_scan(int64_t n, const int32_t *__restrict__ in, int32_t *__restrict__ out,
                                                     int32_t *sums, int32_t *ticket, VS vs)
 {
@@ -520,8 +541,7 @@ int depth_order_impl(int64_t N, int C, const float *depths, const int32_t *radii
     uint32_t *k0 = (uint32_t *)(w + p.off_keys[0]), *k1 = (uint32_t *)(w + p.off_keys[1]);
     // (key, id) pairs ping-pong between the two halves of the view's region (each half = the keys + vals regions of the plan, >= 8 N bytes)
     uint32_t *pa = k0, *pb = k1;
-    for (int c = 0; c < C; ++c)                                                            // tickets of k_table_scan
-        if (hipMemsetAsync(w + region * (size_t)c + p.off_cnt, 0, 4, s) != hipSuccess) return GC_ELAUNCH;
+    { ClearJob cj = {}; cj.base[0] = w + p.off_cnt; cj.stride[0] = region; cj.words[0] = 1; clear_views(s, C, cj); }     // tickets of k_table_scan
     // pairs_in: the projection kernel already wrote the (depth bits | 0xFFFFFFFF, id) pairs ([C][N] uint2): the first pass reads them in place
     if (!pairs_in)
         hipLaunchKernelGGL(k_depth_keys, dim3(gc::cdiv(N, 256), (unsigned)C), dim3(256), 0, s, N, depths, radii, (uint2 *)pa, vs);
@@ -583,9 +603,11 @@ int bin_tiles_impl(int64_t N, int C, int64_t M, const int32_t *m_dev, int32_t *o
 {
     const int num_tiles = tiles_x * tiles_y;
     hipStream_t s = gc::S(stream);
-    if (hipMemsetAsync(tile_bins, 0, sizeof(int32_t) * 2 * (size_t)num_tiles * C, s) != hipSuccess) return GC_ELAUNCH;
-    if (overflow_dev && hipMemsetAsync(overflow_dev, 0, 4 * (size_t)C, s) != hipSuccess) return GC_ELAUNCH;
-    if (M == 0 || N == 0) return GC_OK;
+    if (M == 0 || N == 0 || !workspace) {      // nothing to bin: empty lists (the general path clears these together with its counters, below)
+        if (hipMemsetAsync(tile_bins, 0, sizeof(int32_t) * 2 * (size_t)num_tiles * C, s) != hipSuccess) return GC_ELAUNCH;
+        if (overflow_dev && hipMemsetAsync(overflow_dev, 0, 4 * (size_t)C, s) != hipSuccess) return GC_ELAUNCH;
+        if (M == 0 || N == 0) return GC_OK;
+    }
     if (num_tiles > 65536) { gc::set_error("%s: at most 65536 tiles", what); return GC_EINVAL; }
     if (!(depth_order && cum_sorted && ((xys && radii) || tile_boxes) && (depths || !isect_ids_sorted) && gaussian_ids_sorted && workspace)) { gc::set_error("%s: null pointer", what); return GC_EINVAL; }
     const Plan p = make_plan(M);
@@ -602,10 +624,13 @@ int bin_tiles_impl(int64_t N, int C, int64_t M, const int32_t *m_dev, int32_t *o
     const int passes = tbits <= 6 ? 1 : 2;
     const int dbits = tbits <= 5 ? 5 : (tbits <= 6 ? 6 : (tbits <= 10 ? 5 : (tbits <= 12 ? 6 : 8)));
     const bool fused_hist = dbits <= 6;          // the emission also counts the first pass's digits (64 LDS counters per 4096-block)
-    for (int c = 0; c < C; ++c) {
-        unsigned char *wc = w + p.total * (size_t)c;
-        if (hipMemsetAsync(wc + p.off_cnt, 0, 4, s) != hipSuccess) return GC_ELAUNCH;          // ticket of k_table_scan
-        if (fused_hist && hipMemsetAsync(wc + p.off_hist, 0, sizeof(int32_t) * ((size_t)1 << dbits) * p.nb, s) != hipSuccess) return GC_ELAUNCH;
+    {   // tile_bins, overflow flags, the tickets of k_table_scan and the first pass's digit tables (counted by the emission) of every view: one launch
+        ClearJob cj = {};
+        cj.base[0] = (unsigned char *)tile_bins; cj.stride[0] = sizeof(int32_t) * 2 * (size_t)num_tiles; cj.words[0] = 2 * (int64_t)num_tiles;
+        if (overflow_dev) { cj.base[1] = (unsigned char *)overflow_dev; cj.stride[1] = 4; cj.words[1] = 1; }
+        cj.base[2] = w + p.off_cnt; cj.stride[2] = p.total; cj.words[2] = 1;
+        if (fused_hist) { cj.base[3] = w + p.off_hist; cj.stride[3] = p.total; cj.words[3] = ((int64_t)1 << dbits) * p.nb; }
+        clear_views(s, C, cj);
     }
     // packed pairs: (tile << idb) | id in ONE word when the id and tile bits fit 32 and the staged (5 / 6-bit) scatter runs -- 1 024 tiles and
     // N <= 4 M: every pass moves 4 bytes per pair instead of 8 (emit 4, pass 1 4 + 4, pass 2 4 + 8, bins 4 = 28 instead of 44 bytes per pair)
@@ -866,16 +891,22 @@ int gc_raster_order_boxes_views(int64_t N, int C, const uint32_t *depth_pairs, c
 {
     GC_REQUIRE(N >= 0 && C >= 1 && C <= 65535 && count_dev && visible_dev, "bad arguments");
     hipStream_t s = gc::S(stream);
-    if (hipMemsetAsync(visible_dev, 0, 4 * (size_t)C, s) != hipSuccess) return GC_ELAUNCH;
-    if (N == 0) return hipMemsetAsync(count_dev, 0, 4 * (size_t)C, s) == hipSuccess ? GC_OK : GC_ELAUNCH;
+    if (N == 0) {
+        if (hipMemsetAsync(visible_dev, 0, 4 * (size_t)C, s) != hipSuccess) return GC_ELAUNCH;
+        return hipMemsetAsync(count_dev, 0, 4 * (size_t)C, s) == hipSuccess ? GC_OK : GC_ELAUNCH;
+    }
     GC_REQUIRE(depth_pairs && tile_boxes && depth_order && boxes_sorted && cum_sorted && workspace, "null pointer");
     const TriPlan p = make_tri_plan(N);
     if (workspace_bytes < p.total * (size_t)C) { gc::set_error("gc_raster_order_boxes_views: workspace too small"); return GC_ENOSPC; }
     set_attr_tri();
     unsigned char *w = (unsigned char *)workspace;
     VS vs; vs.ws = (int64_t)(p.total / 4); vs.ext = N; vs.src = N; vs.nd = 1;
-    for (int c = 0; c < C; ++c)                                                            // tickets of k_table_scan
-        if (hipMemsetAsync(w + p.total * (size_t)c + p.off_cnt, 0, 4, s) != hipSuccess) return GC_ELAUNCH;
+    {   // visible counts + the tickets of k_table_scan: one launch
+        ClearJob cj = {};
+        cj.base[0] = (unsigned char *)visible_dev; cj.stride[0] = 4; cj.words[0] = 1;
+        cj.base[1] = w + p.total * (size_t)0 + p.off_cnt; cj.stride[1] = p.total; cj.words[1] = 1;
+        clear_views(s, C, cj);
+    }
     int32_t *hist = (int32_t *)(w + p.off_hist), *offs = (int32_t *)(w + p.off_offs), *tick = (int32_t *)(w + p.off_cnt), *sums = (int32_t *)(w + p.off_scan);
     const dim3 g((unsigned)p.nb, (unsigned)C);
     const int64_t ne = 256 * (int64_t)p.nb;

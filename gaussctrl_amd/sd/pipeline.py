@@ -240,5 +240,12 @@ class DenoisePipeline:
     def decode(self, latents):
         """latents fp32 [f,4,h,w] -> images fp32 [f,3,8h,8w] in [0,1] (vae.decode(z/0.18215); (x/2+0.5).clamp(0,1))."""
         z = to_nhwc8(latents / 0.18215, self.dtype)
-        img = self.vae.decode(z, postprocess=True)[..., :3]
+        # the GEMM / conv kernels index an operand with 32-bit element offsets: the decoder's widest full-resolution maps ([f, 8h, 8w, <= 512]) bound the
+        # frames of one pass (15 at 512 x 512); larger batches decode in groups (frames are independent: GroupNorm is per sample)
+        f, h, w = z.shape[0], z.shape[1], z.shape[2]
+        grp = max(1, ((1 << 31) - 1) // (64 * h * w * 512))
+        if f <= grp:
+            img = self.vae.decode(z, postprocess=True)[..., :3]
+        else:
+            img = torch.cat([self.vae.decode(z[i:i + grp], postprocess=True)[..., :3] for i in range(0, f, grp)], 0)
         return img.permute(0, 3, 1, 2).contiguous()

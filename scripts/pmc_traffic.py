@@ -21,7 +21,7 @@ os.environ["TMPDIR"] = "/tmp"
 STAGE = [  # kernel-name regex -> bench.py stage
     (r"k_project_sh_fwd", "gc_project_sh_fwd"), (r"k_project_sh_bwd", "gc_project_sh_bwd"),
     (r"k_rasterize_fwd", "gc_rasterize_fwd"), (r"k_rasterize_bwd", "gc_rasterize_bwd"),
-    (r"k_depth_keys|k_radix_hist<true>|k_radix_scatter<true>|k_gather_tiles|k_scan_|k_table_scan", "gc_raster_depth_order"),
+    (r"k_depth_keys|k_radix_hist<true>|k_radix_scatter<true>|k_gather_tiles|k_scan_|k_table_scan|k_tri_hist|k_tri_scatter|k_box_counts", "gc_raster_depth_order"),
     (r"k_radix_hist<false>|k_radix_scatter|k_emit_sorted|k_tile_bins", "gc_raster_bin_tiles_dev"),
     (r"k_ssim|k_raster_finalize", "loss+finalize"),
     (r"k_calib_copy<.*4u>", "calib16"), (r"k_calib_copy<.*f3>", "calib12"),

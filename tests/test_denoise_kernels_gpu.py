@@ -840,3 +840,25 @@ def test_attention_head160_wide_form_matches_64_query_form(dt, monkeypatch):
     monkeypatch.setitem(ops.KERNEL_VARIANT, "attn", 128)
     narrow = ops.attention(q, k, vt, heads, sets, f, Lk=L)
     assert torch.equal(wide, narrow)
+
+
+@pytest.mark.gpu
+def test_gemm_refuses_operands_beyond_32bit_element_offsets():
+    """the GEMM / conv kernels index an operand with 32-bit element offsets: a problem that does not fit is refused with an error code
+    (round 6: a 42-view VAE decode batch, 2.8 G elements at 512 x 512 x 256, used to fault), and DenoisePipeline.decode groups its frames"""
+    import ctypes as C
+    from gaussctrl_amd import _lib as L
+    from gaussctrl_amd.sd import ops
+    x = torch.zeros(256, 64, dtype=torch.bfloat16, device=DEV)
+    w = torch.zeros(64, 64, dtype=torch.bfloat16, device=DEV)
+    o = torch.zeros(256, 64, dtype=torch.bfloat16, device=DEV)
+    z = torch.zeros(64, dtype=torch.uint8, device=DEV)
+    d = ops.GemmDesc()
+    d.dtype = 0; d.mode = 0; d.M, d.N, d.K = 1 << 26, 64, 64          # M * lda = 2^32 elements (the tensors behind the pointers are small: nothing is launched)
+    d.A = x.data_ptr(); d.lda = 64; d.W = w.data_ptr(); d.out = o.data_ptr(); d.ldc = 64; d.out_scale = 1.0; d.zeros = z.data_ptr()
+    with pytest.raises(L.GaussCtrlHipError, match="32-bit"):
+        L.check(L.lib().gc_dn_gemm(C.byref(d), C.c_void_p(ops.stream_handle())), "gc_dn_gemm")
+    d.mode = 1; d.M = 48 * 512 * 512; d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.stride, d.pad_lo = 48, 512, 512, 256, 512, 512, 1, 1; d.K = 9 * 256
+    with pytest.raises(L.GaussCtrlHipError, match="32-bit"):
+        L.check(L.lib().gc_dn_gemm(C.byref(d), C.c_void_p(ops.stream_handle())), "gc_dn_gemm")
+    torch.cuda.synchronize()
