@@ -284,9 +284,9 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
         if constexpr (PV16) {
             uint4 qa, qc;
             os[1][0] = T::mfma32(vf[0][0], pf[1][0], os[1][0]);      // D
-            p16(pf[1][0], pf[1][1], qa, qc);
             __builtin_amdgcn_sched_barrier(0);
             os[1][0] = T::mfma32(vf[1][0], pf[1][1], os[1][0]);
+            p16(pf[1][0], pf[1][1], qa, qc);      // after BOTH 32x32x16 MFMAs have read P: the lane swaps run in place (no copies of the 8 P registers)
             unit(S0, pf[0][0], 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             o1[1][0] = T::mfma(vf16, qa, o1[1][0]);
@@ -331,9 +331,9 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
         if constexpr (PV16) {
             uint4 qa, qc;
             os[0][0] = T::mfma32(vf[0][0], pf[0][0], os[0][0]);      // G
-            p16(pf[0][0], pf[0][1], qa, qc);
             __builtin_amdgcn_sched_barrier(0);
             os[0][0] = T::mfma32(vf[1][0], pf[0][1], os[0][0]);
+            p16(pf[0][0], pf[0][1], qa, qc);
             unit(S1, pf[1][0], 0, 0); unit(S1, pf[1][0], 1, 0);
             __builtin_amdgcn_sched_barrier(0);
             o1[0][0] = T::mfma(vf16, qa, o1[0][0]);

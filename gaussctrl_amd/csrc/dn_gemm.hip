@@ -290,7 +290,6 @@ extern "C" int gc_dn_gemm(const gc_gemm_desc *d, void *stream)
                "out_fp8: an fp8 linear with a plain output (no fp32 / transposed output, no statistics, no LayerNorm fold), ldc % 4 == 0");
     g.dbg = (d->kernel_variant >> 8) & 0x0f;
     g.conv_korder = (d->kernel_variant & 0x1000) ? 0 : 1;
-    g.prio_half = (d->kernel_variant & 0x2000) ? 1 : 0;
     g.w_set_rows = d->w_set_rows; g.w_set_stride = d->w_set_stride; g.sm_keys = d->softmax_keys;
     GC_REQUIRE(d->w_set_rows >= 0 && d->softmax_keys >= 0 && d->softmax_keys <= 80, "bad weight-set / softmax arguments");
     GC_REQUIRE(!d->softmax_keys || (d->ln_row_stats && d->N % 80 == 0 && d->out && !d->out_f32 && !d->out_t && !d->geglu && !d->residual && d->act == 0),

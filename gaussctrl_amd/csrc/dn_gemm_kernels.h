@@ -69,7 +69,6 @@ struct GemmArgs {
     int pw;                             // column-panel width of the tile order (tile_coords below); 0 = m-major
     int sm_keys;
     int conv_korder;                    // k_gemm8 fast convs: 1 = tap-inner k-tile sequence (default), 0 = tap-outer (kernel_variant 0x1000)
-    int prio_half;                      // experiment (kernel_variant 0x2000): waves 4..7 of k_gemm8 run the k loop at s_setprio 1
 };
 
 // (blockIdx.x, blockIdx.y) of a (tiles, k-slices) launch grid -> (m block, n block, k-slice) of this workgroup.
@@ -993,7 +992,6 @@ __global__ __launch_bounds__(512, MT <= 2 ? 2 : 1) void k_gemm8(const GemmArgs g
         auto wait_tiles = [&](auto n_) __attribute__((always_inline)) {        // n tiles may stay in flight
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(n_)::value * GRPW) : "memory");
         };
-        if (g.prio_half && wid >= 4) __builtin_amdgcn_s_setprio(1);
         issue(0, 0);
         if (nk > 1) issue(1, 1);
         if (nk > 2) issue(2, 2);
