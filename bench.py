@@ -84,6 +84,7 @@ class GemmProfiler:
         self.shapes = []            # (op, M, N, K, flags, start, end) of every linear / conv launch (GC_BENCH_SHAPES=1: per-shape table on stderr)
         self.dt = dt
         self.true_cin = {}          # e4m3 conv weight pointer -> un-padded input channels (the fp8 convs pad Cin to 128)
+        self.att_kinds = []         # (kernel, frames, queries per frame, K/V sets, start, end) of every attention launch
 
     @staticmethod
     def _given(v):
@@ -132,6 +133,7 @@ class GemmProfiler:
             else:
                 name = f"k_attn3<{prof.dt},{D},{2 if D == 40 else 1},3>" if fast else f"k_attn<{prof.dt},{D},{1 if D == 160 else 2}>"
             prof.rec.append((name, 4.0 * q.shape[0] * q.shape[1] * lk * q.shape[2] * len(sets), s, e))
+            prof.att_kinds.append((name, int(q.shape[0]), int(q.shape[1]), len(sets), s, e))
             return out
 
         def lin(x, w, *a, **k):
@@ -917,6 +919,21 @@ def denoise_roofline(args, dtype_name, pipe, sdops, z0, ctx_neg, ctx_pos, bank, 
             "other": {k: {"launches": v["launches"], "ms": round(v["ms"], 2),
                           "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2), "frac_of_its_peak": round(v["flop"] / (v["ms"] * 1e-3) / 1e12 / peak_of(k), 4)}
                       for k, v in sm.items() if k != kind}}
+    if kind.startswith("k_attn"):
+        # the dominant kernel's launches of the instrumented set by size.  rocprofv3's per-kernel average covers EVERY launch of a run (full launch sets,
+        # the 2-chunk set that ends a scene, the 8- / 4-frame reference trajectories), so it is lower than avg_launch_us above whenever the sets are larger
+        # than a trajectory batch: compare per workgroup count (`python scripts/rocpd_stats.py <db> 70 k_attn5` prints the same groups from the trace)
+        groups = {}
+        for nm, fr, lq, ns, s_, e_ in prof.att_kinds:
+            if nm != kind:
+                continue
+            g_ = groups.setdefault((fr, lq, ns), [0, 0.0]); g_[0] += 1; g_[1] += s_.elapsed_time(e_)
+        roof["rocprofv3_note"] = ("avg_launch_us / launch_kinds are single-stream HIP-event durations of ONE full launch set; a rocprofv3 trace of this command averages every "
+                                  "k_attn5 launch of the run (2-chunk sets, 8- / 4-frame reference trajectories: smaller) and times them while a second launch set shares "
+                                  "the GPU (--inflight 2: longer) -- compare per workgroup count with the trace of `bench.py --inflight 1` "
+                                  "(profiles/r06_bench_kernel_stats_bf16_inflight1.txt, `scripts/rocpd_stats.py <db> 70 k_attn5`)")
+        roof["launch_kinds"] = [{"frames": fr, "queries_per_frame": lq, "kv_sets": ns, "workgroups": fr * 8 * max(1, lq // 256), "launches": n_,
+                                 "avg_us": round(1e3 * ms_ / n_, 1)} for (fr, lq, ns), (n_, ms_) in sorted(groups.items(), reverse=True)]
     # share of the instrumented chunk's algorithmic FLOP that runs on e4m3 operands -> the mixed peak a whole-step utilisation is priced against:
     # peak_mixed = 1 / (f8 / 5 PF + (1 - f8) / 2.5 PF) (time to run each share at its own dense peak)
     f_tot = sum(v["flop"] for v in sm.values())
