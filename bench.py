@@ -931,7 +931,7 @@ def denoise_roofline(args, dtype_name, pipe, sdops, z0, ctx_neg, ctx_pos, bank, 
         roof["rocprofv3_note"] = ("avg_launch_us / launch_kinds are single-stream HIP-event durations of ONE full launch set; a rocprofv3 trace of this command averages every "
                                   "k_attn5 launch of the run (2-chunk sets, 8- / 4-frame reference trajectories: smaller) and times them while a second launch set shares "
                                   "the GPU (--inflight 2: longer) -- compare per workgroup count with the trace of `bench.py --inflight 1` "
-                                  "(profiles/r06_bench_kernel_stats_bf16_inflight1.txt, `scripts/rocpd_stats.py <db> 70 k_attn5`)")
+                                  "(profiles/r06_bench_kernel_stats_bf16_single_stream.txt: 2 717 us in the trace vs 2 724 us live for the 3 072-workgroup launches; `scripts/rocpd_stats.py <db> 70 k_attn5`)")
         roof["launch_kinds"] = [{"frames": fr, "queries_per_frame": lq, "kv_sets": ns, "workgroups": fr * 8 * max(1, lq // 256), "launches": n_,
                                  "avg_us": round(1e3 * ms_ / n_, 1)} for (fr, lq, ns), (n_, ms_) in sorted(groups.items(), reverse=True)]
     # share of the instrumented chunk's algorithmic FLOP that runs on e4m3 operands -> the mixed peak a whole-step utilisation is priced against:
