@@ -237,13 +237,18 @@ class DenoisePipeline:
         ctx = self._ctx(None, ctx_pos)
         return self._denoise(latents, disparity, ctx, False, "plain", 0.0, 0.0, 0.0, True, steps, None, latents.shape[0], on_step)
 
+    @staticmethod
+    def decode_group(h, w):
+        """frames of one VAE decode pass at h x w latents: [f, 8h, 8w, 512] elements stay below 2^31 (32-bit element offsets in the kernels)"""
+        return max(1, ((1 << 31) - 1) // (64 * h * w * 512))
+
     def decode(self, latents):
         """latents fp32 [f,4,h,w] -> images fp32 [f,3,8h,8w] in [0,1] (vae.decode(z/0.18215); (x/2+0.5).clamp(0,1))."""
         z = to_nhwc8(latents / 0.18215, self.dtype)
         # the GEMM / conv kernels index an operand with 32-bit element offsets: the decoder's widest full-resolution maps ([f, 8h, 8w, <= 512]) bound the
         # frames of one pass (15 at 512 x 512); larger batches decode in groups (frames are independent: GroupNorm is per sample)
         f, h, w = z.shape[0], z.shape[1], z.shape[2]
-        grp = max(1, ((1 << 31) - 1) // (64 * h * w * 512))
+        grp = self.decode_group(h, w)
         if f <= grp:
             img = self.vae.decode(z, postprocess=True)[..., :3]
         else:

@@ -105,6 +105,25 @@ def test_vae_decode_matches_oracle():
     within("err", err, 1.0 / 255.0)  # images in [0,1]; f16 activations through 30 convs
 
 
+def test_pipeline_decode_groups_large_batches(monkeypatch):
+    """DenoisePipeline.decode splits a batch whose widest full-resolution map would pass 2^31 elements (the kernels' 32-bit element offsets; 15 frames at
+    512 x 512) into groups of frames: the grouped path (forced here at a small size) equals one pass -- frames are independent (GroupNorm is per sample)."""
+    from oracle import sd15_torch as sd
+    from gaussctrl_amd.sd.pipeline import DenoisePipeline
+    from gaussctrl_amd.sd.vae import prepare_vae_weights
+    assert DenoisePipeline.decode_group(64, 64) == 15 and DenoisePipeline.decode_group(8, 8) >= 960
+    dt = torch.float16          # (kernel plans follow the row count: the two paths differ by accumulation order -- one 8-bit level in f16, several in bf16)
+    pipe = DenoisePipeline.__new__(DenoisePipeline)          # decode() needs the VAE and the dtype only
+    from gaussctrl_amd.sd.vae import VAEDecoder
+    pipe.vae = VAEDecoder(prepare_vae_weights(sd.make_vae_decoder_weights(sd.VAE_SD, 300), dt, DEV)); pipe.dtype = dt
+    z = torch.randn(5, 4, 8, 8, generator=torch.Generator().manual_seed(2)).to(DEV)
+    one = pipe.decode(z)
+    monkeypatch.setattr(DenoisePipeline, "decode_group", staticmethod(lambda h, w: 2))
+    grouped = pipe.decode(z)                                  # 2 + 2 + 1 frames
+    assert grouped.shape == one.shape == (5, 3, 64, 64)
+    within("grouped vs one-pass decode (max abs, [0,1] image)", float((grouped - one).abs().max()), 2.0 / 255.0)
+
+
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_cfg_shared_prefix_equals_duplicated_computation(sd15, dt, monkeypatch):
     """KernelOptions.cfg_share (sd.unet.AttnCtx.share, default on): conv_in .. the first transformer block's cross-view self-attention run for ONE

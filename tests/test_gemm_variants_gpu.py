@@ -10,15 +10,16 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VARIANTS = [{"GC_GEMM_MT": "2"}, {"GC_GEMM_MT": "3"}, {"GC_GEMM_MT": "4"}, {"GC_GEMM8": "0"}, {"GC_ATTN_SAFE": "1"}]
+VARIANTS = [{"GC_GEMM_MT": "2"}, {"GC_GEMM_MT": "3"}, {"GC_GEMM_MT": "4"}, {"GC_GEMM8": "0"}, {"GC_ATTN_SAFE": "1"},
+            {"GC_GEMM_DBG": "16"}]          # (16 = kernel_variant 0x1000: the 3 x 3 convolutions on the tap-outer k order of rounds 1-5; default since round 6: tap-inner)
 
 
 def test_forced_kernel_variants():
     procs = []
     for env in VARIANTS:
         e = dict(os.environ); e.update(env)
-        e["OMP_NUM_THREADS"] = e["MKL_NUM_THREADS"] = "8"          # five children share the host
-        sel = "attention" if "GC_ATTN_SAFE" in env else "linear or geglu or conv"
+        e["OMP_NUM_THREADS"] = e["MKL_NUM_THREADS"] = "8"          # the children share the host
+        sel = "attention" if "GC_ATTN_SAFE" in env else ("conv" if "GC_GEMM_DBG" in env else "linear or geglu or conv")
         log = tempfile.TemporaryFile(mode="w+")        # (a file, not a pipe: nobody drains five pipes at once)
         procs.append((env, log, subprocess.Popen([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_denoise_kernels_gpu.py"), "-x", "-q",
                                                   "-p", "no:cacheprovider", "-k", sel], cwd=ROOT, env=e, stdout=log, stderr=subprocess.STDOUT, text=True)))
