@@ -215,6 +215,23 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
         else if (w == 2) p.z = v;
         else p.w = v;
     };
+    // The same work at OP granularity (round 6): op k of an S tile = (unit u = k / 3: registers 2 u, 2 u + 1; k % 3 = 0 / 1: v_exp_f32 of one register IN PLACE,
+    // 2: v_cvt_pk of the pair into word u & 3 of P fragment u >> 2).  ops [a, b) of the 24: lets the tile schedule put ~4 VALU under every MFMA.
+    auto uops = [&](f32x16 &S, uint4 &p0, uint4 &p1, auto a_, auto b_) __attribute__((always_inline)) {
+        static_for<decltype(a_)::value, decltype(b_)::value>([&](auto k_) __attribute__((always_inline)) {
+            constexpr int k = decltype(k_)::value, u = k / 3, sub = k % 3, r0 = 2 * u;
+            if constexpr (sub == 0) S[r0] = __builtin_amdgcn_exp2f(PRE ? S[r0] : S[r0] * c2);
+            else if constexpr (sub == 1) S[r0 + 1] = __builtin_amdgcn_exp2f(PRE ? S[r0 + 1] : S[r0 + 1] * c2);
+            else {
+                const unsigned v = pack2<T>(S[r0], S[r0 + 1]);
+                uint4 &p = u < 4 ? p0 : p1;
+                if constexpr ((u & 3) == 0) p.x = v;
+                else if constexpr ((u & 3) == 1) p.y = v;
+                else if constexpr ((u & 3) == 2) p.z = v;
+                else p.w = v;
+            }
+        });
+    };
     // PV16: the two 16x16x32 B operands (queries 0..15 / 16..31 x 32 keys) from the 32x32x16 P fragments of the two 16-key k-steps
     auto p16 = [&](const uint4 &p0, const uint4 &p1, uint4 &qa, uint4 &qb_) __attribute__((always_inline)) {
         const auto x = __builtin_amdgcn_permlane16_swap(p0.x, p1.x, false, false), y = __builtin_amdgcn_permlane16_swap(p0.y, p1.y, false, false);
@@ -272,6 +289,77 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PV16) {
+            // Issue packing (round 6).  The loop is ISSUE-bound, not dependency-bound (scripts/ubench/attn_pingpong.hip: the same instruction stream with the exp units
+            // detached from the MFMAs takes the same time), and a gfx950 SIMD hides ~24 cycles of VALU under a 32x32x16 MFMA and ~8 under a 16x16x32 one, the rest
+            // adds to the loop (scripts/ubench/attn_pack.hip, profiles/r06_attn_issue_packing_ubench.txt: the round-3 distribution -- two bare MFMAs, bursts of 6-10 ops
+            // behind others -- 1 180 ticks per tile, ~4 ops under every MFMA 1 100).  Ops of S1 (P1, read by D of the NEXT tile): G2 1, g1 3, g2 3 | C1 4, C2 4, C3 5,
+            // D1 4; ops of S0 (P0, read by G): d1 3, d2 3, F1 5, F2 5, F3 5, G1 3; the lane swaps stay alone under D2 / G2.  Every P word is complete before the MFMA that
+            // reads it issues (P1 words 0..3 by C2, 4..7 by D1 < D2; P0 words 0..3 by F2, 4..7 by G1 < G2); S0 / S1 are exponentiated in place.
+            using std::integral_constant;
+            uint4 qa, qc;
+            S0 = T::mfma32(kf[0], qf[0][0], zero16);                                                                                  // C
+            __builtin_amdgcn_sched_barrier(0);          // (the MFMA issues first: its ops run in its shadow)
+            uops(S1, pf[1][0], pf[1][1], integral_constant<int, 7>{}, integral_constant<int, 11>{});
+            __builtin_amdgcn_sched_barrier(0);
+            S0 = T::mfma32(kf[1], qf[0][1], S0);
+            __builtin_amdgcn_sched_barrier(0);          // (the MFMA issues first: its ops run in its shadow)
+            uops(S1, pf[1][0], pf[1][1], integral_constant<int, 11>{}, integral_constant<int, 15>{});
+            __builtin_amdgcn_sched_barrier(0);
+            S0 = T::mfma32(kf[2], qf[0][2], S0);
+            __builtin_amdgcn_sched_barrier(0);          // (the MFMA issues first: its ops run in its shadow)
+            uops(S1, pf[1][0], pf[1][1], integral_constant<int, 15>{}, integral_constant<int, 20>{});
+            __builtin_amdgcn_sched_barrier(0);
+            os[1][0] = T::mfma32(vf[0][0], pf[1][0], os[1][0]);                                                                     // D
+            __builtin_amdgcn_sched_barrier(0);          // (the MFMA issues first: its ops run in its shadow)
+            uops(S1, pf[1][0], pf[1][1], integral_constant<int, 20>{}, integral_constant<int, 24>{});
+            __builtin_amdgcn_sched_barrier(0);
+            os[1][0] = T::mfma32(vf[1][0], pf[1][1], os[1][0]);
+            __builtin_amdgcn_sched_barrier(0);          // (the MFMA issues first: its ops run in its shadow)
+            p16(pf[1][0], pf[1][1], qa, qc);
+            __builtin_amdgcn_sched_barrier(0);
+            o1[1][0] = T::mfma(vf16, qa, o1[1][0]);
+            __builtin_amdgcn_sched_barrier(0);          // (the MFMA issues first: its ops run in its shadow)
+            uops(S0, pf[0][0], pf[0][1], integral_constant<int, 0>{}, integral_constant<int, 3>{});
+            __builtin_amdgcn_sched_barrier(0);
+            o1[1][1] = T::mfma(vf16, qc, o1[1][1]);
+            __builtin_amdgcn_sched_barrier(0);          // (the MFMA issues first: its ops run in its shadow)
+            uops(S0, pf[0][0], pf[0][1], integral_constant<int, 3>{}, integral_constant<int, 6>{});
+            __builtin_amdgcn_sched_barrier(0);
+            vf[0][0] = *reinterpret_cast<const uint4 *>(vb_ + vfo[0]); vf[1][0] = *reinterpret_cast<const uint4 *>(vb_ + vfo[1]);     // E
+            vf16 = *reinterpret_cast<const uint4 *>(vb_ + vfo16);
+            S1 = T::mfma32(kf[0], qf[1][0], zero16);                                                                                  // F
+            __builtin_amdgcn_sched_barrier(0);          // (the MFMA issues first: its ops run in its shadow)
+            uops(S0, pf[0][0], pf[0][1], integral_constant<int, 6>{}, integral_constant<int, 11>{});
+            __builtin_amdgcn_sched_barrier(0);
+            S1 = T::mfma32(kf[1], qf[1][1], S1);
+            __builtin_amdgcn_sched_barrier(0);          // (the MFMA issues first: its ops run in its shadow)
+            uops(S0, pf[0][0], pf[0][1], integral_constant<int, 11>{}, integral_constant<int, 16>{});
+            __builtin_amdgcn_sched_barrier(0);
+            S1 = T::mfma32(kf[2], qf[1][2], S1);
+            __builtin_amdgcn_sched_barrier(0);          // (the MFMA issues first: its ops run in its shadow)
+            uops(S0, pf[0][0], pf[0][1], integral_constant<int, 16>{}, integral_constant<int, 21>{});
+            __builtin_amdgcn_sched_barrier(0);
+            rd_kf(SLOT < 0 ? rk : sK + ((SLOT + 1) % NST) * KBYTES);      // tile i+1 (landed: the barrier above waited for it)
+            os[0][0] = T::mfma32(vf[0][0], pf[0][0], os[0][0]);                                                                     // G
+            __builtin_amdgcn_sched_barrier(0);          // (the MFMA issues first: its ops run in its shadow)
+            uops(S0, pf[0][0], pf[0][1], integral_constant<int, 21>{}, integral_constant<int, 24>{});
+            __builtin_amdgcn_sched_barrier(0);
+            os[0][0] = T::mfma32(vf[1][0], pf[0][1], os[0][0]);
+            __builtin_amdgcn_sched_barrier(0);          // (the MFMA issues first: its ops run in its shadow)
+            p16(pf[0][0], pf[0][1], qa, qc);
+            uops(S1, pf[1][0], pf[1][1], integral_constant<int, 0>{}, integral_constant<int, 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            o1[0][0] = T::mfma(vf16, qa, o1[0][0]);
+            __builtin_amdgcn_sched_barrier(0);          // (the MFMA issues first: its ops run in its shadow)
+            uops(S1, pf[1][0], pf[1][1], integral_constant<int, 1>{}, integral_constant<int, 4>{});
+            __builtin_amdgcn_sched_barrier(0);
+            o1[0][1] = T::mfma(vf16, qc, o1[0][1]);
+            __builtin_amdgcn_sched_barrier(0);          // (the MFMA issues first: its ops run in its shadow)
+            uops(S1, pf[1][0], pf[1][1], integral_constant<int, 4>{}, integral_constant<int, 7>{});
+            __builtin_amdgcn_sched_barrier(0);
+            return;
+        }
         S0 = T::mfma32(kf[0], qf[0][0], zero16);        // C
         unit(S1, pf[1][1], 0, 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -359,7 +447,8 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
     // end of a K/V set: finish the pipeline (B and D of the last tile), then O_total += w / (l_a + l_b) * O_set; a wave's partial
     // denominator is row D of its O^T (the ones row of V^T)
     auto fold = [&](int s) __attribute__((always_inline)) {
-        unit(S1, pf[1][1], 0, 1); unit(S1, pf[1][1], 1, 1); unit(S1, pf[1][1], 2, 1); unit(S1, pf[1][1], 3, 1);
+        if constexpr (PV16) uops(S1, pf[1][0], pf[1][1], std::integral_constant<int, 7>{}, std::integral_constant<int, 24>{});      // (ops 0..6 ran under the last tile's G)
+        else { unit(S1, pf[1][1], 0, 1); unit(S1, pf[1][1], 1, 1); unit(S1, pf[1][1], 2, 1); unit(S1, pf[1][1], 3, 1); }
         constexpr int db_l = D / 32, dl = D % 32, r_l = (dl >> 3) * 4 + (dl & 3), hg_l = (dl >> 2) & 1;
         static_assert(!PV16 || (db_l == 1 && dl == 8), "PV16: the ones row is row 8 of the 16-row block (D = 40)");
         const bool lden = PV16 ? (lane >> 4) == 2 : hg == hg_l;       // lanes that hold partial denominators (PV16: rows 8..11 of the 16x16 tiles)
@@ -446,7 +535,8 @@ __global__ __launch_bounds__(512, 1) void k_attn5(const AttnArgs a)
     for (int s = 0; s < a.nsets; ++s) {
         samp = smem + XS + (s & 1) * KBYTES;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) S1[r] = -BIG;                  // exp2 -> 0: the pipeline starts with P1 = 0
+        for (int r = 0; r < 16; ++r) S1[r] = (PV16 && r < 5) ? 0.f : -BIG;      // exp2 -> 0: the pipeline starts with P1 = 0 (PV16: ops 0..6 of the op schedule
+                                                                                // "already ran": registers 0..4 hold exponentials, words 0, 1 of P1 are packed)
         pf[1][0] = make_uint4(0, 0, 0, 0);
         if (ABL && (abl & 128)) {       // P fragments hold non-trivial constants instead of zeros (with bit 6: is the cost the dependency or the data?)
             const uint4 c = make_uint4(0x3F2A3E91u + lane, 0x3DD73F11u ^ (lane << 3), 0x3E4C3F60u, 0x3F053D9Au + 7 * lane);

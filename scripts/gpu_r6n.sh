@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6, call N: k_attn5 with the P lane swaps AFTER both 32x32x16 P V MFMAs (in place: 8 v_mov per tile gone) -- attention tests, then same-box A/B of the
+# round 6, call N (re-used for every k_attn5 A/B): attention tests, then same-box A/B of two builds
 # two builds (the previous libgaussctrl_hip.so kept as attn5_old_build.so.bak), k_attn5 timing at the production launch + default bench
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r6n

@@ -72,7 +72,39 @@ __global__ __launch_bounds__(512, 1) void k(float *out, long long *cyc, int iter
     };
     __syncthreads();
     const long long t0 = __builtin_readcyclecounter();
-    if (MODE == 0) {
+    if (MODE == 3 || MODE == 4) {
+        // MODE 3: the interleaved instruction stream with the units DETACHED from the MFMAs (they read private constants and write private sinks): the pure issue
+        // bound of the mix.  MODE 4: the MFMAs alone in that order (one barrier per tile).
+        f32x16 Sc0 = S0, Sc1 = S1;
+        uint4 sk[2][2] = {{pf[0][0], pf[0][1]}, {pf[1][0], pf[1][1]}};
+        for (int it = 0; it < iters; ++it) {
+            __builtin_amdgcn_s_barrier();
+#define U(Sx, a, b, lo, hi) if (MODE == 3) units(Sx, a, b, lo, hi)
+            S0 = mm32(kf[0], qf[0][0], z16); U(Sc1, sk[1][0], sk[1][1], 4, 5); SB;
+            S0 = mm32(kf[1], qf[0][1], S0); U(Sc1, sk[1][0], sk[1][1], 5, 6); SB;
+            S0 = mm32(kf[2], qf[0][2], S0); U(Sc1, sk[1][0], sk[1][1], 6, 8); SB;
+            os1 = mm32(vf[0], pf[1][0], os1); SB;
+            os1 = mm32(vf[1], pf[1][1], os1); if (MODE == 3) p16(sk[1][0], sk[1][1]); U(Sc0, sk[0][0], sk[0][1], 0, 1); SB;
+            o1[1][0] = mm16(vf16, pf[1][0], o1[1][0]); U(Sc0, sk[0][0], sk[0][1], 1, 2); SB;
+            o1[1][1] = mm16(vf16, pf[1][1], o1[1][1]); U(Sc0, sk[0][0], sk[0][1], 2, 3); SB;
+            S1 = mm32(kf[0], qf[1][0], z16); U(Sc0, sk[0][0], sk[0][1], 3, 5); SB;
+            S1 = mm32(kf[1], qf[1][1], S1); U(Sc0, sk[0][0], sk[0][1], 5, 7); SB;
+            S1 = mm32(kf[2], qf[1][2], S1); U(Sc0, sk[0][0], sk[0][1], 7, 8); SB;
+            os0 = mm32(vf[0], pf[0][0], os0); SB;
+            os0 = mm32(vf[1], pf[0][1], os0); if (MODE == 3) p16(sk[0][0], sk[0][1]); U(Sc1, sk[1][0], sk[1][1], 0, 2); SB;
+            o1[0][0] = mm16(vf16, pf[0][0], o1[0][0]); U(Sc1, sk[1][0], sk[1][1], 2, 3); SB;
+            o1[0][1] = mm16(vf16, pf[0][1], o1[0][1]); U(Sc1, sk[1][0], sk[1][1], 3, 4); SB;
+#undef U
+        }
+        S0[0] += __uint_as_float(sk[0][0].x ^ sk[0][1].y ^ sk[1][0].z ^ sk[1][1].w) + Sc0[3] + Sc1[5];
+    } else if (MODE == 5) {
+        // the VALU of a tile alone (32 v_exp + 16 v_cvt_pk + 8 lane swaps per wave), one barrier per tile
+        for (int it = 0; it < iters; ++it) {
+            __builtin_amdgcn_s_barrier();
+            units(S0, pf[0][0], pf[0][1], 0, 8); units(S1, pf[1][0], pf[1][1], 0, 8); SB;
+            p16(pf[0][0], pf[0][1]); p16(pf[1][0], pf[1][1]); SB;
+        }
+    } else if (MODE == 0) {
         for (int it = 0; it < iters; ++it) {
             __builtin_amdgcn_s_barrier();
             // C
@@ -133,6 +165,9 @@ int main()
     for (int blocks : {1, 256}) {
         run<0>("interleaved, lockstep (product schedule)", blocks);
         run<2>("segments X | Y, both halves in phase", blocks);
+        run<3>("interleaved order, units detached from the MFMAs", blocks);
+        run<4>("the 14 MFMAs alone (+ barrier)", blocks);
+        run<5>("the 56 VALU alone (+ barrier)", blocks);
         run<1>("ping-pong, late waves 4..7 (mask f0)", blocks, 0xf0);
         run<1>("ping-pong, late waves 1,3,5,7 (mask aa)", blocks, 0xaa);
         run<1>("ping-pong, late waves 2,3,6,7 (mask cc)", blocks, 0xcc);
