@@ -312,8 +312,15 @@ def _group_sums(out_bln, G):
 
 
 def _stats_close(got, ref):
-    err = (got.double().cpu() - ref.cpu()).abs()
-    assert float((err / (ref.cpu().abs() + 1e-3 * ref.abs().max().cpu())).max()) < 2e-5, float(err.max())
+    got = got.double().cpu(); ref = ref.cpu()
+    err = (got - ref).abs()
+    rel = err / (ref.abs() + 1e-3 * ref.abs().max())
+    worst = float(rel.max())
+    if not worst < 2e-5:          # compact diagnostics (a forced-variant child only shows the tail of its log)
+        idx = tuple((rel == rel.max()).nonzero()[0].tolist())
+        nbad = int((rel >= 2e-5).sum())
+        raise AssertionError(f"STATS-MISMATCH rel {worst:.3e} at {idx}: got {float(got[idx]):.9g} want {float(ref[idx]):.9g}; {nbad} of {rel.numel()} entries off; "
+                             f"max abs err {float(err.max()):.6g}; got finite {bool(torch.isfinite(got).all())}")
 
 
 @pytest.mark.parametrize("dt", DTS)
