@@ -19,7 +19,7 @@ VARIANTS = [{"GC_GEMM_MT": "2"}, {"GC_GEMM_MT": "3"}, {"GC_GEMM_MT": "4"}, {"GC_
 
 def _child(env):
     e = dict(os.environ); e.update(env)
-    e["OMP_NUM_THREADS"] = e["MKL_NUM_THREADS"] = "16"
+    e["OMP_NUM_THREADS"] = e["MKL_NUM_THREADS"] = "32"          # (the children are bound by their CPU fp64 references)
     sel = "attention" if "GC_ATTN_SAFE" in env else ("conv" if "GC_GEMM_DBG" in env else "linear or geglu or conv")
     log = tempfile.TemporaryFile(mode="w+")
     p = subprocess.Popen([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_denoise_kernels_gpu.py"), "-x", "-q",
