@@ -1,11 +1,14 @@
 #!/bin/bash
-# round 6, call Y: the files of the -m gpu suite up to the forced-variant test, repeated (the in-suite context in which the group-statistics test failed twice)
+# round 6, call Y2: the whole -m gpu suite twice with seeded tests and the two-form statistics bar (+ the margins summary)
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r6y
 mkdir -p $O
-for i in 1 2 3 4 5 6; do
+for i in 1 2; do
   S=$(date +%s)
-  timeout 900 python -m pytest tests/test_denoise_kernels_gpu.py tests/test_denoise_model_gpu.py tests/test_dist_gpu.py tests/test_fullgeom_gpu.py tests/test_gemm_variants_gpu.py -m gpu -q -x > $O/part_$i.txt 2>&1
-  echo "run $i ($(( $(date +%s) - S )) s): $(tail -1 $O/part_$i.txt)"
-  grep -h "STATS-MISMATCH" $O/part_$i.txt | head -3 | cut -c1-400
+  timeout 1500 python -m pytest tests -m gpu -q -x --durations=5 > $O/full_$i.txt 2>&1
+  echo "suite $i seconds: $(( $(date +%s) - S ))" | tee -a $O/full_$i.txt
+  grep -E "passed|failed" $O/full_$i.txt | tail -1
+  grep -E "STATS-MISMATCH|^FAILED" $O/full_$i.txt | head -5 | cut -c1-300
 done
+grep -A12 "^margins:" $O/full_2.txt | cut -c1-200
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3

@@ -22,6 +22,16 @@ def pytest_configure(config):
     ops.configure(ops.options_from_env())
 
 
+@pytest.fixture(autouse=True)
+def _seeded():
+    """Every test starts from the same torch seeds (CPU and every GPU).  torch's CUDA default generator is seeded per PROCESS from a non-deterministic source:
+    tests that draw a bias / row vector from it without a generator of their own ran on different inputs every time (round 6: one statistics bar sat within
+    fp32 accumulation noise for 1-7 draws in 2 000 -- an intermittent failure that took two sightings to place)."""
+    import torch
+    torch.manual_seed(20260930)
+    yield
+
+
 @pytest.fixture(scope="session")
 def oracle_c():
     from oracle import raster_c

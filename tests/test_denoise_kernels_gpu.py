@@ -311,16 +311,34 @@ def _group_sums(out_bln, G):
     return _sums(out_bln.double().reshape(B, L, G, N // G).permute(0, 2, 1, 3).reshape(B, G, -1))
 
 
-def _stats_close(got, ref):
-    got = got.double().cpu(); ref = ref.cpu()
+def _sums_abs(t):
+    """the scale of _sums' two columns: (sum |x|, sum x^2) -- what fp32 accumulation noise is relative to"""
+    t = t.double()
+    return torch.stack([t.abs().sum(-1), (t * t).sum(-1)], -1)
+
+
+def _group_sums_abs(out_bln, G):
+    B, L, N = out_bln.shape
+    return _sums_abs(out_bln.double().reshape(B, L, G, N // G).permute(0, 2, 1, 3).reshape(B, G, -1))
+
+
+def _stats_close(got, ref, scale):
+    """(sum, sum^2) partials accumulated in fp32 by the kernel (lane sums, DPP / LDS reduction, atomics in arbitrary order) against the fp64 sums of the stored
+    output: |err| <= 2e-6 x (sum |x|, sum x^2) -- ~30 fp32 ulps of what was added up, the bar of test_groupnorm_from_producer_partials -- or the original bar.  Round 6: the bar was ONLY
+    2e-5 relative to the SIGNED sum (+ 1e-3 of the largest entry); a group whose sum happens to be near zero then has an absolute allowance of a few 1e-4 on ten
+    thousand fp32 additions of O(1) values, and with bias / row vector drawn from the (per-process random) CUDA generator 1-7 draws in 2 000 exceeded it
+    (scripts/diag/group_stats_margin.py: errors of 1.2e-3 on sum |x| = 1.6e4, i.e. 7.5e-8 = 1.3 ulp) -- the intermittent failure of the forced-tile children."""
+    got = got.double().cpu(); ref = ref.cpu(); scale = scale.cpu().clamp_min(1e-6)
     err = (got - ref).abs()
-    rel = err / (ref.abs() + 1e-3 * ref.abs().max())
-    worst = float(rel.max())
-    if not worst < 2e-5:          # compact diagnostics (a forced-variant child only shows the tail of its log)
-        idx = tuple((rel == rel.max()).nonzero()[0].tolist())
-        nbad = int((rel >= 2e-5).sum())
-        raise AssertionError(f"STATS-MISMATCH rel {worst:.3e} at {idx}: got {float(got[idx]):.9g} want {float(ref[idx]):.9g}; {nbad} of {rel.numel()} entries off; "
-                             f"max abs err {float(err.max()):.6g}; got finite {bool(torch.isfinite(got).all())}")
+    # an entry passes on EITHER form, each normalised to 1: the original relative bar (2e-5 of |ref| + 1e-3 max|ref|) or the accumulation-noise floor (2e-6 of the
+    # entry's scale); the noise floor is what the near-zero sums need, the relative one what the large all-positive sums were always held to
+    used = torch.minimum(err / (2e-5 * (ref.abs() + 1e-3 * ref.abs().max())), err / (2e-6 * scale))
+    worst = float(used.max())
+    if not worst < 1.0:
+        idx = tuple((used == used.max()).nonzero()[0].tolist())
+        raise AssertionError(f"STATS-MISMATCH x{worst:.3f} of the bar at {idx}: got {float(got[idx]):.9g} want {float(ref[idx]):.9g} scale {float(scale[idx]):.6g}; "
+                             f"{int((used >= 1.0).sum())} of {used.numel()} entries off; got finite {bool(torch.isfinite(got).all())}")
+    within("statistics partials: |err| / min(2e-5 (|ref| + 1e-3 max|ref|), 2e-6 (sum |x| resp. sum x^2))", worst, 1.0)
 
 
 @pytest.mark.parametrize("dt", DTS)
@@ -336,8 +354,8 @@ def test_linear_output_statistics(dt, B, L, N, K):
     out = ops.linear(x, w, b, residual=r, rows_per_batch=L, row_stats=rs, group_stats=gs)
     _close(out, x.double() @ w.double().T + b.double() + r.double(), dt)
     assert rs.buf.shape == (rs.slots, B * L, 2) and rs.slots >= 1
-    _stats_close(rs.buf.sum(0), _sums(out.view(B * L, N)))
-    _stats_close(gs, _group_sums(out, 32))
+    _stats_close(rs.buf.sum(0), _sums(out.view(B * L, N)), _sums_abs(out.view(B * L, N)))
+    _stats_close(gs, _group_sums(out, 32), _group_sums_abs(out, 32))
 
 
 @pytest.mark.parametrize("dt", DTS)
@@ -351,7 +369,7 @@ def test_conv_output_group_statistics(dt, B, H, W, Cin, Cout, stride):
     b = torch.randn(Cout, device=DEV); rv = torch.randn(B, Cout, device=DEV)
     gs = torch.zeros(B, 32, 2, device=DEV)
     out = ops.conv3x3(x, w, b, stride=stride, rowvec=rv, group_stats=gs)
-    _stats_close(gs, _group_sums(out.reshape(B, -1, Cout), 32))
+    _stats_close(gs, _group_sums(out.reshape(B, -1, Cout), 32), _group_sums_abs(out.reshape(B, -1, Cout), 32))
 
 
 @pytest.mark.parametrize("kind,B,H,Cin,Cout", [("conv", 6, 64, 320, 320), ("conv", 3, 64, 640, 320), ("conv", 6, 16, 1280, 1280), ("down", 6, 64, 320, 320),
@@ -550,7 +568,7 @@ def test_concat_add_with_statistics(dt, B, HW, C1, C2):
         gs = torch.zeros(B, 32, 2, device=DEV)
         out = ops.concat_add(a, b, cc, group_stats=gs)
         assert torch.equal(out, ops.concat_add(a, b, cc))
-        _stats_close(gs, _group_sums(out, 32))
+        _stats_close(gs, _group_sums(out, 32), _group_sums_abs(out, 32))
 
 
 # ------------------------------------------------------------------------------------------- fp8 (e4m3, block-scaled MFMA)
@@ -583,7 +601,7 @@ def test_conv3x3_fp8(dt, B, H, W, Cin, Cout, stride):
         got = ops.conv3x3_fp8(x8.to(DEV), w8.to(DEV), wsc.to(DEV), dt, b.to(DEV), stride=stride, a_scale=a_scale, group_stats=gs)
         _close(got[..., :Cout], ref, dt)
         if gs is not None and w8.shape[0] == Cout:
-            _stats_close(gs, _group_sums(got.reshape(B, -1, Cout), 32))
+            _stats_close(gs, _group_sums(got.reshape(B, -1, Cout), 32), _group_sums_abs(got.reshape(B, -1, Cout), 32))
 
 
 @pytest.mark.parametrize("dt", DTS)
@@ -795,7 +813,7 @@ def test_group_stats_then_apply(dt, B, HW, C):
     x = (_rand((B, HW, C), dt, 1.0, 1).float() * 1.5 + 0.8).to(dt)
     gamma = torch.randn(C, device=DEV); beta = torch.randn(C, device=DEV)
     gs = ops.group_stats(x, torch.zeros(B, 32, 2, device=DEV))
-    _stats_close(gs, _group_sums(x, 32))
+    _stats_close(gs, _group_sums(x, 32), _group_sums_abs(x, 32))
     ref = F.silu(F.group_norm(x.double().transpose(1, 2), 32, gamma.double(), beta.double(), 1e-5).transpose(1, 2))
     _close(ops.groupnorm_apply(x, gs, gamma, beta, 32, 1e-5, True), ref, dt, extra=2.0)
 
