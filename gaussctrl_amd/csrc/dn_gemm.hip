@@ -183,7 +183,10 @@ int select(const gc_gemm_desc *d, Sel *o, bool want_parts)
         int s8 = 1, tps8 = nk_host;
         if (want_split) {
             const int smt = (kv >> 24) & 7;                                  // experiments: forced m-tiles per wave of the k-sliced problems
-            const int mts = (smt >= 2 && smt <= 4) ? smt : ((mode != 0 && !small) ? 3 : 2);    // 16 x 16-map convs: 192-row tiles x 3 slices (60.4 vs 63.7 us); the small grids and the linears: 128 rows
+            // 16 x 16-map convs: 192-row tiles x 3 slices (60.4 vs 63.7 us); the small grids and the linears: 128 rows; round 6: the 8 x 8-map convs of a 4-chunk launch
+            // set (M = 1 536 = 24 whole images) 256-row tiles x 4 slices = four whole images per tile (profiles/r06_gemm_mt_scan_launch_sets.txt: 73.4 -> 65.8 us, 126.7 -> 111.4 us)
+            const bool img8 = mode != 0 && !small && d->Ho * d->Wo <= 64 && Msel % 256 == 0;
+            const int mts = (smt >= 2 && smt <= 4) ? smt : (img8 ? 4 : ((mode != 0 && !small) ? 3 : 2));
             const int64_t tiles_s = ((Msel + 64 * mts - 1) / (64 * mts)) * nbn;
             s8 = (int)std::min<int64_t>(std::max<int64_t>(256 / tiles_s, 2), nk_host / 12);         // one round: tiles x slices <= 256 workgroups
             if (s8 >= 2 && d->workspace_bytes >= sizeof(float) * (size_t)s8 * (size_t)d->M * (size_t)d->N) {
